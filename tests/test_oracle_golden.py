@@ -1,0 +1,102 @@
+"""CPU: the oracle reproduces every golden vector generated from the reference (tests/golden/make_golden.py)."""
+import torch
+
+from conftest import load_golden, unpack_draws, SMALL_CFG, state_from_golden
+from oracle import mind as omind, gin as ogin, tta as otta, unet as ounet
+
+
+def test_mind_golden():
+    for tag in ("16", "ragged", "const"):
+        g = load_golden(f"mind3d_{tag}")
+        assert torch.equal(omind.mind3d(g["img"], g["noise"]), g["out"])
+
+
+def test_mind_constants():
+    taps = omind.gauss_taps(1.0)
+    ref = torch.tensor([0.054488689, 0.244201362, 0.402619958, 0.244201362, 0.054488689])
+    assert torch.allclose(taps, ref, atol=1e-8)
+    assert len(omind.SHIFT1) == len(omind.SHIFT2) == 12
+
+
+def test_gin_golden():
+    for i in range(7):
+        g = load_golden(f"gin_{i}")
+        ks = [int(k) for k in g["ks"]]
+        out = ogin.gin_chain(g["x"], g["alpha"], ks, [g[f"ker{j}"] for j in range(4)],
+                             [g[f"shift{j}"] for j in range(4)])
+        assert torch.equal(out, g["out"])
+
+
+def test_loss_golden():
+    g = load_golden("loss")
+    assert torch.equal(otta.soft_dice_loss(g["a"], g["b"]), g["d_ab"])
+    assert torch.equal(otta.soft_dice_loss(g["a"], g["a"]), g["d_aa"])
+    assert torch.equal(otta.consistency_loss(g["ta"], g["tb"]), torch.as_tensor(g["loss"]))
+    assert torch.equal(otta.dice_coeff(g["dc_out"], g["dc_lab"], 4), g["dc"])
+    z = torch.zeros(1, 3, 4, 4, 4)
+    assert torch.equal(otta.soft_dice_loss(z, z), torch.ones(1, 3))
+
+
+def test_mapping_golden():
+    g = load_golden("mapping")
+    assert torch.equal(otta.map_label(g["logits"], g["idx"], "logits"), g["mapped"])
+    assert torch.equal(otta.map_label(g["am"], g["idx"], "argmaxed"), g["am_mapped"])
+
+
+def test_get_batch_golden():
+    g = load_golden("get_batch")
+    img, lbl = otta.get_batch_item(g["data"], [16, 16, 16], g["rand3"])
+    assert torch.equal(img, g["img"]) and torch.equal(lbl, g["lbl"])
+    img, lbl = otta.get_batch_item(g["data"], [16, 16, 16], None)
+    assert torch.equal(img, g["cimg"]) and torch.equal(lbl, g["clbl"])
+    # centre crop of an even margin is a plain crop (up to the (x-min)+min rounding of torch_utils.py:58-62)
+    assert torch.allclose(img[0, 0], g["data"][0, 2:18, 1:17, 3:19], rtol=0, atol=1e-4)
+    img, lbl = otta.get_batch_item(g["small"], [16, 16, 16], g["small_rand3"])
+    assert lbl is None and torch.equal(img, g["small_img"])
+
+
+def test_rand_affine_golden():
+    g = load_golden("rand_affine")
+    r, rinv = otta.rand_affine_from_draw(g["draw"])
+    assert torch.equal(r, g["r"]) and torch.equal(rinv, g["rinv"])
+
+
+def test_calc_branch_golden():
+    g = load_golden("calc_branch")
+    m = ounet.PlainConvUNetOracle(SMALL_CFG)
+    m.load_state_dict(state_from_golden(g), strict=False)
+    for br in ("a", "b"):
+        out = otta.calc_branch(m, g["imgs"], g["map_idxs"], **unpack_draws(g, br))
+        assert torch.allclose(out, g[f"out_{br}"], rtol=0, atol=1e-6)
+
+
+def test_tta_epoch_golden():
+    g = load_golden("tta_epoch")
+    m = ounet.PlainConvUNetOracle(SMALL_CFG)
+    m.load_state_dict(state_from_golden(g), strict=False)
+    opt = torch.optim.AdamW(m.parameters(), lr=float(g["lr"]))
+    losses = []
+    for p in m.parameters():
+        p.requires_grad_(False)
+    for epoch in range(3):
+        if epoch == 1:
+            for p in m.parameters():
+                p.requires_grad_(True)
+        for acc in range(2):
+            losses.append(otta.tta_step(m, g["imgs"], g["map_idxs"], unpack_draws(g, f"e{epoch}s{acc}_a"),
+                                        unpack_draws(g, f"e{epoch}s{acc}_b"), accum=2, backward=epoch >= 1))
+        if epoch >= 1:
+            opt.step(), opt.zero_grad()
+    assert torch.allclose(torch.stack(losses), g["losses"], rtol=0, atol=1e-6)
+    with torch.no_grad():
+        logits = otta.map_label(m(omind.mind3d(g["imgs"], g["eval_noise"])), g["map_idxs"], "logits")
+    assert (logits.argmax(1) == g["eval_argmax"]).float().mean() > 0.999
+
+
+def test_unet_keys_and_size():
+    m = ounet.PlainConvUNetOracle()
+    assert abs(sum(p.numel() for p in m.parameters()) - 16_606_948) == 0
+    keys = m.state_dict().keys()
+    assert "encoder.stages.0.0.convs.0.all_modules.1.weight" in keys
+    assert "decoder.encoder.stages.4.0.convs.1.conv.bias" in keys
+    assert "decoder.transpconvs.3.weight" in keys and "decoder.seg_layers.0.bias" in keys

@@ -50,7 +50,7 @@ def test_get_batch_golden():
     img, lbl = otta.get_batch_item(g["data"], [16, 16, 16], None)
     assert torch.equal(img, g["cimg"]) and torch.equal(lbl, g["clbl"])
     # centre crop of an even margin is a plain crop (up to the (x-min)+min rounding of torch_utils.py:58-62)
-    assert torch.allclose(img[0, 0], g["data"][0, 2:18, 1:17, 3:19], rtol=0, atol=1e-4)
+    assert torch.allclose(img[0, 0], g["data"][0, 2:18, 1:17, 3:19], rtol=0, atol=2e-3)
     img, lbl = otta.get_batch_item(g["small"], [16, 16, 16], g["small_rand3"])
     assert lbl is None and torch.equal(img, g["small_img"])
 

@@ -67,7 +67,7 @@ def test_calc_branch_golden():
     m.load_state_dict(state_from_golden(g), strict=False)
     for br in ("a", "b"):
         out = otta.calc_branch(m, g["imgs"], g["map_idxs"], **unpack_draws(g, br))
-        assert torch.allclose(out, g[f"out_{br}"], rtol=0, atol=1e-6)
+        assert torch.allclose(out, g[f"out_{br}"], rtol=0, atol=2e-5)  # thread-count dependent conv summation
 
 
 def test_tta_epoch_golden():
@@ -87,7 +87,7 @@ def test_tta_epoch_golden():
                                         unpack_draws(g, f"e{epoch}s{acc}_b"), accum=2, backward=epoch >= 1))
         if epoch >= 1:
             opt.step(), opt.zero_grad()
-    assert torch.allclose(torch.stack(losses), g["losses"], rtol=0, atol=1e-6)
+    assert torch.allclose(torch.stack(losses), g["losses"], rtol=0, atol=1e-5)
     with torch.no_grad():
         logits = otta.map_label(m(omind.mind3d(g["imgs"], g["eval_noise"])), g["map_idxs"], "logits")
     assert (logits.argmax(1) == g["eval_argmax"]).float().mean() > 0.999

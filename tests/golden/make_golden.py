@@ -256,7 +256,7 @@ def gold_branch_and_epoch():
             out[f"{prefix}_shift{li}"] = shifts[li]
         return out
 
-    sd = {f"w::{k}": v for k, v in omodel.state_dict().items()
+    sd = {f"w::{k}": v.clone() for k, v in omodel.state_dict().items()
           if ".all_modules." not in k and not k.startswith("decoder.encoder.")}
     save("calc_branch", imgs=imgs, map_idxs=map_idxs, out_a=ra, out_b=rb, **pack("a", da), **pack("b", db), **sd)
 

@@ -1,0 +1,90 @@
+// Shared device/host helpers for libdgtta_hip.so (gfx950 only; wave = 64 lanes).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_bf16.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+
+#include "../../include/dgtta.h"
+
+#define WAVE 64
+
+void dgtta_set_error(const char *fmt, ...);
+
+#define DG_REQUIRE(cond, code, ...)      \
+  do {                                   \
+    if (!(cond)) {                       \
+      dgtta_set_error(__VA_ARGS__);      \
+      return (code);                     \
+    }                                    \
+  } while (0)
+
+#define DG_CHECK_LAUNCH(name)                                                     \
+  do {                                                                            \
+    hipError_t e__ = hipGetLastError();                                           \
+    if (e__ != hipSuccess) {                                                      \
+      dgtta_set_error("%s: launch failed: %s", name, hipGetErrorString(e__));     \
+      return DGTTA_ERR_LAUNCH;                                                    \
+    }                                                                             \
+  } while (0)
+
+__host__ __device__ static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+__host__ __device__ static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// ---------------------------------------------------------------- bf16 storage helpers
+typedef unsigned short bf16_t;  // raw bits
+
+__device__ __forceinline__ float bf16_to_f32(bf16_t h) { return __uint_as_float(((unsigned)h) << 16); }
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
+  // plain cast path: hipcc emits v_cvt_pk_bf16_f32 (round-to-nearest-even, NaN preserved)
+  __hip_bfloat16 b = __float2bfloat16(f);
+  return *reinterpret_cast<bf16_t *>(&b);
+}
+
+template <typename T>
+__device__ __forceinline__ float ld_f(const T *p);
+template <>
+__device__ __forceinline__ float ld_f<float>(const float *p) { return *p; }
+template <>
+__device__ __forceinline__ float ld_f<bf16_t>(const bf16_t *p) { return bf16_to_f32(*p); }
+
+template <typename T>
+__device__ __forceinline__ void st_f(T *p, float v);
+template <>
+__device__ __forceinline__ void st_f<float>(float *p, float v) { *p = v; }
+template <>
+__device__ __forceinline__ void st_f<bf16_t>(bf16_t *p, float v) { *p = f32_to_bf16(v); }
+
+// ---------------------------------------------------------------- reductions
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_min(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// Block-wide sum for blockDim.x <= 1024 (multiple of 64). `red` = LDS scratch of >= 16 floats.
+// Result valid in every thread.  Deterministic (fixed tree).
+__device__ __forceinline__ float block_sum(float v, float *red) {
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  __syncthreads();
+  if (lane == 0) red[w] = v;
+  __syncthreads();
+  float r = 0.f;
+  for (int i = 0; i < nw; ++i) r += red[i];
+  return r;
+}
+
+__device__ __forceinline__ float lrelu(float a, float slope) { return a > 0.f ? a : a * slope; }

@@ -1,0 +1,229 @@
+// MIND3D 12-channel self-similarity descriptor, fused (HBM-bound).
+// Replaces MIND3D.forward / smooth / filter1D of the reference (dg_tta/mind.py:142-164, :27-43, :5-24).
+//
+// Pass A (mind_ssd_kernel): one workgroup per 8x8x32 output tile.  The image tile (+3 halo, replicate
+//   = clamped coordinates) is staged once in LDS; per channel c the squared edge response
+//   q = (p[v+s1]-p[v+s2] + rw*noise)^2 is formed on the tile +2 halo, then smoothed by the separable
+//   5-tap Gaussian D -> H -> W entirely in LDS; the 12 smoothed values of a voxel stay in registers.
+//   Writes m_c = ssd_c - min_c (fp32, voxel-major [B][V][12]) to the workspace and a per-workgroup
+//   partial sum of var = mean_c m_c.
+// Pass B (mind_reduce_kernel): fixed-order sum of the partials in double -> global mean of var.
+// Pass C (mind_finish_kernel): var clamp to [1e-3, 1e3] x global mean, out = exp(-m/var), written
+//   NCDHW fp32 or NDHWC fp32/bf16.
+// Algorithmic HBM bytes per voxel: img 4 + noise 48 + ws 48 w + 48 r + out 48 (fp32) = 196 B.
+#include "common.h"
+
+namespace {
+
+constexpr int TD = 8, TH = 8, TW = 32;
+constexpr int ID = TD + 6, IH = TH + 6, IW = TW + 6;   // image tile (halo 3)
+constexpr int QD = TD + 4, QH = TH + 4, QW = TW + 4;   // q tile (halo 2)
+constexpr int NT = 256;
+constexpr int VPT = TD * TH * TW / NT;                 // 8 voxels per thread
+
+// (d,h,w) offsets inside the 3x3x3 window minus 1, from mshift1/mshift2 (mind.py:112-135).
+__constant__ signed char c_s1[12][3] = {{0, 0, -1}, {0, -1, 0}, {0, -1, 0}, {0, 0, 1}, {0, 0, 1}, {1, 0, 0},
+                                        {1, 0, 0},  {1, 0, 0},  {0, 1, 0},  {0, 1, 0}, {0, 1, 0}, {0, 1, 0}};
+__constant__ signed char c_s2[12][3] = {{-1, 0, 0}, {-1, 0, 0}, {0, 0, -1}, {-1, 0, 0}, {0, -1, 0}, {0, 0, -1},
+                                        {0, -1, 0}, {0, 0, 1},  {-1, 0, 0}, {0, 0, -1}, {0, 0, 1},  {1, 0, 0}};
+
+__device__ __forceinline__ int clampi(int x, int lo, int hi) { return x < lo ? lo : (x > hi ? hi : x); }
+
+struct Taps { float g[5]; };
+
+__global__ __launch_bounds__(NT) void mind_ssd_kernel(const float *__restrict__ img, const float *__restrict__ noise,
+                                                      float rw, float *__restrict__ mws, double *__restrict__ partial,
+                                                      int D, int H, int W, int tilesD, Taps taps) {
+  __shared__ float simg[ID * IH * IW];
+  __shared__ float sq[QD * QH * QW];      // q, later reused for r2
+  __shared__ float sr1[TD * QH * QW];
+  __shared__ float sred[16];
+
+  const int tid = threadIdx.x;
+  const int b = blockIdx.z / tilesD;
+  const int d0 = (blockIdx.z % tilesD) * TD, h0 = blockIdx.y * TH, w0 = blockIdx.x * TW;
+  const int64_t V = (int64_t)D * H * W;
+  const float *imgb = img + (int64_t)b * V;
+
+  for (int i = tid; i < ID * IH * IW; i += NT) {
+    int iw = i % IW, ih = (i / IW) % IH, id = i / (IW * IH);
+    int gd = clampi(d0 - 3 + id, 0, D - 1), gh = clampi(h0 - 3 + ih, 0, H - 1), gw = clampi(w0 - 3 + iw, 0, W - 1);
+    simg[i] = imgb[((int64_t)gd * H + gh) * W + gw];
+  }
+
+  float ssd[VPT][12];
+
+#pragma unroll
+  for (int c = 0; c < 12; ++c) {
+    __syncthreads();  // simg ready (c==0) / previous channel's r2 reads done
+    const float *nz = noise + ((int64_t)b * 12 + c) * V;
+    const int a0 = c_s1[c][0], a1 = c_s1[c][1], a2 = c_s1[c][2];
+    const int e0 = c_s2[c][0], e1 = c_s2[c][1], e2 = c_s2[c][2];
+    for (int i = tid; i < QD * QH * QW; i += NT) {
+      int qw = i % QW, qh = (i / QW) % QH, qd = i / (QW * QH);
+      int gd = clampi(d0 - 2 + qd, 0, D - 1), gh = clampi(h0 - 2 + qh, 0, H - 1), gw = clampi(w0 - 2 + qw, 0, W - 1);
+      int p1 = ((clampi(gd + a0, 0, D - 1) - (d0 - 3)) * IH + (clampi(gh + a1, 0, H - 1) - (h0 - 3))) * IW +
+               (clampi(gw + a2, 0, W - 1) - (w0 - 3));
+      int p2 = ((clampi(gd + e0, 0, D - 1) - (d0 - 3)) * IH + (clampi(gh + e1, 0, H - 1) - (h0 - 3))) * IW +
+               (clampi(gw + e2, 0, W - 1) - (w0 - 3));
+      float n = nz[((int64_t)gd * H + gh) * W + gw];
+      float e = (simg[p1] - simg[p2]) + rw * n;
+      sq[i] = e * e;
+    }
+    __syncthreads();
+    // D filter: r1[d][h'][w'] = sum_t g[t] q[d+t][h'][w']
+    for (int i = tid; i < TD * QH * QW; i += NT) {
+      const float *q = sq + i;  // (d,h',w') has the same (h',w') strides in sq and sr1
+      float acc = taps.g[0] * q[0];
+#pragma unroll
+      for (int t = 1; t < 5; ++t) acc += taps.g[t] * q[t * QH * QW];
+      sr1[i] = acc;
+    }
+    __syncthreads();
+    // H filter into sq (as r2[d][h][w'], row length QW)
+    for (int i = tid; i < TD * TH * QW; i += NT) {
+      int qw = i % QW, h = (i / QW) % TH, d = i / (QW * TH);
+      const float *r = sr1 + (d * QH + h) * QW + qw;
+      float acc = taps.g[0] * r[0];
+#pragma unroll
+      for (int t = 1; t < 5; ++t) acc += taps.g[t] * r[t * QW];
+      sq[i] = acc;
+    }
+    __syncthreads();
+    // W filter into registers
+#pragma unroll
+    for (int k = 0; k < VPT; ++k) {
+      int idx = tid + k * NT;
+      int w = idx % TW, h = (idx / TW) % TH, d = idx / (TW * TH);
+      const float *r = sq + (d * TH + h) * QW + w;
+      float acc = taps.g[0] * r[0];
+#pragma unroll
+      for (int t = 1; t < 5; ++t) acc += taps.g[t] * r[t];
+      ssd[k][c] = acc;
+    }
+  }
+
+  float vsum = 0.f;
+#pragma unroll
+  for (int k = 0; k < VPT; ++k) {
+    int idx = tid + k * NT;
+    int w = w0 + idx % TW, h = h0 + (idx / TW) % TH, d = d0 + idx / (TW * TH);
+    if (d < D && h < H && w < W) {
+      float mn = ssd[k][0];
+#pragma unroll
+      for (int c = 1; c < 12; ++c) mn = fminf(mn, ssd[k][c]);
+      float s = 0.f;
+      float m[12];
+#pragma unroll
+      for (int c = 0; c < 12; ++c) {
+        m[c] = ssd[k][c] - mn;
+        s += m[c];
+      }
+      vsum += s / 12.0f;
+      float4 *dst = reinterpret_cast<float4 *>(mws + ((int64_t)b * V + ((int64_t)d * H + h) * W + w) * 12);
+      dst[0] = make_float4(m[0], m[1], m[2], m[3]);
+      dst[1] = make_float4(m[4], m[5], m[6], m[7]);
+      dst[2] = make_float4(m[8], m[9], m[10], m[11]);
+    }
+  }
+  float tot = block_sum(vsum, sred);
+  if (tid == 0) partial[(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = (double)tot;
+}
+
+__global__ void mind_reduce_kernel(const double *__restrict__ partial, int n, double inv_count, float *gmean) {
+  __shared__ double sh[256];
+  double s = 0.0;
+  for (int i = threadIdx.x; i < n; i += 256) s += partial[i];
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) gmean[0] = (float)(sh[0] * inv_count);
+}
+
+template <typename TO, bool NDHWC>
+__global__ void mind_finish_kernel(const float *__restrict__ mws, const float *__restrict__ gmean, TO *__restrict__ out,
+                                   int ldc, int64_t V, int64_t total) {
+  const float gm = gmean[0];
+  const float lo = gm * 0.001f, hi = gm * 1000.0f;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const float4 *src = reinterpret_cast<const float4 *>(mws + i * 12);
+    float4 a = src[0], bq = src[1], cq = src[2];
+    float m[12] = {a.x, a.y, a.z, a.w, bq.x, bq.y, bq.z, bq.w, cq.x, cq.y, cq.z, cq.w};
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < 12; ++c) s += m[c];
+    float var = s / 12.0f;
+    var = fminf(fmaxf(var, lo), hi);
+    if (NDHWC) {
+      TO *o = out + i * ldc;
+#pragma unroll
+      for (int c = 0; c < 12; ++c) st_f<TO>(o + c, expf(-(m[c] / var)));
+      for (int c = 12; c < ldc; ++c) st_f<TO>(o + c, 0.f);
+    } else {
+      int64_t b = i / V, v = i % V;
+      TO *o = out + b * 12 * V + v;
+#pragma unroll
+      for (int c = 0; c < 12; ++c) st_f<TO>(o + (int64_t)c * V, expf(-(m[c] / var)));
+    }
+  }
+}
+
+void tile_counts(int D, int H, int W, int &td, int &th, int &tw) {
+  td = cdiv(D, TD);
+  th = cdiv(H, TH);
+  tw = cdiv(W, TW);
+}
+
+}  // namespace
+
+extern "C" size_t dgtta_mind3d_ws_bytes(int B, int D, int H, int W) {
+  int td, th, tw;
+  tile_counts(D, H, W, td, th, tw);
+  size_t m = align_up((size_t)B * D * H * W * 12 * sizeof(float), 256);
+  size_t p = align_up((size_t)B * td * th * tw * sizeof(double), 256);
+  return m + p + 256;
+}
+
+extern "C" int dgtta_mind3d_fwd(const float *img, const float *noise, float rw, void *out, int out_ndhwc, int out_ldc,
+                                int out_dtype, void *ws, size_t ws_bytes, int B, int D, int H, int W, void *stream) {
+  DG_REQUIRE(img && noise && out && ws, DGTTA_ERR_BADARG, "mind3d_fwd: null pointer");
+  DG_REQUIRE(B > 0 && D > 0 && H > 0 && W > 0, DGTTA_ERR_BADARG, "mind3d_fwd: bad dims %d %d %d %d", B, D, H, W);
+  DG_REQUIRE(ws_bytes >= dgtta_mind3d_ws_bytes(B, D, H, W), DGTTA_ERR_WORKSPACE, "mind3d_fwd: workspace too small");
+  DG_REQUIRE(out_ndhwc ? (out_ldc >= 12) : (out_dtype == DGTTA_F32), DGTTA_ERR_BADARG,
+             "mind3d_fwd: NCDHW output must be fp32; NDHWC needs ldc >= 12");
+  DG_REQUIRE(out_dtype == DGTTA_F32 || out_dtype == DGTTA_BF16, DGTTA_ERR_BADARG, "mind3d_fwd: bad dtype");
+  hipStream_t st = (hipStream_t)stream;
+  int td, th, tw;
+  tile_counts(D, H, W, td, th, tw);
+  DG_REQUIRE((int64_t)td * B <= 65535 && th <= 65535, DGTTA_ERR_UNSUPPORTED, "mind3d_fwd: volume too large for grid");
+  const int64_t V = (int64_t)D * H * W;
+  float *mws = (float *)ws;
+  double *partial = (double *)((char *)ws + align_up((size_t)B * V * 12 * sizeof(float), 256));
+  const int nblk = B * td * th * tw;
+  float *gmean = (float *)((char *)partial + align_up((size_t)nblk * sizeof(double), 256));
+
+  // taps as mind.py:30-37 evaluates them in fp32 for sigma=1: exp(-x^2/2)/sum, x=-2..2 (bit patterns of torch's result)
+  Taps taps = {{0x1.be5f1p-5f, 0x1.f41fd8p-3f, 0x1.9c4868p-2f, 0x1.f41fd8p-3f, 0x1.be5f1p-5f}};
+  dim3 grid(tw, th, td * B);
+  hipLaunchKernelGGL(mind_ssd_kernel, grid, dim3(NT), 0, st, img, noise, rw, mws, partial, D, H, W, td, taps);
+  DG_CHECK_LAUNCH("mind_ssd_kernel");
+  hipLaunchKernelGGL(mind_reduce_kernel, dim3(1), dim3(256), 0, st, partial, nblk, 1.0 / ((double)B * V), gmean);
+  DG_CHECK_LAUNCH("mind_reduce_kernel");
+  const int64_t total = (int64_t)B * V;
+  int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+  if (!out_ndhwc) {
+    hipLaunchKernelGGL((mind_finish_kernel<float, false>), dim3(blocks), dim3(256), 0, st, mws, gmean, (float *)out, 12,
+                       V, total);
+  } else if (out_dtype == DGTTA_F32) {
+    hipLaunchKernelGGL((mind_finish_kernel<float, true>), dim3(blocks), dim3(256), 0, st, mws, gmean, (float *)out,
+                       out_ldc, V, total);
+  } else {
+    hipLaunchKernelGGL((mind_finish_kernel<bf16_t, true>), dim3(blocks), dim3(256), 0, st, mws, gmean, (bf16_t *)out,
+                       out_ldc, V, total);
+  }
+  DG_CHECK_LAUNCH("mind_finish_kernel");
+  return DGTTA_OK;
+}

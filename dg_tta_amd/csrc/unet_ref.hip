@@ -1,0 +1,814 @@
+// Network building blocks, general-shape VALU kernels ("impl 1"): correct for every Cin/Cout/stride/ld, used
+//  (a) as the on-GPU cross-check for the MFMA implicit-GEMM kernels (conv_mfma.hip) at sizes where the CPU oracle
+//      is too slow, and (b) for layer shapes the MFMA kernels do not cover.
+// Also hosts the HBM-bound pieces that stay on the VALU: InstanceNorm+LeakyReLU fwd/bwd, the per-channel
+// reductions, layout converters, weight packing, argmax/Dice counting.
+// Semantics follow torch.nn.{Conv3d, InstanceNorm3d, LeakyReLU, ConvTranspose3d} as used by nnUNet's PlainConvUNet
+// (dynamic-network-architectures==0.2; built at dg_tta/pretraining/nnUNetTrainer_GIN_MIND.py:46-53).
+#include "common.h"
+
+namespace {
+
+// ============================================================================ weight packing
+template <typename T>
+__global__ void pack_weights_kernel(const float *__restrict__ w, T *__restrict__ wf, T *__restrict__ wb, int Cin,
+                                    int Cout, int CinP, int CoutP) {
+  const int64_t nf = (int64_t)27 * CinP * CoutP;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nf; i += (int64_t)gridDim.x * blockDim.x) {
+    {  // wf[tap][ci][co]
+      int co = (int)(i % CoutP), ci = (int)((i / CoutP) % CinP), tap = (int)(i / ((int64_t)CoutP * CinP));
+      float v = (co < Cout && ci < Cin) ? w[((int64_t)co * Cin + ci) * 27 + tap] : 0.f;
+      if (wf) st_f<T>(wf + i, v);
+    }
+    {  // wb[tap'][co][ci] = w[co][ci][26-tap']
+      int ci = (int)(i % CinP), co = (int)((i / CinP) % CoutP), tap = (int)(i / ((int64_t)CoutP * CinP));
+      float v = (co < Cout && ci < Cin) ? w[((int64_t)co * Cin + ci) * 27 + (26 - tap)] : 0.f;
+      if (wb) st_f<T>(wb + i, v);
+    }
+  }
+}
+
+// ============================================================================ conv 3x3x3 forward (reference grade)
+// one thread per (voxel, co); lanes run over co so the x value is a broadcast and wf[tap][ci][co] is coalesced.
+template <typename T>
+__global__ void conv3_fwd_ref_kernel(const T *__restrict__ x, int ldx, const T *__restrict__ wf,
+                                     const float *__restrict__ bias, T *__restrict__ y, int ldy, int Cin, int Cout,
+                                     int CinP, int CoutP, int Di, int Hi, int Wi, int Do, int Ho, int Wo, int s,
+                                     int64_t total) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int co = (int)(i % Cout);
+    const int64_t vox = i / Cout;
+    const int wo = (int)(vox % Wo), ho = (int)((vox / Wo) % Ho);
+    const int d_o = (int)((vox / ((int64_t)Wo * Ho)) % Do), b = (int)(vox / ((int64_t)Wo * Ho * Do));
+    float acc = 0.f;
+    for (int kd = 0; kd < 3; ++kd) {
+      const int di = d_o * s + kd - 1;
+      if ((unsigned)di >= (unsigned)Di) continue;
+      for (int kh = 0; kh < 3; ++kh) {
+        const int hi = ho * s + kh - 1;
+        if ((unsigned)hi >= (unsigned)Hi) continue;
+        for (int kw = 0; kw < 3; ++kw) {
+          const int wi = wo * s + kw - 1;
+          if ((unsigned)wi >= (unsigned)Wi) continue;
+          const T *xp = x + ((((int64_t)b * Di + di) * Hi + hi) * Wi + wi) * ldx;
+          const T *wp = wf + ((int64_t)(kd * 9 + kh * 3 + kw) * CinP) * CoutP + co;
+          for (int ci = 0; ci < Cin; ++ci) acc = __builtin_fmaf(ld_f<T>(xp + ci), ld_f<T>(wp + (int64_t)ci * CoutP), acc);
+        }
+      }
+    }
+    st_f<T>(y + vox * ldy + co, acc + (bias ? bias[co] : 0.f));
+  }
+}
+
+// data gradient, any stride: thread per (input voxel, ci); wb[26-tap][co][ci] is coalesced over ci.
+template <typename T>
+__global__ void conv3_dgrad_ref_kernel(const T *__restrict__ dy, int lddy, const T *__restrict__ wb, T *__restrict__ dx,
+                                       int lddx, int Cin, int Cout, int CinP, int CoutP, int Di, int Hi, int Wi, int Do,
+                                       int Ho, int Wo, int s, int accumulate, int64_t total) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int ci = (int)(i % Cin);
+    const int64_t vox = i / Cin;
+    const int wi = (int)(vox % Wi), hi = (int)((vox / Wi) % Hi);
+    const int di = (int)((vox / ((int64_t)Wi * Hi)) % Di), b = (int)(vox / ((int64_t)Wi * Hi * Di));
+    float acc = 0.f;
+    for (int kd = 0; kd < 3; ++kd) {
+      int td = di + 1 - kd;
+      if (td < 0 || td % s) continue;
+      td /= s;
+      if (td >= Do) continue;
+      for (int kh = 0; kh < 3; ++kh) {
+        int th = hi + 1 - kh;
+        if (th < 0 || th % s) continue;
+        th /= s;
+        if (th >= Ho) continue;
+        for (int kw = 0; kw < 3; ++kw) {
+          int tw = wi + 1 - kw;
+          if (tw < 0 || tw % s) continue;
+          tw /= s;
+          if (tw >= Wo) continue;
+          const T *gp = dy + ((((int64_t)b * Do + td) * Ho + th) * Wo + tw) * lddy;
+          const T *wp = wb + ((int64_t)(26 - (kd * 9 + kh * 3 + kw)) * CoutP) * CinP + ci;
+          for (int co = 0; co < Cout; ++co) acc = __builtin_fmaf(ld_f<T>(gp + co), ld_f<T>(wp + (int64_t)co * CinP), acc);
+        }
+      }
+    }
+    T *o = dx + vox * lddx + ci;
+    st_f<T>(o, accumulate ? ld_f<T>(o) + acc : acc);
+  }
+}
+
+// weight gradient partials: grid (pairs/256, 27, nsplit); thread = one (ci,co) pair, loops over a voxel slice.
+// partial layout [split][co][ci][tap] (torch order) so the final reduction is a plain sum over splits.
+template <typename T>
+__global__ void conv3_wgrad_ref_kernel(const T *__restrict__ x, int ldx, const T *__restrict__ dy, int lddy,
+                                       float *__restrict__ part, int Cin, int Cout, int B, int Di, int Hi, int Wi,
+                                       int Do, int Ho, int Wo, int s) {
+  const int pair = blockIdx.x * blockDim.x + threadIdx.x;
+  if (pair >= Cin * Cout) return;
+  const int co = pair % Cout, ci = pair / Cout;
+  const int tap = blockIdx.y, kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
+  const int64_t nvox = (int64_t)B * Do * Ho * Wo;
+  const int64_t per = cdiv64(nvox, gridDim.z);
+  const int64_t v0 = (int64_t)blockIdx.z * per, v1 = (v0 + per < nvox) ? v0 + per : nvox;
+  float acc = 0.f;
+  for (int64_t vox = v0; vox < v1; ++vox) {
+    const int wo = (int)(vox % Wo), ho = (int)((vox / Wo) % Ho);
+    const int d_o = (int)((vox / ((int64_t)Wo * Ho)) % Do), b = (int)(vox / ((int64_t)Wo * Ho * Do));
+    const int di = d_o * s + kd - 1, hi = ho * s + kh - 1, wi = wo * s + kw - 1;
+    if ((unsigned)di >= (unsigned)Di || (unsigned)hi >= (unsigned)Hi || (unsigned)wi >= (unsigned)Wi) continue;
+    const float xv = ld_f<T>(x + ((((int64_t)b * Di + di) * Hi + hi) * Wi + wi) * ldx + ci);
+    acc = __builtin_fmaf(xv, ld_f<T>(dy + vox * lddy + co), acc);
+  }
+  part[(((int64_t)blockIdx.z * Cout + co) * Cin + ci) * 27 + tap] = acc;
+}
+
+__global__ void reduce_splits_kernel(const float *__restrict__ part, float *__restrict__ out, int64_t n, int nsplit,
+                                     int accumulate) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    float s = 0.f;
+    for (int k = 0; k < nsplit; ++k) s += part[(int64_t)k * n + i];
+    out[i] = accumulate ? out[i] + s : s;
+  }
+}
+
+// ============================================================================ per-channel reductions over rows
+// rows = voxels of one batch sample; MODE 0: (sum y, sum y^2)          [InstanceNorm statistics]
+//                                     MODE 1: (sum da, sum da*xhat)     [InstanceNorm backward]; da = gz*lrelu'(a)
+//                                     MODE 2: (sum y, 0)                [bias gradient]
+// grid (nblk, B); partial[b][blk][c][2] double; the finalize kernels sum blocks in fixed order.
+template <typename T, int MODE>
+__global__ __launch_bounds__(256) void chan_reduce_kernel(const T *__restrict__ y, int ldy, const T *__restrict__ gz,
+                                                          int ldgz, const float *__restrict__ mean_rstd,
+                                                          const float *__restrict__ gamma,
+                                                          const float *__restrict__ beta, float slope,
+                                                          double *__restrict__ partial, int C, int64_t V) {
+  __shared__ float red[2][256];
+  const int b = blockIdx.y;
+  int CL = 1;
+  while (CL < C && CL < 64) CL <<= 1;  // channel lanes (power of two <= 64)
+  const int RG = 256 / CL;             // row groups
+  const int cl = threadIdx.x % CL, rg = threadIdx.x / CL;
+  const int64_t rows_per_blk = cdiv64(V, gridDim.x);
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_blk, r1 = (r0 + rows_per_blk < V) ? r0 + rows_per_blk : V;
+  for (int c0 = 0; c0 < C; c0 += CL) {
+    const int c = c0 + cl;
+    float s0 = 0.f, s1 = 0.f;
+    if (c < C) {
+      float mu = 0.f, rs = 0.f, ga = 0.f, be = 0.f;
+      if (MODE == 1) {
+        mu = mean_rstd[((int64_t)b * C + c) * 2];
+        rs = mean_rstd[((int64_t)b * C + c) * 2 + 1];
+        ga = gamma[c];
+        be = beta[c];
+      }
+      for (int64_t r = r0 + rg; r < r1; r += RG) {
+        const float v = ld_f<T>(y + ((int64_t)b * V + r) * ldy + c);
+        if (MODE == 0) {
+          s0 += v;
+          s1 += v * v;
+        } else if (MODE == 2) {
+          s0 += v;
+        } else {
+          const float xh = (v - mu) * rs;
+          const float a = xh * ga + be;
+          float g = ld_f<T>(gz + ((int64_t)b * V + r) * ldgz + c);
+          g = a > 0.f ? g : g * slope;
+          s0 += g;
+          s1 += g * xh;
+        }
+      }
+    }
+    __syncthreads();
+    red[0][threadIdx.x] = s0;
+    red[1][threadIdx.x] = s1;
+    __syncthreads();
+    if (rg == 0 && c < C) {
+      double t0 = 0.0, t1 = 0.0;
+      for (int k = 0; k < RG; ++k) {
+        t0 += (double)red[0][k * CL + cl];
+        t1 += (double)red[1][k * CL + cl];
+      }
+      double *p = partial + ((((int64_t)b * gridDim.x + blockIdx.x) * C) + c) * 2;
+      p[0] = t0;
+      p[1] = t1;
+    }
+  }
+}
+
+// InstanceNorm statistics finalize: mean, rstd = 1/sqrt(biased var + eps)
+__global__ void in_stats_finalize_kernel(const double *__restrict__ partial, int nblk, int B, int C, int64_t V, float eps,
+                                         float *__restrict__ mean_rstd) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * C) return;
+  const int b = i / C, c = i % C;
+  double s = 0.0, ss = 0.0;
+  for (int k = 0; k < nblk; ++k) {
+    const double *p = partial + ((((int64_t)b * nblk + k) * C) + c) * 2;
+    s += p[0];
+    ss += p[1];
+  }
+  const double mean = s / (double)V;
+  double var = ss / (double)V - mean * mean;
+  if (var < 0.0) var = 0.0;
+  mean_rstd[2 * i] = (float)mean;
+  mean_rstd[2 * i + 1] = (float)(1.0 / sqrt(var + (double)eps));
+}
+
+// z = lrelu(y*alpha + beta'), alpha = rstd*gamma, beta' = beta - mean*alpha  (ATen's batch_norm transform form)
+template <typename T>
+__global__ void in_lrelu_apply_kernel(const T *__restrict__ y, int ldy, const float *__restrict__ mean_rstd,
+                                      const float *__restrict__ gamma, const float *__restrict__ beta,
+                                      T *__restrict__ z, int ldz, int C, int64_t V, float slope, int64_t total) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    const int64_t row = i / C;  // b*V + v
+    const int b = (int)(row / V);
+    const float mu = mean_rstd[((int64_t)b * C + c) * 2], rs = mean_rstd[((int64_t)b * C + c) * 2 + 1];
+    const float al = rs * gamma[c];
+    const float bt = beta[c] - mu * al;
+    const float a = ld_f<T>(y + row * ldy + c) * al + bt;
+    st_f<T>(z + row * ldz + c, lrelu(a, slope));
+  }
+}
+
+// backward finalize: c1 = mean(da), c2 = mean(da*xhat); dgamma (+)= sum_b sum(da*xhat); dbeta (+)= sum_b sum(da)
+__global__ void in_bwd_finalize_kernel(const double *__restrict__ partial, int nblk, int B, int C, int64_t V,
+                                       float *__restrict__ c12, float *__restrict__ dgamma, float *__restrict__ dbeta,
+                                       int accumulate) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double g_acc = 0.0, b_acc = 0.0;
+  for (int b = 0; b < B; ++b) {
+    double s0 = 0.0, s1 = 0.0;
+    for (int k = 0; k < nblk; ++k) {
+      const double *p = partial + ((((int64_t)b * nblk + k) * C) + c) * 2;
+      s0 += p[0];
+      s1 += p[1];
+    }
+    c12[((int64_t)b * C + c) * 2] = (float)(s0 / (double)V);
+    c12[((int64_t)b * C + c) * 2 + 1] = (float)(s1 / (double)V);
+    b_acc += s0;
+    g_acc += s1;
+  }
+  dgamma[c] = accumulate ? dgamma[c] + (float)g_acc : (float)g_acc;
+  dbeta[c] = accumulate ? dbeta[c] + (float)b_acc : (float)b_acc;
+}
+
+// dy = gamma*rstd*(da - c1 - xhat*c2)
+template <typename T>
+__global__ void in_lrelu_bwd_apply_kernel(const T *__restrict__ gz, int ldgz, const T *__restrict__ y, int ldy,
+                                          const float *__restrict__ mean_rstd, const float *__restrict__ gamma,
+                                          const float *__restrict__ beta, const float *__restrict__ c12,
+                                          T *__restrict__ dy, int lddy, int C, int64_t V, float slope, int64_t total) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    const int64_t row = i / C;
+    const int b = (int)(row / V);
+    const int64_t bc = (int64_t)b * C + c;
+    const float mu = mean_rstd[bc * 2], rs = mean_rstd[bc * 2 + 1], ga = gamma[c];
+    const float xh = (ld_f<T>(y + row * ldy + c) - mu) * rs;
+    const float a = xh * ga + beta[c];
+    float g = ld_f<T>(gz + row * ldgz + c);
+    g = a > 0.f ? g : g * slope;
+    st_f<T>(dy + row * lddy + c, (ga * rs) * ((g - c12[bc * 2]) - xh * c12[bc * 2 + 1]));
+  }
+}
+
+__global__ void bias_finalize_kernel(const double *__restrict__ partial, int nblk, int B, int C, float *__restrict__ db,
+                                     int accumulate) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s = 0.0;
+  for (int b = 0; b < B; ++b)
+    for (int k = 0; k < nblk; ++k) s += partial[((((int64_t)b * nblk + k) * C) + c) * 2];
+  db[c] = accumulate ? db[c] + (float)s : (float)s;
+}
+
+// ============================================================================ ConvTranspose3d k2 s2
+template <typename T>
+__global__ void convT_fwd_ref_kernel(const T *__restrict__ x, int ldx, const float *__restrict__ w,
+                                     const float *__restrict__ bias, T *__restrict__ out, int ldo, int Cin, int Cout,
+                                     int Di, int Hi, int Wi, int64_t total) {
+  const int Do = 2 * Di, Ho = 2 * Hi, Wo = 2 * Wi;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int co = (int)(i % Cout);
+    const int64_t vox = i / Cout;
+    const int wo = (int)(vox % Wo), ho = (int)((vox / Wo) % Ho);
+    const int d_o = (int)((vox / ((int64_t)Wo * Ho)) % Do), b = (int)(vox / ((int64_t)Wo * Ho * Do));
+    const int o = ((d_o & 1) * 2 + (ho & 1)) * 2 + (wo & 1);
+    const T *xp = x + ((((int64_t)b * Di + (d_o >> 1)) * Hi + (ho >> 1)) * Wi + (wo >> 1)) * ldx;
+    float acc = 0.f;
+    for (int ci = 0; ci < Cin; ++ci) acc = __builtin_fmaf(ld_f<T>(xp + ci), w[((int64_t)ci * Cout + co) * 8 + o], acc);
+    st_f<T>(out + vox * ldo + co, acc + (bias ? bias[co] : 0.f));
+  }
+}
+
+template <typename T>
+__global__ void convT_dgrad_ref_kernel(const T *__restrict__ dout, int lddo, const float *__restrict__ w,
+                                       T *__restrict__ dx, int lddx, int Cin, int Cout, int Di, int Hi, int Wi,
+                                       int64_t total) {
+  const int Ho = 2 * Hi, Wo = 2 * Wi, Do = 2 * Di;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int ci = (int)(i % Cin);
+    const int64_t vox = i / Cin;
+    const int wi = (int)(vox % Wi), hi = (int)((vox / Wi) % Hi);
+    const int di = (int)((vox / ((int64_t)Wi * Hi)) % Di), b = (int)(vox / ((int64_t)Wi * Hi * Di));
+    float acc = 0.f;
+    for (int o = 0; o < 8; ++o) {
+      const T *gp =
+          dout + ((((int64_t)b * Do + 2 * di + (o >> 2)) * Ho + 2 * hi + ((o >> 1) & 1)) * Wo + 2 * wi + (o & 1)) * lddo;
+      for (int co = 0; co < Cout; ++co) acc = __builtin_fmaf(ld_f<T>(gp + co), w[((int64_t)ci * Cout + co) * 8 + o], acc);
+    }
+    st_f<T>(dx + vox * lddx + ci, acc);
+  }
+}
+
+// partial[split][ci][co][o]; grid (pairs/256, 8, nsplit)
+template <typename T>
+__global__ void convT_wgrad_ref_kernel(const T *__restrict__ x, int ldx, const T *__restrict__ dout, int lddo,
+                                       float *__restrict__ part, int Cin, int Cout, int B, int Di, int Hi, int Wi) {
+  const int pair = blockIdx.x * blockDim.x + threadIdx.x;
+  if (pair >= Cin * Cout) return;
+  const int co = pair % Cout, ci = pair / Cout, o = blockIdx.y;
+  const int Ho = 2 * Hi, Wo = 2 * Wi, Do = 2 * Di;
+  const int64_t nvox = (int64_t)B * Di * Hi * Wi;
+  const int64_t per = cdiv64(nvox, gridDim.z);
+  const int64_t v0 = (int64_t)blockIdx.z * per, v1 = (v0 + per < nvox) ? v0 + per : nvox;
+  float acc = 0.f;
+  for (int64_t vox = v0; vox < v1; ++vox) {
+    const int wi = (int)(vox % Wi), hi = (int)((vox / Wi) % Hi);
+    const int di = (int)((vox / ((int64_t)Wi * Hi)) % Di), b = (int)(vox / ((int64_t)Wi * Hi * Di));
+    const T *gp =
+        dout + ((((int64_t)b * Do + 2 * di + (o >> 2)) * Ho + 2 * hi + ((o >> 1) & 1)) * Wo + 2 * wi + (o & 1)) * lddo;
+    acc = __builtin_fmaf(ld_f<T>(x + vox * ldx + ci), ld_f<T>(gp + co), acc);
+  }
+  part[(((int64_t)blockIdx.z * Cin + ci) * Cout + co) * 8 + o] = acc;
+}
+
+// ============================================================================ 1x1x1 head on selected rows
+template <typename T, bool NDHWC>
+__global__ void head_fwd_kernel(const T *__restrict__ x, int ldx, const float *__restrict__ w,
+                                const float *__restrict__ bias, const int *__restrict__ sel, int nsel,
+                                float *__restrict__ out, int ldo, int Cin, int64_t V, int64_t total) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    int k;
+    int64_t row;
+    if (NDHWC) {
+      k = (int)(i % nsel);
+      row = i / nsel;
+    } else {  // i = (b*nsel + k)*V + v
+      const int64_t v = i % V;
+      k = (int)((i / V) % nsel);
+      row = (i / (V * nsel)) * V + v;
+    }
+    const int r = sel ? sel[k] : k;
+    const T *xp = x + row * ldx;
+    const float *wp = w + (int64_t)r * Cin;
+    float acc = 0.f;
+    for (int ci = 0; ci < Cin; ++ci) acc = __builtin_fmaf(ld_f<T>(xp + ci), wp[ci], acc);
+    acc += bias[r];
+    if (NDHWC) out[row * ldo + k] = acc;
+    else out[i] = acc;
+  }
+}
+
+template <typename T>
+__global__ void head_dgrad_kernel(const float *__restrict__ dout, int lddo, const float *__restrict__ w,
+                                  const int *__restrict__ sel, int nsel, T *__restrict__ dx, int lddx, int Cin,
+                                  int64_t total) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int ci = (int)(i % Cin);
+    const int64_t row = i / Cin;
+    float acc = 0.f;
+    for (int k = 0; k < nsel; ++k) acc = __builtin_fmaf(dout[row * lddo + k], w[(int64_t)(sel ? sel[k] : k) * Cin + ci], acc);
+    st_f<T>(dx + row * lddx + ci, acc);
+  }
+}
+
+// partial[split][k][ci] ; grid (pairs/256, nsplit)
+template <typename T>
+__global__ void head_wgrad_kernel(const T *__restrict__ x, int ldx, const float *__restrict__ dout, int lddo,
+                                  float *__restrict__ part, int Cin, int nsel, int64_t rows) {
+  const int pair = blockIdx.x * blockDim.x + threadIdx.x;
+  if (pair >= Cin * nsel) return;
+  const int ci = pair % Cin, k = pair / Cin;
+  const int64_t per = cdiv64(rows, gridDim.y);
+  const int64_t r0 = (int64_t)blockIdx.y * per, r1 = (r0 + per < rows) ? r0 + per : rows;
+  float acc = 0.f;
+  for (int64_t r = r0; r < r1; ++r) acc = __builtin_fmaf(dout[r * lddo + k], ld_f<T>(x + r * ldx + ci), acc);
+  part[((int64_t)blockIdx.y * nsel + k) * Cin + ci] = acc;
+}
+
+// ============================================================================ layout converters, argmax/dice
+template <typename T>
+__global__ void ncdhw_to_ndhwc_kernel(const float *__restrict__ src, T *__restrict__ dst, int C, int64_t V, int ldc,
+                                      int64_t total) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % ldc);
+    const int64_t row = i / ldc;
+    const int64_t b = row / V, v = row % V;
+    st_f<T>(dst + i, c < C ? src[(b * C + c) * V + v] : 0.f);
+  }
+}
+template <typename T>
+__global__ void ndhwc_to_ncdhw_kernel(const T *__restrict__ src, float *__restrict__ dst, int C, int64_t V, int ldc,
+                                      int64_t total) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t v = i % V;
+    const int c = (int)((i / V) % C);
+    const int64_t b = i / (V * C);
+    dst[i] = ld_f<T>(src + (b * V + v) * ldc + c);
+  }
+}
+
+__global__ void argmax_dice_kernel(const float *__restrict__ logits, int ldc, int C, const int64_t *__restrict__ labels,
+                                   int64_t *__restrict__ amax, unsigned long long *__restrict__ counts, int64_t total) {
+  extern __shared__ unsigned int scnt[];  // [3*C]
+  for (int i = threadIdx.x; i < 3 * C; i += blockDim.x) scnt[i] = 0;
+  __syncthreads();
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const float *p = logits + i * ldc;
+    int best = 0;
+    float bv = p[0];
+    for (int c = 1; c < C; ++c)
+      if (p[c] > bv) {  // first maximum wins, as torch.argmax
+        bv = p[c];
+        best = c;
+      }
+    if (amax) amax[i] = best;
+    if (labels) {
+      const int gt = (int)labels[i];
+      atomicAdd(&scnt[best], 1u);
+      if ((unsigned)gt < (unsigned)C) {
+        atomicAdd(&scnt[C + gt], 1u);
+        if (gt == best) atomicAdd(&scnt[2 * C + gt], 1u);
+      }
+    }
+  }
+  __syncthreads();
+  if (labels)
+    for (int i = threadIdx.x; i < 3 * C; i += blockDim.x)
+      if (scnt[i]) atomicAdd(&counts[i], (unsigned long long)scnt[i]);
+}
+
+int gs_blocks(int64_t total, int cap = 16384) {
+  int64_t b = (total + 255) / 256;
+  return (int)(b < cap ? (b > 0 ? b : 1) : cap);
+}
+
+int reduce_blocks(int64_t V) {
+  int64_t b = cdiv64(V, 2048);
+  return (int)(b < 512 ? (b > 0 ? b : 1) : 512);
+}
+
+int wgrad_splits(int64_t nvox) {
+  int64_t s = cdiv64(nvox, 4096);
+  return (int)(s < 64 ? (s > 0 ? s : 1) : 64);
+}
+
+}  // namespace
+
+#define DISPATCH_T(dtype, CALL)                                                        \
+  do {                                                                                 \
+    if ((dtype) == DGTTA_F32) {                                                        \
+      typedef float T;                                                                 \
+      CALL;                                                                            \
+    } else if ((dtype) == DGTTA_BF16) {                                                \
+      typedef bf16_t T;                                                                \
+      CALL;                                                                            \
+    } else {                                                                           \
+      dgtta_set_error("bad dtype %d", (int)(dtype));                                   \
+      return DGTTA_ERR_BADARG;                                                         \
+    }                                                                                  \
+  } while (0)
+
+// MFMA implementations (conv_mfma.hip); return DGTTA_ERR_UNSUPPORTED when the shape is not covered.
+int conv3_fwd_mfma(const void *x, int ldx, const void *wf, const float *bias, void *y, int ldy, void *stats, int B,
+                   int Cin, int Cout, int CinP, int CoutP, int Di, int Hi, int Wi, int stride, int dtype,
+                   hipStream_t st);
+int conv3_wgrad_mfma(const void *x, int ldx, const void *dy, int lddy, float *dw_t, float *db, void *ws, size_t ws_bytes,
+                     int B, int Cin, int Cout, int Di, int Hi, int Wi, int stride, int accumulate, int dtype,
+                     hipStream_t st);
+
+extern "C" int dgtta_conv3d_pack_weights(const float *w_t, void *wf, void *wb, int Cin, int Cout, int CinP, int CoutP,
+                                         int dtype, void *stream) {
+  DG_REQUIRE(w_t && (wf || wb), DGTTA_ERR_BADARG, "pack_weights: null pointer");
+  DG_REQUIRE(Cin > 0 && Cout > 0 && CinP >= Cin && CoutP >= Cout, DGTTA_ERR_BADARG, "pack_weights: bad channel counts");
+  const int64_t n = (int64_t)27 * CinP * CoutP;
+  DISPATCH_T(dtype, hipLaunchKernelGGL((pack_weights_kernel<T>), dim3(gs_blocks(n)), dim3(256), 0, (hipStream_t)stream,
+                                       w_t, (T *)wf, (T *)wb, Cin, Cout, CinP, CoutP));
+  DG_CHECK_LAUNCH("pack_weights_kernel");
+  return DGTTA_OK;
+}
+
+static int out_dim(int i, int s) { return (i + 2 - 3) / s + 1; }
+
+extern "C" size_t dgtta_conv3d_stats_bytes(int B, int Cout, int Do, int Ho, int Wo) {
+  (void)Do; (void)Ho; (void)Wo;
+  return (size_t)B * 512 * Cout * 2 * sizeof(double);
+}
+
+extern "C" int dgtta_conv3d_k3_fwd(const void *x, int ldx, const void *wf, const float *bias, void *y, int ldy,
+                                   void *stats, int B, int Cin, int Cout, int CinP, int CoutP, int Di, int Hi, int Wi,
+                                   int stride, int dtype, int impl, void *stream) {
+  DG_REQUIRE(x && wf && y, DGTTA_ERR_BADARG, "conv3d_k3_fwd: null pointer");
+  DG_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && CinP >= Cin && CoutP >= Cout && Di > 0 && Hi > 0 && Wi > 0,
+             DGTTA_ERR_BADARG, "conv3d_k3_fwd: bad dims");
+  DG_REQUIRE(stride == 1 || stride == 2, DGTTA_ERR_UNSUPPORTED, "conv3d_k3_fwd: stride %d", stride);
+  DG_REQUIRE(ldx >= Cin && ldy >= Cout, DGTTA_ERR_BADARG, "conv3d_k3_fwd: ld < C");
+  DG_REQUIRE(stats == nullptr, DGTTA_ERR_UNSUPPORTED, "conv3d_k3_fwd: fused stats not available in this build");
+  hipStream_t st = (hipStream_t)stream;
+  if (impl != 1) {
+    int rc = conv3_fwd_mfma(x, ldx, wf, bias, y, ldy, stats, B, Cin, Cout, CinP, CoutP, Di, Hi, Wi, stride, dtype, st);
+    if (rc != DGTTA_ERR_UNSUPPORTED) return rc;
+    DG_REQUIRE(impl == 0, DGTTA_ERR_UNSUPPORTED, "conv3d_k3_fwd: shape not covered by the MFMA kernel");
+  }
+  const int Do = out_dim(Di, stride), Ho = out_dim(Hi, stride), Wo = out_dim(Wi, stride);
+  const int64_t total = (int64_t)B * Do * Ho * Wo * Cout;
+  DISPATCH_T(dtype, hipLaunchKernelGGL((conv3_fwd_ref_kernel<T>), dim3(gs_blocks(total, 1 << 20)), dim3(256), 0, st,
+                                       (const T *)x, ldx, (const T *)wf, bias, (T *)y, ldy, Cin, Cout, CinP, CoutP, Di,
+                                       Hi, Wi, Do, Ho, Wo, stride, total));
+  DG_CHECK_LAUNCH("conv3_fwd_ref_kernel");
+  return DGTTA_OK;
+}
+
+extern "C" int dgtta_conv3d_k3_dgrad(const void *dy, int lddy, const void *wb, void *dx, int lddx, int B, int Cin,
+                                     int Cout, int CinP, int CoutP, int Di, int Hi, int Wi, int stride, int accumulate,
+                                     int dtype, int impl, void *stream) {
+  DG_REQUIRE(dy && wb && dx, DGTTA_ERR_BADARG, "conv3d_k3_dgrad: null pointer");
+  DG_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && CinP >= Cin && CoutP >= Cout && Di > 0 && Hi > 0 && Wi > 0,
+             DGTTA_ERR_BADARG, "conv3d_k3_dgrad: bad dims");
+  DG_REQUIRE(stride == 1 || stride == 2, DGTTA_ERR_UNSUPPORTED, "conv3d_k3_dgrad: stride %d", stride);
+  DG_REQUIRE(lddx >= Cin && lddy >= Cout, DGTTA_ERR_BADARG, "conv3d_k3_dgrad: ld < C");
+  hipStream_t st = (hipStream_t)stream;
+  if (impl != 1 && stride == 1 && !accumulate) {
+    // stride-1 data gradient == forward conv of dy with the mirrored, transposed weights (wb)
+    int rc = conv3_fwd_mfma(dy, lddy, wb, nullptr, dx, lddx, nullptr, B, Cout, Cin, CoutP, CinP, Di, Hi, Wi, 1, dtype, st);
+    if (rc != DGTTA_ERR_UNSUPPORTED) return rc;
+    DG_REQUIRE(impl == 0, DGTTA_ERR_UNSUPPORTED, "conv3d_k3_dgrad: shape not covered by the MFMA kernel");
+  }
+  const int Do = out_dim(Di, stride), Ho = out_dim(Hi, stride), Wo = out_dim(Wi, stride);
+  const int64_t total = (int64_t)B * Di * Hi * Wi * Cin;
+  DISPATCH_T(dtype, hipLaunchKernelGGL((conv3_dgrad_ref_kernel<T>), dim3(gs_blocks(total, 1 << 20)), dim3(256), 0, st,
+                                       (const T *)dy, lddy, (const T *)wb, (T *)dx, lddx, Cin, Cout, CinP, CoutP, Di, Hi,
+                                       Wi, Do, Ho, Wo, stride, accumulate, total));
+  DG_CHECK_LAUNCH("conv3_dgrad_ref_kernel");
+  return DGTTA_OK;
+}
+
+extern "C" size_t dgtta_conv3d_wgrad_ws_bytes(int B, int Cin, int Cout, int Do, int Ho, int Wo) {
+  const int64_t nvox = (int64_t)B * Do * Ho * Wo;
+  size_t a = align_up((size_t)wgrad_splits(nvox) * Cout * Cin * 27 * sizeof(float), 256);
+  size_t b = align_up((size_t)B * reduce_blocks((int64_t)Do * Ho * Wo) * Cout * 2 * sizeof(double), 256);
+  // the MFMA wgrad uses one slab per workgroup: bounded by 1024 slabs
+  size_t c = align_up((size_t)1024 * 27 * (size_t)((Cin + 31) / 32 * 32) * ((Cout + 31) / 32 * 32) * sizeof(float), 256);
+  (void)c;
+  return a + b;
+}
+
+static int bias_grad(const void *dy, int lddy, float *db, void *ws, int B, int C, int64_t V, int accumulate, int dtype,
+                     hipStream_t st) {
+  const int nblk = reduce_blocks(V);
+  double *partial = (double *)ws;
+  DISPATCH_T(dtype, hipLaunchKernelGGL((chan_reduce_kernel<T, 2>), dim3(nblk, B), dim3(256), 0, st, (const T *)dy, lddy,
+                                       (const T *)nullptr, 0, nullptr, nullptr, nullptr, 0.f, partial, C, V));
+  DG_CHECK_LAUNCH("chan_reduce_kernel<2>");
+  hipLaunchKernelGGL(bias_finalize_kernel, dim3(cdiv(C, 128)), dim3(128), 0, st, partial, nblk, B, C, db, accumulate);
+  DG_CHECK_LAUNCH("bias_finalize_kernel");
+  return DGTTA_OK;
+}
+
+extern "C" int dgtta_conv3d_k3_wgrad(const void *x, int ldx, const void *dy, int lddy, float *dw_t, float *db, void *ws,
+                                     size_t ws_bytes, int B, int Cin, int Cout, int Di, int Hi, int Wi, int stride,
+                                     int accumulate, int dtype, int impl, void *stream) {
+  DG_REQUIRE(x && dy && dw_t && ws, DGTTA_ERR_BADARG, "conv3d_k3_wgrad: null pointer");
+  DG_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && Di > 0 && Hi > 0 && Wi > 0, DGTTA_ERR_BADARG, "conv3d_k3_wgrad: bad dims");
+  DG_REQUIRE(stride == 1 || stride == 2, DGTTA_ERR_UNSUPPORTED, "conv3d_k3_wgrad: stride %d", stride);
+  const int Do = out_dim(Di, stride), Ho = out_dim(Hi, stride), Wo = out_dim(Wi, stride);
+  DG_REQUIRE(ws_bytes >= dgtta_conv3d_wgrad_ws_bytes(B, Cin, Cout, Do, Ho, Wo), DGTTA_ERR_WORKSPACE,
+             "conv3d_k3_wgrad: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t nvox = (int64_t)B * Do * Ho * Wo;
+  const int nsplit = wgrad_splits(nvox);
+  float *part = (float *)ws;
+  void *ws2 = (char *)ws + align_up((size_t)nsplit * Cout * Cin * 27 * sizeof(float), 256);
+  bool done = false;
+  if (impl != 1) {
+    int rc = conv3_wgrad_mfma(x, ldx, dy, lddy, dw_t, nullptr, ws, ws_bytes, B, Cin, Cout, Di, Hi, Wi, stride, accumulate,
+                              dtype, st);
+    if (rc == DGTTA_OK) done = true;
+    else if (rc != DGTTA_ERR_UNSUPPORTED) return rc;
+    else DG_REQUIRE(impl == 0, DGTTA_ERR_UNSUPPORTED, "conv3d_k3_wgrad: shape not covered by the MFMA kernel");
+  }
+  if (!done) {
+    DISPATCH_T(dtype, hipLaunchKernelGGL((conv3_wgrad_ref_kernel<T>), dim3(cdiv(Cin * Cout, 256), 27, nsplit), dim3(256),
+                                         0, st, (const T *)x, ldx, (const T *)dy, lddy, part, Cin, Cout, B, Di, Hi, Wi,
+                                         Do, Ho, Wo, stride));
+    DG_CHECK_LAUNCH("conv3_wgrad_ref_kernel");
+    const int64_t n = (int64_t)Cout * Cin * 27;
+    hipLaunchKernelGGL(reduce_splits_kernel, dim3(gs_blocks(n)), dim3(256), 0, st, part, dw_t, n, nsplit, accumulate);
+    DG_CHECK_LAUNCH("reduce_splits_kernel");
+  }
+  if (db) return bias_grad(dy, lddy, db, ws2, B, Cout, (int64_t)Do * Ho * Wo, accumulate, dtype, st);
+  return DGTTA_OK;
+}
+
+extern "C" size_t dgtta_instnorm_ws_bytes(int B, int C, int64_t V) {
+  return align_up((size_t)B * reduce_blocks(V) * C * 2 * sizeof(double), 256) +
+         align_up((size_t)B * C * 2 * sizeof(float), 256);
+}
+
+extern "C" int dgtta_instnorm_lrelu_fwd(const void *y, int ldy, const void *stats, const float *gamma, const float *beta,
+                                        float *mean_rstd, void *z, int ldz, void *ws, size_t ws_bytes, int B, int C,
+                                        int64_t V, float eps, float slope, int dtype, void *stream) {
+  DG_REQUIRE(y && gamma && beta && mean_rstd && z && ws, DGTTA_ERR_BADARG, "instnorm_lrelu_fwd: null pointer");
+  DG_REQUIRE(B > 0 && C > 0 && V > 0 && ldy >= C && ldz >= C, DGTTA_ERR_BADARG, "instnorm_lrelu_fwd: bad dims");
+  DG_REQUIRE(stats == nullptr, DGTTA_ERR_UNSUPPORTED, "instnorm_lrelu_fwd: fused conv statistics not in this build");
+  DG_REQUIRE(ws_bytes >= dgtta_instnorm_ws_bytes(B, C, V), DGTTA_ERR_WORKSPACE, "instnorm_lrelu_fwd: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  const int nblk = reduce_blocks(V);
+  double *partial = (double *)ws;
+  DISPATCH_T(dtype, hipLaunchKernelGGL((chan_reduce_kernel<T, 0>), dim3(nblk, B), dim3(256), 0, st, (const T *)y, ldy,
+                                       (const T *)nullptr, 0, nullptr, nullptr, nullptr, 0.f, partial, C, V));
+  DG_CHECK_LAUNCH("chan_reduce_kernel<0>");
+  hipLaunchKernelGGL(in_stats_finalize_kernel, dim3(cdiv(B * C, 128)), dim3(128), 0, st, partial, nblk, B, C, V, eps,
+                     mean_rstd);
+  DG_CHECK_LAUNCH("in_stats_finalize_kernel");
+  const int64_t total = (int64_t)B * V * C;
+  DISPATCH_T(dtype, hipLaunchKernelGGL((in_lrelu_apply_kernel<T>), dim3(gs_blocks(total)), dim3(256), 0, st,
+                                       (const T *)y, ldy, mean_rstd, gamma, beta, (T *)z, ldz, C, V, slope, total));
+  DG_CHECK_LAUNCH("in_lrelu_apply_kernel");
+  return DGTTA_OK;
+}
+
+extern "C" int dgtta_instnorm_lrelu_bwd(const void *gz, int ldgz, const void *y, int ldy, const float *gamma,
+                                        const float *beta, const float *mean_rstd, void *dy, int lddy, float *dgamma,
+                                        float *dbeta, void *ws, size_t ws_bytes, int B, int C, int64_t V, float slope,
+                                        int accumulate, int dtype, void *stream) {
+  DG_REQUIRE(gz && y && gamma && beta && mean_rstd && dy && dgamma && dbeta && ws, DGTTA_ERR_BADARG,
+             "instnorm_lrelu_bwd: null pointer");
+  DG_REQUIRE(B > 0 && C > 0 && V > 0 && ldy >= C && ldgz >= C && lddy >= C, DGTTA_ERR_BADARG,
+             "instnorm_lrelu_bwd: bad dims");
+  DG_REQUIRE(ws_bytes >= dgtta_instnorm_ws_bytes(B, C, V), DGTTA_ERR_WORKSPACE, "instnorm_lrelu_bwd: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  const int nblk = reduce_blocks(V);
+  double *partial = (double *)ws;
+  float *c12 = (float *)((char *)ws + align_up((size_t)B * nblk * C * 2 * sizeof(double), 256));
+  DISPATCH_T(dtype, hipLaunchKernelGGL((chan_reduce_kernel<T, 1>), dim3(nblk, B), dim3(256), 0, st, (const T *)y, ldy,
+                                       (const T *)gz, ldgz, mean_rstd, gamma, beta, slope, partial, C, V));
+  DG_CHECK_LAUNCH("chan_reduce_kernel<1>");
+  hipLaunchKernelGGL(in_bwd_finalize_kernel, dim3(cdiv(C, 128)), dim3(128), 0, st, partial, nblk, B, C, V, c12, dgamma,
+                     dbeta, accumulate);
+  DG_CHECK_LAUNCH("in_bwd_finalize_kernel");
+  const int64_t total = (int64_t)B * V * C;
+  DISPATCH_T(dtype, hipLaunchKernelGGL((in_lrelu_bwd_apply_kernel<T>), dim3(gs_blocks(total)), dim3(256), 0, st,
+                                       (const T *)gz, ldgz, (const T *)y, ldy, mean_rstd, gamma, beta, c12, (T *)dy, lddy,
+                                       C, V, slope, total));
+  DG_CHECK_LAUNCH("in_lrelu_bwd_apply_kernel");
+  return DGTTA_OK;
+}
+
+extern "C" int dgtta_convT3d_k2s2_fwd(const void *x, int ldx, const float *w_t, const float *bias, void *out, int ldo,
+                                      int B, int Cin, int Cout, int Di, int Hi, int Wi, int dtype, void *stream) {
+  DG_REQUIRE(x && w_t && out, DGTTA_ERR_BADARG, "convT3d_k2s2_fwd: null pointer");
+  DG_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && Di > 0 && Hi > 0 && Wi > 0 && ldx >= Cin && ldo >= Cout, DGTTA_ERR_BADARG,
+             "convT3d_k2s2_fwd: bad dims");
+  const int64_t total = (int64_t)B * Di * Hi * Wi * 8 * Cout;
+  DISPATCH_T(dtype, hipLaunchKernelGGL((convT_fwd_ref_kernel<T>), dim3(gs_blocks(total, 1 << 20)), dim3(256), 0,
+                                       (hipStream_t)stream, (const T *)x, ldx, w_t, bias, (T *)out, ldo, Cin, Cout, Di,
+                                       Hi, Wi, total));
+  DG_CHECK_LAUNCH("convT_fwd_ref_kernel");
+  return DGTTA_OK;
+}
+
+extern "C" size_t dgtta_convT3d_bwd_ws_bytes(int B, int Cin, int Cout, int Di, int Hi, int Wi) {
+  const int64_t nvox = (int64_t)B * Di * Hi * Wi;
+  return align_up((size_t)wgrad_splits(nvox) * Cin * Cout * 8 * sizeof(float), 256) +
+         align_up((size_t)B * reduce_blocks((int64_t)Di * Hi * Wi * 8) * Cout * 2 * sizeof(double), 256);
+}
+
+extern "C" int dgtta_convT3d_k2s2_bwd(const void *x, int ldx, const void *dout, int lddo, const float *w_t, void *dx,
+                                      int lddx, float *dw_t, float *db, void *ws, size_t ws_bytes, int B, int Cin,
+                                      int Cout, int Di, int Hi, int Wi, int accumulate, int dtype, void *stream) {
+  DG_REQUIRE(x && dout && w_t && ws, DGTTA_ERR_BADARG, "convT3d_k2s2_bwd: null pointer");
+  DG_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && Di > 0 && Hi > 0 && Wi > 0 && ldx >= Cin && lddo >= Cout,
+             DGTTA_ERR_BADARG, "convT3d_k2s2_bwd: bad dims");
+  DG_REQUIRE(ws_bytes >= dgtta_convT3d_bwd_ws_bytes(B, Cin, Cout, Di, Hi, Wi), DGTTA_ERR_WORKSPACE,
+             "convT3d_k2s2_bwd: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t nvox = (int64_t)B * Di * Hi * Wi;
+  if (dx) {
+    DG_REQUIRE(lddx >= Cin, DGTTA_ERR_BADARG, "convT3d_k2s2_bwd: lddx < Cin");
+    const int64_t total = nvox * Cin;
+    DISPATCH_T(dtype, hipLaunchKernelGGL((convT_dgrad_ref_kernel<T>), dim3(gs_blocks(total, 1 << 20)), dim3(256), 0, st,
+                                         (const T *)dout, lddo, w_t, (T *)dx, lddx, Cin, Cout, Di, Hi, Wi, total));
+    DG_CHECK_LAUNCH("convT_dgrad_ref_kernel");
+  }
+  if (dw_t) {
+    const int nsplit = wgrad_splits(nvox);
+    float *part = (float *)ws;
+    DISPATCH_T(dtype, hipLaunchKernelGGL((convT_wgrad_ref_kernel<T>), dim3(cdiv(Cin * Cout, 256), 8, nsplit), dim3(256), 0,
+                                         st, (const T *)x, ldx, (const T *)dout, lddo, part, Cin, Cout, B, Di, Hi, Wi));
+    DG_CHECK_LAUNCH("convT_wgrad_ref_kernel");
+    const int64_t n = (int64_t)Cin * Cout * 8;
+    hipLaunchKernelGGL(reduce_splits_kernel, dim3(gs_blocks(n)), dim3(256), 0, st, part, dw_t, n, nsplit, accumulate);
+    DG_CHECK_LAUNCH("reduce_splits_kernel");
+  }
+  if (db) {
+    void *ws2 = (char *)ws + align_up((size_t)wgrad_splits(nvox) * Cin * Cout * 8 * sizeof(float), 256);
+    return bias_grad(dout, lddo, db, ws2, B, Cout, (int64_t)Di * Hi * Wi * 8, accumulate, dtype, st);
+  }
+  return DGTTA_OK;
+}
+
+extern "C" int dgtta_seghead_fwd(const void *x, int ldx, const float *w, const float *bias, const int *sel, int nsel,
+                                 float *out, int out_ndhwc, int ldo, int B, int Cin, int64_t V, int dtype,
+                                 void *stream) {
+  DG_REQUIRE(x && w && bias && out, DGTTA_ERR_BADARG, "seghead_fwd: null pointer");
+  DG_REQUIRE(B > 0 && Cin > 0 && nsel > 0 && V > 0 && ldx >= Cin && (!out_ndhwc || ldo >= nsel), DGTTA_ERR_BADARG,
+             "seghead_fwd: bad dims");
+  const int64_t total = (int64_t)B * V * nsel;
+  if (out_ndhwc)
+    DISPATCH_T(dtype, hipLaunchKernelGGL((head_fwd_kernel<T, true>), dim3(gs_blocks(total, 1 << 20)), dim3(256), 0,
+                                         (hipStream_t)stream, (const T *)x, ldx, w, bias, sel, nsel, out, ldo, Cin, V,
+                                         total));
+  else
+    DISPATCH_T(dtype, hipLaunchKernelGGL((head_fwd_kernel<T, false>), dim3(gs_blocks(total, 1 << 20)), dim3(256), 0,
+                                         (hipStream_t)stream, (const T *)x, ldx, w, bias, sel, nsel, out, ldo, Cin, V,
+                                         total));
+  DG_CHECK_LAUNCH("head_fwd_kernel");
+  return DGTTA_OK;
+}
+
+static int head_splits(int64_t rows) {
+  int64_t s = cdiv64(rows, 2048);
+  return (int)(s < 256 ? (s > 0 ? s : 1) : 256);
+}
+
+extern "C" size_t dgtta_seghead_bwd_ws_bytes(int B, int Cin, int nsel, int64_t V) {
+  return align_up((size_t)head_splits((int64_t)B * V) * nsel * Cin * sizeof(float), 256) +
+         align_up((size_t)B * reduce_blocks(V) * nsel * 2 * sizeof(double), 256);
+}
+
+extern "C" int dgtta_seghead_bwd(const void *x, int ldx, const float *dout, int lddo, const float *w, const int *sel,
+                                 int nsel, void *dx, int lddx, float *dw_sel, float *db_sel, void *ws, size_t ws_bytes,
+                                 int B, int Cin, int64_t V, int accumulate, int dtype, void *stream) {
+  DG_REQUIRE(x && dout && w && ws, DGTTA_ERR_BADARG, "seghead_bwd: null pointer");
+  DG_REQUIRE(B > 0 && Cin > 0 && nsel > 0 && V > 0 && ldx >= Cin && lddo >= nsel, DGTTA_ERR_BADARG, "seghead_bwd: bad dims");
+  DG_REQUIRE(ws_bytes >= dgtta_seghead_bwd_ws_bytes(B, Cin, nsel, V), DGTTA_ERR_WORKSPACE, "seghead_bwd: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t rows = (int64_t)B * V;
+  if (dx) {
+    DG_REQUIRE(lddx >= Cin, DGTTA_ERR_BADARG, "seghead_bwd: lddx < Cin");
+    const int64_t total = rows * Cin;
+    DISPATCH_T(dtype, hipLaunchKernelGGL((head_dgrad_kernel<T>), dim3(gs_blocks(total, 1 << 20)), dim3(256), 0, st, dout,
+                                         lddo, w, sel, nsel, (T *)dx, lddx, Cin, total));
+    DG_CHECK_LAUNCH("head_dgrad_kernel");
+  }
+  if (dw_sel) {
+    const int ns = head_splits(rows);
+    float *part = (float *)ws;
+    DISPATCH_T(dtype, hipLaunchKernelGGL((head_wgrad_kernel<T>), dim3(cdiv(Cin * nsel, 256), ns), dim3(256), 0, st,
+                                         (const T *)x, ldx, dout, lddo, part, Cin, nsel, rows));
+    DG_CHECK_LAUNCH("head_wgrad_kernel");
+    const int64_t n = (int64_t)nsel * Cin;
+    hipLaunchKernelGGL(reduce_splits_kernel, dim3(gs_blocks(n)), dim3(256), 0, st, part, dw_sel, n, ns, accumulate);
+    DG_CHECK_LAUNCH("reduce_splits_kernel");
+  }
+  if (db_sel) {
+    void *ws2 = (char *)ws + align_up((size_t)head_splits(rows) * nsel * Cin * sizeof(float), 256);
+    return bias_grad(dout, lddo, db_sel, ws2, B, nsel, V, accumulate, DGTTA_F32, st);
+  }
+  return DGTTA_OK;
+}
+
+extern "C" int dgtta_ncdhw_to_ndhwc(const float *src, void *dst, int B, int C, int64_t V, int ldc, int dtype,
+                                    void *stream) {
+  DG_REQUIRE(src && dst && B > 0 && C > 0 && V > 0 && ldc >= C, DGTTA_ERR_BADARG, "ncdhw_to_ndhwc: bad args");
+  const int64_t total = (int64_t)B * V * ldc;
+  DISPATCH_T(dtype, hipLaunchKernelGGL((ncdhw_to_ndhwc_kernel<T>), dim3(gs_blocks(total)), dim3(256), 0,
+                                       (hipStream_t)stream, src, (T *)dst, C, V, ldc, total));
+  DG_CHECK_LAUNCH("ncdhw_to_ndhwc_kernel");
+  return DGTTA_OK;
+}
+
+extern "C" int dgtta_ndhwc_to_ncdhw(const void *src, float *dst, int B, int C, int64_t V, int ldc, int dtype,
+                                    void *stream) {
+  DG_REQUIRE(src && dst && B > 0 && C > 0 && V > 0 && ldc >= C, DGTTA_ERR_BADARG, "ndhwc_to_ncdhw: bad args");
+  const int64_t total = (int64_t)B * V * C;
+  DISPATCH_T(dtype, hipLaunchKernelGGL((ndhwc_to_ncdhw_kernel<T>), dim3(gs_blocks(total)), dim3(256), 0,
+                                       (hipStream_t)stream, (const T *)src, dst, C, V, ldc, total));
+  DG_CHECK_LAUNCH("ndhwc_to_ncdhw_kernel");
+  return DGTTA_OK;
+}
+
+extern "C" int dgtta_argmax_dice(const float *logits, int ldc, int C, const int64_t *labels, int64_t *argmax_out,
+                                 int64_t *counts, int B, int64_t V, void *stream) {
+  DG_REQUIRE(logits && C > 0 && C <= 1024 && ldc >= C && B > 0 && V > 0, DGTTA_ERR_BADARG, "argmax_dice: bad args");
+  DG_REQUIRE(!labels || counts, DGTTA_ERR_BADARG, "argmax_dice: labels without counts");
+  const int64_t total = (int64_t)B * V;
+  hipLaunchKernelGGL(argmax_dice_kernel, dim3(gs_blocks(total, 2048)), dim3(256), 3 * C * sizeof(unsigned int),
+                     (hipStream_t)stream, logits, ldc, C, labels, argmax_out, (unsigned long long *)counts, total);
+  DG_CHECK_LAUNCH("argmax_dice_kernel");
+  return DGTTA_OK;
+}

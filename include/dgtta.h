@@ -1,0 +1,199 @@
+/*
+ * dgtta.h — C ABI of libdgtta_hip.so: hand-written gfx950 (MI355X / CDNA4) kernels for the
+ * DG-TTA test-time-adaptation hot path.
+ *
+ * The reference (multimodallearning/DG-TTA) is pure Python on stock PyTorch ops and has no FFI of
+ * its own; this ABI is the drop-in boundary that sits UNDER the reference's Python operator
+ * signatures (dg_tta_amd/ mirrors those).  Each entry point cites the reference code it replaces
+ * (paths relative to /root/reference).  INTEGRATION.md shows the ctypes binding a maintainer adds.
+ *
+ * Conventions
+ *  - plain pointers + sizes, no torch types; all pointers are DEVICE pointers unless named h_*.
+ *  - every call only ENQUEUES work on `stream` (a hipStream_t passed as void*) and returns;
+ *    nothing here allocates, frees or synchronises, so calls may be captured into a hipGraph.
+ *  - the caller owns all memory, including workspaces (sizes from the *_ws_bytes queries).
+ *  - return value: 0 = OK, <0 = DGTTA_ERR_*; dgtta_last_error() gives a thread-local message.
+ *  - volumes are D x H x W (W fastest).  Layouts:
+ *        NCDHW  [B][C][D][H][W]          (PyTorch contiguous; the reference's layout)
+ *        NDHWC  [B][D][H][W][ldc]        (channels-last; `ldc` >= C elements per voxel, so a
+ *                                          tensor may be a channel slice of a wider buffer)
+ *  - dtype: 0 = fp32, 1 = bf16 (storage; accumulation is always fp32).
+ */
+#ifndef DGTTA_H
+#define DGTTA_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DGTTA_OK 0
+#define DGTTA_ERR_BADARG (-1)
+#define DGTTA_ERR_UNSUPPORTED (-2)
+#define DGTTA_ERR_WORKSPACE (-3)
+#define DGTTA_ERR_LAUNCH (-4)
+
+#define DGTTA_F32 0
+#define DGTTA_BF16 1
+
+#define DGTTA_PAD_ZEROS 0
+#define DGTTA_PAD_BORDER 1
+#define DGTTA_INTERP_LINEAR 0
+#define DGTTA_INTERP_NEAREST 1
+
+int dgtta_version(void);
+const char *dgtta_last_error(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * MIND3D descriptor.  Replaces MIND3D.forward + smooth + filter1D (dg_tta/mind.py:142-164, :27-43,
+ * :5-24) and mind_hook (:167-168).  img [B,1,D,H,W] fp32; noise [B,12,D,H,W] fp32 = the
+ * torch.randn_like draw of mind.py:150 (caller supplies it so RNG semantics stay the caller's).
+ * out: 12 channels, either NCDHW fp32 (out_ndhwc=0) or NDHWC with row length out_ldc (>=12;
+ * channels 12..out_ldc-1 are written as zero) in out_dtype.  delta is fixed to 1, sigma to 1
+ * (the only values the reference ever uses: mind.py:98).
+ * ws: dgtta_mind3d_ws_bytes(B,D,H,W) bytes.
+ * ------------------------------------------------------------------------------------------- */
+size_t dgtta_mind3d_ws_bytes(int B, int D, int H, int W);
+int dgtta_mind3d_fwd(const float *img, const float *noise, float randn_weighting, void *out, int out_ndhwc,
+                     int out_ldc, int out_dtype, void *ws, size_t ws_bytes, int B, int D, int H, int W,
+                     void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * GIN random-convolution chain.  Replaces GINGroupConv.forward / GradlessGCReplayNonlinBlock.forward
+ * (dg_tta/gin.py:168-230, :59-122) for gin_aug's fixed config (1->2->2->2->1 channels, 4 layers).
+ * x,out [B,1,D,H,W] fp32.  alpha [B].  ksz[4] HOST ints in {1,3}.  ker[l] = device pointer to
+ * [B*cout_l, cin_l, k,k,k] fp32 exactly as drawn at gin.py:94-97; shift[l] = [B*cout_l] (gin.py:98-103).
+ * ws: dgtta_gin_ws_bytes(B,D,H,W).
+ * ------------------------------------------------------------------------------------------- */
+size_t dgtta_gin_ws_bytes(int B, int D, int H, int W);
+int dgtta_gin_chain_fwd(const float *x, const float *alpha, const int *h_ksz, const float *const *h_ker,
+                        const float *const *h_shift, float *out, void *ws, size_t ws_bytes, int B, int D, int H,
+                        int W, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Affine resampling = F.affine_grid + F.grid_sample(align_corners=False) without materialising
+ * the grid.  Replaces the call sites dg_tta/tta/tta.py:523-551 (image, border), :572-575 (logits,
+ * zeros) and dg_tta/tta/torch_utils.py:55-73 (get_batch; zeros; linear / nearest).
+ * theta [B,3,4] fp32 device (x,y,z order of F.affine_grid).  If tta_grid_algebra != 0 the sampling
+ * grid is formed as ((affine_grid(theta) - identity) + identity) in fp32, as tta.py:523-548 does.
+ * src [B,C,Ds,Hs,Ws] / dst [B,C,Dd,Hd,Wd], layout NCDHW (ndhwc=0) or NDHWC with row lengths
+ * src_ldc/dst_ldc.  fp32 only.  add_const is added to every output sample (get_batch's "+ img_min").
+ * bwd: grad_src += d(dst)/d(src)^T grad_dst (linear only; theta gets no gradient, as in the
+ * reference where R is a constant).  grad_src must be zero-initialised by the caller.
+ * ------------------------------------------------------------------------------------------- */
+int dgtta_affine_warp3d_fwd(const float *src, const float *theta, float *dst, int B, int C, int Ds, int Hs,
+                            int Ws, int Dd, int Hd, int Wd, int ndhwc, int src_ldc, int dst_ldc, int pad_mode,
+                            int interp_mode, int tta_grid_algebra, const float *sub_const_dev, void *stream);
+int dgtta_affine_warp3d_bwd(const float *grad_dst, const float *theta, float *grad_src, int B, int C, int Ds,
+                            int Hs, int Ws, int Dd, int Hd, int Wd, int ndhwc, int src_ldc, int dst_ldc,
+                            int pad_mode, int tta_grid_algebra, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Consistency loss.  Replaces dg_tta/tta/tta.py:263-271 + soft_dice_loss (torch_utils.py:90-104):
+ * mask=(sum_c a>0)(sum_c b>0); sm=softmax_c * mask; dice_c = mean(2ab)/mean((a+b)^2/2);
+ * loss = 1 - mean_{b, c>=start_class} dice.  la, lb: logits NDHWC [B][V][ldc], C classes, fp32.
+ * fwd writes dice[B*C], loss[1] and keeps what bwd needs in ws.  bwd writes grad_la/grad_lb
+ * (same layout) = grad_scale * dloss/dlogits (mask treated as constant, as autograd does).
+ * ------------------------------------------------------------------------------------------- */
+size_t dgtta_softdice_ws_bytes(int B, int C, int64_t V);
+int dgtta_softdice_fwd(const float *la, const float *lb, float *dice, float *loss, void *ws, size_t ws_bytes,
+                       int B, int C, int64_t V, int ldc, int start_class, void *stream);
+int dgtta_softdice_bwd(const float *la, const float *lb, float *grad_la, float *grad_lb, const void *ws,
+                       float grad_scale, int B, int C, int64_t V, int ldc, int start_class, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * AdamW (decoupled weight decay, bias-corrected, no amsgrad) over a list of tensors.  Replaces
+ * torch.optim.AdamW(model.parameters(), lr).step() at dg_tta/tta/tta.py:185,278 (betas 0.9/0.999,
+ * eps 1e-8, weight_decay 0.01 = PyTorch defaults).  h_* are HOST arrays of ntensors device
+ * pointers / element counts; tensors whose h_g[i] is NULL are skipped (grad None in PyTorch).
+ * step is the 1-based step count of those tensors.
+ * ------------------------------------------------------------------------------------------- */
+int dgtta_adamw_step(float *const *h_p, const float *const *h_g, float *const *h_m, float *const *h_v,
+                     const int64_t *h_n, int ntensors, float lr, float beta1, float beta2, float eps,
+                     float weight_decay, int step, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * nnUNet PlainConvUNet building blocks (third-party dynamic-network-architectures==0.2, built at
+ * dg_tta/pretraining/nnUNetTrainer_GIN_MIND.py:46-53 from plans.json:279-401): Conv3d 3x3x3 (pad 1,
+ * stride 1|2, bias) -> InstanceNorm3d(eps, affine) -> LeakyReLU(0.01); ConvTranspose3d k2 s2;
+ * 1x1x1 segmentation head.  Activations are NDHWC with explicit row lengths (ld*), so that
+ * torch.cat((up, skip), 1) is realised by writing into channel slices of one buffer.
+ * Weights: w_t = torch layout [Cout][Cin][3][3][3] fp32 (read-only); the kernels use packed copies
+ * produced by dgtta_conv3d_pack_weights.
+ * ------------------------------------------------------------------------------------------- */
+
+/* packs torch [Cout][Cin][27] fp32 into wf [27][CinP][CoutP] (forward / wgrad order) and
+ * wb [27][CoutP][CinP] with taps mirrored (data-gradient order), dtype fp32|bf16, zero padded. */
+int dgtta_conv3d_pack_weights(const float *w_t, void *wf, void *wb, int Cin, int Cout, int CinP, int CoutP,
+                              int dtype, void *stream);
+
+/* y[b][vo][co] = bias[co] + sum_{tap,ci} x[b][s*vo+tap-1][ci] * w[co][ci][tap]      (zero padding)
+ * Optionally accumulates per-(b,co) partial sums of y and y^2 for the following InstanceNorm
+ * (stats != NULL: dgtta_conv3d_stats_bytes).  impl: 0 = auto, 1 = reference-grade VALU kernel,
+ * 2 = MFMA implicit GEMM. */
+size_t dgtta_conv3d_stats_bytes(int B, int Cout, int Do, int Ho, int Wo);
+int dgtta_conv3d_k3_fwd(const void *x, int ldx, const void *wf, const float *bias, void *y, int ldy, void *stats,
+                        int B, int Cin, int Cout, int CinP, int CoutP, int Di, int Hi, int Wi, int stride,
+                        int dtype, int impl, void *stream);
+/* dx[b][vi][ci] = sum_{tap,co} dy[b][(vi+1-tap)/s][co] * w[co][ci][tap]   (terms with non-integer
+ * or out-of-range index dropped).  accumulate != 0: dx += (skip-connection gradient sum). */
+int dgtta_conv3d_k3_dgrad(const void *dy, int lddy, const void *wb, void *dx, int lddx, int B, int Cin, int Cout,
+                          int CinP, int CoutP, int Di, int Hi, int Wi, int stride, int accumulate, int dtype,
+                          int impl, void *stream);
+/* dw_t[co][ci][tap] (+)= sum_{b,vo} x[b][s*vo+tap-1][ci] * dy[b][vo][co];  db[co] (+)= sum dy.
+ * fp32 outputs in torch layout; accumulate != 0 adds to existing gradients (gradient accumulation
+ * over tta.py:221's 16 steps and over both branches). */
+size_t dgtta_conv3d_wgrad_ws_bytes(int B, int Cin, int Cout, int Do, int Ho, int Wo);
+int dgtta_conv3d_k3_wgrad(const void *x, int ldx, const void *dy, int lddy, float *dw_t, float *db, void *ws,
+                          size_t ws_bytes, int B, int Cin, int Cout, int Di, int Hi, int Wi, int stride,
+                          int accumulate, int dtype, int impl, void *stream);
+
+/* InstanceNorm3d(eps, affine, biased variance) + LeakyReLU(slope), per (b,c) over the volume.
+ * fwd: stats = partial sums from the conv epilogue, or NULL (then computed here from y).
+ *      writes mean_rstd[B][C][2] (saved for backward) and z = lrelu(gamma*(y-mean)*rstd + beta). */
+size_t dgtta_instnorm_ws_bytes(int B, int C, int64_t V);
+int dgtta_instnorm_lrelu_fwd(const void *y, int ldy, const void *stats, const float *gamma, const float *beta,
+                             float *mean_rstd, void *z, int ldz, void *ws, size_t ws_bytes, int B, int C,
+                             int64_t V, float eps, float slope, int dtype, void *stream);
+/* bwd: given gz = dL/dz and saved y, mean_rstd: writes dy (may alias gz), and dgamma/dbeta (+)=. */
+int dgtta_instnorm_lrelu_bwd(const void *gz, int ldgz, const void *y, int ldy, const float *gamma,
+                             const float *beta, const float *mean_rstd, void *dy, int lddy, float *dgamma,
+                             float *dbeta, void *ws, size_t ws_bytes, int B, int C, int64_t V, float slope,
+                             int accumulate, int dtype, void *stream);
+
+/* ConvTranspose3d(Cin, Cout, kernel 2, stride 2, bias): w_t torch layout [Cin][Cout][2][2][2] fp32.
+ * out[b][2v+o][co] = bias[co] + sum_ci x[b][v][ci] * w[ci][co][o]. */
+int dgtta_convT3d_k2s2_fwd(const void *x, int ldx, const float *w_t, const float *bias, void *out, int ldo, int B,
+                           int Cin, int Cout, int Di, int Hi, int Wi, int dtype, void *stream);
+size_t dgtta_convT3d_bwd_ws_bytes(int B, int Cin, int Cout, int Di, int Hi, int Wi);
+int dgtta_convT3d_k2s2_bwd(const void *x, int ldx, const void *dout, int lddo, const float *w_t, void *dx, int lddx,
+                           float *dw_t, float *db, void *ws, size_t ws_bytes, int B, int Cin, int Cout, int Di,
+                           int Hi, int Wi, int accumulate, int dtype, void *stream);
+
+/* 1x1x1 head fused with map_label(input_format="logits") (torch_utils.py:214-221): only the rows
+ * sel[0..nsel) of the [Ccls][Cin] weight are evaluated (sel == NULL: all Ccls rows).
+ * out fp32: NDHWC [B][V][ldo] (out_ndhwc=1) or NCDHW [B][nsel][V]. */
+int dgtta_seghead_fwd(const void *x, int ldx, const float *w, const float *bias, const int *sel, int nsel,
+                      float *out, int out_ndhwc, int ldo, int B, int Cin, int64_t V, int dtype, void *stream);
+/* dx = dout . W_sel ; dw_sel[nsel][Cin], db_sel[nsel] (+)= (fp32, compact rows; caller scatters). */
+size_t dgtta_seghead_bwd_ws_bytes(int B, int Cin, int nsel, int64_t V);
+int dgtta_seghead_bwd(const void *x, int ldx, const float *dout, int lddo, const float *w, const int *sel,
+                      int nsel, void *dx, int lddx, float *dw_sel, float *db_sel, void *ws, size_t ws_bytes,
+                      int B, int Cin, int64_t V, int accumulate, int dtype, void *stream);
+
+/* Layout / dtype converters between the reference's NCDHW fp32 and internal NDHWC. */
+int dgtta_ncdhw_to_ndhwc(const float *src, void *dst, int B, int C, int64_t V, int ldc, int dtype, void *stream);
+int dgtta_ndhwc_to_ncdhw(const void *src, float *dst, int B, int C, int64_t V, int ldc, int dtype, void *stream);
+
+/* argmax over channels + per-label hard Dice counts; replaces tta.py:321 + dice_coeff
+ * (torch_utils.py:107-117).  logits NDHWC fp32; labels int64 [B][V] or NULL; argmax_out int64 [B][V];
+ * counts[3*C] int64 (|pred==l|, |gt==l|, |both|), zeroed by the caller. */
+int dgtta_argmax_dice(const float *logits, int ldc, int C, const int64_t *labels, int64_t *argmax_out,
+                      int64_t *counts, int B, int64_t V, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DGTTA_H */

@@ -126,9 +126,11 @@ __global__ void softdice_finalize_kernel(const double *__restrict__ partial, int
 
 __global__ __launch_bounds__(NT) void softdice_bwd_kernel(const float *__restrict__ la, const float *__restrict__ lb,
                                                           float *__restrict__ ga, float *__restrict__ gb,
-                                                          const float *__restrict__ coef, float scale, int C, int64_t V,
+                                                          const float *__restrict__ coef, float scale_h,
+                                                          const float *__restrict__ scale_dev, int C, int64_t V,
                                                           int ldc) {
   __shared__ float sc[MAXC * 2];
+  const float scale = scale_dev ? scale_h * scale_dev[0] : scale_h;
   const int b = blockIdx.y;
   for (int i = threadIdx.x; i < 2 * C; i += NT) sc[i] = coef[(int64_t)b * C * 2 + i];
   __syncthreads();
@@ -190,7 +192,8 @@ extern "C" int dgtta_softdice_fwd(const float *la, const float *lb, float *dice,
 }
 
 extern "C" int dgtta_softdice_bwd(const float *la, const float *lb, float *grad_la, float *grad_lb, const void *ws,
-                                  float grad_scale, int B, int C, int64_t V, int ldc, int start_class, void *stream) {
+                                  float grad_scale, const float *grad_scale_dev, int B, int C, int64_t V, int ldc,
+                                  int start_class, void *stream) {
   DG_REQUIRE(la && lb && grad_la && grad_lb && ws, DGTTA_ERR_BADARG, "softdice_bwd: null pointer");
   DG_REQUIRE(B > 0 && B <= 8 && C > 0 && C <= MAXC && V > 0 && ldc >= C, DGTTA_ERR_BADARG, "softdice_bwd: bad dims");
   (void)start_class;
@@ -200,7 +203,7 @@ extern "C" int dgtta_softdice_bwd(const float *la, const float *lb, float *grad_
   int64_t gb = (V + NT - 1) / NT;
   if (gb > 4096) gb = 4096;
   hipLaunchKernelGGL(softdice_bwd_kernel, dim3((int)gb, B), dim3(NT), 0, st, la, lb, grad_la, grad_lb, coef, grad_scale,
-                     C, V, ldc);
+                     grad_scale_dev, C, V, ldc);
   DG_CHECK_LAUNCH("softdice_bwd_kernel");
   return DGTTA_OK;
 }

@@ -427,18 +427,23 @@ __global__ void argmax_dice_kernel(const float *__restrict__ logits, int ldc, in
   for (int i = threadIdx.x; i < 3 * C; i += blockDim.x) scnt[i] = 0;
   __syncthreads();
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const float *p = logits + i * ldc;
     int best = 0;
-    float bv = p[0];
-    for (int c = 1; c < C; ++c)
-      if (p[c] > bv) {  // first maximum wins, as torch.argmax
-        bv = p[c];
-        best = c;
-      }
-    if (amax) amax[i] = best;
+    if (logits) {
+      const float *p = logits + i * ldc;
+      float bv = p[0];
+      for (int c = 1; c < C; ++c)
+        if (p[c] > bv) {  // first maximum wins, as torch.argmax
+          bv = p[c];
+          best = c;
+        }
+      if (amax) amax[i] = best;
+    } else {
+      best = (int)amax[i];  // predictions given
+      if ((unsigned)best >= (unsigned)C) best = -1;
+    }
     if (labels) {
       const int gt = (int)labels[i];
-      atomicAdd(&scnt[best], 1u);
+      if (best >= 0) atomicAdd(&scnt[best], 1u);
       if ((unsigned)gt < (unsigned)C) {
         atomicAdd(&scnt[C + gt], 1u);
         if (gt == best) atomicAdd(&scnt[2 * C + gt], 1u);
@@ -804,7 +809,8 @@ extern "C" int dgtta_ndhwc_to_ncdhw(const void *src, float *dst, int B, int C, i
 
 extern "C" int dgtta_argmax_dice(const float *logits, int ldc, int C, const int64_t *labels, int64_t *argmax_out,
                                  int64_t *counts, int B, int64_t V, void *stream) {
-  DG_REQUIRE(logits && C > 0 && C <= 1024 && ldc >= C && B > 0 && V > 0, DGTTA_ERR_BADARG, "argmax_dice: bad args");
+  DG_REQUIRE((logits || argmax_out) && C > 0 && C <= 1024 && (!logits || ldc >= C) && B > 0 && V > 0, DGTTA_ERR_BADARG,
+             "argmax_dice: bad args");
   DG_REQUIRE(!labels || counts, DGTTA_ERR_BADARG, "argmax_dice: labels without counts");
   const int64_t total = (int64_t)B * V;
   hipLaunchKernelGGL(argmax_dice_kernel, dim3(gs_blocks(total, 2048)), dim3(256), 3 * C * sizeof(unsigned int),

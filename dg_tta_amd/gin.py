@@ -1,0 +1,36 @@
+"""GIN intensity augmentation — drop-in for dg_tta/gin.py (gin_aug :233-241, gin_hook :244-247).
+
+Draw order and generators follow the reference exactly (gin.py:193-195 alpha on x.device; :65-66, :94-103 kernel size,
+kernels and shifts on the CPU generator, then moved to the device); the convolution chain, blend and Frobenius
+re-normalisation run in the fused HIP kernels of csrc/gin.hip."""
+import torch
+
+from . import ops
+from .utils import get_internal_augmentation_enabled
+
+N_LAYER, INTERM_CHANNELS, SCALE_POOL = 4, 2, (1, 3)
+
+
+def draw_gin_params(nb, device):
+    alpha = torch.rand(nb, device=device)
+    chans = [1] + [INTERM_CHANNELS] * (N_LAYER - 1) + [1]
+    ks, kers, shifts = [], [], []
+    for cin, cout in zip(chans[:-1], chans[1:]):
+        k = SCALE_POOL[int(torch.randint(high=len(SCALE_POOL), size=(1,))[0])]
+        kers.append(torch.randn([cout * nb, cin, k, k, k]).to(device))
+        shifts.append((torch.randn([cout * nb, 1, 1, 1]) * 1.0).to(device))
+        ks.append(k)
+    return alpha, ks, kers, shifts
+
+
+def gin_aug(input):
+    if input.dim() != 5 or input.shape[1] != 1:
+        raise ValueError("gin_aug (HIP) expects [B,1,D,H,W]")
+    alpha, ks, kers, shifts = draw_gin_params(input.shape[0], input.device)
+    return ops.gin_chain(input, alpha, ks, kers, shifts)
+
+
+def gin_hook(module, input):
+    if get_internal_augmentation_enabled():
+        return gin_aug(*input)
+    return input

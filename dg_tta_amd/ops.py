@@ -1,0 +1,238 @@
+"""Tensor-level wrappers over the C ABI (include/dgtta.h).  PyTorch is used for device memory, streams and autograd
+glue only; every number is produced by the HIP kernels in dg_tta_amd/csrc.  All functions require CUDA(HIP) tensors.
+
+Channel-last convention: a logical [B,C,D,H,W] tensor whose memory is [B,D,H,W,C] is exactly PyTorch's
+`torch.channels_last_3d`; kernels that work voxel-major return such tensors, so callers keep NCDHW semantics.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import check, ptr, require_cuda, stream_of
+
+F32, BF16 = 0, 1
+PAD_ZEROS, PAD_BORDER = 0, 1
+LINEAR, NEAREST = 0, 1
+
+
+def _ws(nbytes, device):
+    return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+
+
+def _f32c(t):
+    return t.contiguous().float() if (t.dtype != torch.float32 or not t.is_contiguous()) else t
+
+
+def is_cl3d(t):
+    """True when a 5-D tensor's memory is dense [B,D,H,W,C]."""
+    return t.dim() == 5 and t.is_contiguous(memory_format=torch.channels_last_3d)
+
+
+def empty_cl3d(b, c, d, h, w, dtype, device):
+    return torch.empty((b, d, h, w, c), dtype=dtype, device=device).permute(0, 4, 1, 2, 3)
+
+
+# ------------------------------------------------------------------------------------------------ MIND
+def mind3d(img, noise, randn_weighting=0.05, out_format="ncdhw", out_ldc=12, out_dtype=torch.float32):
+    """MIND3D descriptor of img [B,1,D,H,W] with the randn draw `noise` [B,12,D,H,W] (reference: dg_tta/mind.py:142-164).
+
+    out_format 'ncdhw' -> contiguous [B,12,D,H,W] fp32; 'ndhwc' -> raw [B,D,H,W,out_ldc] buffer (fp32 or bf16).
+    """
+    require_cuda(img, noise)
+    lib = _lib.load()
+    b, c, d, h, w = img.shape
+    assert c == 1 and tuple(noise.shape) == (b, 12, d, h, w)
+    img, noise = _f32c(img), _f32c(noise)
+    ndhwc = out_format == "ndhwc"
+    if ndhwc:
+        out = torch.empty((b, d, h, w, out_ldc), dtype=out_dtype, device=img.device)
+    else:
+        out = torch.empty((b, 12, d, h, w), dtype=torch.float32, device=img.device)
+    nbytes = lib.dgtta_mind3d_ws_bytes(b, d, h, w)
+    ws = _ws(nbytes, img.device)
+    check(lib.dgtta_mind3d_fwd(ptr(img), ptr(noise), float(randn_weighting), ptr(out), int(ndhwc), int(out_ldc),
+                               BF16 if out_dtype == torch.bfloat16 else F32, ptr(ws), nbytes, b, d, h, w,
+                               stream_of(img.device)), "dgtta_mind3d_fwd")
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ GIN
+def gin_chain(x, alpha, ks, kers, shifts):
+    """GIN chain on x [B,1,D,H,W] with explicit draws (reference: dg_tta/gin.py:168-230)."""
+    require_cuda(x, alpha, *kers, *shifts)
+    lib = _lib.load()
+    b, c, d, h, w = x.shape
+    assert c == 1 and len(ks) == len(kers) == len(shifts) == 4
+    x = _f32c(x)
+    alpha = _f32c(alpha)
+    kers = [_f32c(k) for k in kers]
+    shifts = [_f32c(s) for s in shifts]
+    out = torch.empty_like(x)
+    nbytes = lib.dgtta_gin_ws_bytes(b, d, h, w)
+    ws = _ws(nbytes, x.device)
+    ksz = (C.c_int * 4)(*[int(k) for k in ks])
+    kp = (C.c_void_p * 4)(*[k.data_ptr() for k in kers])
+    sp = (C.c_void_p * 4)(*[s.data_ptr() for s in shifts])
+    check(lib.dgtta_gin_chain_fwd(ptr(x), ptr(alpha), ksz, kp, sp, ptr(out), ptr(ws), nbytes, b, d, h, w,
+                                  stream_of(x.device)), "dgtta_gin_chain_fwd")
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ warp
+def _warp_layout(t):
+    """(tensor to pass, ndhwc flag, ldc)."""
+    if is_cl3d(t) and t.shape[1] > 1:
+        return t, 1, t.shape[1]
+    t = t.contiguous()
+    return t, 0, 0
+
+
+def _warp_fwd_raw(src, theta, out_size, pad_mode, interp, algebra, sub_const):
+    lib = _lib.load()
+    b, c, ds, hs, wsz = src.shape
+    dd, hd, wd = out_size
+    src, ndhwc, ldc = _warp_layout(src)
+    dst = empty_cl3d(b, c, dd, hd, wd, torch.float32, src.device) if ndhwc else \
+        torch.empty((b, c, dd, hd, wd), dtype=torch.float32, device=src.device)
+    check(lib.dgtta_affine_warp3d_fwd(ptr(src), ptr(theta), ptr(dst), b, c, ds, hs, wsz, dd, hd, wd, ndhwc, ldc, ldc,
+                                      pad_mode, interp, int(algebra), ptr(sub_const), stream_of(src.device)),
+          "dgtta_affine_warp3d_fwd")
+    return dst
+
+
+class _AffineWarp(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, src, theta, out_size, pad_mode, algebra):
+        ctx.save_for_backward(theta)
+        ctx.meta = (tuple(src.shape), tuple(out_size), pad_mode, algebra, is_cl3d(src) and src.shape[1] > 1)
+        return _warp_fwd_raw(src, theta, out_size, pad_mode, LINEAR, algebra, None)
+
+    @staticmethod
+    def backward(ctx, grad):
+        (theta,) = ctx.saved_tensors
+        shape, out_size, pad_mode, algebra, ndhwc = ctx.meta
+        lib = _lib.load()
+        b, c, ds, hs, wsz = shape
+        dd, hd, wd = out_size
+        if ndhwc:
+            grad = grad.contiguous(memory_format=torch.channels_last_3d)
+            gsrc = torch.zeros((b, ds, hs, wsz, c), dtype=torch.float32, device=grad.device).permute(0, 4, 1, 2, 3)
+        else:
+            grad = grad.contiguous()
+            gsrc = torch.zeros(shape, dtype=torch.float32, device=grad.device)
+        check(lib.dgtta_affine_warp3d_bwd(ptr(grad), ptr(theta), ptr(gsrc), b, c, ds, hs, wsz, dd, hd, wd, int(ndhwc), c,
+                                          c, pad_mode, int(algebra), stream_of(grad.device)), "dgtta_affine_warp3d_bwd")
+        return gsrc, None, None, None, None
+
+
+def affine_warp(src, theta, out_size=None, padding_mode="zeros", tta_grid_algebra=False):
+    """F.grid_sample(src, F.affine_grid(theta, ...), align_corners=False) (reference call sites tta.py:523-551,572-575).
+
+    src [B,C,D,H,W] fp32 (contiguous or channels_last_3d; the layout is preserved), theta [B,3,4].
+    Differentiable w.r.t. src (theta is a constant, as in the reference)."""
+    require_cuda(src, theta)
+    theta = _f32c(theta)
+    src = src if src.dtype == torch.float32 else src.float()
+    out_size = tuple(src.shape[2:]) if out_size is None else tuple(out_size)
+    pad = PAD_BORDER if padding_mode == "border" else PAD_ZEROS
+    return _AffineWarp.apply(src, theta, out_size, pad, bool(tta_grid_algebra))
+
+
+def affine_sample(src, theta, out_size, padding_mode="zeros", mode="bilinear", sub_const=None):
+    """Non-differentiable sampler with nearest mode and the (x - c) ... + c trick of get_batch (torch_utils.py:58-62)."""
+    require_cuda(src, theta)
+    pad = PAD_BORDER if padding_mode == "border" else PAD_ZEROS
+    interp = NEAREST if mode == "nearest" else LINEAR
+    return _warp_fwd_raw(src.float(), _f32c(theta), tuple(out_size), pad, interp, False, sub_const)
+
+
+# ------------------------------------------------------------------------------------------------ loss
+class _ConsistencyLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, la, lb, start_class):
+        lib = _lib.load()
+        b, c = la.shape[:2]
+        v = la.shape[2] * la.shape[3] * la.shape[4]
+        la = la.contiguous(memory_format=torch.channels_last_3d)
+        lb = lb.contiguous(memory_format=torch.channels_last_3d)
+        dice = torch.empty((b, c), dtype=torch.float32, device=la.device)
+        loss = torch.empty((), dtype=torch.float32, device=la.device)
+        nbytes = lib.dgtta_softdice_ws_bytes(b, c, v)
+        ws = _ws(nbytes, la.device)
+        check(lib.dgtta_softdice_fwd(ptr(la), ptr(lb), ptr(dice), ptr(loss), ptr(ws), nbytes, b, c, v, c, start_class,
+                                     stream_of(la.device)), "dgtta_softdice_fwd")
+        ctx.save_for_backward(la, lb, ws)
+        ctx.meta = (b, c, v, start_class)
+        ctx.mark_non_differentiable(dice)
+        return loss, dice
+
+    @staticmethod
+    def backward(ctx, gloss, _gdice):
+        la, lb, ws = ctx.saved_tensors
+        b, c, v, start_class = ctx.meta
+        lib = _lib.load()
+        ga = torch.empty_like(la, memory_format=torch.preserve_format)
+        gb = torch.empty_like(lb, memory_format=torch.preserve_format)
+        # the upstream gradient (e.g. 1/patches_to_be_accumulated) is read on the device: no host sync, no torch math
+        gs = gloss.reshape(1).float().contiguous()
+        check(lib.dgtta_softdice_bwd(ptr(la), ptr(lb), ptr(ga), ptr(gb), ptr(ws), 1.0, ptr(gs), b, c, v, c, start_class,
+                                     stream_of(la.device)), "dgtta_softdice_bwd")
+        return ga, gb, None
+
+
+def consistency_loss(target_a, target_b, start_class=1):
+    """tta.py:263-269: masked softmax of both branches + `1 - soft_dice[:, start_class:].mean()`. Returns (loss, dice[B,C])."""
+    require_cuda(target_a, target_b)
+    return _ConsistencyLoss.apply(target_a.float(), target_b.float(), int(start_class))
+
+
+# ------------------------------------------------------------------------------------------------ AdamW
+def adamw_step(params, grads, exp_avgs, exp_avg_sqs, step, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01):
+    lib = _lib.load()
+    n = len(params)
+    if n == 0:
+        return
+    require_cuda(*params)
+    P = C.c_void_p * n
+    hp = P(*[p.data_ptr() for p in params])
+    hg = P(*[(g.data_ptr() if g is not None else None) for g in grads])
+    hm = P(*[m.data_ptr() for m in exp_avgs])
+    hv = P(*[v.data_ptr() for v in exp_avg_sqs])
+    hn = (C.c_int64 * n)(*[p.numel() for p in params])
+    check(lib.dgtta_adamw_step(hp, hg, hm, hv, hn, n, float(lr), float(betas[0]), float(betas[1]), float(eps),
+                               float(weight_decay), int(step), stream_of(params[0].device)), "dgtta_adamw_step")
+
+
+# ------------------------------------------------------------------------------------------------ eval helpers
+def argmax_dice(logits, labels=None):
+    """argmax over channels (+ per-label counts for hard Dice, tta.py:321, torch_utils.py:107-117).
+
+    Returns (argmax [B,D,H,W] int64, counts [3,C] int64 or None)."""
+    require_cuda(logits)
+    lib = _lib.load()
+    b, c, d, h, w = logits.shape
+    lg = logits.float().contiguous(memory_format=torch.channels_last_3d)
+    am = torch.empty((b, d, h, w), dtype=torch.int64, device=lg.device)
+    counts = None
+    lp = None
+    if labels is not None:
+        labels = labels.reshape(b, d, h, w).to(torch.int64).contiguous()
+        counts = torch.zeros((3, c), dtype=torch.int64, device=lg.device)
+        lp = labels.data_ptr()
+    check(lib.dgtta_argmax_dice(ptr(lg), c, c, lp, ptr(am), ptr(counts), b, d * h * w, stream_of(lg.device)),
+          "dgtta_argmax_dice")
+    return am, counts
+
+
+def argmax_dice_from_labels(pred, labels, num_classes):
+    """Per-label counts for two integer label maps (dice_coeff, torch_utils.py:107-117): counts [3,C] int64."""
+    require_cuda(pred, labels)
+    lib = _lib.load()
+    pr = pred.reshape(-1).to(torch.int64).contiguous()
+    lb = labels.reshape(-1).to(torch.int64).contiguous()
+    assert pr.numel() == lb.numel()
+    counts = torch.zeros((3, num_classes), dtype=torch.int64, device=pr.device)
+    check(lib.dgtta_argmax_dice(None, 0, num_classes, ptr(lb), ptr(pr), ptr(counts), 1, pr.numel(),
+                                stream_of(pr.device)), "dgtta_argmax_dice")
+    return pr, counts

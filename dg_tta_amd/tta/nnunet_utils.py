@@ -1,0 +1,136 @@
+"""Bridge to the nnU-Net model folder and target data WITHOUT nnunetv2 (not installable offline) — the role of the
+reference's dg_tta/tta/nnunet_utils.py (load_network :88-113, load_tta_data :63-85, preprocess_fromfile :170-204).
+
+* `load_network` reads `<model_folder>/{plans.json,dataset.json}` + `fold_k/checkpoint_final.pth` (nnU-Net layout),
+  builds a HipPlainConvUNet with the plans' topology and registers the trainer's forward pre-hooks in the reference's
+  order (gin_hook, then mind_hook: dg_tta/pretraining/nnUNetTrainer_GIN_MIND.py:55-57).
+* `load_tta_data` yields `{"data": FloatTensor[1+K,D,H,W], "data_properties", "ofile"}` items like
+  preprocess_fromfile.  Cases are read from PRE-PROCESSED arrays (`.npy`, `.npz` with key `data`, or `.pt`);
+  reading NIfTI + nnU-Net resampling/normalisation is the "next" row of SURVEY.md §8f and needs SimpleITK/nnunetv2.
+"""
+import json
+import re
+from itertools import chain
+from pathlib import Path
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+
+from ..gin import gin_hook
+from ..mind import mind_hook
+from ..unet import HipPlainConvUNet
+from ..utils import enable_internal_augmentation
+
+
+def unet_cfg_from_plans(plans, dataset_json, configuration, in_channels):
+    conf = plans["configurations"][configuration]
+    while "inherits_from" in conf:
+        parent = dict(plans["configurations"][conf["inherits_from"]])
+        parent.update({k: v for k, v in conf.items() if k != "inherits_from"})
+        conf = parent
+    if conf.get("UNet_class_name", "PlainConvUNet") != "PlainConvUNet":
+        raise NotImplementedError(f"only PlainConvUNet is built, plans ask for {conf['UNet_class_name']}")
+    pools = conf["pool_op_kernel_sizes"]
+    if any(len(set(p)) != 1 or p[0] not in (1, 2) for p in pools) or any(k != [3, 3, 3] for k in conf["conv_kernel_sizes"]):
+        raise NotImplementedError("only isotropic stride 1/2 and 3x3x3 kernels are built")
+    base, cap = conf["UNet_base_num_features"], conf["unet_max_num_features"]
+    feats = tuple(min(base * 2 ** i, cap) for i in range(len(pools)))
+    return dict(features=feats, strides=tuple(p[0] for p in pools), n_conv_enc=tuple(conf["n_conv_per_stage_encoder"]),
+                n_conv_dec=tuple(conf["n_conv_per_stage_decoder"]), in_channels=in_channels,
+                num_classes=len(dataset_json["labels"])), list(conf["patch_size"])
+
+
+def trainer_hooks(trainer_name):
+    """(input channels, [pre-hooks]) for the DG trainers (nnUNetTrainer_{GIN,MIND,GIN_MIND}[_MultiRes].py:38-59)."""
+    name = trainer_name.replace("_MultiRes", "")
+    if name.endswith("GIN_MIND"):
+        return 12, [gin_hook, mind_hook]
+    if name.endswith("MIND"):
+        return 12, [mind_hook]
+    if name.endswith("GIN"):
+        return 1, [gin_hook]
+    raise NotImplementedError(f"trainer {trainer_name}: only the DG-TTA trainers (GIN / MIND / GIN_MIND) are built")
+
+
+def load_network(weights_file, device, act_dtype=torch.float32, conv_impl=0):
+    weights_file = Path(weights_file)
+    model_folder = weights_file.parents[1]
+    configuration = model_folder.name.split("__")[-1]
+    trainer_name = model_folder.name.split("__")[0]
+    with open(model_folder / "plans.json") as f:
+        plans = json.load(f)
+    with open(model_folder / "dataset.json") as f:
+        dataset_json = json.load(f)
+    checkpoint = torch.load(weights_file, map_location="cpu", weights_only=False)
+    if isinstance(checkpoint, dict) and "network_weights" in checkpoint:
+        trainer_name = checkpoint.get("trainer_name", trainer_name)
+        state = checkpoint["network_weights"]
+    else:
+        state = checkpoint
+    in_ch, hooks = trainer_hooks(trainer_name)
+    cfg, patch_size = unet_cfg_from_plans(plans, dataset_json, configuration, in_ch)
+    network = HipPlainConvUNet(cfg, act_dtype=act_dtype, conv_impl=conv_impl)
+    state = {k.replace("_orig_mod.", ""): v for k, v in state.items()}
+    network.load_state_dict(state)
+    enable_internal_augmentation()          # as build_network_architecture does; tta_main switches it off again
+    for h in hooks:
+        network.register_forward_pre_hook(h)
+    predictor = SimpleNamespace(plans=plans, dataset_json=dataset_json, configuration=configuration,
+                                trainer_name=trainer_name, device=torch.device(device), network=network,
+                                list_of_parameters=[state], patch_size=patch_size)
+    return predictor, patch_size, network, [state]
+
+
+_CASE_RE = re.compile(r"(.*)_[0-9]{4}$")
+
+
+def _read_array(path):
+    path = Path(path)
+    if path.suffix == ".npy":
+        return torch.from_numpy(np.load(path))
+    if path.suffix == ".npz":
+        return torch.from_numpy(np.load(path)["data"])
+    if path.suffix == ".pt":
+        return torch.load(path, map_location="cpu")
+    raise NotImplementedError(f"{path.name}: reading raw medical image formats needs SimpleITK + nnU-Net preprocessing "
+                              f"(SURVEY.md §8f 'next'); provide preprocessed .npy/.npz/.pt arrays [C,D,H,W]")
+
+
+def preprocess_fromfile(image_file, label_file, ofile):
+    img = _read_array(image_file).float()
+    if img.dim() == 3:
+        img = img[None]
+    data = img
+    if label_file is not None and Path(label_file).is_file():
+        seg = _read_array(label_file)
+        seg = seg[0] if seg.dim() == 4 else seg
+        k = int(seg.max())
+        onehot = torch.stack([(seg == i + 1).float() for i in range(k)]) if k > 0 else torch.zeros((0, *seg.shape))
+        data = torch.cat([img[:1], onehot], 0)
+    return {"data": data.contiguous().float(), "data_properties": {"shape": tuple(img.shape[1:])}, "ofile": ofile}
+
+
+def get_data_iterator(tta_data_filepaths, dataset_raw_path, bucket):
+    assert bucket in ("imagesTs", "imagesTr")
+    files = [Path(p) for p in tta_data_filepaths if Path(p).parts[-2] == bucket]
+    label_folder = Path(dataset_raw_path) / ("labelsTs" if bucket == "imagesTs" else "labelsTr")
+    out_folder = "tta_outputTs" if bucket == "imagesTs" else "tta_outputTr"
+
+    def gen():
+        for f in files:
+            stem = f.name[: -len("".join(f.suffixes))] if f.suffixes else f.name
+            m = _CASE_RE.match(stem)
+            case = m.group(1) if m else stem
+            lbl = label_folder / (case + "".join(f.suffixes))
+            yield preprocess_fromfile(f, lbl if lbl.is_file() else None, f"{out_folder}/{case}")
+
+    return gen(), len(files)
+
+
+def load_tta_data(config, dataset_raw_path, predictor=None, tta_across_all_samples=False):
+    ts_it, ts_n = get_data_iterator(config["tta_data_filepaths"], dataset_raw_path, "imagesTs")
+    tr_it, tr_n = get_data_iterator(config["tta_data_filepaths"], dataset_raw_path, "imagesTr")
+    if tta_across_all_samples:
+        return list(ts_it) + list(tr_it), ts_n + tr_n
+    return chain(ts_it, tr_it), ts_n + tr_n

@@ -1,0 +1,250 @@
+"""TTA driver — the per-sample / per-ensemble / per-epoch / accumulation loops of the reference's
+dg_tta/tta/tta.py (tta_main :93-373, calc_branch :480-579), with every tensor op executed by the HIP kernels:
+
+    get_batch (csrc/warp.hip) -> 2x calc_branch {GIN (gin.hip) -> affine warp, border (warp.hip) -> MIND pre-hook
+    (mind3d.hip) -> PlainConvUNet fwd (unet_ref.hip / conv_mfma.hip) with map_label fused into the head -> inverse
+    warp, zeros (warp.hip)} -> masked softmax + soft-Dice (softdice.hip) -> backward through both branches ->
+    AdamW once per epoch (adamw.hip).
+
+Behaviour kept bug-compatible with the reference: `have_grad_in` enables/disables autograd for BOTH
+branches (tta.py:496-498); epochs before `start_tta_at_epoch` only evaluate the loss; background is excluded from the
+loss mean; AdamW receives all parameters.  Multi-GPU: samples are sharded round-robin over ranks (one process per GPU,
+no collectives; `shard=(rank, world)`), every (sample, ensemble) unit being independent (tta.py:157-182).
+"""
+import json
+from contextlib import nullcontext
+from itertools import tee
+from pathlib import Path
+
+import numpy as np
+import torch
+
+from .. import ops
+from ..gin import gin_aug
+from ..optim import HipAdamW
+from ..utils import disable_internal_augmentation
+from .augmentation_utils import get_rand_affine
+from .config_log_utils import (get_global_idx, get_parameters_save_path, is_template_modifier, plot_run_results)
+from .model_utils import apply_running_stats, buffer_running_stats, get_model_from_network
+from .torch_utils import (dice_coeff, fix_all, get_batch, get_map_idxs, map_label, release_all, release_norms)
+
+INTENSITY_AUG_FUNCTION_DICT = {"disabled": lambda img: img, "GIN": gin_aug}
+START_CLASS = 1  # Do not use background for consistency loss (tta.py:103)
+
+
+def repair_ofilename_and_add_fileextension(config, sample):
+    """tta.py:57-69: recovers `<case>` and the file extension from the plan's file list (names with `_0000`)."""
+    import re
+    ofile = sample["ofile"]
+    sample.setdefault("file_extension", "")
+    for _path in config.get("tta_data_filepaths", []):
+        _path = Path(_path)
+        prefix, name = "/".join(ofile.split("/")[:-1]), ofile.split("/")[-1]
+        if name in str(_path):
+            suffixes = "".join(_path.suffixes)
+            m = re.match(r"(.*)_[0-9]{4}" + re.escape(suffixes), _path.name)
+            if m:
+                sample["ofile"] = prefix + "/" + m.group(1)
+                sample["file_extension"] = suffixes
+
+
+def get_sample_specs(config, smp_idx, tta_data, save_path, across_all_samples=False):
+    if across_all_samples:
+        for e in tta_data:
+            repair_ofilename_and_add_fileextension(config, e)
+        return None, [e["data"] for e in tta_data], "all_samples", None, save_path / "tta_output"
+    sample = next(tta_data)
+    repair_ofilename_and_add_fileextension(config, sample)
+    sample_id = sample["ofile"]
+    return sample, [sample["data"]], sample_id, sample["file_extension"], save_path / Path(sample_id).parent
+
+
+def calc_branch(branch_id, config, model, intensity_aug_func, identity_grid, patch_size, batch_size, label_mapping,
+                optimized_labels, modifier_fn_module, imgs, device, head_is_fused=False):
+    """One augmented forward pass mapped back to the common frame (reference: tta.py:480-579).
+    `identity_grid` is unused (the affine grid is evaluated analytically inside the warp kernel) and kept for API parity."""
+    assert branch_id in ["branch_a", "branch_b"]
+    grad_context = nullcontext if config["have_grad_in"] in ["branch_a", "both"] else torch.no_grad
+    after_mapping = modifier_fn_module.ModifierFunctions.modify_tta_output_after_mapping_fn
+    with grad_context():
+        imgs_aug = imgs
+        if config["do_intensity_aug_in"] in [branch_id, "both"]:
+            imgs_aug = intensity_aug_func(imgs_aug)
+        spatial = config["do_spatial_aug_in"] in [branch_id, "both"]
+        R_inverse = None
+        if spatial:
+            if config["spatial_aug_type"] == "affine":
+                R, R_inverse = get_rand_affine(batch_size, flip=False)
+                R, R_inverse = R.to(device), R_inverse.to(device)
+            elif config["spatial_aug_type"] == "deformable":
+                from .augmentation_utils import get_disp_field
+                get_disp_field()
+            else:   # no displacement: identity resampling, as the reference's zero grid does
+                R = R_inverse = torch.eye(4, device=device)[:3][None].repeat(batch_size, 1, 1)
+            imgs_aug = ops.affine_warp(imgs_aug, R, padding_mode="border", tta_grid_algebra=True)
+        model.apply(buffer_running_stats if branch_id == "branch_a" else apply_running_stats)
+        branch_target = model(imgs_aug)
+        if isinstance(branch_target, tuple):
+            branch_target = branch_target[0]
+        if not head_is_fused:
+            branch_target = map_label(branch_target,
+                                      get_map_idxs(label_mapping, optimized_labels, input_type="pretrain_labels"),
+                                      input_format="logits")
+        branch_target = after_mapping(branch_target)
+        if isinstance(branch_target, tuple):
+            branch_target = branch_target[0]
+        if spatial:
+            branch_target = ops.affine_warp(branch_target, R_inverse, padding_mode="zeros", tta_grid_algebra=True)
+        return branch_target
+
+
+def _fuse_head_if_possible(model, modifier_fn_module, label_mapping, optimized_labels):
+    """map_label(logits) == evaluating only the mapped rows of the 1x1x1 head; valid iff the user's model-output
+    modifier is the untouched template (identity)."""
+    mf = modifier_fn_module.ModifierFunctions
+    if hasattr(model, "set_selected_classes") and is_template_modifier(mf.modfify_tta_model_output_fn,
+                                                                       "modfify_tta_model_output_fn"):
+        model.set_selected_classes(get_map_idxs(label_mapping, optimized_labels, input_type="pretrain_labels"))
+        return True
+    return False
+
+
+def tta_unit(model, optimizer, config, tta_tens_list, patch_size, label_mapping, modifier_fn_module, device,
+             head_is_fused, debug=False, progress=None):
+    """Adapts `model` on one sample for config['epochs'] epochs (reference: tta.py:189-362). Returns (losses, dices)."""
+    B = config["batch_size"]
+    accum = config["patches_to_be_accumulated"]
+    num_epochs, start = config["epochs"], config["start_tta_at_epoch"]
+    optimized_labels = config["optimized_labels"]
+    intensity_aug_func = INTENSITY_AUG_FUNCTION_DICT[config["intensity_aug_function"]]
+    tta_losses, eval_dices = torch.zeros(num_epochs), torch.zeros(num_epochs)
+    inv_accum = torch.full((), 1.0 / accum, dtype=torch.float32, device=device)
+    model.apply(fix_all)
+    for epoch in range(num_epochs):
+        model.train()
+        step_losses = []
+        if epoch == start:
+            model.apply(fix_all)
+            mode = config["params_with_grad"]
+            if mode == "all":
+                model.apply(release_all)
+            elif mode == "norms":
+                model.apply(release_norms)
+            elif mode == "encoder":
+                model.encoder.apply(release_all)
+            else:
+                raise ValueError()
+            n_released = sum(p.numel() for p in model.parameters() if p.requires_grad)
+            print(f"Released #{n_released / 1e6:.2f} million trainable params")
+        for _ in range(accum):
+            with torch.no_grad():
+                imgs, _ = get_batch(tta_tens_list, np.random.choice(range(len(tta_tens_list)), B).tolist(), patch_size,
+                                    fixed_patch_idx=None, device=device)
+            imgs = imgs[0] if len(imgs) == 1 else torch.cat(imgs, dim=0)
+            args = (config, model, intensity_aug_func, None, patch_size, B, label_mapping, optimized_labels,
+                    modifier_fn_module, imgs, device, head_is_fused)
+            target_a = calc_branch("branch_a", *args)
+            target_b = calc_branch("branch_b", *args)
+            loss, _ = ops.consistency_loss(target_a, target_b, START_CLASS)
+            step_losses.append(loss.detach())
+            if epoch >= start and loss.requires_grad:
+                # d(loss/accum): the 1/accum factor is handed to the loss kernel as a device scalar
+                torch.autograd.backward(loss, grad_tensors=inv_accum)
+        if epoch >= start:
+            optimizer.step()
+            optimizer.zero_grad()
+        tta_losses[epoch] = torch.stack(step_losses).mean().item()
+
+        with torch.inference_mode():
+            model.eval()
+            for _ in range(config["tta_eval_patches"]):
+                imgs, labels = get_batch(tta_tens_list, np.random.choice(range(len(tta_tens_list)), B).tolist(),
+                                         patch_size, fixed_patch_idx="center", device=device)
+                keep = [i for i, l in enumerate(labels) if l is not None]
+                if len(keep) == 0:
+                    eval_dices[epoch] = float("nan")
+                    continue
+                f_imgs = torch.cat([imgs[i] for i in keep], dim=0)
+                f_labels = torch.cat([labels[i] for i in keep], dim=0)
+                out = model(f_imgs)
+                if isinstance(out, tuple):
+                    out = out[0]
+                if not head_is_fused:
+                    out = map_label(out, get_map_idxs(label_mapping, optimized_labels, "pretrain_labels"), "logits")
+                target_argmax, _ = ops.argmax_dice(out)
+                f_labels = map_label(f_labels, get_map_idxs(label_mapping, optimized_labels, "tta_labels"),
+                                     input_format="argmaxed").long()
+                d = dice_coeff(target_argmax, f_labels, len(optimized_labels))
+                eval_dices[epoch] += 1 / config["tta_eval_patches"] * d.nanmean().item()
+            if debug:
+                break
+        if progress is not None:
+            progress(epoch, float(tta_losses[epoch]), float(eval_dices[epoch]))
+    return tta_losses, eval_dices
+
+
+def tta_main(run_name, config, tta_data_dir, save_base_path, label_mapping, modifier_fn_module, device, debug=False,
+             network_bundle=None, tta_data=None, shard=(0, 1), act_dtype=torch.float32, conv_impl=0):
+    """Same signature as the reference's tta_main (tta.py:93-102) plus optional injection points:
+    network_bundle=(predictor, patch_size, network, parameters) and tta_data=(iterable, num_samples) replace the
+    nnU-Net loaders (used by tests / bench with synthetic data); shard=(rank, world) selects this process's samples."""
+    from .nnunet_utils import load_network, load_tta_data
+    device = torch.device(device)
+    if device.type != "cuda":
+        raise RuntimeError("dg_tta_amd runs on the MI355X only (device must be 'cuda' / 'cuda:N'); there is no CPU path")
+    if network_bundle is None:
+        network_bundle = load_network(config["pretrained_weights_filepath"], device, act_dtype=act_dtype,
+                                      conv_impl=conv_impl)
+    predictor, patch_size, network, parameters = network_bundle
+    across = config["tta_across_all_samples"]
+    print("\n# Loading data")
+    if tta_data is None:
+        tta_data = load_tta_data(config, tta_data_dir, predictor, across)
+    tta_data, num_samples = tta_data
+    if not across:
+        tta_data, _inference_data = tee(tta_data)
+    ensemble_count = config["ensemble_count"]
+    num_epochs = config["epochs"]
+    save_path = Path(save_base_path) / run_name
+    save_path.mkdir(exist_ok=True, parents=False)
+    with open(save_path / "tta_plan.json", "w") as f:
+        json.dump({k: v for k, v in config.items()}, f, indent=4)
+    disable_internal_augmentation()
+    rank, world = shard
+    results = {}
+    print("\n# Starting TTA")
+    for smp_idx in ([0] if across else range(num_samples)):
+        _, tta_tens_list, sample_id, _ext, sub_dir_tta = get_sample_specs(config, smp_idx, tta_data, save_path, across)
+        if smp_idx % world != rank:
+            continue        # another GPU's sample (independent unit: nothing to exchange)
+        print(f"\nSample {sample_id}")
+        sub_dir_tta.mkdir(exist_ok=True, parents=True)
+        for ensemble_idx in range(ensemble_count):
+            ppath = get_parameters_save_path(sub_dir_tta, sample_id, ensemble_idx)
+            if ppath.is_file():
+                print(f"TTA parameters file already exists. Skipping '{ppath}'")
+                continue
+            if config.get("seed") is not None:      # optional, not a reference key: reproducible units on any GPU count
+                unit = get_global_idx([(smp_idx, max(num_samples, 1)), (ensemble_idx, ensemble_count)])
+                torch.manual_seed(int(config["seed"]) + unit)
+                np.random.seed(int(config["seed"]) + unit)
+            model = get_model_from_network(network, modifier_fn_module, parameters).to(device)
+            fused = _fuse_head_if_possible(model, modifier_fn_module, label_mapping, config["optimized_labels"])
+            optimizer = HipAdamW(model.parameters(), lr=config["lr"])
+
+            def progress(epoch, loss, dice):
+                print(f"  epoch {epoch}: loss={loss:.3f}, Pseudo-Dice={dice * 100:.1f}%", flush=True)
+
+            losses, dices = tta_unit(model, optimizer, config, tta_tens_list, patch_size, label_mapping,
+                                     modifier_fn_module, device, fused, debug, progress)
+            if fused:
+                model.set_selected_classes(None)
+            torch.save([model.state_dict()], ppath)
+            results[(sample_id, ensemble_idx)] = (losses, dices)
+            if num_epochs > 0:
+                plot_run_results(sub_dir_tta, sample_id, ensemble_idx, losses, dices)
+            if debug:
+                break
+    # The reference continues with ensemble sliding-window inference + evaluation (tta.py:376-477), which needs
+    # nnU-Net's predictor / SimpleITK; that stage is the "next" row of the scope table and is not part of this path.
+    return results

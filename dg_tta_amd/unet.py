@@ -1,0 +1,446 @@
+"""nnUNet 3d_fullres PlainConvUNet executed by the HIP kernels (forward AND backward), as one autograd node.
+
+Drop-in for the network object the reference obtains from nnUNetPredictor (dg_tta/tta/nnunet_utils.py:88-113; class
+`dynamic_network_architectures.architectures.unet.PlainConvUNet`, built at
+dg_tta/pretraining/nnUNetTrainer_GIN_MIND.py:46-53): same state-dict keys (incl. the duplicated `all_modules.*` and
+`decoder.encoder.*` entries), `.encoder` attribute (tta.py:210), norm modules whose class name contains
+"instancenorm" (torch_utils.py:130-137), forward (pre-)hooks honoured (model_utils.py:22-33).
+
+Data layout in HBM: activations are channels-last [B][D][H][W][C] (fp32, or bf16 storage with fp32 accumulation);
+`torch.cat((up, skip), 1)` never happens: the transposed conv writes the first channel half of a pre-allocated
+[.., 2C] buffer and the encoder's InstanceNorm+LeakyReLU writes the skip directly into the second half.
+"""
+import ctypes as C
+
+import torch
+from torch import nn
+
+from . import _lib
+from ._lib import check, ptr, stream_of
+from .ops import F32, BF16, _ws, is_cl3d
+
+PLANS_3D_FULLRES = dict(features=(32, 64, 128, 256, 320), strides=(1, 2, 2, 2, 2),
+                        n_conv_enc=(2, 2, 2, 2, 2), n_conv_dec=(2, 2, 2, 2),
+                        in_channels=12, num_classes=105)
+EPS, SLOPE = 1e-5, 1e-2
+
+
+def _pad(c, m):
+    return (c + m - 1) // m * m
+
+
+# ------------------------------------------------------------------------------------------------ parameter holders
+class HipConv3d(nn.Module):
+    """Parameter holder for a 3x3x3 / 1x1x1 conv (weights in PyTorch layout so checkpoints load unchanged)."""
+
+    def __init__(self, cin, cout, k, stride):
+        super().__init__()
+        self.in_channels, self.out_channels, self.kernel_size, self.stride = cin, cout, k, stride
+        self.weight = nn.Parameter(torch.empty(cout, cin, k, k, k))
+        self.bias = nn.Parameter(torch.empty(cout))
+
+
+class HipConvTranspose3d(nn.Module):
+    def __init__(self, cin, cout, k):
+        super().__init__()
+        self.in_channels, self.out_channels, self.kernel_size = cin, cout, k
+        self.weight = nn.Parameter(torch.empty(cin, cout, k, k, k))
+        self.bias = nn.Parameter(torch.empty(cout))
+
+
+class HipInstanceNorm3d(nn.Module):
+    """name contains 'instancenorm' so that release_norms (torch_utils.py:130-137) finds it."""
+
+    def __init__(self, c):
+        super().__init__()
+        self.num_features, self.eps = c, EPS
+        self.weight = nn.Parameter(torch.ones(c))
+        self.bias = nn.Parameter(torch.zeros(c))
+
+
+class HipLeakyReLU(nn.Module):
+    negative_slope = SLOPE
+
+
+class ConvNormAct(nn.Module):
+    def __init__(self, cin, cout, stride):
+        super().__init__()
+        self.conv = HipConv3d(cin, cout, 3, stride)
+        self.norm = HipInstanceNorm3d(cout)
+        self.nonlin = HipLeakyReLU()
+        self.all_modules = nn.Sequential(self.conv, self.norm, self.nonlin)
+
+
+class StackedConvs(nn.Module):
+    def __init__(self, n, cin, cout, first_stride):
+        super().__init__()
+        self.convs = nn.Sequential(*[ConvNormAct(cin if i == 0 else cout, cout, first_stride if i == 0 else 1)
+                                     for i in range(n)])
+
+
+class Encoder(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        stages, cin = [], cfg["in_channels"]
+        for f, s, n in zip(cfg["features"], cfg["strides"], cfg["n_conv_enc"]):
+            stages.append(nn.Sequential(StackedConvs(n, cin, f, s)))
+            cin = f
+        self.stages = nn.Sequential(*stages)
+
+
+class Decoder(nn.Module):
+    def __init__(self, encoder, cfg):
+        super().__init__()
+        self.encoder = encoder
+        f, st = cfg["features"], cfg["strides"]
+        stages, ups, segs = [], [], []
+        for s in range(1, len(f)):
+            below, skip = f[-s], f[-(s + 1)]
+            assert st[-s] == 2, "only stride-2 (kernel-2) transposed convolutions are built"
+            ups.append(HipConvTranspose3d(below, skip, 2))
+            stages.append(StackedConvs(cfg["n_conv_dec"][s - 1], 2 * skip, skip, 1))
+            segs.append(HipConv3d(skip, cfg["num_classes"], 1, 1))
+        self.stages = nn.ModuleList(stages)
+        self.transpconvs = nn.ModuleList(ups)
+        self.seg_layers = nn.ModuleList(segs)
+
+
+# ------------------------------------------------------------------------------------------------ execution plan
+class _Block:
+    """One Conv3d+InstanceNorm+LeakyReLU block with its static shape info."""
+    __slots__ = ("mod", "cin", "cout", "stride", "cinp", "coutp", "di", "do", "name")
+
+
+class HipPlainConvUNet(nn.Module):
+    """PlainConvUNet whose forward/backward run on hand-written gfx950 kernels.
+
+    act_dtype: torch.float32 (parity mode) or torch.bfloat16 (bf16 storage + MFMA, fp32 accumulation).
+    conv_impl: 0 auto (MFMA where covered, else general VALU kernel), 1 force VALU, 2 force MFMA.
+    """
+
+    def __init__(self, cfg=None, act_dtype=torch.float32, conv_impl=0):
+        super().__init__()
+        cfg = dict(PLANS_3D_FULLRES if cfg is None else cfg)
+        self.cfg = cfg
+        self.encoder = Encoder(cfg)
+        self.decoder = Decoder(self.encoder, cfg)
+        self.act_dtype = act_dtype
+        self.conv_impl = conv_impl
+        self._packed = {}        # id(weight) -> (version, wf, wb)
+        self.selected_classes = None   # optional LongTensor: evaluate only these head rows (== map_label 'logits')
+
+    def __deepcopy__(self, memo):
+        # get_model_from_network deep-copies the network per ensemble member: do not drag the packed-weight cache along
+        import copy
+        new = self.__class__.__new__(self.__class__)
+        memo[id(self)] = new
+        for k, v in self.__dict__.items():
+            new.__dict__[k] = {} if k == "_packed" else copy.deepcopy(v, memo)
+        return new
+
+    # -- structure helpers
+    def conv_blocks(self):
+        enc = [[c for c in st[0].convs] for st in self.encoder.stages]
+        dec = [[c for c in st.convs] for st in self.decoder.stages]
+        return enc, dec
+
+    def set_selected_classes(self, idx):
+        """Fuses map_label(..., 'logits') (torch_utils.py:214-221) into the head: forward returns only these rows."""
+        self.selected_classes = None if idx is None else torch.as_tensor(idx, dtype=torch.int32)
+
+    def forward(self, x):
+        sel = self.selected_classes
+        if sel is not None and sel.device != x.device:
+            sel = self.selected_classes = sel.to(x.device)
+        params = [p for p in self.parameters()]
+        return _UNetFn.apply(self, x, sel, *params)
+
+    # -- packed weights (re-packed only when the parameter changed)
+    def packed(self, conv, dtype_code, cinp, coutp):
+        w = conv.weight
+        key = (id(w), dtype_code, cinp, coutp)
+        ent = self._packed.get(key)
+        if ent is not None and ent[0] == w._version and ent[1].device == w.device:
+            return ent[1], ent[2]
+        lib = _lib.load()
+        tdt = torch.float32 if dtype_code == F32 else torch.bfloat16
+        wf = torch.empty((27, cinp, coutp), dtype=tdt, device=w.device)
+        wb = torch.empty((27, coutp, cinp), dtype=tdt, device=w.device)
+        check(lib.dgtta_conv3d_pack_weights(ptr(w.detach()), ptr(wf), ptr(wb), conv.in_channels, conv.out_channels,
+                                            cinp, coutp, dtype_code, stream_of(w.device)), "dgtta_conv3d_pack_weights")
+        self._packed[key] = (w._version, wf, wb)
+        return wf, wb
+
+
+def _odim(i, s):
+    return (i + 2 - 3) // s + 1
+
+
+class _UNetFn(torch.autograd.Function):
+    """Whole-network autograd node: forward saves raw conv outputs, normalised activations and IN statistics."""
+
+    @staticmethod
+    def forward(ctx, net, x, sel, *params):
+        lib = _lib.load()
+        _lib.require_cuda(x)
+        dev = x.device
+        st = stream_of(dev)
+        cfg = net.cfg
+        adt = net.act_dtype
+        dt = F32 if adt == torch.float32 else BF16
+        impl = net.conv_impl
+        B, cin0, D, H, W = x.shape
+        assert cin0 == cfg["in_channels"], f"expected {cfg['in_channels']} input channels, got {cin0}"
+        nst = len(cfg["features"])
+        tot_stride = 1
+        for s in cfg["strides"]:
+            tot_stride *= s
+        assert D % tot_stride == 0 and H % tot_stride == 0 and W % tot_stride == 0, \
+            f"patch {D}x{H}x{W} must be divisible by {tot_stride}"
+        need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in params)
+        enc, dec = net.conv_blocks()
+        CP = 16 if dt == BF16 else 8      # channel padding granule of packed weights / first-layer input
+
+        # ---- input -> NDHWC, padded to CP channels
+        cin0p = _pad(cin0, CP)
+        if (x.dtype == adt and x.stride(1) == 1 and x.stride(4) == cin0p and x.stride(3) == W * cin0p
+                and x.stride(2) == H * W * cin0p and x.stride(0) == D * H * W * cin0p):
+            xin = x            # already voxel-major with rows of cin0p (zero padded) channels, e.g. from mind_hook
+        else:
+            xin = torch.empty((B, D, H, W, cin0p), dtype=adt, device=dev)
+            xs = x.contiguous().float()
+            check(lib.dgtta_ncdhw_to_ndhwc(ptr(xs), ptr(xin), B, cin0, D * H * W, cin0p, dt, st), "dgtta_ncdhw_to_ndhwc")
+
+        saved = []   # per conv block: dict(u, ldu, y, mr, dims...)
+        ws_cache = {}
+
+        def ws_for(nbytes):
+            nb = int(nbytes)
+            t = ws_cache.get("ws")
+            if t is None or t.numel() < nb:
+                t = _ws(nb, dev)
+                ws_cache["ws"] = t
+            return t
+
+        def run_block(blk_mod, u, ldu, cin, dims_in, z_out=None, ldz=None):
+            """conv -> IN -> lrelu. u: tensor whose data_ptr()+offset is the input; returns (z, ldz, dims_out, rec)."""
+            conv, norm = blk_mod.conv, blk_mod.norm
+            s = conv.stride
+            cout = conv.out_channels
+            di, hi, wi = dims_in
+            do, ho, wo = _odim(di, s), _odim(hi, s), _odim(wi, s)
+            cinp, coutp = _pad(cin, CP), _pad(cout, CP)
+            wf, wb = net.packed(conv, dt, cinp, coutp)
+            y = torch.empty((B, do, ho, wo, cout), dtype=adt, device=dev)
+            check(lib.dgtta_conv3d_k3_fwd(u, ldu, ptr(wf), ptr(conv.bias), ptr(y), cout, None, B, cin, cout, cinp, coutp,
+                                          di, hi, wi, s, dt, impl, st), "dgtta_conv3d_k3_fwd")
+            v = do * ho * wo
+            mr = torch.empty((B, cout, 2), dtype=torch.float32, device=dev)
+            if z_out is None:
+                zt = torch.empty((B, do, ho, wo, cout), dtype=adt, device=dev)
+                zp, ldz_ = zt.data_ptr(), cout
+            else:
+                zt, zp, ldz_ = z_out[0], z_out[1], ldz
+            nb = lib.dgtta_instnorm_ws_bytes(B, cout, v)
+            w_ = ws_for(nb)
+            check(lib.dgtta_instnorm_lrelu_fwd(ptr(y), cout, None, ptr(norm.weight), ptr(norm.bias), ptr(mr), zp, ldz_,
+                                               ptr(w_), nb, B, cout, v, EPS, SLOPE, dt, st), "dgtta_instnorm_lrelu_fwd")
+            rec = dict(mod=blk_mod, u=u, ldu=ldu, cin=cin, cout=cout, s=s, din=dims_in, dout=(do, ho, wo), y=y, mr=mr,
+                       zt=zt, zp=zp, ldz=ldz_, cinp=cinp, coutp=coutp)
+            return zp, ldz_, (do, ho, wo), rec, zt
+
+        esz = 4 if dt == F32 else 2
+        # ---- encoder
+        dims = (D, H, W)
+        u_ptr, ldu, cin = xin.data_ptr(), cin0p, cin0
+        keep = [xin]
+        cat_bufs = []     # per encoder stage (except last): (tensor [B,d,h,w,2C], C, dims)
+        skip_info = []
+        for si, blocks in enumerate(enc):
+            cstage = cfg["features"][si]
+            for bi, blk in enumerate(blocks):
+                last = bi == len(blocks) - 1
+                z_out, ldz = None, None
+                if last and si < nst - 1:
+                    s = blk.conv.stride
+                    do, ho, wo = _odim(dims[0], s), _odim(dims[1], s), _odim(dims[2], s)
+                    cat = torch.empty((B, do, ho, wo, 2 * cstage), dtype=adt, device=dev)
+                    cat_bufs.append((cat, cstage, (do, ho, wo)))
+                    z_out, ldz = (cat, cat.data_ptr() + cstage * esz), 2 * cstage
+                u_ptr, ldu, dims, rec, zt = run_block(blk, u_ptr, ldu, cin, dims, z_out, ldz)
+                rec["where"] = ("enc", si, bi)
+                saved.append(rec)
+                keep.append(zt)
+                cin = cstage
+        # ---- decoder
+        x_low_ptr, x_low_ld, x_low_c, low_dims = u_ptr, ldu, cin, dims
+        ups = []
+        for k, blocks in enumerate(dec):
+            cat, cskip, cdims = cat_bufs[-(k + 1)]
+            up = net.decoder.transpconvs[k]
+            check(lib.dgtta_convT3d_k2s2_fwd(x_low_ptr, x_low_ld, ptr(up.weight), ptr(up.bias), ptr(cat), 2 * cskip, B,
+                                             x_low_c, cskip, low_dims[0], low_dims[1], low_dims[2], dt, st),
+                  "dgtta_convT3d_k2s2_fwd")
+            ups.append(dict(mod=up, x=x_low_ptr, ldx=x_low_ld, cin=x_low_c, cout=cskip, din=low_dims, cat=cat))
+            u_ptr, ldu, cin, dims = cat.data_ptr(), 2 * cskip, 2 * cskip, cdims
+            for bi, blk in enumerate(blocks):
+                u_ptr, ldu, dims, rec, zt = run_block(blk, u_ptr, ldu, cin, dims)
+                rec["where"] = ("dec", k, bi)
+                saved.append(rec)
+                keep.append(zt)
+                cin = cskip
+            x_low_ptr, x_low_ld, x_low_c, low_dims = u_ptr, ldu, cin, dims
+        # ---- head (restricted to the selected rows when requested)
+        head = net.decoder.seg_layers[-1]
+        ncls = head.out_channels
+        nsel = ncls if sel is None else int(sel.numel())
+        V = D * H * W
+        out = torch.empty((B, D, H, W, nsel), dtype=torch.float32, device=dev)
+        check(lib.dgtta_seghead_fwd(u_ptr, ldu, ptr(head.weight), ptr(head.bias), ptr(sel), nsel, ptr(out), 1, nsel, B,
+                                    head.in_channels, V, dt, st), "dgtta_seghead_fwd")
+        if need_grad:
+            ctx.net, ctx.sel, ctx.saved, ctx.ups, ctx.keep, ctx.cat_bufs = net, sel, saved, ups, keep, cat_bufs
+            ctx.meta = (B, D, H, W, dt, impl, nsel, u_ptr, ldu)
+            ctx.params = params
+        return out.permute(0, 4, 1, 2, 3)
+
+    @staticmethod
+    def backward(ctx, gout):
+        lib = _lib.load()
+        net, sel, saved, ups, cat_bufs = ctx.net, ctx.sel, ctx.saved, ctx.ups, ctx.cat_bufs
+        B, D, H, W, dt, impl, nsel, zlast_ptr, zlast_ld = ctx.meta
+        params = ctx.params
+        dev = gout.device
+        st = stream_of(dev)
+        adt = net.act_dtype
+        esz = 4 if dt == F32 else 2
+        grads = {}          # id(param) -> grad tensor
+
+        def want(p):
+            return p.requires_grad
+
+        def gbuf(p):
+            g = grads.get(id(p))
+            if g is None:
+                g = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                grads[id(p)] = g
+            return g
+
+        ws_cache = {}
+
+        def ws_for(nbytes):
+            nb = int(nbytes)
+            t = ws_cache.get("ws")
+            if t is None or t.numel() < nb:
+                t = _ws(nb, dev)
+                ws_cache["ws"] = t
+            return t
+
+        V = D * H * W
+        g = gout.contiguous(memory_format=torch.channels_last_3d).float()      # [B,nsel,D,H,W] stored NDHWC
+        head = net.decoder.seg_layers[-1]
+        cin_h = head.in_channels
+        # ---- head backward
+        gz = torch.empty((B, D, H, W, cin_h), dtype=adt, device=dev)
+        nb = lib.dgtta_seghead_bwd_ws_bytes(B, cin_h, nsel, V)
+        w_ = ws_for(nb)
+        need_hw = want(head.weight) or want(head.bias)
+        dws = torch.empty((nsel, cin_h), dtype=torch.float32, device=dev) if need_hw else None
+        dbs = torch.empty((nsel,), dtype=torch.float32, device=dev) if need_hw else None
+        check(lib.dgtta_seghead_bwd(zlast_ptr, zlast_ld, ptr(g), nsel, ptr(head.weight), ptr(sel), nsel, ptr(gz), cin_h,
+                                    ptr(dws), ptr(dbs), ptr(w_), nb, B, cin_h, V, 0, dt, st), "dgtta_seghead_bwd")
+        if need_hw:
+            gw, gb = gbuf(head.weight), gbuf(head.bias)
+            if sel is None:
+                gw.view(-1, cin_h).copy_(dws)
+                gb.copy_(dbs)
+            else:
+                gw.view(-1, cin_h).index_add_(0, sel.long(), dws)
+                gb.index_add_(0, sel.long(), dbs)
+
+        # gradient buffers for the concat tensors (zero-free: fully written by the consuming conv's dgrad)
+        gcat = {}
+
+        gz_ptr, gz_ld = gz.data_ptr(), cin_h
+        keep_alive = [gz]
+        first_rec = saved[0]
+        # walk blocks in reverse order
+        idx = len(saved) - 1
+        n_dec_stages = len(ups)
+        while idx >= 0:
+            rec = saved[idx]
+            blk = rec["mod"]
+            conv, norm = blk.conv, blk.norm
+            cin, cout, s = rec["cin"], rec["cout"], rec["s"]
+            di, hi, wi = rec["din"]
+            do, ho, wo = rec["dout"]
+            v = do * ho * wo
+            # -- InstanceNorm + LeakyReLU backward (dy overwrites a fresh dense buffer)
+            dy = torch.empty((B, do, ho, wo, cout), dtype=adt, device=dev)
+            nb = lib.dgtta_instnorm_ws_bytes(B, cout, v)
+            w_ = ws_for(nb)
+            dgam = gbuf(norm.weight) if want(norm.weight) else torch.empty_like(norm.weight)
+            dbet = gbuf(norm.bias) if want(norm.bias) else torch.empty_like(norm.bias)
+            check(lib.dgtta_instnorm_lrelu_bwd(gz_ptr, gz_ld, ptr(rec["y"]), cout, ptr(norm.weight), ptr(norm.bias),
+                                               ptr(rec["mr"]), ptr(dy), cout, ptr(dgam), ptr(dbet), ptr(w_), nb, B, cout,
+                                               v, SLOPE, 0, dt, st), "dgtta_instnorm_lrelu_bwd")
+            # -- weight / bias gradient
+            if want(conv.weight) or want(conv.bias):
+                nb = lib.dgtta_conv3d_wgrad_ws_bytes(B, cin, cout, do, ho, wo)
+                w_ = ws_for(nb)
+                dw = gbuf(conv.weight) if want(conv.weight) else torch.empty_like(conv.weight)
+                db = gbuf(conv.bias) if want(conv.bias) else None
+                check(lib.dgtta_conv3d_k3_wgrad(rec["u"], rec["ldu"], ptr(dy), cout, ptr(dw), ptr(db), ptr(w_), nb, B,
+                                                cin, cout, di, hi, wi, s, 0, dt, impl, st), "dgtta_conv3d_k3_wgrad")
+            # -- data gradient towards the block input
+            where = rec["where"]
+            if idx == 0:
+                break
+            wf, wb = net.packed(conv, dt, rec["cinp"], rec["coutp"])
+            kind, sidx, bidx = where
+            if kind == "dec" and bidx == 0:
+                # input was the concat buffer of decoder stage sidx: gradient for [up | skip]
+                cat, cskip, cdims = cat_bufs[-(sidx + 1)]
+                gc = torch.empty_like(cat)
+                gcat[sidx] = gc
+                check(lib.dgtta_conv3d_k3_dgrad(ptr(dy), cout, ptr(wb), ptr(gc), 2 * cskip, B, cin, cout, rec["cinp"],
+                                                rec["coutp"], di, hi, wi, s, 0, dt, impl, st), "dgtta_conv3d_k3_dgrad")
+                # transposed-conv backward: dout = first half of gc
+                up = ups[sidx]
+                upm = up["mod"]
+                ld0, lh0, lw0 = up["din"]
+                glow = torch.empty((B, ld0, lh0, lw0, up["cin"]), dtype=adt, device=dev)
+                nb = lib.dgtta_convT3d_bwd_ws_bytes(B, up["cin"], up["cout"], ld0, lh0, lw0)
+                w_ = ws_for(nb)
+                need_w = want(upm.weight) or want(upm.bias)
+                dwu = (gbuf(upm.weight) if want(upm.weight) else torch.empty_like(upm.weight)) if need_w else None
+                dbu = gbuf(upm.bias) if want(upm.bias) else None
+                check(lib.dgtta_convT3d_k2s2_bwd(up["x"], up["ldx"], ptr(gc), 2 * cskip, ptr(upm.weight), ptr(glow),
+                                                 up["cin"], ptr(dwu), ptr(dbu), ptr(w_), nb, B, up["cin"], up["cout"],
+                                                 ld0, lh0, lw0, 0, dt, st), "dgtta_convT3d_k2s2_bwd")
+                gz_ptr, gz_ld = glow.data_ptr(), up["cin"]
+                keep_alive = [glow, gc]
+            elif kind == "enc" and bidx == 0:
+                # input was the previous encoder stage's output, which lives in the second half of a concat buffer
+                # and already holds the decoder's skip gradient: accumulate into it.
+                prev_stage = sidx - 1
+                dec_k = n_dec_stages - 1 - prev_stage
+                gc = gcat[dec_k]
+                cskip = cat_bufs[prev_stage][1]
+                gptr = gc.data_ptr() + cskip * esz
+                check(lib.dgtta_conv3d_k3_dgrad(ptr(dy), cout, ptr(wb), gptr, 2 * cskip, B, cin, cout, rec["cinp"],
+                                                rec["coutp"], di, hi, wi, s, 1, dt, impl, st), "dgtta_conv3d_k3_dgrad")
+                gz_ptr, gz_ld = gptr, 2 * cskip
+                keep_alive = [gc]
+            else:
+                gin = torch.empty((B, di, hi, wi, cin), dtype=adt, device=dev)
+                check(lib.dgtta_conv3d_k3_dgrad(ptr(dy), cout, ptr(wb), ptr(gin), cin, B, cin, cout, rec["cinp"],
+                                                rec["coutp"], di, hi, wi, s, 0, dt, impl, st), "dgtta_conv3d_k3_dgrad")
+                gz_ptr, gz_ld = gin.data_ptr(), cin
+                keep_alive = [gin]
+            idx -= 1
+        del keep_alive, first_rec
+        out = [None, None, None]
+        for p in params:
+            out.append(grads.get(id(p)) if p.requires_grad else None)
+        return tuple(out)

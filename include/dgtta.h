@@ -95,13 +95,15 @@ int dgtta_affine_warp3d_bwd(const float *grad_dst, const float *theta, float *gr
  * mask=(sum_c a>0)(sum_c b>0); sm=softmax_c * mask; dice_c = mean(2ab)/mean((a+b)^2/2);
  * loss = 1 - mean_{b, c>=start_class} dice.  la, lb: logits NDHWC [B][V][ldc], C classes, fp32.
  * fwd writes dice[B*C], loss[1] and keeps what bwd needs in ws.  bwd writes grad_la/grad_lb
- * (same layout) = grad_scale * dloss/dlogits (mask treated as constant, as autograd does).
+ * (same layout) = grad_scale * (grad_scale_dev ? *grad_scale_dev : 1) * dloss/dlogits (mask treated as
+ * a constant, as autograd does; the device scalar lets autograd's upstream gradient stay on the GPU).
  * ------------------------------------------------------------------------------------------- */
 size_t dgtta_softdice_ws_bytes(int B, int C, int64_t V);
 int dgtta_softdice_fwd(const float *la, const float *lb, float *dice, float *loss, void *ws, size_t ws_bytes,
                        int B, int C, int64_t V, int ldc, int start_class, void *stream);
 int dgtta_softdice_bwd(const float *la, const float *lb, float *grad_la, float *grad_lb, const void *ws,
-                       float grad_scale, int B, int C, int64_t V, int ldc, int start_class, void *stream);
+                       float grad_scale, const float *grad_scale_dev, int B, int C, int64_t V, int ldc,
+                       int start_class, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * AdamW (decoupled weight decay, bias-corrected, no amsgrad) over a list of tensors.  Replaces
@@ -188,8 +190,9 @@ int dgtta_ncdhw_to_ndhwc(const float *src, void *dst, int B, int C, int64_t V, i
 int dgtta_ndhwc_to_ncdhw(const void *src, float *dst, int B, int C, int64_t V, int ldc, int dtype, void *stream);
 
 /* argmax over channels + per-label hard Dice counts; replaces tta.py:321 + dice_coeff
- * (torch_utils.py:107-117).  logits NDHWC fp32; labels int64 [B][V] or NULL; argmax_out int64 [B][V];
- * counts[3*C] int64 (|pred==l|, |gt==l|, |both|), zeroed by the caller. */
+ * (torch_utils.py:107-117).  logits NDHWC fp32 (or NULL: predictions are read from argmax_out);
+ * labels int64 [B][V] or NULL; argmax_out int64 [B][V]; counts[3*C] int64 (|pred==l|, |gt==l|,
+ * |both|), zeroed by the caller. */
 int dgtta_argmax_dice(const float *logits, int ldc, int C, const int64_t *labels, int64_t *argmax_out,
                       int64_t *counts, int B, int64_t V, void *stream);
 

@@ -1,0 +1,310 @@
+"""GPU parity: HIP kernels (through the C ABI) vs the CPU oracle and the reference-generated golden vectors.
+
+Tolerances (fp32 path): the kernels and the oracle sum in different orders, so float results agree to a few ulp of
+the accumulated magnitude; stated per test.  Integer outputs (argmax, label patches) must be bit-exact.
+"""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import load_golden, SMALL_CFG, state_from_golden
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+def _close(a, b, atol, rtol=0.0, what=""):
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    assert a.shape == b.shape, f"{what}: shape {tuple(a.shape)} vs {tuple(b.shape)}"
+    err = (a - b).abs()
+    lim = atol + rtol * b.abs()
+    assert bool((err <= lim).all()), f"{what}: max err {err.max().item():.3e} (limit {atol:g}+{rtol:g}*|ref|), " \
+                                     f"ref max {b.abs().max().item():.3e}"
+
+
+# ------------------------------------------------------------------------------------------------ MIND
+@pytest.mark.parametrize("tag", ["16", "ragged", "const"])
+def test_mind_golden(tag):
+    from dg_tta_amd import ops
+    g = load_golden(f"mind3d_{tag}")
+    out = ops.mind3d(g["img"].to(DEV), g["noise"].to(DEV))
+    _close(out, g["out"], atol=2e-6, rtol=2e-5, what=f"mind3d {tag}")     # outputs are exp(-x) in (0,1]
+
+
+def test_mind_multitile_and_layouts():
+    from dg_tta_amd import ops
+    from oracle import mind as omind
+    torch.manual_seed(3)
+    img = torch.randn(1, 1, 19, 21, 70) * 3 + 1      # several tiles per axis, ragged edges
+    noise = torch.randn(1, 12, 19, 21, 70)
+    ref = omind.mind3d(img, noise)
+    out = ops.mind3d(img.to(DEV), noise.to(DEV))
+    _close(out, ref, atol=2e-6, rtol=2e-5, what="mind3d multitile")
+    nd = ops.mind3d(img.to(DEV), noise.to(DEV), out_format="ndhwc", out_ldc=16)
+    assert tuple(nd.shape) == (1, 19, 21, 70, 16)
+    assert torch.equal(nd[..., :12].permute(0, 4, 1, 2, 3).contiguous(), out)       # same numbers, other layout
+    assert float(nd[..., 12:].abs().max()) == 0.0
+    bf = ops.mind3d(img.to(DEV), noise.to(DEV), out_format="ndhwc", out_ldc=16, out_dtype=torch.bfloat16)
+    _close(bf[..., :12].float(), nd[..., :12], atol=4e-3, what="mind3d bf16 store")
+
+
+def test_mind_module_draws_device_noise():
+    from dg_tta_amd.mind import MIND3D, mind_hook
+    x = torch.randn(1, 1, 16, 16, 16, device=DEV)
+    torch.manual_seed(5)
+    a = MIND3D()(x)
+    torch.manual_seed(5)
+    n = torch.randn(1, 12, 16, 16, 16, device=DEV)
+    b = MIND3D()(x, n)
+    assert torch.equal(a, b)
+    torch.manual_seed(5)
+    assert torch.equal(mind_hook(None, (x,)), a)
+
+
+# ------------------------------------------------------------------------------------------------ GIN
+@pytest.mark.parametrize("i", range(7))
+def test_gin_golden(i):
+    from dg_tta_amd import ops
+    g = load_golden(f"gin_{i}")
+    ks = [int(k) for k in g["ks"]]
+    out = ops.gin_chain(g["x"].to(DEV), g["alpha"].to(DEV), ks, [g[f"ker{j}"].to(DEV) for j in range(4)],
+                        [g[f"shift{j}"].to(DEV) for j in range(4)])
+    scale = float(g["out"].abs().max())
+    _close(out, g["out"], atol=2e-5 * scale, what=f"gin {i} ks={ks}")
+
+
+def test_gin_multitile():
+    from dg_tta_amd import ops
+    from oracle import gin as ogin
+    torch.manual_seed(9)
+    x = torch.randn(2, 1, 21, 19, 37)
+    torch.manual_seed(10)
+    alpha, ks, kers, shifts = ogin.draw_gin_params(2)
+    ref = ogin.gin_chain(x, alpha, ks, kers, shifts)
+    out = ops.gin_chain(x.to(DEV), alpha.to(DEV), ks, [k.to(DEV) for k in kers], [s.to(DEV) for s in shifts])
+    _close(out, ref, atol=2e-5 * float(ref.abs().max()), what="gin multitile")
+    # Frobenius norm preservation (gin.py:197-228): ||out|| == ||x|| per sample
+    for b in range(2):
+        assert abs(float(out[b].norm()) / float(x[b].norm()) - 1.0) < 1e-4
+
+
+def test_gin_aug_draw_order_matches_reference():
+    from dg_tta_amd.gin import draw_gin_params
+    from oracle import gin as ogin
+    torch.manual_seed(77)
+    a1, k1, w1, s1 = ogin.draw_gin_params(1)
+    torch.manual_seed(77)
+    torch.rand(1)                       # the oracle drew alpha from the CPU generator; the device draw does not touch it
+    a2, k2, w2, s2 = draw_gin_params(1, DEV)
+    assert k1 == k2
+    for p, q in zip(w1 + s1, w2 + s2):
+        assert torch.equal(p, q.cpu())
+
+
+# ------------------------------------------------------------------------------------------------ warp / sampling
+def _theta(b, seed, strength=0.05):
+    from oracle import tta as otta
+    torch.manual_seed(seed)
+    return otta.rand_affine_from_draw(torch.randn(b, 3, 4), strength)
+
+
+@pytest.mark.parametrize("pad", ["border", "zeros"])
+@pytest.mark.parametrize("cl", [False, True])
+def test_warp_forward(pad, cl):
+    from dg_tta_amd import ops
+    from oracle import tta as otta
+    r, _ = _theta(2, 1, 0.08)
+    torch.manual_seed(2)
+    x = torch.randn(2, 4, 12, 14, 18)
+    ref = otta.warp(x, r, pad)
+    xd = x.to(DEV)
+    if cl:
+        xd = xd.contiguous(memory_format=torch.channels_last_3d)
+    out = ops.affine_warp(xd, r.to(DEV), padding_mode=pad, tta_grid_algebra=True)
+    _close(out, ref, atol=2e-5, what=f"warp {pad} cl={cl}")
+
+
+def test_warp_backward_matches_autograd():
+    from dg_tta_amd import ops
+    from oracle import tta as otta
+    _, rinv = _theta(1, 4, 0.08)
+    torch.manual_seed(5)
+    x = torch.randn(1, 8, 10, 12, 14, requires_grad=True)
+    gy = torch.randn(1, 8, 10, 12, 14)
+    otta.warp(x, rinv, "zeros").backward(gy)
+    for cl in (False, True):
+        xd = x.detach().to(DEV)
+        if cl:
+            xd = xd.contiguous(memory_format=torch.channels_last_3d)
+        xd.requires_grad_(True)
+        ops.affine_warp(xd, rinv.to(DEV), padding_mode="zeros", tta_grid_algebra=True).backward(gy.to(DEV))
+        _close(xd.grad, x.grad, atol=5e-5, what=f"warp bwd cl={cl}")
+
+
+def test_get_batch_golden():
+    from dg_tta_amd.tta.torch_utils import get_batch
+    g = load_golden("get_batch")
+    torch.manual_seed(21)      # the reference draws torch.rand(3) on the CPU generator
+    imgs, lbls = get_batch([g["data"]], [0], [16, 16, 16], device=DEV)
+    _close(imgs[0], g["img"], atol=3e-3, what="get_batch img")          # values ~ -300 +- 100: 1e-5 relative
+    assert torch.equal(lbls[0].cpu(), g["lbl"])                          # integer label patch: bit exact
+    imgs, lbls = get_batch([g["data"]], [0], [16, 16, 16], fixed_patch_idx="center", device=DEV)
+    _close(imgs[0], g["cimg"], atol=3e-3, what="get_batch center img")
+    assert torch.equal(lbls[0].cpu(), g["clbl"])
+    torch.manual_seed(22)
+    imgs, lbls = get_batch([g["small"]], [0], [16, 16, 16], device=DEV)
+    assert lbls[0] is None
+    _close(imgs[0], g["small_img"], atol=1e-4, what="get_batch small img")
+
+
+# ------------------------------------------------------------------------------------------------ loss
+def test_consistency_loss_golden_and_grad():
+    from dg_tta_amd import ops
+    from oracle import tta as otta
+    g = load_golden("loss")
+    ta, tb = g["ta"].clone().requires_grad_(True), g["tb"].clone().requires_grad_(True)
+    ref = otta.consistency_loss(ta, tb)
+    assert abs(float(ref) - float(g["loss"])) < 1e-6
+    (ref / 16).backward()
+    da, db = g["ta"].to(DEV).requires_grad_(True), g["tb"].to(DEV).requires_grad_(True)
+    loss, dice = ops.consistency_loss(da, db)
+    assert abs(float(loss) - float(g["loss"])) < 2e-6
+    (loss / 16).backward()
+    _close(da.grad, ta.grad, atol=1e-8, rtol=1e-3, what="dloss/dlogits_a")
+    _close(db.grad, tb.grad, atol=1e-8, rtol=1e-3, what="dloss/dlogits_b")
+
+
+def test_consistency_loss_edge_cases():
+    from dg_tta_amd import ops
+    from oracle import tta as otta
+    # all voxels masked out (channel sums <= 0) -> denominator.sum()==0 -> dice = 1 -> loss = 0 (torch_utils.py:97-98)
+    neg = -torch.rand(1, 3, 4, 5, 6) - 0.1
+    loss, dice = ops.consistency_loss(neg.to(DEV), neg.to(DEV))
+    assert float(loss) == 0.0 and torch.equal(dice.cpu(), torch.ones(1, 3))
+    assert float(otta.consistency_loss(neg, neg)) == 0.0
+    # identical, unmasked inputs -> dice 1
+    pos = torch.rand(2, 5, 6, 7, 9) + 0.1
+    loss, dice = ops.consistency_loss(pos.to(DEV), pos.to(DEV))
+    assert abs(float(loss)) < 1e-6
+    # many classes, B=2, ragged volume
+    torch.manual_seed(1)
+    a, b = torch.randn(2, 21, 5, 7, 11), torch.randn(2, 21, 5, 7, 11)
+    loss, _ = ops.consistency_loss(a.to(DEV), b.to(DEV))
+    assert abs(float(loss) - float(otta.consistency_loss(a, b))) < 2e-6
+
+
+def test_argmax_dice_bit_exact():
+    from dg_tta_amd import ops
+    from dg_tta_amd.tta.torch_utils import dice_coeff
+    from oracle import tta as otta
+    g = load_golden("loss")
+    torch.manual_seed(3)
+    logits = torch.randn(1, 4, 8, 8, 8)
+    am, counts = ops.argmax_dice(logits.to(DEV), g["dc_lab"].to(DEV))
+    assert torch.equal(am.cpu(), logits.argmax(1))
+    d = dice_coeff(am, g["dc_lab"].to(DEV), 4)
+    assert torch.allclose(d.cpu(), otta.dice_coeff(logits.argmax(1), g["dc_lab"], 4), atol=1e-6)
+    d2 = dice_coeff(g["dc_out"].to(DEV), g["dc_lab"].to(DEV), 4)
+    assert torch.allclose(d2.cpu(), g["dc"], atol=1e-6)
+
+
+# ------------------------------------------------------------------------------------------------ AdamW
+def test_adamw_golden():
+    from dg_tta_amd.optim import HipAdamW
+    g = load_golden("adamw")
+    p = torch.nn.Parameter(g["p0"].to(DEV))
+    frozen = torch.nn.Parameter(torch.ones(5, device=DEV))        # grad None -> untouched (no decay either)
+    opt = HipAdamW([p, frozen], lr=float(g["lr"]))
+    for grad in (g["g1"], g["g2"]):
+        p.grad = grad.to(DEV)
+        opt.step()
+        opt.zero_grad()
+    _close(p, g["p2"], atol=1e-6, what="adamw 2 steps")
+    assert torch.equal(frozen.detach().cpu(), torch.ones(5))
+    assert p.grad is None
+
+
+# ------------------------------------------------------------------------------------------------ network
+def _models(cfg, seed=0):
+    from oracle import unet as ounet
+    from dg_tta_amd.unet import HipPlainConvUNet
+    om = ounet.perturb_affine(ounet.init_he(ounet.PlainConvUNetOracle(cfg), seed), seed + 1)
+    hm = HipPlainConvUNet(cfg, conv_impl=1)
+    hm.load_state_dict(om.state_dict())
+    return om, hm.to(DEV)
+
+
+def _grad_check(om, hm, x, sel=None, atol_rel=2e-4):
+    y_ref = om(x)
+    if sel is not None:
+        y_ref = y_ref[:, sel]
+        hm.set_selected_classes(sel)
+    y = hm(x.to(DEV))
+    _close(y, y_ref, atol=2e-4 * float(y_ref.abs().max()), what="unet logits")
+    torch.manual_seed(11)
+    gy = torch.randn_like(y_ref)
+    y_ref.backward(gy)
+    y.backward(gy.to(DEV))
+    ref = dict(om.named_parameters())
+    worst = 0.0
+    for name, p in hm.named_parameters():
+        r = ref[name].grad
+        if r is None:
+            assert p.grad is None, name
+            continue
+        assert p.grad is not None, name
+        scale = float(r.abs().max())
+        if name.endswith("conv.bias") and ".convs." in name:
+            # bias in front of InstanceNorm: mathematically zero gradient, both sides hold rounding noise only
+            assert float(p.grad.abs().max()) < 1e-3 * max(1.0, float(gy.abs().max()))
+            continue
+        err = float((p.grad.cpu() - r).abs().max())
+        worst = max(worst, err / max(scale, 1e-12))
+        assert err <= atol_rel * scale + 1e-7, f"{name}: grad err {err:.3e} vs scale {scale:.3e}"
+    return worst
+
+
+def test_unet_small_forward_backward():
+    om, hm = _models(SMALL_CFG)
+    torch.manual_seed(2)
+    x = torch.randn(1, 12, 16, 16, 16)
+    _grad_check(om, hm, x)
+
+
+def test_unet_selected_rows_and_batch2():
+    cfg = dict(SMALL_CFG, features=(6, 10, 14), num_classes=11)       # odd channel counts
+    om, hm = _models(cfg, seed=3)
+    torch.manual_seed(4)
+    x = torch.randn(2, 12, 8, 16, 24)
+    _grad_check(om, hm, x, sel=torch.tensor([0, 3, 4, 9]))
+
+
+def test_unet_frozen_and_norm_only_grads():
+    from dg_tta_amd.tta.torch_utils import fix_all, release_norms
+    om, hm = _models(SMALL_CFG)
+    x = torch.randn(1, 12, 16, 16, 16)
+    hm.apply(fix_all)
+    y = hm(x.to(DEV))
+    assert not y.requires_grad
+    hm.apply(release_norms)
+    om.apply(fix_all)
+    for m in om.modules():
+        if isinstance(m, torch.nn.InstanceNorm3d):
+            for p in m.parameters():
+                p.requires_grad_(True)
+    y = hm(x.to(DEV))
+    y.square().mean().backward()
+    om(x).square().mean().backward()
+    for (n, p), (_, q) in zip(hm.named_parameters(), om.named_parameters()):
+        if ".norm." in n:
+            _close(p.grad, q.grad, atol=2e-4 * float(q.grad.abs().max()) + 1e-9, what=n)
+        else:
+            assert p.grad is None
+
+
+def test_cpu_tensor_is_rejected():
+    from dg_tta_amd import ops
+    from dg_tta_amd._lib import DgttaError
+    with pytest.raises(DgttaError):
+        ops.mind3d(torch.zeros(1, 1, 8, 8, 8), torch.zeros(1, 12, 8, 8, 8))

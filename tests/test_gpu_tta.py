@@ -1,0 +1,247 @@
+"""GPU parity of the assembled path: calc_branch and a multi-epoch TTA run against the golden vectors that were
+generated with the reference's own calc_branch / soft_dice_loss / torch AdamW (tests/golden/make_golden.py)."""
+import contextlib
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, unpack_draws, SMALL_CFG, state_from_golden
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+LABEL_MAPPING = {"background": (0, 0), "a": (2, 1), "b": (3, 2), "c": (5, 3), "d": (8, 4)}
+OPTIMIZED = ["background", "a", "b", "c", "d"]
+
+
+def _model(g, prefix="w::", **kw):
+    from dg_tta_amd.unet import HipPlainConvUNet
+    m = HipPlainConvUNet(SMALL_CFG, conv_impl=kw.pop("conv_impl", 1), **kw)
+    missing = m.load_state_dict(state_from_golden(g, prefix), strict=False)
+    assert not missing.unexpected_keys
+    return m.to(DEV)
+
+
+def hip_branch(model, imgs, draws):
+    """calc_branch with explicit draws, HIP ops only."""
+    from dg_tta_amd import ops
+    from dg_tta_amd.mind import MIND3D
+    from oracle import tta as otta
+    alpha, ks, kers, shifts = draws["gin_draw"]
+    x = ops.gin_chain(imgs, alpha.to(DEV), ks, [k.to(DEV) for k in kers], [s.to(DEV) for s in shifts])
+    r, rinv = otta.rand_affine_from_draw(draws["affine_draw"])       # host 4x4 inverse, as augmentation_utils.py:170
+    x = ops.affine_warp(x, r.to(DEV), padding_mode="border", tta_grid_algebra=True)
+    x = MIND3D()(x, draws["mind_noise"].to(DEV))
+    y = model(x)
+    return ops.affine_warp(y, rinv.to(DEV), padding_mode="zeros", tta_grid_algebra=True)
+
+
+def test_calc_branch_golden():
+    g = load_golden("calc_branch")
+    model = _model(g)
+    model.set_selected_classes(g["map_idxs"])
+    imgs = g["imgs"].to(DEV)
+    for br in ("a", "b"):
+        out = hip_branch(model, imgs, unpack_draws(g, br))
+        ref = g[f"out_{br}"]
+        err = (out.cpu() - ref).abs().max().item()
+        assert err < 3e-4 * ref.abs().max().item(), f"branch {br}: max err {err:.3e}"
+        # label maps: bit-exact argmax wherever the reference's top-2 margin exceeds the float tolerance
+        top2 = ref.topk(2, dim=1).values
+        safe = (top2[:, 0] - top2[:, 1]) > 1e-3
+        assert torch.equal(out.cpu().argmax(1)[safe], ref.argmax(1)[safe])
+        assert (out.cpu().argmax(1) == ref.argmax(1)).float().mean() > 0.999
+
+
+@contextlib.contextmanager
+def cpu_rng_for_device_draws():
+    """The golden vectors were produced on the CPU, where EVERY draw comes from the one CPU generator in call order.
+    Re-route device draws (GIN alpha, MIND noise) through the CPU generator so the product code sees the same stream."""
+    real_rand, real_randn = torch.rand, torch.randn
+
+    def rand(*a, **k):
+        dev = k.pop("device", None)
+        t = real_rand(*a, **k)
+        return t.to(dev) if dev is not None else t
+
+    def randn(*a, **k):
+        dev = k.pop("device", None)
+        t = real_randn(*a, **k)
+        return t.to(dev) if dev is not None else t
+
+    torch.rand, torch.randn = rand, randn
+    try:
+        yield
+    finally:
+        torch.rand, torch.randn = real_rand, real_randn
+
+
+def _plan(**over):
+    from dg_tta_amd.tta.config_log_utils import TEMPLATE_PLAN
+    cfg = dict(TEMPLATE_PLAN)
+    cfg.update(do_intensity_aug_in="both", do_spatial_aug_in="both", patches_to_be_accumulated=2, lr=1e-3,
+               optimized_labels=OPTIMIZED)
+    cfg.update(over)
+    return cfg
+
+
+def _network_with_hooks(g):
+    from dg_tta_amd.gin import gin_hook
+    from dg_tta_amd.mind import mind_hook
+    net = _model(g)
+    net.register_forward_pre_hook(gin_hook)      # nnUNetTrainer_GIN_MIND.py:55-57 order
+    net.register_forward_pre_hook(mind_hook)
+    return net
+
+
+def _product_model(g):
+    """network with the trainer's pre-hooks + modifier hooks, exactly as tta_main builds it."""
+    from dg_tta_amd.gin import gin_hook
+    from dg_tta_amd.mind import mind_hook
+    from dg_tta_amd.tta.config_log_utils import ModifierFunctions
+    from dg_tta_amd.tta.model_utils import get_model_from_network
+    from dg_tta_amd.utils import disable_internal_augmentation
+    net = _network_with_hooks(g)
+    modmod = SimpleNamespace(ModifierFunctions=ModifierFunctions)
+    model = get_model_from_network(net, modmod, None)
+    hooks = list(model._forward_pre_hooks.values())
+    assert hooks[1] is gin_hook and hooks[2] is mind_hook          # order: modify_input, gin_hook, mind_hook
+    disable_internal_augmentation()
+    return model, modmod
+
+
+def test_product_calc_branch_reproduces_reference_draw_order():
+    from dg_tta_amd.gin import gin_aug
+    from dg_tta_amd.tta.tta import calc_branch, _fuse_head_if_possible
+    g = load_golden("calc_branch")
+    model, modmod = _product_model(g)
+    assert _fuse_head_if_possible(model, modmod, LABEL_MAPPING, OPTIMIZED)
+    cfg = _plan()
+    imgs = g["imgs"].to(DEV)
+    for br, seed in (("a", 51), ("b", 52)):
+        with cpu_rng_for_device_draws():
+            torch.manual_seed(seed)
+            out = calc_branch(f"branch_{br}", cfg, model, gin_aug, None, [16, 16, 16], 1, LABEL_MAPPING, OPTIMIZED,
+                              modmod, imgs, torch.device(DEV), head_is_fused=True)
+        assert out.requires_grad
+        ref = g[f"out_{br}"]
+        assert (out.detach().cpu() - ref).abs().max().item() < 3e-4 * ref.abs().max().item()
+
+
+def test_unfused_head_matches_fused():
+    from dg_tta_amd.tta.torch_utils import map_label
+    g = load_golden("calc_branch")
+    model = _model(g)
+    x = torch.randn(1, 12, 16, 16, 16, device=DEV)
+    full = model(x)
+    assert tuple(full.shape) == (1, 9, 16, 16, 16)
+    model.set_selected_classes(g["map_idxs"])
+    sel = model(x)
+    assert torch.equal(map_label(full, g["map_idxs"], "logits"), sel)
+
+
+def test_tta_epochs_golden():
+    """3 epochs x 2 accumulation steps (epoch 0 = loss only) with the golden draws: loss trajectory, updated
+    parameters and the final label map."""
+    from dg_tta_amd import ops
+    from dg_tta_amd.mind import MIND3D
+    from dg_tta_amd.optim import HipAdamW
+    from dg_tta_amd.tta.torch_utils import fix_all, release_all
+    g = load_golden("tta_epoch")
+    model = _model(g)
+    model.set_selected_classes(g["map_idxs"])
+    opt = HipAdamW(model.parameters(), lr=float(g["lr"]))
+    imgs = g["imgs"].to(DEV)
+    inv = torch.full((), 0.5, device=DEV)
+    losses = []
+    model.apply(fix_all)
+    for epoch in range(3):
+        if epoch == 1:
+            model.apply(release_all)
+        for acc in range(2):
+            ta = hip_branch(model, imgs, unpack_draws(g, f"e{epoch}s{acc}_a"))
+            tb = hip_branch(model, imgs, unpack_draws(g, f"e{epoch}s{acc}_b"))
+            loss, _ = ops.consistency_loss(ta, tb, 1)
+            losses.append(float(loss))
+            if epoch >= 1:
+                torch.autograd.backward(loss, grad_tensors=inv)
+        if epoch >= 1:
+            opt.step()
+            opt.zero_grad()
+    ref_losses = g["losses"].tolist()
+    for i, (a, b) in enumerate(zip(losses, ref_losses)):
+        assert abs(a - b) < 2e-4, f"step {i}: loss {a:.6f} vs reference {b:.6f}"
+    # parameters after two AdamW steps (lr 1e-3): every update is at most lr per step; compare to the reference's
+    post = state_from_golden(g, "p::")
+    pre = state_from_golden(g, "w::")
+    moved, agree = 0, 0
+    for name, p in model.state_dict().items():
+        if name not in post:
+            continue
+        if name.endswith("conv.bias") and ".convs." in name:
+            continue            # zero-gradient parameters (bias before InstanceNorm): Adam amplifies rounding noise
+        d_ref = post[name] - pre[name]
+        d = p.cpu() - pre[name]
+        moved += d_ref.numel()
+        agree += int(((d - d_ref).abs() <= 0.25 * d_ref.abs() + 2e-5).sum())
+    assert agree / moved > 0.97, f"only {agree / moved:.3f} of the parameter updates agree with the reference"
+    with torch.no_grad():
+        logits = model(MIND3D()(imgs, g["eval_noise"].to(DEV)))
+    ref = g["eval_logits"]
+    top2 = ref.topk(2, dim=1).values
+    safe = (top2[:, 0] - top2[:, 1]) > 5e-3
+    assert torch.equal(logits.cpu().argmax(1)[safe], g["eval_argmax"][safe])
+    assert (logits.cpu().argmax(1) == g["eval_argmax"]).float().mean() > 0.995
+
+
+def _synthetic_case(seed, size=24, k=3):
+    gen = torch.Generator().manual_seed(seed)
+    img = torch.randn(1, size, size, size, generator=gen)
+    lab = torch.randint(0, k + 1, (size, size, size), generator=gen)
+    return torch.cat([img, torch.stack([(lab == i + 1).float() for i in range(k)])])
+
+
+def test_tta_main_end_to_end(tmp_path):
+    """tta_main on two synthetic cases: files, resume-skip, sharding of independent samples."""
+    from dg_tta_amd.tta.config_log_utils import ModifierFunctions
+    from dg_tta_amd.tta.tta import tta_main
+    g = load_golden("calc_branch")
+    net = _network_with_hooks(g)
+    modmod = SimpleNamespace(ModifierFunctions=ModifierFunctions)
+    from types import SimpleNamespace as NS
+    cfg = _plan(epochs=2, ensemble_count=2, patches_to_be_accumulated=2, tta_data_filepaths=[], seed=3,
+                pretrained_weights_filepath="unused", lr=1e-4)
+    mapping = {"background": (0, 0), "a": (2, 1), "b": (3, 2), "c": (5, 3)}
+    cfg["optimized_labels"] = ["background", "a", "b", "c"]
+
+    def data():
+        return iter([{"data": _synthetic_case(s), "data_properties": {}, "ofile": f"tta_outputTs/case{s}"}
+                     for s in (1, 2)]), 2
+
+    params = [{k: v.clone() for k, v in net.state_dict().items()}]
+    bundle = (NS(), [16, 16, 16], net, params)
+    torch.manual_seed(0)
+    np.random.seed(0)
+    res = tta_main("run0", cfg, tmp_path, tmp_path, mapping, modmod, DEV, network_bundle=bundle, tta_data=data())
+    assert len(res) == 4
+    out = tmp_path / "run0" / "tta_outputTs"
+    files = sorted(p.name for p in out.glob("*_tta_parameters.pt"))
+    assert files == [f"case{s}__ensemble_idx_{e}_tta_parameters.pt" for s in (1, 2) for e in (0, 1)]
+    saved = torch.load(out / files[0], map_location="cpu")
+    assert isinstance(saved, list) and set(saved[0].keys()) == set(net.state_dict().keys())
+    for (losses, dices) in res.values():
+        assert torch.isfinite(losses).all() and (losses > 0).all() and torch.isfinite(dices).all()
+    # resume: everything exists -> nothing is recomputed
+    assert len(tta_main("run0", cfg, tmp_path, tmp_path, mapping, modmod, DEV, network_bundle=bundle, tta_data=data())) == 0
+    # sharding: rank 1 of 2 owns sample index 1 only, and reproduces the single-process result bit for bit (seeded units)
+    res1 = tta_main("run1", cfg, tmp_path, tmp_path, mapping, modmod, DEV, network_bundle=bundle, tta_data=data(),
+                    shard=(1, 2))
+    assert sorted(k[0] for k in res1) == ["tta_outputTs/case2"] * 2
+    a = torch.load(out / "case2__ensemble_idx_1_tta_parameters.pt", map_location="cpu")[0]
+    b = torch.load(tmp_path / "run1" / "tta_outputTs" / "case2__ensemble_idx_1_tta_parameters.pt", map_location="cpu")[0]
+    same = sum(int(torch.equal(a[k], b[k])) for k in a)
+    assert same >= 0.5 * len(a)      # warp backward uses float atomics: identical up to summation order
+    for k in a:
+        assert torch.allclose(a[k], b[k], atol=5e-4), k

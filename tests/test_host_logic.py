@@ -1,0 +1,224 @@
+"""CPU tests: C-ABI surface (header <-> library <-> ctypes table), plan/CLI/folder logic, label mapping,
+nnU-Net model-folder parsing, and that the product refuses to run without the GPU (no CPU fallback)."""
+import ctypes
+import json
+import os
+import re
+import subprocess
+import sys
+from pathlib import Path
+
+import pytest
+import torch
+
+ROOT = Path(__file__).resolve().parents[1]
+
+
+def _header_prototypes():
+    text = (ROOT / "include" / "dgtta.h").read_text()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    protos = {}
+    for m in re.finditer(r"\b(?:int|size_t|const char \*)\s*\*?\s*(dgtta_\w+)\s*\(([^;]*?)\)\s*;", text, flags=re.S):
+        args = m.group(2).strip()
+        protos[m.group(1)] = 0 if args in ("", "void") else len(args.split(","))
+    return protos
+
+
+def test_library_exports_every_declared_symbol():
+    from dg_tta_amd import _lib
+    protos = _header_prototypes()
+    assert len(protos) >= 30
+    lib = ctypes.CDLL(str(_lib.LIB_PATH))          # loads without a GPU (no compute calls here)
+    for name in protos:
+        assert hasattr(lib, name), f"{name} declared in include/dgtta.h but not exported"
+    assert set(protos) == set(_lib.SIGNATURES), set(protos) ^ set(_lib.SIGNATURES)
+    for name, n in protos.items():
+        assert len(_lib.SIGNATURES[name][1]) == n, f"{name}: header has {n} args, ctypes table {len(_lib.SIGNATURES[name][1])}"
+    loaded = _lib.load()
+    assert loaded.dgtta_version() >= 10000
+    # host-side argument validation works without a device
+    assert loaded.dgtta_mind3d_fwd(None, None, 0.05, None, 0, 12, 0, None, 0, 1, 8, 8, 8, None) == -1
+    assert b"null pointer" in loaded.dgtta_last_error()
+    assert loaded.dgtta_mind3d_ws_bytes(1, 16, 16, 16) >= 16 ** 3 * 12 * 4
+
+
+def test_no_cpu_fallback():
+    from dg_tta_amd import ops
+    from dg_tta_amd._lib import DgttaError
+    from dg_tta_amd.gin import gin_aug
+    from dg_tta_amd.mind import MIND3D
+    from dg_tta_amd.unet import HipPlainConvUNet
+    with pytest.raises(DgttaError):
+        MIND3D()(torch.zeros(1, 1, 8, 8, 8))
+    with pytest.raises(DgttaError):
+        gin_aug(torch.zeros(1, 1, 8, 8, 8))
+    with pytest.raises(DgttaError):
+        ops.consistency_loss(torch.zeros(1, 2, 4, 4, 4), torch.zeros(1, 2, 4, 4, 4))
+    small = dict(features=(4, 8), strides=(1, 2), n_conv_enc=(1, 1), n_conv_dec=(1,), in_channels=12, num_classes=3)
+    with pytest.raises(DgttaError):
+        HipPlainConvUNet(small)(torch.zeros(1, 12, 8, 8, 8))
+
+
+def test_product_never_imports_oracle():
+    for py in (ROOT / "dg_tta_amd").rglob("*.py"):
+        src = py.read_text()
+        assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f"{py} imports the oracle"
+        assert "/root/reference" not in src
+
+
+def test_missing_library_fails_loudly(tmp_path):
+    code = ("import os; os.environ['DGTTA_LIB']=%r\n"
+            "from dg_tta_amd import _lib\n"
+            "try:\n    _lib.load()\nexcept _lib.DgttaError as e:\n    print('RAISED', 'no CPU fallback' in str(e))\n") % str(tmp_path / "nope.so")
+    out = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True)
+    assert "RAISED True" in out.stdout, out.stdout + out.stderr
+
+
+def test_state_dict_layout_matches_nnunet():
+    from dg_tta_amd.unet import HipPlainConvUNet
+    from oracle.unet import PlainConvUNetOracle
+    h, o = HipPlainConvUNet(), PlainConvUNetOracle()
+    assert list(h.state_dict().keys()) == list(o.state_dict().keys())
+    assert [tuple(v.shape) for v in h.state_dict().values()] == [tuple(v.shape) for v in o.state_dict().values()]
+    assert sum(p.numel() for p in h.parameters()) == 16_606_948
+    assert hasattr(h, "encoder")
+    norms = [m for m in h.modules() if "instancenorm" in m.__class__.__name__.lower()]
+    assert len(norms) == 18
+    import copy
+    h._packed[("x",)] = (0, torch.zeros(1), torch.zeros(1))
+    assert copy.deepcopy(h)._packed == {}
+
+
+def test_label_mapping_and_indices(golden):
+    from dg_tta_amd.tta.torch_utils import generate_label_mapping, get_map_idxs, map_label
+    g = golden("mapping")
+    src = {"background": 0, "spleen": 1, "kidney_right": 2, "liver": 5, "aorta": 7}
+    tgt = {"background": 0, "liver": 1, "spleen": 2, "pancreas": 3, "aorta": 4}
+    lm = generate_label_mapping(src, tgt)
+    assert lm == {"background": (0, 0), "spleen": (1, 2), "liver": (5, 1), "aorta": (7, 4)}
+    opt = ["background", "aorta", "liver", "spleen"]
+    assert torch.equal(get_map_idxs(lm, opt, "pretrain_labels"), g["idx"])
+    assert torch.equal(get_map_idxs(lm, opt, "tta_labels"), g["idx_tta"])
+    assert torch.equal(map_label(g["logits"], g["idx"], "logits"), g["mapped"])
+    assert torch.equal(map_label(g["am"], g["idx"], "argmaxed"), g["am_mapped"])
+    with pytest.raises(AssertionError):
+        generate_label_mapping({"a": 1}, {"b": 1})
+
+
+def test_rand_affine_matches_golden(golden):
+    from dg_tta_amd.tta.augmentation_utils import get_rand_affine
+    g = golden("rand_affine")
+    torch.manual_seed(31)
+    r, rinv = get_rand_affine(2)
+    assert torch.equal(r, g["r"]) and torch.equal(rinv, g["rinv"])
+
+
+def test_plan_template_and_helpers():
+    from dg_tta_amd.tta import config_log_utils as clu
+    assert clu.TEMPLATE_PLAN == dict(
+        tta_across_all_samples=False, tta_eval_patches=1, batch_size=1, patches_to_be_accumulated=16, lr=1e-5,
+        ensemble_count=3, epochs=12, start_tta_at_epoch=1, intensity_aug_function="GIN", spatial_aug_type="affine",
+        params_with_grad="all", have_grad_in="branch_a", do_intensity_aug_in="none", do_spatial_aug_in="both",
+        num_processes=1, wandb_mode="disabled")
+    assert clu.get_global_idx([(2, 3), (250, 1000)]) == 20250
+    assert clu.get_global_idx([(1, 5), (2, 3), (11, 12)]) == 1211
+    p = clu.get_parameters_save_path(Path("/x"), "tta_outputTs/case_7", 2)
+    assert p == Path("/x/case_7__ensemble_idx_2_tta_parameters.pt")
+    assert clu.check_dataset_pretrain_config("TS104_GIN_MIND", None, "3d_fullres", "0") == \
+        ("TS104_GIN_MIND", "nnUNetTrainer_GIN_MIND", "3d_fullres", "0")
+    assert clu.check_dataset_pretrain_config("802", "nnUNetTrainer_GIN", "3d_fullres", "all") == \
+        (802, "nnUNetTrainer_GIN", "3d_fullres", "all")
+    with pytest.raises(AssertionError):
+        clu.check_dataset_pretrain_config("TS104_FOO", None, "3d_fullres", "0")
+    assert clu.is_template_modifier(clu.ModifierFunctions.modfify_tta_model_output_fn, "modfify_tta_model_output_fn")
+    assert not clu.is_template_modifier(lambda x: x * 2, "modfify_tta_model_output_fn")
+
+
+def _make_nnunet_tree(tmp_path):
+    raw = tmp_path / "raw" / "Dataset803_Target"
+    (raw / "imagesTs").mkdir(parents=True)
+    (raw / "labelsTs").mkdir()
+    import numpy as np
+    for c in ("caseA", "caseB"):
+        np.save(raw / "imagesTs" / f"{c}_0000.npy", np.random.rand(1, 20, 20, 20).astype("float32"))
+        np.save(raw / "labelsTs" / f"{c}.npy", np.random.randint(0, 3, (20, 20, 20)).astype("int16"))
+    json.dump({"labels": {"background": 0, "liver": 1, "spleen": 2, "my_organ": 3}}, open(raw / "dataset.json", "w"))
+    root = tmp_path / "dgroot"
+    root.mkdir()
+    env = {"nnUNet_raw": str(tmp_path / "raw"), "nnUNet_results": str(tmp_path / "res"),
+           "nnUNet_preprocessed": str(tmp_path / "pre"), "DG_TTA_ROOT": str(root)}
+    return raw, root, env
+
+
+def test_prepare_tta_cli_writes_reference_plan_dir(tmp_path, monkeypatch):
+    raw, root, env = _make_nnunet_tree(tmp_path)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    from dg_tta_amd.run import DGTTAProgram
+    DGTTAProgram(["dgtta", "prepare_tta", "TS104_GIN_MIND", "803"])
+    plan_dir = root / "plans" / "Pretrained_TS104_GIN_MIND_at_Dataset803_Target" / "nnUNetTrainer_GIN_MIND__3d_fullres" / "fold_0"
+    names = sorted(p.name for p in plan_dir.iterdir())
+    assert names == ["Dataset803_Target_label_mapping.json", "TS104_GIN_MIND_label_mapping.json",
+                     "modifier_functions.py", "tta_plan.json"]
+    plan = json.load(open(plan_dir / "tta_plan.json"))
+    from dg_tta_amd.tta.config_log_utils import TEMPLATE_PLAN, load_current_modifier_functions
+    for k, v in TEMPLATE_PLAN.items():
+        assert plan[k] == v
+    assert plan["optimized_labels"] == ["background", "liver", "spleen"]
+    assert plan["__pretrained_dataset_name__"] == "TS104_GIN_MIND" and plan["__tta_dataset_name__"] == "Dataset803_Target"
+    assert plan["pretrained_weights_filepath"].endswith(
+        "_pretrained_weights/nnUNetTrainer_GIN_MIND__nnUNetPlans__3d_fullres/fold_0/checkpoint_final.pth")
+    assert [Path(p).name for p in plan["tta_data_filepaths"]] == ["caseA_0000.npy", "caseB_0000.npy"]
+    src_labels = json.load(open(plan_dir / "TS104_GIN_MIND_label_mapping.json"))
+    assert len(src_labels) == 105 and src_labels["spleen"] == 1
+    mod = load_current_modifier_functions(plan_dir)
+    x = torch.zeros(1, 1, 2, 2, 2)
+    assert mod.ModifierFunctions.modify_tta_input_fn(x) is x
+    assert (root / "results" / "Pretrained_TS104_GIN_MIND_at_Dataset803_Target").is_dir()
+    with pytest.raises(SystemExit):
+        DGTTAProgram(["dgtta", "no_such_command"])
+
+
+def test_model_folder_parsing_and_data_iterator(tmp_path, monkeypatch):
+    raw, root, env = _make_nnunet_tree(tmp_path)
+    from dg_tta_amd.tta import nnunet_utils as nu
+    skel = ROOT / "dg_tta_amd" / "__resources__" / "model_skeleton"
+    plans, ds = json.load(open(skel / "plans.json")), json.load(open(skel / "dataset.json"))
+    cfg, patch = nu.unet_cfg_from_plans(plans, ds, "3d_fullres", 12)
+    assert cfg["features"] == (32, 64, 128, 256, 320) and cfg["strides"] == (1, 2, 2, 2, 2)
+    assert cfg["num_classes"] == 105 and patch == [112, 112, 128]
+    assert nu.trainer_hooks("nnUNetTrainer_GIN_MIND_MultiRes")[0] == 12
+    assert nu.trainer_hooks("nnUNetTrainer_GIN")[0] == 1 and len(nu.trainer_hooks("nnUNetTrainer_MIND")[1]) == 1
+    files = sorted(str(p) for p in (raw / "imagesTs").iterdir())
+    it, n = nu.load_tta_data({"tta_data_filepaths": files}, raw)
+    items = list(it)
+    assert n == 2 and [i["ofile"] for i in items] == ["tta_outputTs/caseA", "tta_outputTs/caseB"]
+    assert items[0]["data"].shape[0] == 3 and items[0]["data"].dtype == torch.float32
+    # checkpoint loading: a nnU-Net style checkpoint of a small net round-trips through load_network
+    small_plans = json.loads(json.dumps(plans))
+    c = small_plans["configurations"]["3d_fullres"]
+    c.update(UNet_base_num_features=4, unet_max_num_features=8, n_conv_per_stage_encoder=[1, 1],
+             n_conv_per_stage_decoder=[1], pool_op_kernel_sizes=[[1, 1, 1], [2, 2, 2]],
+             conv_kernel_sizes=[[3, 3, 3], [3, 3, 3]], patch_size=[16, 16, 16])
+    folder = tmp_path / "res" / "DatasetX" / "nnUNetTrainer_GIN_MIND__nnUNetPlans__3d_fullres"
+    (folder / "fold_0").mkdir(parents=True)
+    json.dump(small_plans, open(folder / "plans.json", "w"))
+    json.dump({"labels": {"background": 0, "a": 1, "b": 2}}, open(folder / "dataset.json", "w"))
+    from dg_tta_amd.unet import HipPlainConvUNet
+    ref = HipPlainConvUNet(dict(features=(4, 8), strides=(1, 2), n_conv_enc=(1, 1), n_conv_dec=(1,), in_channels=12,
+                                num_classes=3))
+    for p in ref.parameters():
+        torch.nn.init.normal_(p)
+    torch.save({"network_weights": ref.state_dict(), "trainer_name": "nnUNetTrainer_GIN_MIND"},
+               folder / "fold_0" / "checkpoint_final.pth")
+    pred, patch, net, params = nu.load_network(folder / "fold_0" / "checkpoint_final.pth", "cpu")
+    assert patch == [16, 16, 16] and len(net._forward_pre_hooks) == 2
+    for k, v in ref.state_dict().items():
+        assert torch.equal(net.state_dict()[k], v)
+    assert os.environ["DG_TTA_INTERNAL_AUGMENTATION"] == "true"
+
+
+def test_tta_main_refuses_cpu_device(tmp_path):
+    from dg_tta_amd.tta.tta import tta_main
+    with pytest.raises(RuntimeError, match="MI355X only"):
+        tta_main("r", {}, tmp_path, tmp_path, {}, None, "cpu")

@@ -1,0 +1,217 @@
+#!/usr/bin/env python3
+"""Benchmark of the DG-TTA hot path on MI355X: TTA epochs per second on a 128^3 patch (BASELINE.json metric).
+
+One "step" = one TTA epoch of the reference's inner loop (dg_tta/tta/tta.py:190-338): 16 accumulation steps x
+{get_batch, 2 augmented branches (GIN -> affine warp -> MIND -> nnUNet 3d_fullres fwd -> inverse warp), masked
+soft-Dice loss, backward through both branches}, one AdamW step, one centre-patch eval forward.
+N > 1: one independent TTA instance per GPU (different sample per rank, no data-path collective); torch.distributed is
+used only for the barrier and the max-over-ranks time.  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+from types import SimpleNamespace
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+# algorithmic work of one PlainConvUNet forward at 128^3
+FWD_GFLOP_128 = 998.84
+
+
+def conv_flops(cin, cout, vout):
+    return 2.0 * 27 * cin * cout * vout
+
+
+def build_workload(args, device, rank):
+    from dg_tta_amd.gin import gin_hook
+    from dg_tta_amd.mind import mind_hook
+    from dg_tta_amd.synthetic import he_init_, synthetic_case, synthetic_label_mapping
+    from dg_tta_amd.tta.config_log_utils import ModifierFunctions, TEMPLATE_PLAN
+    from dg_tta_amd.unet import HipPlainConvUNet
+    act = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    net = he_init_(HipPlainConvUNet(act_dtype=act, conv_impl=args.impl), seed=7)
+    net.register_forward_pre_hook(gin_hook)
+    net.register_forward_pre_hook(mind_hook)
+    net = net.to(device)
+    k = args.copt - 1
+    mapping, names = synthetic_label_mapping(k)
+    vol = args.size + 32
+    data = synthetic_case(size=vol, k=k, seed=20240704 + rank)
+    cfg = dict(TEMPLATE_PLAN)
+    cfg.update(do_intensity_aug_in="both", do_spatial_aug_in="both", patches_to_be_accumulated=args.accum,
+               optimized_labels=names, epochs=10 ** 6, ensemble_count=1, lr=1e-5)
+    modmod = SimpleNamespace(ModifierFunctions=ModifierFunctions)
+    return net, cfg, mapping, modmod, data
+
+
+class EpochRunner:
+    """Runs TTA epochs back to back on one sample (the body of tta_unit, one epoch per call)."""
+
+    def __init__(self, args, device, rank):
+        from dg_tta_amd.optim import HipAdamW
+        from dg_tta_amd.tta.model_utils import get_model_from_network
+        from dg_tta_amd.tta.tta import _fuse_head_if_possible
+        from dg_tta_amd.tta.torch_utils import fix_all, release_all
+        from dg_tta_amd.utils import disable_internal_augmentation
+        self.args, self.device = args, device
+        net, self.cfg, self.mapping, self.modmod, data = build_workload(args, device, rank)
+        self.data = [data]
+        self.patch = [args.size] * 3
+        self.model = get_model_from_network(net, self.modmod, None)
+        self.fused = _fuse_head_if_possible(self.model, self.modmod, self.mapping, self.cfg["optimized_labels"])
+        self.opt = HipAdamW(self.model.parameters(), lr=self.cfg["lr"])
+        disable_internal_augmentation()
+        self.model.apply(fix_all)
+        self.model.apply(release_all)            # measured epochs are adaptation epochs (epoch >= start_tta_at_epoch)
+        self.inv = torch.full((), 1.0 / args.accum, dtype=torch.float32, device=device)
+        self.losses = []
+
+    def epoch(self):
+        from dg_tta_amd import ops
+        from dg_tta_amd.gin import gin_aug
+        from dg_tta_amd.tta.tta import calc_branch, START_CLASS
+        from dg_tta_amd.tta.torch_utils import dice_coeff, get_batch, get_map_idxs, map_label
+        cfg, model, dev = self.cfg, self.model, self.device
+        model.train()
+        step_losses = []
+        for _ in range(cfg["patches_to_be_accumulated"]):
+            with torch.no_grad():
+                imgs, _ = get_batch(self.data, np.random.choice(range(1), 1).tolist(), self.patch, None, dev)
+            a = (cfg, model, gin_aug, None, self.patch, 1, self.mapping, cfg["optimized_labels"], self.modmod, imgs[0],
+                 dev, self.fused)
+            ta = calc_branch("branch_a", *a)
+            tb = calc_branch("branch_b", *a)
+            loss, _ = ops.consistency_loss(ta, tb, START_CLASS)
+            step_losses.append(loss.detach())
+            torch.autograd.backward(loss, grad_tensors=self.inv)
+        self.opt.step()
+        self.opt.zero_grad()
+        self.losses.append(torch.stack(step_losses).mean().item())
+        with torch.inference_mode():
+            model.eval()
+            imgs, labels = get_batch(self.data, [0], self.patch, "center", dev)
+            out = model(imgs[0])
+            am, _ = ops.argmax_dice(out)
+            lab = map_label(labels[0], get_map_idxs(self.mapping, cfg["optimized_labels"], "tta_labels"), "argmaxed")
+            self.dice = dice_coeff(am, lab.long(), len(cfg["optimized_labels"])).nanmean().item()
+
+
+def cpu_baseline(args):
+    """Times the CPU oracle (restatement of the reference, kind 'port') on a bounded sample of the same workload:
+    ONE accumulation step (2 branches + loss + backward) on a `cpu_size`^3 patch, scaled by voxel count to 128^3 and
+    by (accum + eval forward) to one epoch."""
+    from oracle import gin as ogin, tta as otta, unet as ounet
+    n = args.cpu_size
+    cores = min(len(os.sched_getaffinity(0)), 16)     # a one-GPU box's CPU share is 16 cores (oversubscribing 256 hurts)
+    torch.set_num_threads(cores)
+    om = ounet.init_he(ounet.PlainConvUNetOracle(), 7)
+    sel = torch.arange(args.copt) * 3
+    torch.manual_seed(0)
+    imgs = torch.randn(1, 1, n, n, n)
+
+    def draws(seed):
+        torch.manual_seed(seed)
+        return dict(gin_draw=ogin.draw_gin_params(1), affine_draw=torch.randn(1, 3, 4),
+                    mind_noise=torch.randn(1, 12, n, n, n))
+    t0 = time.perf_counter()
+    otta.tta_step(om, imgs, sel, draws(1), draws(2), accum=args.accum, backward=True)
+    dt = time.perf_counter() - t0
+    scale = (args.size / n) ** 3
+    epoch_s = dt * scale * (args.accum + 1.0 / 6.0)       # eval forward ~ 1/6 of a step (1 of 6 network passes)
+    return {"value": 1.0 / epoch_s, "unit": "TTA-epochs/s", "cores": cores, "kind": "port",
+            "sample": f"1 accumulation step (2 branches fwd + loss + bwd) of the CPU oracle on a {n}^3 patch = "
+                      f"{dt:.1f} s, scaled x{scale:.2f} (voxels) x{args.accum + 1 / 6:.2f} (steps per epoch)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--size", type=int, default=128)
+    ap.add_argument("--accum", type=int, default=16)
+    ap.add_argument("--copt", type=int, default=16)
+    ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16"])
+    ap.add_argument("--impl", type=int, default=0)
+    ap.add_argument("--cpu-size", type=int, default=64)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
+    device = torch.device(f"cuda:{local}")
+    torch.manual_seed(1234 + rank)
+    np.random.seed(1234 + rank)
+
+    runner = EpochRunner(args, device, rank)
+    from dg_tta_amd.unet import set_probe
+    for _ in range(args.warmup):
+        runner.epoch()
+    probe = set_probe(("dec", 3, 1))          # the 128^3 32->32 conv block (largest single-shape FLOP share)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        runner.epoch()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    set_probe(None)
+
+    if rank == 0:
+        ms = dt / args.steps * 1e3
+        value = world * args.steps / dt
+        # roofline of the dominant kernel, timed with events on the launch stream inside the timed region
+        roof = None
+        if probe["events"]:
+            times = [s.elapsed_time(e) for s, e in probe["events"]]
+            avg_ms = sum(times) / len(times)
+            v = args.size ** 3
+            flop = conv_flops(probe["cin"], probe["cout"], probe["vout"])
+            peak = 2500.0 if args.dtype == "bf16" else 157.3
+            ach = flop / (avg_ms * 1e-3) / 1e12
+            roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
+                    "frac": round(ach / peak, 4), "traffic": None, "kernel": probe.get("kernel", "conv3d_k3_fwd"),
+                    "launches": len(times), "avg_ms": round(avg_ms, 4),
+                    "flop_per_launch": flop}
+        out = {"metric": "TTA-epochs/sec per GPU on 128^3 patch", "value": round(value, 5), "unit": "TTA-epochs/s",
+               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 2),
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
+               "data": "synthetic",
+               "config": {"workload": f"tta_epoch: {args.size}^3 patch from a {args.size + 32}^3 volume, "
+                                      f"{args.accum} accumulation steps, GIN+affine in both branches, MIND 12ch, "
+                                      f"nnUNet 3d_fullres 105 classes, C_opt={args.copt}, AdamW, 1 eval patch",
+                          "patch": args.size, "accum": args.accum, "c_opt": args.copt,
+                          "parallelism": f"{world} independent TTA instance(s), sample-sharded"},
+               "loss_last_epoch": runner.losses[-1], "pseudo_dice": runner.dice,
+               "epoch_tflop": round(96.89 * (args.size / 128) ** 3 * (args.accum * 6 + 1) / 97.0, 2),
+               "roofline": roof}
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(args)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -63,6 +63,9 @@ def load():
     if _load_error is not None:
         raise DgttaError(_load_error)
     path = os.environ.get("DGTTA_LIB", str(LIB_PATH))
+    # PyTorch-ROCm ships its own libamdhip64.so.7; import it first so that this library binds to the SAME HIP runtime
+    # instance (same streams / allocations) instead of pulling in /opt/rocm's copy as a second runtime.
+    import torch  # noqa: F401
     try:
         lib = C.CDLL(path)
     except OSError as e:

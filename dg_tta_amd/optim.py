@@ -38,4 +38,6 @@ class HipAdamW(torch.optim.Optimizer):
                 ops.adamw_step([p.data for p in ps], [p.grad for p in ps], [self.state[p]["exp_avg"] for p in ps],
                                [self.state[p]["exp_avg_sq"] for p in ps], step, group["lr"], group["betas"],
                                group["eps"], group["weight_decay"])
+                # the kernel wrote through raw pointers: tell autograd / weight caches that the tensors changed
+                torch.autograd.graph.increment_version(ps)
         return loss

@@ -153,7 +153,8 @@ class HipPlainConvUNet(nn.Module):
         if sel is not None and sel.device != x.device:
             sel = self.selected_classes = sel.to(x.device)
         params = [p for p in self.parameters()]
-        return _UNetFn.apply(self, x, sel, *params)
+        need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in params)
+        return _UNetFn.apply(self, x, sel, need_grad, *params)
 
     # -- packed weights (re-packed only when the parameter changed)
     def packed(self, conv, dtype_code, cinp, coutp):
@@ -172,6 +173,16 @@ class HipPlainConvUNet(nn.Module):
         return wf, wb
 
 
+_PROBE = None
+
+
+def set_probe(where):
+    """bench.py hook: record (start, end) events around the forward conv launch of block `where` = (kind, stage, idx)."""
+    global _PROBE
+    _PROBE = None if where is None else dict(where=where, events=[])
+    return _PROBE
+
+
 def _odim(i, s):
     return (i + 2 - 3) // s + 1
 
@@ -180,7 +191,7 @@ class _UNetFn(torch.autograd.Function):
     """Whole-network autograd node: forward saves raw conv outputs, normalised activations and IN statistics."""
 
     @staticmethod
-    def forward(ctx, net, x, sel, *params):
+    def forward(ctx, net, x, sel, need_grad, *params):
         lib = _lib.load()
         _lib.require_cuda(x)
         dev = x.device
@@ -197,7 +208,6 @@ class _UNetFn(torch.autograd.Function):
             tot_stride *= s
         assert D % tot_stride == 0 and H % tot_stride == 0 and W % tot_stride == 0, \
             f"patch {D}x{H}x{W} must be divisible by {tot_stride}"
-        need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in params)
         enc, dec = net.conv_blocks()
         CP = 16 if dt == BF16 else 8      # channel padding granule of packed weights / first-layer input
 
@@ -222,7 +232,7 @@ class _UNetFn(torch.autograd.Function):
                 ws_cache["ws"] = t
             return t
 
-        def run_block(blk_mod, u, ldu, cin, dims_in, z_out=None, ldz=None):
+        def run_block(blk_mod, u, ldu, cin, dims_in, z_out=None, ldz=None, where=None):
             """conv -> IN -> lrelu. u: tensor whose data_ptr()+offset is the input; returns (z, ldz, dims_out, rec)."""
             conv, norm = blk_mod.conv, blk_mod.norm
             s = conv.stride
@@ -232,8 +242,16 @@ class _UNetFn(torch.autograd.Function):
             cinp, coutp = _pad(cin, CP), _pad(cout, CP)
             wf, wb = net.packed(conv, dt, cinp, coutp)
             y = torch.empty((B, do, ho, wo, cout), dtype=adt, device=dev)
+            pr = _PROBE if (_PROBE is not None and _PROBE["where"] == where) else None
+            if pr is not None:       # bench.py: time this layer's conv launch with events on the launch stream
+                ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                ev0.record()
             check(lib.dgtta_conv3d_k3_fwd(u, ldu, ptr(wf), ptr(conv.bias), ptr(y), cout, None, B, cin, cout, cinp, coutp,
                                           di, hi, wi, s, dt, impl, st), "dgtta_conv3d_k3_fwd")
+            if pr is not None:
+                ev1.record()
+                pr["events"].append((ev0, ev1))
+                pr.update(cin=cin, cout=cout, vout=do * ho * wo)
             v = do * ho * wo
             mr = torch.empty((B, cout, 2), dtype=torch.float32, device=dev)
             if z_out is None:
@@ -267,7 +285,7 @@ class _UNetFn(torch.autograd.Function):
                     cat = torch.empty((B, do, ho, wo, 2 * cstage), dtype=adt, device=dev)
                     cat_bufs.append((cat, cstage, (do, ho, wo)))
                     z_out, ldz = (cat, cat.data_ptr() + cstage * esz), 2 * cstage
-                u_ptr, ldu, dims, rec, zt = run_block(blk, u_ptr, ldu, cin, dims, z_out, ldz)
+                u_ptr, ldu, dims, rec, zt = run_block(blk, u_ptr, ldu, cin, dims, z_out, ldz, ("enc", si, bi))
                 rec["where"] = ("enc", si, bi)
                 saved.append(rec)
                 keep.append(zt)
@@ -284,7 +302,7 @@ class _UNetFn(torch.autograd.Function):
             ups.append(dict(mod=up, x=x_low_ptr, ldx=x_low_ld, cin=x_low_c, cout=cskip, din=low_dims, cat=cat))
             u_ptr, ldu, cin, dims = cat.data_ptr(), 2 * cskip, 2 * cskip, cdims
             for bi, blk in enumerate(blocks):
-                u_ptr, ldu, dims, rec, zt = run_block(blk, u_ptr, ldu, cin, dims)
+                u_ptr, ldu, dims, rec, zt = run_block(blk, u_ptr, ldu, cin, dims, None, None, ("dec", k, bi))
                 rec["where"] = ("dec", k, bi)
                 saved.append(rec)
                 keep.append(zt)
@@ -440,7 +458,7 @@ class _UNetFn(torch.autograd.Function):
                 keep_alive = [gin]
             idx -= 1
         del keep_alive, first_rec
-        out = [None, None, None]
+        out = [None, None, None, None]
         for p in params:
             out.append(grads.get(id(p)) if p.requires_grad else None)
         return tuple(out)

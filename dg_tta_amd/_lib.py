@@ -27,7 +27,8 @@ SIGNATURES = {
     "dgtta_softdice_bwd": (I, [P, P, P, P, P, F, P, I, I, I64, I, I, P]),
     "dgtta_adamw_step": (I, [C.POINTER(P), C.POINTER(P), C.POINTER(P), C.POINTER(P), C.POINTER(I64), I, F, F, F, F, F,
                              I, P]),
-    "dgtta_conv3d_pack_weights": (I, [P, P, P, I, I, I, I, I, P]),
+    "dgtta_conv3d_packed_bytes": (SZ, [I, I, I]),
+    "dgtta_conv3d_pack_weights": (I, [P, P, I, I, I, I, I, P]),
     "dgtta_conv3d_stats_bytes": (SZ, [I, I, I, I, I]),
     "dgtta_conv3d_k3_fwd": (I, [P, I, P, P, P, I, P, I, I, I, I, I, I, I, I, I, I, I, P]),
     "dgtta_conv3d_k3_dgrad": (I, [P, I, P, P, I, I, I, I, I, I, I, I, I, I, I, I, I, P]),

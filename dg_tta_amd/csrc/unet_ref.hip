@@ -488,16 +488,27 @@ int wgrad_splits(int64_t nvox) {
   } while (0)
 
 // MFMA implementations (conv_mfma.hip); return DGTTA_ERR_UNSUPPORTED when the shape is not covered.
-int conv3_fwd_mfma(const void *x, int ldx, const void *wf, const float *bias, void *y, int ldy, void *stats, int B,
+int conv3_fwd_mfma(const void *x, int ldx, const void *w_kmajor, int mirror, const float *bias, void *y, int ldy, int B,
                    int Cin, int Cout, int CinP, int CoutP, int Di, int Hi, int Wi, int stride, int dtype,
                    hipStream_t st);
 int conv3_wgrad_mfma(const void *x, int ldx, const void *dy, int lddy, float *dw_t, float *db, void *ws, size_t ws_bytes,
                      int B, int Cin, int Cout, int Di, int Hi, int Wi, int stride, int accumulate, int dtype,
                      hipStream_t st);
 
-extern "C" int dgtta_conv3d_pack_weights(const float *w_t, void *wf, void *wb, int Cin, int Cout, int CinP, int CoutP,
+static size_t esize(int dtype) { return dtype == DGTTA_BF16 ? 2 : 4; }
+static const void *wb_of(const void *wpack, int CinP, int CoutP, int dtype) {
+  return (const char *)wpack + (size_t)27 * CinP * CoutP * esize(dtype);
+}
+
+extern "C" size_t dgtta_conv3d_packed_bytes(int CinP, int CoutP, int dtype) {
+  return (size_t)2 * 27 * CinP * CoutP * esize(dtype);
+}
+
+extern "C" int dgtta_conv3d_pack_weights(const float *w_t, void *wpack, int Cin, int Cout, int CinP, int CoutP,
                                          int dtype, void *stream) {
-  DG_REQUIRE(w_t && (wf || wb), DGTTA_ERR_BADARG, "pack_weights: null pointer");
+  DG_REQUIRE(w_t && wpack, DGTTA_ERR_BADARG, "pack_weights: null pointer");
+  void *wf = wpack;
+  void *wb = const_cast<void *>(wb_of(wpack, CinP, CoutP, dtype));
   DG_REQUIRE(Cin > 0 && Cout > 0 && CinP >= Cin && CoutP >= Cout, DGTTA_ERR_BADARG, "pack_weights: bad channel counts");
   const int64_t n = (int64_t)27 * CinP * CoutP;
   DISPATCH_T(dtype, hipLaunchKernelGGL((pack_weights_kernel<T>), dim3(gs_blocks(n)), dim3(256), 0, (hipStream_t)stream,
@@ -513,10 +524,11 @@ extern "C" size_t dgtta_conv3d_stats_bytes(int B, int Cout, int Do, int Ho, int 
   return (size_t)B * 512 * Cout * 2 * sizeof(double);
 }
 
-extern "C" int dgtta_conv3d_k3_fwd(const void *x, int ldx, const void *wf, const float *bias, void *y, int ldy,
+extern "C" int dgtta_conv3d_k3_fwd(const void *x, int ldx, const void *wpack, const float *bias, void *y, int ldy,
                                    void *stats, int B, int Cin, int Cout, int CinP, int CoutP, int Di, int Hi, int Wi,
                                    int stride, int dtype, int impl, void *stream) {
-  DG_REQUIRE(x && wf && y, DGTTA_ERR_BADARG, "conv3d_k3_fwd: null pointer");
+  DG_REQUIRE(x && wpack && y, DGTTA_ERR_BADARG, "conv3d_k3_fwd: null pointer");
+  const void *wf = wpack;
   DG_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && CinP >= Cin && CoutP >= Cout && Di > 0 && Hi > 0 && Wi > 0,
              DGTTA_ERR_BADARG, "conv3d_k3_fwd: bad dims");
   DG_REQUIRE(stride == 1 || stride == 2, DGTTA_ERR_UNSUPPORTED, "conv3d_k3_fwd: stride %d", stride);
@@ -524,7 +536,9 @@ extern "C" int dgtta_conv3d_k3_fwd(const void *x, int ldx, const void *wf, const
   DG_REQUIRE(stats == nullptr, DGTTA_ERR_UNSUPPORTED, "conv3d_k3_fwd: fused stats not available in this build");
   hipStream_t st = (hipStream_t)stream;
   if (impl != 1) {
-    int rc = conv3_fwd_mfma(x, ldx, wf, bias, y, ldy, stats, B, Cin, Cout, CinP, CoutP, Di, Hi, Wi, stride, dtype, st);
+    // the MFMA kernel wants K-contiguous weights [tap][co][ci] = the mirrored second half of the blob
+    int rc = conv3_fwd_mfma(x, ldx, wb_of(wpack, CinP, CoutP, dtype), 1, bias, y, ldy, B, Cin, Cout, CinP, CoutP, Di, Hi,
+                            Wi, stride, dtype, st);
     if (rc != DGTTA_ERR_UNSUPPORTED) return rc;
     DG_REQUIRE(impl == 0, DGTTA_ERR_UNSUPPORTED, "conv3d_k3_fwd: shape not covered by the MFMA kernel");
   }
@@ -537,10 +551,11 @@ extern "C" int dgtta_conv3d_k3_fwd(const void *x, int ldx, const void *wf, const
   return DGTTA_OK;
 }
 
-extern "C" int dgtta_conv3d_k3_dgrad(const void *dy, int lddy, const void *wb, void *dx, int lddx, int B, int Cin,
+extern "C" int dgtta_conv3d_k3_dgrad(const void *dy, int lddy, const void *wpack, void *dx, int lddx, int B, int Cin,
                                      int Cout, int CinP, int CoutP, int Di, int Hi, int Wi, int stride, int accumulate,
                                      int dtype, int impl, void *stream) {
-  DG_REQUIRE(dy && wb && dx, DGTTA_ERR_BADARG, "conv3d_k3_dgrad: null pointer");
+  DG_REQUIRE(dy && wpack && dx, DGTTA_ERR_BADARG, "conv3d_k3_dgrad: null pointer");
+  const void *wb = wb_of(wpack, CinP, CoutP, dtype);
   DG_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && CinP >= Cin && CoutP >= Cout && Di > 0 && Hi > 0 && Wi > 0,
              DGTTA_ERR_BADARG, "conv3d_k3_dgrad: bad dims");
   DG_REQUIRE(stride == 1 || stride == 2, DGTTA_ERR_UNSUPPORTED, "conv3d_k3_dgrad: stride %d", stride);
@@ -548,7 +563,8 @@ extern "C" int dgtta_conv3d_k3_dgrad(const void *dy, int lddy, const void *wb, v
   hipStream_t st = (hipStream_t)stream;
   if (impl != 1 && stride == 1 && !accumulate) {
     // stride-1 data gradient == forward conv of dy with the mirrored, transposed weights (wb)
-    int rc = conv3_fwd_mfma(dy, lddy, wb, nullptr, dx, lddx, nullptr, B, Cout, Cin, CoutP, CinP, Di, Hi, Wi, 1, dtype, st);
+    // (the first half of the blob, [tap][ci][co], is K-contiguous for this role; taps mirrored)
+    int rc = conv3_fwd_mfma(dy, lddy, wpack, 1, nullptr, dx, lddx, B, Cout, Cin, CoutP, CinP, Di, Hi, Wi, 1, dtype, st);
     if (rc != DGTTA_ERR_UNSUPPORTED) return rc;
     DG_REQUIRE(impl == 0, DGTTA_ERR_UNSUPPORTED, "conv3d_k3_dgrad: shape not covered by the MFMA kernel");
   }

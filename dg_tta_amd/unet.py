@@ -162,15 +162,14 @@ class HipPlainConvUNet(nn.Module):
         key = (id(w), dtype_code, cinp, coutp)
         ent = self._packed.get(key)
         if ent is not None and ent[0] == w._version and ent[1].device == w.device:
-            return ent[1], ent[2]
+            return ent[1]
         lib = _lib.load()
         tdt = torch.float32 if dtype_code == F32 else torch.bfloat16
-        wf = torch.empty((27, cinp, coutp), dtype=tdt, device=w.device)
-        wb = torch.empty((27, coutp, cinp), dtype=tdt, device=w.device)
-        check(lib.dgtta_conv3d_pack_weights(ptr(w.detach()), ptr(wf), ptr(wb), conv.in_channels, conv.out_channels,
+        wpack = torch.empty((2, 27, cinp, coutp), dtype=tdt, device=w.device)
+        check(lib.dgtta_conv3d_pack_weights(ptr(w.detach()), ptr(wpack), conv.in_channels, conv.out_channels,
                                             cinp, coutp, dtype_code, stream_of(w.device)), "dgtta_conv3d_pack_weights")
-        self._packed[key] = (w._version, wf, wb)
-        return wf, wb
+        self._packed[key] = (w._version, wpack)
+        return wpack
 
 
 _PROBE = None
@@ -240,13 +239,13 @@ class _UNetFn(torch.autograd.Function):
             di, hi, wi = dims_in
             do, ho, wo = _odim(di, s), _odim(hi, s), _odim(wi, s)
             cinp, coutp = _pad(cin, CP), _pad(cout, CP)
-            wf, wb = net.packed(conv, dt, cinp, coutp)
+            wpack = net.packed(conv, dt, cinp, coutp)
             y = torch.empty((B, do, ho, wo, cout), dtype=adt, device=dev)
             pr = _PROBE if (_PROBE is not None and _PROBE["where"] == where) else None
             if pr is not None:       # bench.py: time this layer's conv launch with events on the launch stream
                 ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 ev0.record()
-            check(lib.dgtta_conv3d_k3_fwd(u, ldu, ptr(wf), ptr(conv.bias), ptr(y), cout, None, B, cin, cout, cinp, coutp,
+            check(lib.dgtta_conv3d_k3_fwd(u, ldu, ptr(wpack), ptr(conv.bias), ptr(y), cout, None, B, cin, cout, cinp, coutp,
                                           di, hi, wi, s, dt, impl, st), "dgtta_conv3d_k3_fwd")
             if pr is not None:
                 ev1.record()
@@ -414,7 +413,7 @@ class _UNetFn(torch.autograd.Function):
             where = rec["where"]
             if idx == 0:
                 break
-            wf, wb = net.packed(conv, dt, rec["cinp"], rec["coutp"])
+            wb = net.packed(conv, dt, rec["cinp"], rec["coutp"])
             kind, sidx, bidx = where
             if kind == "dec" and bidx == 0:
                 # input was the concat buffer of decoder stage sidx: gradient for [up | skip]

@@ -126,22 +126,25 @@ int dgtta_adamw_step(float *const *h_p, const float *const *h_g, float *const *h
  * produced by dgtta_conv3d_pack_weights.
  * ------------------------------------------------------------------------------------------- */
 
-/* packs torch [Cout][Cin][27] fp32 into wf [27][CinP][CoutP] (forward / wgrad order) and
- * wb [27][CoutP][CinP] with taps mirrored (data-gradient order), dtype fp32|bf16, zero padded. */
-int dgtta_conv3d_pack_weights(const float *w_t, void *wf, void *wb, int Cin, int Cout, int CinP, int CoutP,
-                              int dtype, void *stream);
+/* packs torch [Cout][Cin][27] fp32 into one blob `wpack` of 2*27*CinP*CoutP elements (dtype fp32|bf16, zero padded):
+ *   wf [27][CinP][CoutP] = w[co][ci][tap]        (first half)
+ *   wb [27][CoutP][CinP] = w[co][ci][26-tap]     (second half: taps mirrored, channel roles swapped)
+ * forward, data-gradient and MFMA kernels pick the orientation they need from the blob. */
+size_t dgtta_conv3d_packed_bytes(int CinP, int CoutP, int dtype);
+int dgtta_conv3d_pack_weights(const float *w_t, void *wpack, int Cin, int Cout, int CinP, int CoutP, int dtype,
+                              void *stream);
 
 /* y[b][vo][co] = bias[co] + sum_{tap,ci} x[b][s*vo+tap-1][ci] * w[co][ci][tap]      (zero padding)
  * Optionally accumulates per-(b,co) partial sums of y and y^2 for the following InstanceNorm
  * (stats != NULL: dgtta_conv3d_stats_bytes).  impl: 0 = auto, 1 = reference-grade VALU kernel,
  * 2 = MFMA implicit GEMM. */
 size_t dgtta_conv3d_stats_bytes(int B, int Cout, int Do, int Ho, int Wo);
-int dgtta_conv3d_k3_fwd(const void *x, int ldx, const void *wf, const float *bias, void *y, int ldy, void *stats,
+int dgtta_conv3d_k3_fwd(const void *x, int ldx, const void *wpack, const float *bias, void *y, int ldy, void *stats,
                         int B, int Cin, int Cout, int CinP, int CoutP, int Di, int Hi, int Wi, int stride,
                         int dtype, int impl, void *stream);
 /* dx[b][vi][ci] = sum_{tap,co} dy[b][(vi+1-tap)/s][co] * w[co][ci][tap]   (terms with non-integer
  * or out-of-range index dropped).  accumulate != 0: dx += (skip-connection gradient sum). */
-int dgtta_conv3d_k3_dgrad(const void *dy, int lddy, const void *wb, void *dx, int lddx, int B, int Cin, int Cout,
+int dgtta_conv3d_k3_dgrad(const void *dy, int lddy, const void *wpack, void *dx, int lddx, int B, int Cin, int Cout,
                           int CinP, int CoutP, int Di, int Hi, int Wi, int stride, int accumulate, int dtype,
                           int impl, void *stream);
 /* dw_t[co][ci][tap] (+)= sum_{b,vo} x[b][s*vo+tap-1][ci] * dy[b][vo][co];  db[co] (+)= sum dy.

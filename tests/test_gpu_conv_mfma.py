@@ -1,0 +1,117 @@
+"""GPU: MFMA implicit-GEMM conv kernels vs the general VALU kernels (same C ABI, impl=2 vs impl=1) and vs torch CPU
+conv3d at a small size.  fp32 must agree to summation-order noise; bf16 is compared against the fp32 kernels run on
+the same bf16-rounded operands (bf16 storage, fp32 accumulation => only the output rounding differs)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _call_fwd(x, w, bias, stride, dt, impl, cinp, coutp):
+    from dg_tta_amd import _lib
+    from dg_tta_amd._lib import check, ptr, stream_of
+    lib = _lib.load()
+    B, D, H, W, ld = x.shape
+    cout, cin = w.shape[:2]
+    tdt = torch.float32 if dt == 0 else torch.bfloat16
+    wpack = torch.empty((2, 27, cinp, coutp), dtype=tdt, device=DEV)
+    check(lib.dgtta_conv3d_pack_weights(ptr(w), ptr(wpack), cin, cout, cinp, coutp, dt, stream_of()), "pack")
+    do, ho, wo = [(n - 1) // stride + 1 for n in (D, H, W)]
+    y = torch.empty((B, do, ho, wo, cout), dtype=tdt, device=DEV)
+    check(lib.dgtta_conv3d_k3_fwd(ptr(x), ld, ptr(wpack), ptr(bias), ptr(y), cout, None, B, cin, cout, cinp, coutp, D, H,
+                                  W, stride, dt, impl, stream_of()), "fwd")
+    return y, wpack
+
+
+def _call_dgrad(dy, wpack, cin, cinp, coutp, dims, stride, dt, impl):
+    from dg_tta_amd import _lib
+    from dg_tta_amd._lib import check, ptr, stream_of
+    lib = _lib.load()
+    B = dy.shape[0]
+    cout = dy.shape[-1]
+    D, H, W = dims
+    dx = torch.empty((B, D, H, W, cin), dtype=dy.dtype, device=DEV)
+    check(lib.dgtta_conv3d_k3_dgrad(ptr(dy), cout, ptr(wpack), ptr(dx), cin, B, cin, cout, cinp, coutp, D, H, W, stride,
+                                    0, dt, impl, stream_of()), "dgrad")
+    return dx
+
+
+CASES = [  # (B, cin, cout, D, H, W, stride)
+    (1, 16, 32, 8, 8, 32, 1), (1, 32, 32, 9, 7, 45, 1), (2, 8, 64, 6, 10, 16, 1), (1, 24, 40, 8, 8, 8, 1),
+    (1, 64, 32, 5, 9, 20, 1), (1, 32, 64, 8, 8, 32, 2), (1, 16, 24, 10, 12, 14, 2), (1, 320, 320, 4, 4, 4, 1),
+]
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_conv_mfma_fp32_matches_valu_and_torch(case):
+    B, cin, cout, D, H, W, s = case
+    torch.manual_seed(sum(case))
+    x = torch.randn(B, D, H, W, cin, device=DEV)
+    w = torch.randn(cout, cin, 3, 3, 3, device=DEV) / (27 * cin) ** 0.5
+    bias = torch.randn(cout, device=DEV)
+    cinp, coutp = (cin + 7) // 8 * 8, (cout + 7) // 8 * 8
+    y1, wp = _call_fwd(x, w, bias, s, 0, 1, cinp, coutp)
+    y2, _ = _call_fwd(x, w, bias, s, 0, 2, cinp, coutp)
+    ref = F.conv3d(x.permute(0, 4, 1, 2, 3).cpu(), w.cpu(), bias.cpu(), stride=s, padding=1).permute(0, 2, 3, 4, 1)
+    assert (y1.cpu() - ref).abs().max() < 2e-5 * ref.abs().max() + 1e-5
+    assert (y2.cpu() - ref).abs().max() < 2e-5 * ref.abs().max() + 1e-5
+    if s == 1:
+        dy = torch.randn_like(y1)
+        g1 = _call_dgrad(dy, wp, cin, cinp, coutp, (D, H, W), s, 0, 1)
+        g2 = _call_dgrad(dy, wp, cin, cinp, coutp, (D, H, W), s, 0, 2)
+        assert (g1 - g2).abs().max() < 2e-5 * g1.abs().max() + 1e-5
+
+
+@pytest.mark.parametrize("case", [c for c in CASES if c[1] % 8 == 0])
+def test_conv_mfma_bf16(case):
+    B, cin, cout, D, H, W, s = case
+    torch.manual_seed(sum(case) + 1)
+    xb = torch.randn(B, D, H, W, cin, device=DEV).bfloat16()
+    w = (torch.randn(cout, cin, 3, 3, 3, device=DEV) / (27 * cin) ** 0.5).bfloat16().float()
+    bias = torch.randn(cout, device=DEV)
+    cinp, coutp = (cin + 15) // 16 * 16, (cout + 15) // 16 * 16
+    y_ref, _ = _call_fwd(xb.float(), w, bias, s, 0, 1, (cin + 7) // 8 * 8, (cout + 7) // 8 * 8)    # fp32 math, same operands
+    y, wp = _call_fwd(xb, w, bias, s, 1, 2, cinp, coutp)
+    err = (y.float() - y_ref).abs().max()
+    assert err < 1.0 / 128 * y_ref.abs().max() + 1e-3, f"bf16 conv err {err}"
+    y_valu, _ = _call_fwd(xb, w, bias, s, 1, 1, cinp, coutp)
+    assert (y.float() - y_valu.float()).abs().max() < 1.0 / 64 * y_ref.abs().max() + 1e-3
+
+
+def test_conv_mfma_timing_report(capsys):
+    """Not a pass/fail perf gate: prints achieved TFLOP/s of the main layer shapes (read in gpurun logs)."""
+    from dg_tta_amd import _lib
+    from dg_tta_amd._lib import check, ptr, stream_of
+    lib = _lib.load()
+    rows = []
+    for dt, name in ((1, "bf16"), (0, "fp32")):
+        tdt = torch.bfloat16 if dt else torch.float32
+        cp = 16 if dt else 8
+        for (cin, cout, n, s) in ((32, 32, 128, 1), (64, 32, 128, 1), (64, 64, 64, 1), (128, 128, 32, 1), (32, 64, 128, 2)):
+            if dt == 0 and n == 128 and cin == 64:
+                continue
+            x = torch.randn(1, n, n, n, cin, device=DEV).to(tdt)
+            w = torch.randn(cout, cin, 3, 3, 3, device=DEV) * 0.05
+            wpack = torch.empty((2, 27, cin, cout), dtype=tdt, device=DEV)
+            check(lib.dgtta_conv3d_pack_weights(ptr(w), ptr(wpack), cin, cout, cin, cout, dt, stream_of()), "pack")
+            no = (n - 1) // s + 1
+            y = torch.empty((1, no, no, no, cout), dtype=tdt, device=DEV)
+
+            def run():
+                check(lib.dgtta_conv3d_k3_fwd(ptr(x), cin, ptr(wpack), None, ptr(y), cout, None, 1, cin, cout, cin, cout,
+                                              n, n, n, s, dt, 2, stream_of()), "fwd")
+            run()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(5):
+                run()
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / 5
+            tf = 2.0 * 27 * cin * cout * no ** 3 / (ms * 1e-3) / 1e12
+            rows.append(f"conv3 {name} {cin:>3}->{cout:<3} {n}^3 s{s}: {ms:8.3f} ms  {tf:8.1f} TFLOP/s")
+    with capsys.disabled():
+        print("\n" + "\n".join(rows))

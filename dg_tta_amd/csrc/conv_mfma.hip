@@ -248,7 +248,303 @@ int conv3_fwd_mfma(const void *x, int ldx, const void *w_kmajor, int mirror, con
   return DGTTA_ERR_UNSUPPORTED;
 }
 
-int conv3_wgrad_mfma(const void *, int, const void *, int, float *, float *, void *, size_t, int, int, int, int, int, int,
-                     int, int, int, hipStream_t) {
+namespace {
+
+// =====================================================================================================================
+// Weight gradient on the matrix cores (stride 1):  dW[tap][ci][co] = sum_v x[v + tap - 1][ci] * dy[v][co]
+//   GEMM view: M = ci, N = co, K = voxels (runs of 32 along W).  A workgroup owns one 32(ci) x 32(co) channel tile and a
+//   column of the volume: TH=4 output rows x 32 voxels, D range [d0,d1); its 4 waves own the four 16x16 sub-blocks and
+//   keep all 27 tap accumulators (27 x f32x4) in registers while the column is swept slice by slice.
+//   MFMA: bf16 v_mfma_f32_16x16x32_bf16 (K=32 = one voxel row per instruction), fp32 v_mfma_f32_16x16x4_f32 x8.
+//   LDS: x and dy are staged TRANSPOSED (channel-major, 16-byte runs of consecutive voxels) with an in-register
+//   EPV x EPV transpose, as a ring of 4 x-slices (halo of 1 in D and H) and 2 dy-slices; global loads for slice d+2 are
+//   issued before the MFMAs of slice d and written to LDS after them.  The W shift of a tap (kw-1) is a funnel shift
+//   of the aligned 16-byte run plus the next run's first dword(s).  Layout [row][run][channel][16 B] makes the 16
+//   lanes of a k-group read consecutive 16-byte slots (no bank conflicts).
+//   Each workgroup writes one fp32 partial slab; wgrad_reduce_kernel sums slabs in fixed order (deterministic).
+// =====================================================================================================================
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+
+template <typename T>
+struct WG {
+  static constexpr int EPV = Elem<T>::EPV;
+  static constexpr int GC = 32 / EPV;            // channel groups (of EPV channels) per 32-channel tile
+  static constexpr int NCH_Y = 32 / EPV;         // voxel runs per dy row
+  static constexpr int NCH_X = 32 / EPV + 1;     // voxel runs per x row; run c covers wx = EPV*c - 1 .. EPV*c + EPV - 2
+  static constexpr int TH = 4, XR = TH + 2;
+  static constexpr int XSLOT = XR * NCH_X * 32;  // uint4 per x slice
+  static constexpr int YSLOT = TH * NCH_Y * 32;
+  static constexpr int NUX = XR * NCH_X * GC, NUY = TH * NCH_Y * GC, NU = NUX + NUY;
+  static constexpr int ROUNDS = (NU + 255) / 256;
+  static constexpr size_t LDS_BYTES = (size_t)(4 * XSLOT + 2 * YSLOT) * 16;
+  static constexpr int NSTEP = 32 / (4 * EPV);   // MFMA k-steps per voxel row (bf16 1, fp32 2)
+};
+
+template <typename T>
+__device__ __forceinline__ void transpose_unit(const uint4 *in, uint4 *out);
+template <>
+__device__ __forceinline__ void transpose_unit<float>(const uint4 *in, uint4 *out) {   // 4 voxels x 4 channels
+  out[0] = make_uint4(in[0].x, in[1].x, in[2].x, in[3].x);
+  out[1] = make_uint4(in[0].y, in[1].y, in[2].y, in[3].y);
+  out[2] = make_uint4(in[0].z, in[1].z, in[2].z, in[3].z);
+  out[3] = make_uint4(in[0].w, in[1].w, in[2].w, in[3].w);
+}
+__device__ __forceinline__ unsigned pack_lo(unsigned a, unsigned b) { return (a & 0xffffu) | (b << 16); }
+__device__ __forceinline__ unsigned pack_hi(unsigned a, unsigned b) { return (a >> 16) | (b & 0xffff0000u); }
+template <>
+__device__ __forceinline__ void transpose_unit<bf16_t>(const uint4 *in, uint4 *out) {  // 8 voxels x 8 channels
+#define TR_PAIR(c, fld)                                                                                      \
+  out[c] = make_uint4(pack_lo(in[0].fld, in[1].fld), pack_lo(in[2].fld, in[3].fld), pack_lo(in[4].fld, in[5].fld), \
+                      pack_lo(in[6].fld, in[7].fld));                                                        \
+  out[c + 1] = make_uint4(pack_hi(in[0].fld, in[1].fld), pack_hi(in[2].fld, in[3].fld),                       \
+                          pack_hi(in[4].fld, in[5].fld), pack_hi(in[6].fld, in[7].fld));
+  TR_PAIR(0, x) TR_PAIR(2, y) TR_PAIR(4, z) TR_PAIR(6, w)
+#undef TR_PAIR
+}
+
+// A operand for tap column kw from the aligned run `c` and the next run's first dwords (e0, e1)
+template <typename T>
+__device__ __forceinline__ uint4 shift_run(const uint4 &c, unsigned e0, unsigned e1, int kw);
+template <>
+__device__ __forceinline__ uint4 shift_run<bf16_t>(const uint4 &c, unsigned e0, unsigned, int kw) {
+  if (kw == 0) return c;
+  if (kw == 2) return make_uint4(c.y, c.z, c.w, e0);
+  return make_uint4((c.x >> 16) | (c.y << 16), (c.y >> 16) | (c.z << 16), (c.z >> 16) | (c.w << 16),
+                    (c.w >> 16) | (e0 << 16));
+}
+template <>
+__device__ __forceinline__ uint4 shift_run<float>(const uint4 &c, unsigned e0, unsigned e1, int kw) {
+  if (kw == 0) return c;
+  if (kw == 1) return make_uint4(c.y, c.z, c.w, e0);
+  return make_uint4(c.z, c.w, e0, e1);
+}
+
+template <typename T>
+__device__ __forceinline__ void mfma16(const uint4 &a, const uint4 &b, f32x4_t &acc);
+template <>
+__device__ __forceinline__ void mfma16<bf16_t>(const uint4 &a, const uint4 &b, f32x4_t &acc) {
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), acc, 0,
+                                                0, 0);
+}
+template <>
+__device__ __forceinline__ void mfma16<float>(const uint4 &a, const uint4 &b, f32x4_t &acc) {
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.x), __uint_as_float(b.x), acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.y), __uint_as_float(b.y), acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.z), __uint_as_float(b.z), acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.w), __uint_as_float(b.w), acc, 0, 0, 0);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void conv3_wgrad_mfma_kernel(const T *__restrict__ x, int ldx, const T *__restrict__ dy,
+                                                               int lddy, float *__restrict__ slabs, int Cin, int Cout,
+                                                               int D, int H, int W, int tilesW, int tilesH, int nsd,
+                                                               int DR, int cobs) {
+  typedef WG<T> C;
+  constexpr int EPV = C::EPV;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  uint4 *sX = reinterpret_cast<uint4 *>(smem);                 // [4][XR][NCH_X][32]
+  uint4 *sY = sX + 4 * C::XSLOT;                               // [2][TH][NCH_Y][32]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int m = lane & 15, kg = lane >> 4;
+  const int cih = wave >> 1, coh = wave & 1;
+
+  int t = blockIdx.x;
+  const int tw = t % tilesW;
+  t /= tilesW;
+  const int th = t % tilesH;
+  t /= tilesH;
+  const int ds = t % nsd;
+  const int b = t / nsd;
+  const int cib = blockIdx.y / cobs, cob = blockIdx.y % cobs;
+  const int h0 = th * C::TH, w0 = tw * 32;
+  const int d_begin = ds * DR, d_end = (d_begin + DR < D) ? d_begin + DR : D;
+  const int64_t vb = (int64_t)b * D * H * W;
+
+  uint4 stg[C::ROUNDS][EPV];
+
+  auto load_units = [&](int dx_slice, bool do_x, int dy_slice, bool do_y) {
+#pragma unroll
+    for (int rd = 0; rd < C::ROUNDS; ++rd) {
+      const int u = tid + rd * 256;
+#pragma unroll
+      for (int j = 0; j < EPV; ++j) stg[rd][j] = make_uint4(0, 0, 0, 0);
+      if (u < C::NUX) {
+        if (!do_x) continue;
+        const int cg = u % C::GC, ch = (u / C::GC) % C::NCH_X, row = u / (C::GC * C::NCH_X);
+        const int gd = dx_slice, gh = h0 - 1 + row, c = cib * 32 + cg * EPV;
+        if ((unsigned)gd < (unsigned)D && (unsigned)gh < (unsigned)H && c < Cin) {
+          const T *base = x + (vb + ((int64_t)gd * H + gh) * W) * ldx + c;
+#pragma unroll
+          for (int j = 0; j < EPV; ++j) {
+            const int gw = w0 + EPV * ch - 1 + j;
+            if ((unsigned)gw < (unsigned)W) stg[rd][j] = *reinterpret_cast<const uint4 *>(base + (int64_t)gw * ldx);
+          }
+        }
+      } else if (u < C::NU) {
+        if (!do_y) continue;
+        const int v = u - C::NUX;
+        const int cg = v % C::GC, ch = (v / C::GC) % C::NCH_Y, row = v / (C::GC * C::NCH_Y);
+        const int gd = dy_slice, gh = h0 + row, c = cob * 32 + cg * EPV;
+        if ((unsigned)gd < (unsigned)D && gh < H && c < Cout) {
+          const T *base = dy + (vb + ((int64_t)gd * H + gh) * W) * lddy + c;
+#pragma unroll
+          for (int j = 0; j < EPV; ++j) {
+            const int gw = w0 + EPV * ch + j;
+            if (gw < W) stg[rd][j] = *reinterpret_cast<const uint4 *>(base + (int64_t)gw * lddy);
+          }
+        }
+      }
+    }
+  };
+  auto store_units = [&](int xslot, bool do_x, int yslot, bool do_y) {
+#pragma unroll
+    for (int rd = 0; rd < C::ROUNDS; ++rd) {
+      const int u = tid + rd * 256;
+      uint4 o[EPV];
+      if (u < C::NUX) {
+        if (!do_x) continue;
+        transpose_unit<T>(stg[rd], o);
+        const int cg = u % C::GC, ch = (u / C::GC) % C::NCH_X, row = u / (C::GC * C::NCH_X);
+        uint4 *dst = sX + xslot * C::XSLOT + (row * C::NCH_X + ch) * 32 + cg * EPV;
+#pragma unroll
+        for (int j = 0; j < EPV; ++j) dst[j] = o[j];
+      } else if (u < C::NU) {
+        if (!do_y) continue;
+        transpose_unit<T>(stg[rd], o);
+        const int v = u - C::NUX;
+        const int cg = v % C::GC, ch = (v / C::GC) % C::NCH_Y, row = v / (C::GC * C::NCH_Y);
+        uint4 *dst = sY + yslot * C::YSLOT + (row * C::NCH_Y + ch) * 32 + cg * EPV;
+#pragma unroll
+        for (int j = 0; j < EPV; ++j) dst[j] = o[j];
+      }
+    }
+  };
+
+  f32x4_t acc[27];
+#pragma unroll
+  for (int i = 0; i < 27; ++i) acc[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  // prologue: x slices d_begin-1, d_begin, d_begin+1 and dy slice d_begin
+  load_units(d_begin - 1, true, d_begin, true);
+  store_units((d_begin - 1) & 3, true, d_begin & 1, true);
+  load_units(d_begin, true, 0, false);
+  store_units(d_begin & 3, true, 0, false);
+  load_units(d_begin + 1, true, 0, false);
+  store_units((d_begin + 1) & 3, true, 0, false);
+  __syncthreads();
+
+  for (int d = d_begin; d < d_end; ++d) {
+    const bool more = d + 1 < d_end;
+    load_units(d + 2, more, d + 1, more);     // in flight during the MFMAs below
+    const uint4 *yb = sY + (d & 1) * C::YSLOT;
+#pragma unroll
+    for (int oh = 0; oh < C::TH; ++oh) {
+#pragma unroll
+      for (int stp = 0; stp < C::NSTEP; ++stp) {
+        const int run = stp * 4 + kg;
+        const uint4 bf = yb[(oh * C::NCH_Y + run) * 32 + coh * 16 + m];
+#pragma unroll
+        for (int kd = 0; kd < 3; ++kd) {
+          const uint4 *xs = sX + ((d + kd - 1) & 3) * C::XSLOT;
+#pragma unroll
+          for (int kh = 0; kh < 3; ++kh) {
+            const uint4 *p = xs + ((oh + kh) * C::NCH_X + run) * 32 + cih * 16 + m;
+            const uint4 c0 = p[0];
+            const uint2 ex = *reinterpret_cast<const uint2 *>(p + 32);
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) mfma16<T>(shift_run<T>(c0, ex.x, ex.y, kw), bf, acc[kd * 9 + kh * 3 + kw]);
+          }
+        }
+      }
+    }
+    store_units((d + 2) & 3, more, (d + 1) & 1, more);
+    __syncthreads();
+  }
+
+  // partial slab [27][32 ci][32 co]; C/D map of the 16x16 MFMA: col = lane&15, row = (lane>>4)*4 + reg
+  float *slab = slabs + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * (27 * 1024);
+#pragma unroll
+  for (int tap = 0; tap < 27; ++tap)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) slab[(tap * 32 + cih * 16 + kg * 4 + q) * 32 + coh * 16 + m] = acc[tap][q];
+}
+
+// dw_t[co][ci][tap] (+)= sum over slabs
+__global__ void wgrad_reduce_kernel(const float *__restrict__ slabs, float *__restrict__ dw, int Cin, int Cout, int cobs,
+                                    int nslab, int accumulate) {
+  const int64_t n = (int64_t)Cout * Cin * 27;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int tap = (int)(i % 27), ci = (int)((i / 27) % Cin), co = (int)(i / (27 * (int64_t)Cin));
+    const int pair = (ci >> 5) * cobs + (co >> 5);
+    const float *p = slabs + (int64_t)pair * nslab * (27 * 1024) + (tap * 32 + (ci & 31)) * 32 + (co & 31);
+    float s = 0.f;
+    for (int k = 0; k < nslab; ++k) s += p[(int64_t)k * (27 * 1024)];
+    dw[i] = accumulate ? dw[i] + s : s;
+  }
+}
+
+struct WgradPlan {
+  int tW, tH, nsd, DR, cibs, cobs;
+  int64_t units;
+};
+
+WgradPlan wgrad_plan(int B, int Cin, int Cout, int D, int H, int W) {
+  WgradPlan p;
+  p.tW = cdiv(W, 32);
+  p.tH = cdiv(H, 4);
+  p.cibs = cdiv(Cin, 32);
+  p.cobs = cdiv(Cout, 32);
+  const int64_t base = (int64_t)B * p.tW * p.tH * p.cibs * p.cobs;
+  int want = (int)cdiv64(1024, base);                 // aim for >= ~1024 workgroups
+  int maxsplit = D / 4 > 0 ? D / 4 : 1;
+  p.nsd = want < 1 ? 1 : (want > maxsplit ? maxsplit : want);
+  p.DR = cdiv(D, p.nsd);
+  p.nsd = cdiv(D, p.DR);
+  p.units = (int64_t)B * p.tW * p.tH * p.nsd;
+  return p;
+}
+
+}  // namespace
+
+size_t conv3_wgrad_mfma_ws_bytes(int B, int Cin, int Cout, int D, int H, int W) {
+  WgradPlan p = wgrad_plan(B, Cin, Cout, D, H, W);
+  return (size_t)p.units * p.cibs * p.cobs * 27 * 1024 * sizeof(float);
+}
+
+template <typename T>
+static int wgrad_launch(const void *x, int ldx, const void *dy, int lddy, float *dw_t, void *ws, size_t ws_bytes, int B,
+                        int Cin, int Cout, int D, int H, int W, int accumulate, hipStream_t st) {
+  constexpr int EPV = Elem<T>::EPV;
+  if (Cin % EPV || Cout % EPV || ldx % EPV || lddy % EPV || ((uintptr_t)x & 15) || ((uintptr_t)dy & 15))
+    return DGTTA_ERR_UNSUPPORTED;
+  WgradPlan p = wgrad_plan(B, Cin, Cout, D, H, W);
+  const size_t need = (size_t)p.units * p.cibs * p.cobs * 27 * 1024 * sizeof(float);
+  if (ws_bytes < need || p.units >= (1ll << 31) || p.cibs * p.cobs > 65535) return DGTTA_ERR_UNSUPPORTED;
+  static bool attr_set = false;
+  auto kern = conv3_wgrad_mfma_kernel<T>;
+  if (!attr_set) {
+    hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                        (int)WG<T>::LDS_BYTES);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)p.units, (unsigned)(p.cibs * p.cobs)), dim3(256), WG<T>::LDS_BYTES, st,
+                     (const T *)x, ldx, (const T *)dy, lddy, (float *)ws, Cin, Cout, D, H, W, p.tW, p.tH, p.nsd, p.DR,
+                     p.cobs);
+  DG_CHECK_LAUNCH("conv3_wgrad_mfma_kernel");
+  const int64_t n = (int64_t)Cout * Cin * 27;
+  int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, (const float *)ws, dw_t, Cin, Cout, p.cobs,
+                     (int)p.units, accumulate);
+  DG_CHECK_LAUNCH("wgrad_reduce_kernel");
+  return DGTTA_OK;
+}
+
+int conv3_wgrad_mfma(const void *x, int ldx, const void *dy, int lddy, float *dw_t, float *db, void *ws, size_t ws_bytes,
+                     int B, int Cin, int Cout, int Di, int Hi, int Wi, int stride, int accumulate, int dtype,
+                     hipStream_t st) {
+  (void)db;
+  if (stride != 1) return DGTTA_ERR_UNSUPPORTED;
+  if (dtype == DGTTA_F32) return wgrad_launch<float>(x, ldx, dy, lddy, dw_t, ws, ws_bytes, B, Cin, Cout, Di, Hi, Wi, accumulate, st);
+  if (dtype == DGTTA_BF16) return wgrad_launch<bf16_t>(x, ldx, dy, lddy, dw_t, ws, ws_bytes, B, Cin, Cout, Di, Hi, Wi, accumulate, st);
   return DGTTA_ERR_UNSUPPORTED;
 }

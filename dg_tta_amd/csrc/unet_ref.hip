@@ -577,14 +577,18 @@ extern "C" int dgtta_conv3d_k3_dgrad(const void *dy, int lddy, const void *wpack
   return DGTTA_OK;
 }
 
+size_t conv3_wgrad_mfma_ws_bytes(int B, int Cin, int Cout, int D, int H, int W);
+
+// workspace layout: [bias partials][main: split partials of the VALU kernel | slabs of the MFMA kernel]
+static size_t wgrad_bias_bytes(int B, int Cout, int Do, int Ho, int Wo) {
+  return align_up((size_t)B * reduce_blocks((int64_t)Do * Ho * Wo) * Cout * 2 * sizeof(double), 256);
+}
+
 extern "C" size_t dgtta_conv3d_wgrad_ws_bytes(int B, int Cin, int Cout, int Do, int Ho, int Wo) {
   const int64_t nvox = (int64_t)B * Do * Ho * Wo;
   size_t a = align_up((size_t)wgrad_splits(nvox) * Cout * Cin * 27 * sizeof(float), 256);
-  size_t b = align_up((size_t)B * reduce_blocks((int64_t)Do * Ho * Wo) * Cout * 2 * sizeof(double), 256);
-  // the MFMA wgrad uses one slab per workgroup: bounded by 1024 slabs
-  size_t c = align_up((size_t)1024 * 27 * (size_t)((Cin + 31) / 32 * 32) * ((Cout + 31) / 32 * 32) * sizeof(float), 256);
-  (void)c;
-  return a + b;
+  size_t c = align_up(conv3_wgrad_mfma_ws_bytes(B, Cin, Cout, Do, Ho, Wo), 256);   // stride 1: input dims == output dims
+  return wgrad_bias_bytes(B, Cout, Do, Ho, Wo) + (a > c ? a : c);
 }
 
 static int bias_grad(const void *dy, int lddy, float *db, void *ws, int B, int C, int64_t V, int accumulate, int dtype,
@@ -611,12 +615,13 @@ extern "C" int dgtta_conv3d_k3_wgrad(const void *x, int ldx, const void *dy, int
   hipStream_t st = (hipStream_t)stream;
   const int64_t nvox = (int64_t)B * Do * Ho * Wo;
   const int nsplit = wgrad_splits(nvox);
-  float *part = (float *)ws;
-  void *ws2 = (char *)ws + align_up((size_t)nsplit * Cout * Cin * 27 * sizeof(float), 256);
+  const size_t bias_bytes = wgrad_bias_bytes(B, Cout, Do, Ho, Wo);
+  void *ws2 = ws;                                   // bias partials
+  float *part = (float *)((char *)ws + bias_bytes); // main region
   bool done = false;
   if (impl != 1) {
-    int rc = conv3_wgrad_mfma(x, ldx, dy, lddy, dw_t, nullptr, ws, ws_bytes, B, Cin, Cout, Di, Hi, Wi, stride, accumulate,
-                              dtype, st);
+    int rc = conv3_wgrad_mfma(x, ldx, dy, lddy, dw_t, nullptr, part, ws_bytes - bias_bytes, B, Cin, Cout, Di, Hi, Wi,
+                              stride, accumulate, dtype, st);
     if (rc == DGTTA_OK) done = true;
     else if (rc != DGTTA_ERR_UNSUPPORTED) return rc;
     else DG_REQUIRE(impl == 0, DGTTA_ERR_UNSUPPORTED, "conv3d_k3_wgrad: shape not covered by the MFMA kernel");

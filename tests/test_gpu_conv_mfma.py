@@ -115,3 +115,87 @@ def test_conv_mfma_timing_report(capsys):
             rows.append(f"conv3 {name} {cin:>3}->{cout:<3} {n}^3 s{s}: {ms:8.3f} ms  {tf:8.1f} TFLOP/s")
     with capsys.disabled():
         print("\n" + "\n".join(rows))
+
+
+def _call_wgrad(x, dy, cin, cout, stride, dt, impl, with_bias=True, accumulate=0, dw=None, db=None):
+    from dg_tta_amd import _lib
+    from dg_tta_amd._lib import check, ptr, stream_of
+    lib = _lib.load()
+    B, D, H, W, ldx = x.shape
+    do, ho, wo = dy.shape[1:4]
+    dw = torch.empty((cout, cin, 3, 3, 3), device=DEV) if dw is None else dw
+    db = (torch.empty((cout,), device=DEV) if db is None else db) if with_bias else None
+    nb = lib.dgtta_conv3d_wgrad_ws_bytes(B, cin, cout, do, ho, wo)
+    ws = torch.empty(nb, dtype=torch.uint8, device=DEV)
+    check(lib.dgtta_conv3d_k3_wgrad(ptr(x), ldx, ptr(dy), dy.shape[-1], ptr(dw), ptr(db), ptr(ws), nb, B, cin, cout, D, H,
+                                    W, stride, accumulate, dt, impl, stream_of()), "wgrad")
+    return dw, db
+
+
+WCASES = [(1, 16, 32, 8, 8, 32), (1, 32, 32, 9, 7, 45), (2, 8, 64, 6, 10, 16), (1, 64, 32, 5, 9, 20),
+          (1, 24, 40, 8, 8, 8), (1, 32, 32, 40, 12, 64), (1, 320, 320, 4, 4, 4)]
+
+
+@pytest.mark.parametrize("case", WCASES)
+def test_wgrad_mfma_fp32(case):
+    B, cin, cout, D, H, W = case
+    torch.manual_seed(sum(case) + 7)
+    x = torch.randn(B, D, H, W, cin, device=DEV)
+    dy = torch.randn(B, D, H, W, cout, device=DEV)
+    dw1, db1 = _call_wgrad(x, dy, cin, cout, 1, 0, 1)
+    dw2, db2 = _call_wgrad(x, dy, cin, cout, 1, 0, 2)
+    xc = x.permute(0, 4, 1, 2, 3).cpu().double()
+    gc = dy.permute(0, 4, 1, 2, 3).cpu().double()
+    ref = torch.nn.grad.conv3d_weight(xc, (cout, cin, 3, 3, 3), gc, stride=1, padding=1).float()
+    scale = ref.abs().max()
+    assert (dw1.cpu() - ref).abs().max() < 3e-5 * scale
+    assert (dw2.cpu() - ref).abs().max() < 3e-5 * scale
+    assert torch.allclose(db1, db2)
+    # accumulate: dw += second gradient
+    dw3, _ = _call_wgrad(x, dy, cin, cout, 1, 0, 2, accumulate=1, dw=dw2.clone(), db=db2.clone())
+    assert (dw3.cpu() - 2 * ref).abs().max() < 6e-5 * scale
+
+
+@pytest.mark.parametrize("case", [c for c in WCASES if c[1] % 8 == 0])
+def test_wgrad_mfma_bf16(case):
+    B, cin, cout, D, H, W = case
+    torch.manual_seed(sum(case) + 8)
+    x = torch.randn(B, D, H, W, cin, device=DEV).bfloat16()
+    dy = torch.randn(B, D, H, W, cout, device=DEV).bfloat16()
+    dw_ref, _ = _call_wgrad(x.float(), dy.float(), cin, cout, 1, 0, 1)     # fp32 math on the same bf16 operands
+    dw, _ = _call_wgrad(x, dy, cin, cout, 1, 1, 2)
+    assert (dw - dw_ref).abs().max() < 1e-4 * dw_ref.abs().max() + 1e-4          # fp32 accumulation: only order differs
+
+
+def test_wgrad_mfma_timing_report(capsys):
+    from dg_tta_amd import _lib
+    from dg_tta_amd._lib import check, ptr, stream_of
+    lib = _lib.load()
+    rows = []
+    for dt, name in ((1, "bf16"), (0, "fp32")):
+        tdt = torch.bfloat16 if dt else torch.float32
+        for (cin, cout, n) in ((32, 32, 128), (64, 32, 128), (64, 64, 64), (128, 128, 32), (256, 256, 16)):
+            if dt == 0 and n == 128 and cin == 64:
+                continue
+            x = torch.randn(1, n, n, n, cin, device=DEV).to(tdt)
+            dy = torch.randn(1, n, n, n, cout, device=DEV).to(tdt)
+            dw = torch.empty((cout, cin, 3, 3, 3), device=DEV)
+            nb = lib.dgtta_conv3d_wgrad_ws_bytes(1, cin, cout, n, n, n)
+            ws = torch.empty(nb, dtype=torch.uint8, device=DEV)
+
+            def run():
+                check(lib.dgtta_conv3d_k3_wgrad(ptr(x), cin, ptr(dy), cout, ptr(dw), None, ptr(ws), nb, 1, cin, cout, n, n,
+                                                n, 1, 0, dt, 2, stream_of()), "wgrad")
+            run()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(5):
+                run()
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / 5
+            tf = 2.0 * 27 * cin * cout * n ** 3 / (ms * 1e-3) / 1e12
+            rows.append(f"wgrad {name} {cin:>3}x{cout:<3} {n}^3: {ms:8.3f} ms  {tf:8.1f} TFLOP/s  (ws {nb / 2**20:.0f} MiB)")
+    with capsys.disabled():
+        print("\n" + "\n".join(rows))

@@ -37,9 +37,10 @@ SIGNATURES = {
     "dgtta_instnorm_ws_bytes": (SZ, [I, I, I64]),
     "dgtta_instnorm_lrelu_fwd": (I, [P, I, P, P, P, P, P, I, P, SZ, I, I, I64, F, F, I, P]),
     "dgtta_instnorm_lrelu_bwd": (I, [P, I, P, I, P, P, P, P, I, P, P, P, SZ, I, I, I64, F, I, I, P]),
-    "dgtta_convT3d_k2s2_fwd": (I, [P, I, P, P, P, I, I, I, I, I, I, I, I, P]),
+    "dgtta_convT3d_fwd_ws_bytes": (SZ, [I, I, I]),
+    "dgtta_convT3d_k2s2_fwd": (I, [P, I, P, P, P, I, P, SZ, I, I, I, I, I, I, I, I, P]),
     "dgtta_convT3d_bwd_ws_bytes": (SZ, [I, I, I, I, I, I]),
-    "dgtta_convT3d_k2s2_bwd": (I, [P, I, P, I, P, P, I, P, P, P, SZ, I, I, I, I, I, I, I, I, P]),
+    "dgtta_convT3d_k2s2_bwd": (I, [P, I, P, I, P, P, I, P, P, P, SZ, I, I, I, I, I, I, I, I, I, P]),
     "dgtta_seghead_fwd": (I, [P, I, P, P, P, I, P, I, I, I, I, I64, I, P]),
     "dgtta_seghead_bwd_ws_bytes": (SZ, [I, I, I, I64]),
     "dgtta_seghead_bwd": (I, [P, I, P, I, P, P, I, P, I, P, P, P, SZ, I, I, I64, I, I, P]),

@@ -75,13 +75,24 @@ struct ConvCfg {
   static constexpr size_t LDS_BYTES = A_BYTES + B_BYTES;
 };
 
-// x: [B][Di][Hi][Wi][ldx];  w: [27][CoutP][CinP] (k contiguous), tap index mirrored when `mirror`;  y: [B][Do][Ho][Wo][ldy]
+// Strided view of a channels-last volume: element strides (channel stride 1) + logical extent.  Lets the same kernel
+// run on parity sub-lattices (stride-2 data gradient, 2x2x2 transposed conv) without copies.
+struct View {
+  long long sb, sd, sh, sw;
+  int D, H, W;
+};
+// weight tap used by each of the 27 virtual taps (-1: tap not present)
+struct Taps {
+  signed char wt[27];
+};
+
+// x: view xv;  w: [ntap][CoutP][CinP] (k contiguous), virtual tap t uses weight tap taps.wt[t];  y: view yv
 template <typename T, int MBW, int MBH, int MBD, int S, int NB, int KSPC>
-__global__ __launch_bounds__(256) void conv3_mfma_kernel(const T *__restrict__ x, int ldx, const T *__restrict__ w,
-                                                         int mirror, const float *__restrict__ bias,
-                                                         T *__restrict__ y, int ldy, int Cin, int Cout, int CinP,
-                                                         int CoutP, int Di, int Hi, int Wi, int Do, int Ho, int Wo,
-                                                         int tilesW, int tilesH, int tilesD) {
+__global__ __launch_bounds__(256) void conv3_mfma_kernel(const T *__restrict__ x, View xv, const T *__restrict__ w,
+                                                         Taps taps, const float *__restrict__ bias,
+                                                         T *__restrict__ y, View yv, int Cin, int Cout, int CinP,
+                                                         int CoutP, int tilesW, int tilesH, int tilesD, int accumulate) {
+  const int Di = xv.D, Hi = xv.H, Wi = xv.W, Do = yv.D, Ho = yv.H, Wo = yv.W;
   typedef ConvCfg<T, MBW, MBH, MBD, S, NB, KSPC> Cfg;
   typedef typename Cfg::G G;
   constexpr int EPV = Cfg::EPV, NG = Cfg::NG, CK = Cfg::CK, NC = Cfg::NC, NV = G::NV, MPW = G::MPW;
@@ -121,7 +132,7 @@ __global__ __launch_bounds__(256) void conv3_mfma_kernel(const T *__restrict__ x
 #pragma unroll
       for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
 
-  const int64_t xb = (int64_t)b * Di * Hi * Wi;
+  const T *xbp = x + (int64_t)b * xv.sb;
   const int cin_lim = (Cin + EPV - 1) / EPV * EPV;       // channels that may be read (caller guarantees ldx >= this)
 
   for (int kc = 0; kc < CinP; kc += CK) {
@@ -137,13 +148,14 @@ __global__ __launch_bounds__(256) void conv3_mfma_kernel(const T *__restrict__ x
       uint4 val = make_uint4(0, 0, 0, 0);
       if ((S == 1 || wx < G::IW) && (unsigned)gd < (unsigned)Di && (unsigned)gh < (unsigned)Hi &&
           (unsigned)gw < (unsigned)Wi && c < cin_lim)
-        val = *reinterpret_cast<const uint4 *>(x + (xb + ((int64_t)gd * Hi + gh) * Wi + gw) * ldx + c);
+        val = *reinterpret_cast<const uint4 *>(xbp + gd * xv.sd + gh * xv.sh + gw * xv.sw + c);
       sA[g * NV + v] = val;
     }
     // ---- stage B: weights of this chunk for output channels n0..n0+NC
     for (int idx = tid; idx < 27 * NC * NG; idx += 256) {
       const int g = idx % NG, n = (idx / NG) % NC, tap = idx / (NG * NC);
-      const int wt = mirror ? 26 - tap : tap;
+      const int wt = taps.wt[tap];
+      if (wt < 0) continue;
       uint4 val = make_uint4(0, 0, 0, 0);
       if (n0 + n < CoutP) val = *reinterpret_cast<const uint4 *>(w + ((int64_t)wt * CoutP + n0 + n) * CinP + kc + g * EPV);
       sB[(tap * NG + g) * NC + n] = val;
@@ -152,6 +164,7 @@ __global__ __launch_bounds__(256) void conv3_mfma_kernel(const T *__restrict__ x
     // ---- 27 taps x KSPC k-steps of MFMA from LDS
 #pragma unroll
     for (int tap = 0; tap < 27; ++tap) {
+      if (taps.wt[tap] < 0) continue;     // wave-uniform
       const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
       const int tap_off = (kd * G::IH + kh) * G::ROW + G::lds_col(kw);
 #pragma unroll
@@ -183,55 +196,113 @@ __global__ __launch_bounds__(256) void conv3_mfma_kernel(const T *__restrict__ x
       for (int q = 0; q < 16; ++q) {
         const int m = (q & 3) + 8 * (q >> 2) + 4 * h;
         const int od = od0 + mbd, oh = oh0 + mbh * G::RPM + m / MBW, ow = ow0 + m % MBW;
-        if (co < Cout && od < Do && oh < Ho && ow < Wo)
-          st_f<T>(y + (((int64_t)b * Do + od) * Ho + oh) * Wo * (int64_t)ldy + (int64_t)ow * ldy + co, acc[i][j][q] + bv);
+        if (co < Cout && od < Do && oh < Ho && ow < Wo) {
+          T *o = y + b * yv.sb + od * yv.sd + oh * yv.sh + ow * yv.sw + co;
+          float v = acc[i][j][q] + bv;
+          if (accumulate) v += ld_f<T>(o);
+          st_f<T>(o, v);
+        }
       }
     }
   }
 }
 
 template <typename T, int MBW, int MBH, int MBD, int S, int NB, int KSPC>
-int launch_conv(const void *x, int ldx, const void *w, int mirror, const float *bias, void *y, int ldy, int B, int Cin,
-                int Cout, int CinP, int CoutP, int Di, int Hi, int Wi, int Do, int Ho, int Wo, hipStream_t st) {
+int launch_conv(const void *x, const View &xv, const void *w, const Taps &taps, const float *bias, void *y,
+                const View &yv, int B, int Cin, int Cout, int CinP, int CoutP, int accumulate, hipStream_t st) {
   typedef ConvCfg<T, MBW, MBH, MBD, S, NB, KSPC> Cfg;
   typedef typename Cfg::G G;
   static bool attr_set = false;
   auto kern = conv3_mfma_kernel<T, MBW, MBH, MBD, S, NB, KSPC>;
   if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                        (int)Cfg::LDS_BYTES);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)Cfg::LDS_BYTES);
     attr_set = true;
   }
-  const int tW = cdiv(Wo, G::TW), tH = cdiv(Ho, G::TH), tD = cdiv(Do, G::TD);
+  const int tW = cdiv(yv.W, G::TW), tH = cdiv(yv.H, G::TH), tD = cdiv(yv.D, G::TD);
   const int64_t tiles = (int64_t)tW * tH * tD * B;
   DG_REQUIRE(tiles < (1ll << 31), DGTTA_ERR_UNSUPPORTED, "conv3_mfma: too many tiles");
   dim3 grid((unsigned)tiles, (unsigned)cdiv(CoutP, Cfg::NC));
-  hipLaunchKernelGGL(kern, grid, dim3(256), Cfg::LDS_BYTES, st, (const T *)x, ldx, (const T *)w, mirror, bias, (T *)y,
-                     ldy, Cin, Cout, CinP, CoutP, Di, Hi, Wi, Do, Ho, Wo, tW, tH, tD);
+  hipLaunchKernelGGL(kern, grid, dim3(256), Cfg::LDS_BYTES, st, (const T *)x, xv, (const T *)w, taps, bias, (T *)y, yv,
+                     Cin, Cout, CinP, CoutP, tW, tH, tD, accumulate);
   DG_CHECK_LAUNCH("conv3_mfma_kernel");
   return DGTTA_OK;
 }
 
+View dense_view(int B, int D, int H, int W, int ld) {
+  (void)B;
+  View v;
+  v.sw = ld;
+  v.sh = (long long)W * ld;
+  v.sd = (long long)H * W * ld;
+  v.sb = (long long)D * H * W * ld;
+  v.D = D;
+  v.H = H;
+  v.W = W;
+  return v;
+}
+// sub-lattice of parity (pd,ph,pw) of a dense volume: elements 2v+p
+View parity_view(int D, int H, int W, int ld, int pd, int ph, int pw, long long *offset) {
+  View v = dense_view(1, D, H, W, ld);
+  *offset = ((long long)pd * H * W + (long long)ph * W + pw) * ld;
+  v.sd *= 2;
+  v.sh *= 2;
+  v.sw *= 2;
+  v.D = (D - pd + 1) / 2;
+  v.H = (H - ph + 1) / 2;
+  v.W = (W - pw + 1) / 2;
+  return v;
+}
+
 template <typename T>
-int dispatch_conv(const void *x, int ldx, const void *w, int mirror, const float *bias, void *y, int ldy, int B, int Cin,
-                  int Cout, int CinP, int CoutP, int Di, int Hi, int Wi, int stride, hipStream_t st) {
+bool operand_ok(const void *p, long long ld_elems, int Cin, int CinP) {
   constexpr int EPV = Elem<T>::EPV;
-  // shape requirements of the vectorised staging
-  if (ldx % EPV != 0 || ((uintptr_t)x & 15) != 0 || CinP % (2 * EPV) != 0 || ldx < (Cin + EPV - 1) / EPV * EPV)
-    return DGTTA_ERR_UNSUPPORTED;
-  const int Do = (Di - 1) / stride + 1, Ho = (Hi - 1) / stride + 1, Wo = (Wi - 1) / stride + 1;
-#define ARGS x, ldx, w, mirror, bias, y, ldy, B, Cin, Cout, CinP, CoutP, Di, Hi, Wi, Do, Ho, Wo, st
+  return ld_elems % EPV == 0 && ((uintptr_t)p & 15) == 0 && CinP % (2 * EPV) == 0 &&
+         ld_elems >= (Cin + EPV - 1) / EPV * EPV;
+}
+
+// picks the tile shape from the (virtual) output extent
+template <typename T>
+int dispatch_conv(const void *x, const View &xv, const void *w, const Taps &taps, const float *bias, void *y,
+                  const View &yv, int B, int Cin, int Cout, int CinP, int CoutP, int stride, int accumulate,
+                  hipStream_t st) {
+#define ARGS x, xv, w, taps, bias, y, yv, B, Cin, Cout, CinP, CoutP, accumulate, st
+  const long long vox = (long long)yv.D * yv.H * yv.W * B;
   if (stride == 1) {
-    if (Wo >= 32) return launch_conv<T, 32, 4, 4, 1, 1, 1>(ARGS);
-    if (Wo >= 16) return launch_conv<T, 16, 4, 4, 1, 1, 1>(ARGS);
+    if (yv.W >= 32) return launch_conv<T, 32, 4, 4, 1, 1, 1>(ARGS);
+    if (yv.W >= 16) return launch_conv<T, 16, 4, 4, 1, 1, 1>(ARGS);
+    if (vox <= 4096) return launch_conv<T, 8, 2, 2, 1, 1, 1>(ARGS);     // tiny volumes: more, smaller workgroups
     return launch_conv<T, 8, 2, 8, 1, 1, 1>(ARGS);
   }
   if (stride == 2) {
-    if (Wo >= 16) return launch_conv<T, 16, 2, 4, 2, 1, 1>(ARGS);
+    if (yv.W >= 16) return launch_conv<T, 16, 2, 4, 2, 1, 1>(ARGS);
     return launch_conv<T, 8, 2, 4, 2, 1, 1>(ARGS);
   }
 #undef ARGS
   return DGTTA_ERR_UNSUPPORTED;
+}
+
+Taps identity_taps(int mirror) {
+  Taps t;
+  for (int i = 0; i < 27; ++i) t.wt[i] = (signed char)(mirror ? 26 - i : i);
+  return t;
+}
+
+// ConvTranspose3d k2 s2 weight packing: w_t[ci][co][o] fp32 -> wf[o][coP][ciP], wb[o][ciP][coP] (zero padded)
+template <typename T>
+__global__ void convT_pack_kernel(const float *__restrict__ w, T *__restrict__ wf, T *__restrict__ wb, int Cin, int Cout,
+                                  int CinP, int CoutP) {
+  const int64_t n = (int64_t)8 * CinP * CoutP;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    {
+      int ci = (int)(i % CinP), co = (int)((i / CinP) % CoutP), o = (int)(i / ((int64_t)CinP * CoutP));
+      st_f<T>(wf + i, (ci < Cin && co < Cout) ? w[((int64_t)ci * Cout + co) * 8 + o] : 0.f);
+    }
+    {
+      int co = (int)(i % CoutP), ci = (int)((i / CoutP) % CinP), o = (int)(i / ((int64_t)CinP * CoutP));
+      st_f<T>(wb + i, (ci < Cin && co < Cout) ? w[((int64_t)ci * Cout + co) * 8 + o] : 0.f);
+    }
+  }
 }
 
 }  // namespace
@@ -240,11 +311,111 @@ int dispatch_conv(const void *x, int ldx, const void *w, int mirror, const float
 int conv3_fwd_mfma(const void *x, int ldx, const void *w_kmajor, int mirror, const float *bias, void *y, int ldy, int B,
                    int Cin, int Cout, int CinP, int CoutP, int Di, int Hi, int Wi, int stride, int dtype,
                    hipStream_t st) {
-  if (dtype == DGTTA_F32)
-    return dispatch_conv<float>(x, ldx, w_kmajor, mirror, bias, y, ldy, B, Cin, Cout, CinP, CoutP, Di, Hi, Wi, stride, st);
-  if (dtype == DGTTA_BF16)
-    return dispatch_conv<bf16_t>(x, ldx, w_kmajor, mirror, bias, y, ldy, B, Cin, Cout, CinP, CoutP, Di, Hi, Wi, stride,
-                                 st);
+  const int Do = (Di - 1) / stride + 1, Ho = (Hi - 1) / stride + 1, Wo = (Wi - 1) / stride + 1;
+  const View xv = dense_view(B, Di, Hi, Wi, ldx), yv = dense_view(B, Do, Ho, Wo, ldy);
+  const Taps taps = identity_taps(mirror);
+  if (dtype == DGTTA_F32) {
+    if (!operand_ok<float>(x, ldx, Cin, CinP)) return DGTTA_ERR_UNSUPPORTED;
+    return dispatch_conv<float>(x, xv, w_kmajor, taps, bias, y, yv, B, Cin, Cout, CinP, CoutP, stride, 0, st);
+  }
+  if (dtype == DGTTA_BF16) {
+    if (!operand_ok<bf16_t>(x, ldx, Cin, CinP)) return DGTTA_ERR_UNSUPPORTED;
+    return dispatch_conv<bf16_t>(x, xv, w_kmajor, taps, bias, y, yv, B, Cin, Cout, CinP, CoutP, stride, 0, st);
+  }
+  return DGTTA_ERR_UNSUPPORTED;
+}
+
+// Data gradient of a stride-2 conv: 8 parity classes of the input lattice, each a stride-1 gather of dy with the
+// 1/2/4/8 taps that reach that class.  w_kmajor = blob first half [27][CinP][CoutP] (K = co contiguous), real taps.
+template <typename T>
+static int dgrad_s2(const void *dy, int lddy, const void *w_kmajor, void *dx, int lddx, int B, int Cin, int Cout, int CinP,
+                    int CoutP, int Di, int Hi, int Wi, int accumulate, hipStream_t st) {
+  if (!operand_ok<T>(dy, lddy, Cout, CoutP)) return DGTTA_ERR_UNSUPPORTED;
+  const int Do = (Di - 1) / 2 + 1, Ho = (Hi - 1) / 2 + 1, Wo = (Wi - 1) / 2 + 1;
+  const View xv = dense_view(B, Do, Ho, Wo, lddy);
+  for (int p = 0; p < 8; ++p) {
+    const int pd = p >> 2, ph = (p >> 1) & 1, pw = p & 1;
+    long long off;
+    View yv = parity_view(Di, Hi, Wi, lddx, pd, ph, pw, &off);
+    yv.sb = (long long)Di * Hi * Wi * lddx;
+    if (yv.D == 0 || yv.H == 0 || yv.W == 0) continue;
+    Taps taps;
+    for (int t = 0; t < 27; ++t) {
+      const int k[3] = {t / 9, (t / 3) % 3, t % 3}, par[3] = {pd, ph, pw};
+      int real[3];
+      bool ok = true;
+      for (int a = 0; a < 3; ++a) {
+        if (par[a] == 0) {
+          ok = ok && (k[a] == 1);
+          real[a] = 1;
+        } else {
+          ok = ok && (k[a] >= 1);
+          real[a] = (k[a] == 1) ? 2 : 0;
+        }
+      }
+      taps.wt[t] = ok ? (signed char)(real[0] * 9 + real[1] * 3 + real[2]) : (signed char)-1;
+    }
+    int rc = dispatch_conv<T>(dy, xv, w_kmajor, taps, nullptr, (T *)dx + off, yv, B, Cout, Cin, CoutP, CinP, 1, accumulate,
+                              st);
+    if (rc != DGTTA_OK) return rc;
+  }
+  return DGTTA_OK;
+}
+
+int conv3_dgrad_s2_mfma(const void *dy, int lddy, const void *w_kmajor, void *dx, int lddx, int B, int Cin, int Cout,
+                        int CinP, int CoutP, int Di, int Hi, int Wi, int accumulate, int dtype, hipStream_t st) {
+  if (dtype == DGTTA_F32) return dgrad_s2<float>(dy, lddy, w_kmajor, dx, lddx, B, Cin, Cout, CinP, CoutP, Di, Hi, Wi, accumulate, st);
+  if (dtype == DGTTA_BF16) return dgrad_s2<bf16_t>(dy, lddy, w_kmajor, dx, lddx, B, Cin, Cout, CinP, CoutP, Di, Hi, Wi, accumulate, st);
+  return DGTTA_ERR_UNSUPPORTED;
+}
+
+// ConvTranspose3d(k2,s2) forward / data gradient as 8 single-tap launches (one per output offset o).
+size_t convT_packed_bytes(int CinP, int CoutP, int dtype) { return (size_t)2 * 8 * CinP * CoutP * (dtype == DGTTA_BF16 ? 2 : 4); }
+
+template <typename T>
+static int convT_run(int mode /*0 fwd, 1 dgrad*/, const void *in, int ldin, const float *w_t, const float *bias, void *out,
+                     int ldout, void *ws, int B, int Cin, int Cout, int Di, int Hi, int Wi, hipStream_t st) {
+  constexpr int EPV = Elem<T>::EPV;
+  const int CinP = (Cin + 2 * EPV - 1) / (2 * EPV) * (2 * EPV), CoutP = (Cout + 2 * EPV - 1) / (2 * EPV) * (2 * EPV);
+  T *wf = (T *)ws, *wb = wf + (size_t)8 * CinP * CoutP;
+  const int64_t n = (int64_t)8 * CinP * CoutP;
+  hipLaunchKernelGGL((convT_pack_kernel<T>), dim3((unsigned)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024)), dim3(256),
+                     0, st, w_t, wf, wb, Cin, Cout, CinP, CoutP);
+  DG_CHECK_LAUNCH("convT_pack_kernel");
+  const int Do = 2 * Di, Ho = 2 * Hi, Wo = 2 * Wi;
+  if (mode == 0 ? !operand_ok<T>(in, ldin, Cin, CinP) : !operand_ok<T>(in, ldin, Cout, CoutP)) return DGTTA_ERR_UNSUPPORTED;
+  for (int o = 0; o < 8; ++o) {
+    long long off;
+    Taps taps;
+    for (int t = 0; t < 27; ++t) taps.wt[t] = -1;
+    taps.wt[13] = (signed char)o;
+    int rc;
+    if (mode == 0) {
+      View yv = parity_view(Do, Ho, Wo, ldout, o >> 2, (o >> 1) & 1, o & 1, &off);
+      yv.sb = (long long)Do * Ho * Wo * ldout;
+      const View xv = dense_view(B, Di, Hi, Wi, ldin);
+      rc = dispatch_conv<T>(in, xv, wf, taps, bias, (T *)out + off, yv, B, Cin, Cout, CinP, CoutP, 1, 0, st);
+    } else {
+      View xv = parity_view(Do, Ho, Wo, ldin, o >> 2, (o >> 1) & 1, o & 1, &off);
+      xv.sb = (long long)Do * Ho * Wo * ldin;
+      const View yv = dense_view(B, Di, Hi, Wi, ldout);
+      rc = dispatch_conv<T>((const T *)in + off, xv, wb, taps, nullptr, out, yv, B, Cout, Cin, CoutP, CinP, 1, o != 0, st);
+    }
+    if (rc != DGTTA_OK) return rc;
+  }
+  return DGTTA_OK;
+}
+
+int convT_fwd_mfma(const void *x, int ldx, const float *w_t, const float *bias, void *out, int ldo, void *ws, int B, int Cin,
+                   int Cout, int Di, int Hi, int Wi, int dtype, hipStream_t st) {
+  if (dtype == DGTTA_F32) return convT_run<float>(0, x, ldx, w_t, bias, out, ldo, ws, B, Cin, Cout, Di, Hi, Wi, st);
+  if (dtype == DGTTA_BF16) return convT_run<bf16_t>(0, x, ldx, w_t, bias, out, ldo, ws, B, Cin, Cout, Di, Hi, Wi, st);
+  return DGTTA_ERR_UNSUPPORTED;
+}
+int convT_dgrad_mfma(const void *dout, int lddo, const float *w_t, void *dx, int lddx, void *ws, int B, int Cin, int Cout,
+                     int Di, int Hi, int Wi, int dtype, hipStream_t st) {
+  if (dtype == DGTTA_F32) return convT_run<float>(1, dout, lddo, w_t, nullptr, dx, lddx, ws, B, Cin, Cout, Di, Hi, Wi, st);
+  if (dtype == DGTTA_BF16) return convT_run<bf16_t>(1, dout, lddo, w_t, nullptr, dx, lddx, ws, B, Cin, Cout, Di, Hi, Wi, st);
   return DGTTA_ERR_UNSUPPORTED;
 }
 
@@ -334,11 +505,14 @@ __device__ __forceinline__ void mfma16<float>(const uint4 &a, const uint4 &b, f3
   acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.w), __uint_as_float(b.w), acc, 0, 0, 0);
 }
 
+// x: view xv (input lattice of the virtual stride-1 problem), dy: view yv (output lattice; tiles run over it).
+// tapmask: bit t set = virtual tap t is accumulated.
 template <typename T>
-__global__ __launch_bounds__(256) void conv3_wgrad_mfma_kernel(const T *__restrict__ x, int ldx, const T *__restrict__ dy,
-                                                               int lddy, float *__restrict__ slabs, int Cin, int Cout,
-                                                               int D, int H, int W, int tilesW, int tilesH, int nsd,
-                                                               int DR, int cobs) {
+__global__ __launch_bounds__(256) void conv3_wgrad_mfma_kernel(const T *__restrict__ x, View xv, const T *__restrict__ dy,
+                                                               View yv, float *__restrict__ slabs, int Cin, int Cout,
+                                                               int tilesW, int tilesH, int nsd, int DR, int cobs,
+                                                               unsigned tapmask) {
+  const int D = yv.D, H = yv.H, W = yv.W;
   typedef WG<T> C;
   constexpr int EPV = C::EPV;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -358,7 +532,8 @@ __global__ __launch_bounds__(256) void conv3_wgrad_mfma_kernel(const T *__restri
   const int cib = blockIdx.y / cobs, cob = blockIdx.y % cobs;
   const int h0 = th * C::TH, w0 = tw * 32;
   const int d_begin = ds * DR, d_end = (d_begin + DR < D) ? d_begin + DR : D;
-  const int64_t vb = (int64_t)b * D * H * W;
+  const T *xb = x + b * xv.sb;
+  const T *yb0 = dy + b * yv.sb;
 
   uint4 stg[C::ROUNDS][EPV];
 
@@ -372,12 +547,12 @@ __global__ __launch_bounds__(256) void conv3_wgrad_mfma_kernel(const T *__restri
         if (!do_x) continue;
         const int cg = u % C::GC, ch = (u / C::GC) % C::NCH_X, row = u / (C::GC * C::NCH_X);
         const int gd = dx_slice, gh = h0 - 1 + row, c = cib * 32 + cg * EPV;
-        if ((unsigned)gd < (unsigned)D && (unsigned)gh < (unsigned)H && c < Cin) {
-          const T *base = x + (vb + ((int64_t)gd * H + gh) * W) * ldx + c;
+        if ((unsigned)gd < (unsigned)xv.D && (unsigned)gh < (unsigned)xv.H && c < Cin) {
+          const T *base = xb + gd * xv.sd + gh * xv.sh + c;
 #pragma unroll
           for (int j = 0; j < EPV; ++j) {
             const int gw = w0 + EPV * ch - 1 + j;
-            if ((unsigned)gw < (unsigned)W) stg[rd][j] = *reinterpret_cast<const uint4 *>(base + (int64_t)gw * ldx);
+            if ((unsigned)gw < (unsigned)xv.W) stg[rd][j] = *reinterpret_cast<const uint4 *>(base + gw * xv.sw);
           }
         }
       } else if (u < C::NU) {
@@ -386,11 +561,11 @@ __global__ __launch_bounds__(256) void conv3_wgrad_mfma_kernel(const T *__restri
         const int cg = v % C::GC, ch = (v / C::GC) % C::NCH_Y, row = v / (C::GC * C::NCH_Y);
         const int gd = dy_slice, gh = h0 + row, c = cob * 32 + cg * EPV;
         if ((unsigned)gd < (unsigned)D && gh < H && c < Cout) {
-          const T *base = dy + (vb + ((int64_t)gd * H + gh) * W) * lddy + c;
+          const T *base = yb0 + gd * yv.sd + gh * yv.sh + c;
 #pragma unroll
           for (int j = 0; j < EPV; ++j) {
             const int gw = w0 + EPV * ch + j;
-            if (gw < W) stg[rd][j] = *reinterpret_cast<const uint4 *>(base + (int64_t)gw * lddy);
+            if (gw < W) stg[rd][j] = *reinterpret_cast<const uint4 *>(base + gw * yv.sw);
           }
         }
       }
@@ -448,11 +623,14 @@ __global__ __launch_bounds__(256) void conv3_wgrad_mfma_kernel(const T *__restri
           const uint4 *xs = sX + ((d + kd - 1) & 3) * C::XSLOT;
 #pragma unroll
           for (int kh = 0; kh < 3; ++kh) {
+            if (((tapmask >> (kd * 9 + kh * 3)) & 7u) == 0) continue;      // wave-uniform: no tap of this (kd,kh) wanted
             const uint4 *p = xs + ((oh + kh) * C::NCH_X + run) * 32 + cih * 16 + m;
             const uint4 c0 = p[0];
             const uint2 ex = *reinterpret_cast<const uint2 *>(p + 32);
 #pragma unroll
-            for (int kw = 0; kw < 3; ++kw) mfma16<T>(shift_run<T>(c0, ex.x, ex.y, kw), bf, acc[kd * 9 + kh * 3 + kw]);
+            for (int kw = 0; kw < 3; ++kw)
+              if ((tapmask >> (kd * 9 + kh * 3 + kw)) & 1u)
+                mfma16<T>(shift_run<T>(c0, ex.x, ex.y, kw), bf, acc[kd * 9 + kh * 3 + kw]);
           }
         }
       }
@@ -469,17 +647,20 @@ __global__ __launch_bounds__(256) void conv3_wgrad_mfma_kernel(const T *__restri
     for (int q = 0; q < 4; ++q) slab[(tap * 32 + cih * 16 + kg * 4 + q) * 32 + coh * 16 + m] = acc[tap][q];
 }
 
-// dw_t[co][ci][tap] (+)= sum over slabs
+// dw[co*s_co + ci*s_ci + real_tap*s_tap] (+)= sum over slabs of virtual tap t (real_tap = real.wt[t], -1: skip)
 __global__ void wgrad_reduce_kernel(const float *__restrict__ slabs, float *__restrict__ dw, int Cin, int Cout, int cobs,
-                                    int nslab, int accumulate) {
+                                    int nslab, int accumulate, Taps real, long long s_co, long long s_ci, long long s_tap) {
   const int64_t n = (int64_t)Cout * Cin * 27;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     const int tap = (int)(i % 27), ci = (int)((i / 27) % Cin), co = (int)(i / (27 * (int64_t)Cin));
+    const int rt = real.wt[tap];
+    if (rt < 0) continue;
     const int pair = (ci >> 5) * cobs + (co >> 5);
     const float *p = slabs + (int64_t)pair * nslab * (27 * 1024) + (tap * 32 + (ci & 31)) * 32 + (co & 31);
     float s = 0.f;
     for (int k = 0; k < nslab; ++k) s += p[(int64_t)k * (27 * 1024)];
-    dw[i] = accumulate ? dw[i] + s : s;
+    float *o = dw + co * s_co + ci * s_ci + rt * s_tap;
+    *o = accumulate ? *o + s : s;
   }
 }
 
@@ -512,30 +693,74 @@ size_t conv3_wgrad_mfma_ws_bytes(int B, int Cin, int Cout, int D, int H, int W) 
 }
 
 template <typename T>
-static int wgrad_launch(const void *x, int ldx, const void *dy, int lddy, float *dw_t, void *ws, size_t ws_bytes, int B,
-                        int Cin, int Cout, int D, int H, int W, int accumulate, hipStream_t st) {
+static int wgrad_launch(const void *x, const View &xv, const void *dy, const View &yv, float *dw, void *ws, size_t ws_bytes,
+                        int B, int Cin, int Cout, unsigned tapmask, const Taps &real, long long s_co, long long s_ci,
+                        long long s_tap, int accumulate, hipStream_t st) {
   constexpr int EPV = Elem<T>::EPV;
-  if (Cin % EPV || Cout % EPV || ldx % EPV || lddy % EPV || ((uintptr_t)x & 15) || ((uintptr_t)dy & 15))
+  if (Cin % EPV || Cout % EPV || xv.sw % EPV || yv.sw % EPV || ((uintptr_t)x & 15) || ((uintptr_t)dy & 15))
     return DGTTA_ERR_UNSUPPORTED;
-  WgradPlan p = wgrad_plan(B, Cin, Cout, D, H, W);
+  WgradPlan p = wgrad_plan(B, Cin, Cout, yv.D, yv.H, yv.W);
   const size_t need = (size_t)p.units * p.cibs * p.cobs * 27 * 1024 * sizeof(float);
   if (ws_bytes < need || p.units >= (1ll << 31) || p.cibs * p.cobs > 65535) return DGTTA_ERR_UNSUPPORTED;
   static bool attr_set = false;
   auto kern = conv3_wgrad_mfma_kernel<T>;
   if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                        (int)WG<T>::LDS_BYTES);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)WG<T>::LDS_BYTES);
     attr_set = true;
   }
   hipLaunchKernelGGL(kern, dim3((unsigned)p.units, (unsigned)(p.cibs * p.cobs)), dim3(256), WG<T>::LDS_BYTES, st,
-                     (const T *)x, ldx, (const T *)dy, lddy, (float *)ws, Cin, Cout, D, H, W, p.tW, p.tH, p.nsd, p.DR,
-                     p.cobs);
+                     (const T *)x, xv, (const T *)dy, yv, (float *)ws, Cin, Cout, p.tW, p.tH, p.nsd, p.DR, p.cobs, tapmask);
   DG_CHECK_LAUNCH("conv3_wgrad_mfma_kernel");
   const int64_t n = (int64_t)Cout * Cin * 27;
   int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, (const float *)ws, dw_t, Cin, Cout, p.cobs,
-                     (int)p.units, accumulate);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, (const float *)ws, dw, Cin, Cout, p.cobs,
+                     (int)p.units, accumulate, real, s_co, s_ci, s_tap);
   DG_CHECK_LAUNCH("wgrad_reduce_kernel");
+  return DGTTA_OK;
+}
+
+template <typename T>
+static int wgrad_conv(const void *x, int ldx, const void *dy, int lddy, float *dw_t, void *ws, size_t ws_bytes, int B,
+                      int Cin, int Cout, int Di, int Hi, int Wi, int stride, int accumulate, hipStream_t st) {
+  const long long s_co = (long long)Cin * 27, s_ci = 27, s_tap = 1;
+  if (stride == 1) {
+    const View xv = dense_view(B, Di, Hi, Wi, ldx), yv = dense_view(B, Di, Hi, Wi, lddy);
+    return wgrad_launch<T>(x, xv, dy, yv, dw_t, ws, ws_bytes, B, Cin, Cout, 0x7ffffffu, identity_taps(0), s_co, s_ci, s_tap,
+                           accumulate, st);
+  }
+  // stride 2: x[2*vo + tap - 1] lives on parity sub-lattices of x; per axis parity 0 <- tap 1 (offset 0),
+  // parity 1 <- tap 0 (offset -1) and tap 2 (offset 0).  Each real tap belongs to exactly one of the 8 classes.
+  const int Do = (Di - 1) / 2 + 1, Ho = (Hi - 1) / 2 + 1, Wo = (Wi - 1) / 2 + 1;
+  const View yv = dense_view(B, Do, Ho, Wo, lddy);
+  for (int p = 0; p < 8; ++p) {
+    const int par[3] = {p >> 2, (p >> 1) & 1, p & 1};
+    long long off;
+    View xv = parity_view(Di, Hi, Wi, ldx, par[0], par[1], par[2], &off);
+    xv.sb = (long long)Di * Hi * Wi * ldx;
+    if (xv.D == 0 || xv.H == 0 || xv.W == 0) continue;   // (then those taps only ever see padding: gradient 0)
+    Taps real;
+    unsigned mask = 0;
+    for (int t = 0; t < 27; ++t) {
+      const int k[3] = {t / 9, (t / 3) % 3, t % 3};
+      int rl[3];
+      bool ok = true;
+      for (int a = 0; a < 3; ++a) {
+        if (par[a] == 0) {
+          ok = ok && (k[a] == 1);
+          rl[a] = 1;
+        } else {
+          ok = ok && (k[a] <= 1);
+          rl[a] = (k[a] == 0) ? 0 : 2;
+        }
+      }
+      real.wt[t] = ok ? (signed char)(rl[0] * 9 + rl[1] * 3 + rl[2]) : (signed char)-1;
+      if (ok) mask |= 1u << t;
+    }
+    int rc = wgrad_launch<T>((const T *)x + off, xv, dy, yv, dw_t, ws, ws_bytes, B, Cin, Cout, mask, real, s_co, s_ci, s_tap,
+                             accumulate, st);
+    if (rc != DGTTA_OK) return rc;
+  }
   return DGTTA_OK;
 }
 
@@ -543,8 +768,35 @@ int conv3_wgrad_mfma(const void *x, int ldx, const void *dy, int lddy, float *dw
                      int B, int Cin, int Cout, int Di, int Hi, int Wi, int stride, int accumulate, int dtype,
                      hipStream_t st) {
   (void)db;
-  if (stride != 1) return DGTTA_ERR_UNSUPPORTED;
-  if (dtype == DGTTA_F32) return wgrad_launch<float>(x, ldx, dy, lddy, dw_t, ws, ws_bytes, B, Cin, Cout, Di, Hi, Wi, accumulate, st);
-  if (dtype == DGTTA_BF16) return wgrad_launch<bf16_t>(x, ldx, dy, lddy, dw_t, ws, ws_bytes, B, Cin, Cout, Di, Hi, Wi, accumulate, st);
+  if (stride != 1 && stride != 2) return DGTTA_ERR_UNSUPPORTED;
+  if (stride == 2 && ((Di | Hi | Wi) & 1)) return DGTTA_ERR_UNSUPPORTED;   // odd extents: leave to the general kernel
+  if (dtype == DGTTA_F32) return wgrad_conv<float>(x, ldx, dy, lddy, dw_t, ws, ws_bytes, B, Cin, Cout, Di, Hi, Wi, stride, accumulate, st);
+  if (dtype == DGTTA_BF16) return wgrad_conv<bf16_t>(x, ldx, dy, lddy, dw_t, ws, ws_bytes, B, Cin, Cout, Di, Hi, Wi, stride, accumulate, st);
+  return DGTTA_ERR_UNSUPPORTED;
+}
+
+// ConvTranspose3d k2 s2 weight gradient: dw_t[ci][co][o] (+)= sum_v x[v][ci] * dout[2v+o][co]  (8 single-tap launches)
+template <typename T>
+static int convT_wgrad(const void *x, int ldx, const void *dout, int lddo, float *dw_t, void *ws, size_t ws_bytes, int B,
+                       int Cin, int Cout, int Di, int Hi, int Wi, int accumulate, hipStream_t st) {
+  const View xv = dense_view(B, Di, Hi, Wi, ldx);
+  for (int o = 0; o < 8; ++o) {
+    long long off;
+    View yv = parity_view(2 * Di, 2 * Hi, 2 * Wi, lddo, o >> 2, (o >> 1) & 1, o & 1, &off);
+    yv.sb = (long long)8 * Di * Hi * Wi * lddo;
+    Taps real;
+    for (int t = 0; t < 27; ++t) real.wt[t] = -1;
+    real.wt[13] = (signed char)o;
+    int rc = wgrad_launch<T>(x, xv, (const T *)dout + off, yv, dw_t, ws, ws_bytes, B, Cin, Cout, 1u << 13, real, 8,
+                             (long long)Cout * 8, 1, accumulate, st);
+    if (rc != DGTTA_OK) return rc;
+  }
+  return DGTTA_OK;
+}
+
+int convT_wgrad_mfma(const void *x, int ldx, const void *dout, int lddo, float *dw_t, void *ws, size_t ws_bytes, int B,
+                     int Cin, int Cout, int Di, int Hi, int Wi, int accumulate, int dtype, hipStream_t st) {
+  if (dtype == DGTTA_F32) return convT_wgrad<float>(x, ldx, dout, lddo, dw_t, ws, ws_bytes, B, Cin, Cout, Di, Hi, Wi, accumulate, st);
+  if (dtype == DGTTA_BF16) return convT_wgrad<bf16_t>(x, ldx, dout, lddo, dw_t, ws, ws_bytes, B, Cin, Cout, Di, Hi, Wi, accumulate, st);
   return DGTTA_ERR_UNSUPPORTED;
 }

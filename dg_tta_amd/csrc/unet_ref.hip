@@ -491,6 +491,15 @@ int wgrad_splits(int64_t nvox) {
 int conv3_fwd_mfma(const void *x, int ldx, const void *w_kmajor, int mirror, const float *bias, void *y, int ldy, int B,
                    int Cin, int Cout, int CinP, int CoutP, int Di, int Hi, int Wi, int stride, int dtype,
                    hipStream_t st);
+int conv3_dgrad_s2_mfma(const void *dy, int lddy, const void *w_kmajor, void *dx, int lddx, int B, int Cin, int Cout,
+                        int CinP, int CoutP, int Di, int Hi, int Wi, int accumulate, int dtype, hipStream_t st);
+size_t convT_packed_bytes(int CinP, int CoutP, int dtype);
+int convT_fwd_mfma(const void *x, int ldx, const float *w_t, const float *bias, void *out, int ldo, void *ws, int B, int Cin,
+                   int Cout, int Di, int Hi, int Wi, int dtype, hipStream_t st);
+int convT_dgrad_mfma(const void *dout, int lddo, const float *w_t, void *dx, int lddx, void *ws, int B, int Cin, int Cout,
+                     int Di, int Hi, int Wi, int dtype, hipStream_t st);
+int convT_wgrad_mfma(const void *x, int ldx, const void *dout, int lddo, float *dw_t, void *ws, size_t ws_bytes, int B,
+                     int Cin, int Cout, int Di, int Hi, int Wi, int accumulate, int dtype, hipStream_t st);
 int conv3_wgrad_mfma(const void *x, int ldx, const void *dy, int lddy, float *dw_t, float *db, void *ws, size_t ws_bytes,
                      int B, int Cin, int Cout, int Di, int Hi, int Wi, int stride, int accumulate, int dtype,
                      hipStream_t st);
@@ -565,6 +574,11 @@ extern "C" int dgtta_conv3d_k3_dgrad(const void *dy, int lddy, const void *wpack
     // stride-1 data gradient == forward conv of dy with the mirrored, transposed weights (wb)
     // (the first half of the blob, [tap][ci][co], is K-contiguous for this role; taps mirrored)
     int rc = conv3_fwd_mfma(dy, lddy, wpack, 1, nullptr, dx, lddx, B, Cout, Cin, CoutP, CinP, Di, Hi, Wi, 1, dtype, st);
+    if (rc != DGTTA_ERR_UNSUPPORTED) return rc;
+    DG_REQUIRE(impl == 0, DGTTA_ERR_UNSUPPORTED, "conv3d_k3_dgrad: shape not covered by the MFMA kernel");
+  }
+  if (impl != 1 && stride == 2 && !((Di | Hi | Wi) & 1)) {
+    int rc = conv3_dgrad_s2_mfma(dy, lddy, wpack, dx, lddx, B, Cin, Cout, CinP, CoutP, Di, Hi, Wi, accumulate, dtype, st);
     if (rc != DGTTA_ERR_UNSUPPORTED) return rc;
     DG_REQUIRE(impl == 0, DGTTA_ERR_UNSUPPORTED, "conv3d_k3_dgrad: shape not covered by the MFMA kernel");
   }
@@ -694,28 +708,48 @@ extern "C" int dgtta_instnorm_lrelu_bwd(const void *gz, int ldgz, const void *y,
   return DGTTA_OK;
 }
 
+static size_t convT_pack_region(int Cin, int Cout, int dtype) {
+  const int g = (dtype == DGTTA_BF16) ? 16 : 8;
+  return align_up(convT_packed_bytes((Cin + g - 1) / g * g, (Cout + g - 1) / g * g, dtype), 256);
+}
+
+extern "C" size_t dgtta_convT3d_fwd_ws_bytes(int Cin, int Cout, int dtype) { return convT_pack_region(Cin, Cout, dtype); }
+
 extern "C" int dgtta_convT3d_k2s2_fwd(const void *x, int ldx, const float *w_t, const float *bias, void *out, int ldo,
-                                      int B, int Cin, int Cout, int Di, int Hi, int Wi, int dtype, void *stream) {
+                                      void *ws, size_t ws_bytes, int B, int Cin, int Cout, int Di, int Hi, int Wi,
+                                      int dtype, int impl, void *stream) {
   DG_REQUIRE(x && w_t && out, DGTTA_ERR_BADARG, "convT3d_k2s2_fwd: null pointer");
   DG_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && Di > 0 && Hi > 0 && Wi > 0 && ldx >= Cin && ldo >= Cout, DGTTA_ERR_BADARG,
              "convT3d_k2s2_fwd: bad dims");
+  hipStream_t st = (hipStream_t)stream;
+  if (impl != 1 && ws && ws_bytes >= convT_pack_region(Cin, Cout, dtype)) {
+    int rc = convT_fwd_mfma(x, ldx, w_t, bias, out, ldo, ws, B, Cin, Cout, Di, Hi, Wi, dtype, st);
+    if (rc != DGTTA_ERR_UNSUPPORTED) return rc;
+  }
+  DG_REQUIRE(impl != 2, DGTTA_ERR_UNSUPPORTED, "convT3d_k2s2_fwd: shape not covered by the MFMA kernel");
   const int64_t total = (int64_t)B * Di * Hi * Wi * 8 * Cout;
-  DISPATCH_T(dtype, hipLaunchKernelGGL((convT_fwd_ref_kernel<T>), dim3(gs_blocks(total, 1 << 20)), dim3(256), 0,
-                                       (hipStream_t)stream, (const T *)x, ldx, w_t, bias, (T *)out, ldo, Cin, Cout, Di,
-                                       Hi, Wi, total));
+  DISPATCH_T(dtype, hipLaunchKernelGGL((convT_fwd_ref_kernel<T>), dim3(gs_blocks(total, 1 << 20)), dim3(256), 0, st,
+                                       (const T *)x, ldx, w_t, bias, (T *)out, ldo, Cin, Cout, Di, Hi, Wi, total));
   DG_CHECK_LAUNCH("convT_fwd_ref_kernel");
   return DGTTA_OK;
 }
 
+// workspace layout: [bias partials][packed weights][main: split partials (VALU) | slabs (MFMA)]
+static size_t convT_bias_region(int B, int Cout, int Di, int Hi, int Wi) {
+  return align_up((size_t)B * reduce_blocks((int64_t)Di * Hi * Wi * 8) * Cout * 2 * sizeof(double), 256);
+}
+
 extern "C" size_t dgtta_convT3d_bwd_ws_bytes(int B, int Cin, int Cout, int Di, int Hi, int Wi) {
   const int64_t nvox = (int64_t)B * Di * Hi * Wi;
-  return align_up((size_t)wgrad_splits(nvox) * Cin * Cout * 8 * sizeof(float), 256) +
-         align_up((size_t)B * reduce_blocks((int64_t)Di * Hi * Wi * 8) * Cout * 2 * sizeof(double), 256);
+  size_t a = align_up((size_t)wgrad_splits(nvox) * Cin * Cout * 8 * sizeof(float), 256);
+  size_t c = align_up(conv3_wgrad_mfma_ws_bytes(B, Cin, Cout, Di, Hi, Wi), 256);
+  return convT_bias_region(B, Cout, Di, Hi, Wi) + convT_pack_region(Cin, Cout, DGTTA_F32) + (a > c ? a : c);
 }
 
 extern "C" int dgtta_convT3d_k2s2_bwd(const void *x, int ldx, const void *dout, int lddo, const float *w_t, void *dx,
                                       int lddx, float *dw_t, float *db, void *ws, size_t ws_bytes, int B, int Cin,
-                                      int Cout, int Di, int Hi, int Wi, int accumulate, int dtype, void *stream) {
+                                      int Cout, int Di, int Hi, int Wi, int accumulate, int dtype, int impl,
+                                      void *stream) {
   DG_REQUIRE(x && dout && w_t && ws, DGTTA_ERR_BADARG, "convT3d_k2s2_bwd: null pointer");
   DG_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && Di > 0 && Hi > 0 && Wi > 0 && ldx >= Cin && lddo >= Cout,
              DGTTA_ERR_BADARG, "convT3d_k2s2_bwd: bad dims");
@@ -723,27 +757,43 @@ extern "C" int dgtta_convT3d_k2s2_bwd(const void *x, int ldx, const void *dout, 
              "convT3d_k2s2_bwd: workspace too small");
   hipStream_t st = (hipStream_t)stream;
   const int64_t nvox = (int64_t)B * Di * Hi * Wi;
+  void *ws_bias = ws;
+  void *ws_pack = (char *)ws + convT_bias_region(B, Cout, Di, Hi, Wi);
+  void *ws_main = (char *)ws_pack + convT_pack_region(Cin, Cout, DGTTA_F32);
+  const size_t main_bytes = ws_bytes - ((char *)ws_main - (char *)ws);
   if (dx) {
     DG_REQUIRE(lddx >= Cin, DGTTA_ERR_BADARG, "convT3d_k2s2_bwd: lddx < Cin");
-    const int64_t total = nvox * Cin;
-    DISPATCH_T(dtype, hipLaunchKernelGGL((convT_dgrad_ref_kernel<T>), dim3(gs_blocks(total, 1 << 20)), dim3(256), 0, st,
-                                         (const T *)dout, lddo, w_t, (T *)dx, lddx, Cin, Cout, Di, Hi, Wi, total));
-    DG_CHECK_LAUNCH("convT_dgrad_ref_kernel");
+    int rc = DGTTA_ERR_UNSUPPORTED;
+    if (impl != 1) rc = convT_dgrad_mfma(dout, lddo, w_t, dx, lddx, ws_pack, B, Cin, Cout, Di, Hi, Wi, dtype, st);
+    if (rc == DGTTA_ERR_UNSUPPORTED) {
+      DG_REQUIRE(impl != 2, DGTTA_ERR_UNSUPPORTED, "convT3d_k2s2_bwd: dgrad shape not covered by the MFMA kernel");
+      const int64_t total = nvox * Cin;
+      DISPATCH_T(dtype, hipLaunchKernelGGL((convT_dgrad_ref_kernel<T>), dim3(gs_blocks(total, 1 << 20)), dim3(256), 0, st,
+                                           (const T *)dout, lddo, w_t, (T *)dx, lddx, Cin, Cout, Di, Hi, Wi, total));
+      DG_CHECK_LAUNCH("convT_dgrad_ref_kernel");
+    } else if (rc != DGTTA_OK) {
+      return rc;
+    }
   }
   if (dw_t) {
-    const int nsplit = wgrad_splits(nvox);
-    float *part = (float *)ws;
-    DISPATCH_T(dtype, hipLaunchKernelGGL((convT_wgrad_ref_kernel<T>), dim3(cdiv(Cin * Cout, 256), 8, nsplit), dim3(256), 0,
-                                         st, (const T *)x, ldx, (const T *)dout, lddo, part, Cin, Cout, B, Di, Hi, Wi));
-    DG_CHECK_LAUNCH("convT_wgrad_ref_kernel");
-    const int64_t n = (int64_t)Cin * Cout * 8;
-    hipLaunchKernelGGL(reduce_splits_kernel, dim3(gs_blocks(n)), dim3(256), 0, st, part, dw_t, n, nsplit, accumulate);
-    DG_CHECK_LAUNCH("reduce_splits_kernel");
+    int rc = DGTTA_ERR_UNSUPPORTED;
+    if (impl != 1)
+      rc = convT_wgrad_mfma(x, ldx, dout, lddo, dw_t, ws_main, main_bytes, B, Cin, Cout, Di, Hi, Wi, accumulate, dtype, st);
+    if (rc == DGTTA_ERR_UNSUPPORTED) {
+      DG_REQUIRE(impl != 2, DGTTA_ERR_UNSUPPORTED, "convT3d_k2s2_bwd: wgrad shape not covered by the MFMA kernel");
+      const int nsplit = wgrad_splits(nvox);
+      float *part = (float *)ws_main;
+      DISPATCH_T(dtype, hipLaunchKernelGGL((convT_wgrad_ref_kernel<T>), dim3(cdiv(Cin * Cout, 256), 8, nsplit), dim3(256),
+                                           0, st, (const T *)x, ldx, (const T *)dout, lddo, part, Cin, Cout, B, Di, Hi, Wi));
+      DG_CHECK_LAUNCH("convT_wgrad_ref_kernel");
+      const int64_t n = (int64_t)Cin * Cout * 8;
+      hipLaunchKernelGGL(reduce_splits_kernel, dim3(gs_blocks(n)), dim3(256), 0, st, part, dw_t, n, nsplit, accumulate);
+      DG_CHECK_LAUNCH("reduce_splits_kernel");
+    } else if (rc != DGTTA_OK) {
+      return rc;
+    }
   }
-  if (db) {
-    void *ws2 = (char *)ws + align_up((size_t)wgrad_splits(nvox) * Cin * Cout * 8 * sizeof(float), 256);
-    return bias_grad(dout, lddo, db, ws2, B, Cout, (int64_t)Di * Hi * Wi * 8, accumulate, dtype, st);
-  }
+  if (db) return bias_grad(dout, lddo, db, ws_bias, B, Cout, (int64_t)Di * Hi * Wi * 8, accumulate, dtype, st);
   return DGTTA_OK;
 }
 

@@ -295,9 +295,11 @@ class _UNetFn(torch.autograd.Function):
         for k, blocks in enumerate(dec):
             cat, cskip, cdims = cat_bufs[-(k + 1)]
             up = net.decoder.transpconvs[k]
-            check(lib.dgtta_convT3d_k2s2_fwd(x_low_ptr, x_low_ld, ptr(up.weight), ptr(up.bias), ptr(cat), 2 * cskip, B,
-                                             x_low_c, cskip, low_dims[0], low_dims[1], low_dims[2], dt, st),
-                  "dgtta_convT3d_k2s2_fwd")
+            nbt = lib.dgtta_convT3d_fwd_ws_bytes(x_low_c, cskip, dt)
+            wst = ws_for(nbt)
+            check(lib.dgtta_convT3d_k2s2_fwd(x_low_ptr, x_low_ld, ptr(up.weight), ptr(up.bias), ptr(cat), 2 * cskip,
+                                             ptr(wst), nbt, B, x_low_c, cskip, low_dims[0], low_dims[1], low_dims[2], dt,
+                                             impl, st), "dgtta_convT3d_k2s2_fwd")
             ups.append(dict(mod=up, x=x_low_ptr, ldx=x_low_ld, cin=x_low_c, cout=cskip, din=low_dims, cat=cat))
             u_ptr, ldu, cin, dims = cat.data_ptr(), 2 * cskip, 2 * cskip, cdims
             for bi, blk in enumerate(blocks):
@@ -434,7 +436,7 @@ class _UNetFn(torch.autograd.Function):
                 dbu = gbuf(upm.bias) if want(upm.bias) else None
                 check(lib.dgtta_convT3d_k2s2_bwd(up["x"], up["ldx"], ptr(gc), 2 * cskip, ptr(upm.weight), ptr(glow),
                                                  up["cin"], ptr(dwu), ptr(dbu), ptr(w_), nb, B, up["cin"], up["cout"],
-                                                 ld0, lh0, lw0, 0, dt, st), "dgtta_convT3d_k2s2_bwd")
+                                                 ld0, lh0, lw0, 0, dt, impl, st), "dgtta_convT3d_k2s2_bwd")
                 gz_ptr, gz_ld = glow.data_ptr(), up["cin"]
                 keep_alive = [glow, gc]
             elif kind == "enc" and bidx == 0:

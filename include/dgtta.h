@@ -170,12 +170,14 @@ int dgtta_instnorm_lrelu_bwd(const void *gz, int ldgz, const void *y, int ldy, c
 
 /* ConvTranspose3d(Cin, Cout, kernel 2, stride 2, bias): w_t torch layout [Cin][Cout][2][2][2] fp32.
  * out[b][2v+o][co] = bias[co] + sum_ci x[b][v][ci] * w[ci][co][o]. */
-int dgtta_convT3d_k2s2_fwd(const void *x, int ldx, const float *w_t, const float *bias, void *out, int ldo, int B,
-                           int Cin, int Cout, int Di, int Hi, int Wi, int dtype, void *stream);
+size_t dgtta_convT3d_fwd_ws_bytes(int Cin, int Cout, int dtype);
+int dgtta_convT3d_k2s2_fwd(const void *x, int ldx, const float *w_t, const float *bias, void *out, int ldo, void *ws,
+                           size_t ws_bytes, int B, int Cin, int Cout, int Di, int Hi, int Wi, int dtype, int impl,
+                           void *stream);
 size_t dgtta_convT3d_bwd_ws_bytes(int B, int Cin, int Cout, int Di, int Hi, int Wi);
 int dgtta_convT3d_k2s2_bwd(const void *x, int ldx, const void *dout, int lddo, const float *w_t, void *dx, int lddx,
                            float *dw_t, float *db, void *ws, size_t ws_bytes, int B, int Cin, int Cout, int Di,
-                           int Hi, int Wi, int accumulate, int dtype, void *stream);
+                           int Hi, int Wi, int accumulate, int dtype, int impl, void *stream);
 
 /* 1x1x1 head fused with map_label(input_format="logits") (torch_utils.py:214-221): only the rows
  * sel[0..nsel) of the [Ccls][Cin] weight are evaluated (sel == NULL: all Ccls rows).

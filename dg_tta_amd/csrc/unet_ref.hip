@@ -195,23 +195,28 @@ __global__ __launch_bounds__(256) void chan_reduce_kernel(const T *__restrict__ 
   }
 }
 
-// InstanceNorm statistics finalize: mean, rstd = 1/sqrt(biased var + eps)
-__global__ void in_stats_finalize_kernel(const double *__restrict__ partial, int nblk, int B, int C, int64_t V, float eps,
-                                         float *__restrict__ mean_rstd) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= B * C) return;
+// InstanceNorm statistics finalize: mean, rstd = 1/sqrt(biased var + eps).  One wave per (b,c); the number of
+// partial blocks is read from the device-side header when hdr != NULL (statistics produced by the conv epilogue).
+__global__ void in_stats_finalize_kernel(const double *__restrict__ partial, const long long *__restrict__ hdr, int nblk_h,
+                                         int B, int C, int64_t V, float eps, float *__restrict__ mean_rstd) {
+  const int i = blockIdx.x;
   const int b = i / C, c = i % C;
+  const int nblk = hdr ? (int)hdr[0] : nblk_h;
   double s = 0.0, ss = 0.0;
-  for (int k = 0; k < nblk; ++k) {
+  for (int k = threadIdx.x; k < nblk; k += 64) {
     const double *p = partial + ((((int64_t)b * nblk + k) * C) + c) * 2;
     s += p[0];
     ss += p[1];
   }
-  const double mean = s / (double)V;
-  double var = ss / (double)V - mean * mean;
-  if (var < 0.0) var = 0.0;
-  mean_rstd[2 * i] = (float)mean;
-  mean_rstd[2 * i + 1] = (float)(1.0 / sqrt(var + (double)eps));
+  s = wave_sum_d(s);
+  ss = wave_sum_d(ss);
+  if (threadIdx.x == 0) {
+    const double mean = s / (double)V;
+    double var = ss / (double)V - mean * mean;
+    if (var < 0.0) var = 0.0;
+    mean_rstd[2 * i] = (float)mean;
+    mean_rstd[2 * i + 1] = (float)(1.0 / sqrt(var + (double)eps));
+  }
 }
 
 // z = lrelu(y*alpha + beta'), alpha = rstd*gamma, beta' = beta - mean*alpha  (ATen's batch_norm transform form)
@@ -490,7 +495,8 @@ int wgrad_splits(int64_t nvox) {
 // MFMA implementations (conv_mfma.hip); return DGTTA_ERR_UNSUPPORTED when the shape is not covered.
 int conv3_fwd_mfma(const void *x, int ldx, const void *w_kmajor, int mirror, const float *bias, void *y, int ldy, int B,
                    int Cin, int Cout, int CinP, int CoutP, int Di, int Hi, int Wi, int stride, int dtype,
-                   hipStream_t st);
+                   hipStream_t st, double *stats);
+int64_t conv3_mfma_max_tiles(int Do, int Ho, int Wo);
 int conv3_dgrad_s2_mfma(const void *dy, int lddy, const void *w_kmajor, void *dx, int lddx, int B, int Cin, int Cout,
                         int CinP, int CoutP, int Di, int Hi, int Wi, int accumulate, int dtype, hipStream_t st);
 size_t convT_packed_bytes(int CinP, int CoutP, int dtype);
@@ -528,10 +534,15 @@ extern "C" int dgtta_conv3d_pack_weights(const float *w_t, void *wpack, int Cin,
 
 static int out_dim(int i, int s) { return (i + 2 - 3) / s + 1; }
 
+// statistics buffer: [256-byte header: int64 nblk][partial sums: B x nblk x Cout x 2 doubles]
 extern "C" size_t dgtta_conv3d_stats_bytes(int B, int Cout, int Do, int Ho, int Wo) {
-  (void)Do; (void)Ho; (void)Wo;
-  return (size_t)B * 512 * Cout * 2 * sizeof(double);
+  int64_t nb = conv3_mfma_max_tiles(Do, Ho, Wo);
+  const int64_t rb = reduce_blocks((int64_t)Do * Ho * Wo);
+  if (rb > nb) nb = rb;
+  return 256 + (size_t)B * nb * Cout * 2 * sizeof(double);
 }
+
+__global__ void set_header_kernel(long long *hdr, long long v) { hdr[0] = v; }
 
 extern "C" int dgtta_conv3d_k3_fwd(const void *x, int ldx, const void *wpack, const float *bias, void *y, int ldy,
                                    void *stats, int B, int Cin, int Cout, int CinP, int CoutP, int Di, int Hi, int Wi,
@@ -542,12 +553,11 @@ extern "C" int dgtta_conv3d_k3_fwd(const void *x, int ldx, const void *wpack, co
              DGTTA_ERR_BADARG, "conv3d_k3_fwd: bad dims");
   DG_REQUIRE(stride == 1 || stride == 2, DGTTA_ERR_UNSUPPORTED, "conv3d_k3_fwd: stride %d", stride);
   DG_REQUIRE(ldx >= Cin && ldy >= Cout, DGTTA_ERR_BADARG, "conv3d_k3_fwd: ld < C");
-  DG_REQUIRE(stats == nullptr, DGTTA_ERR_UNSUPPORTED, "conv3d_k3_fwd: fused stats not available in this build");
   hipStream_t st = (hipStream_t)stream;
   if (impl != 1) {
     // the MFMA kernel wants K-contiguous weights [tap][co][ci] = the mirrored second half of the blob
     int rc = conv3_fwd_mfma(x, ldx, wb_of(wpack, CinP, CoutP, dtype), 1, bias, y, ldy, B, Cin, Cout, CinP, CoutP, Di, Hi,
-                            Wi, stride, dtype, st);
+                            Wi, stride, dtype, st, (double *)stats);
     if (rc != DGTTA_ERR_UNSUPPORTED) return rc;
     DG_REQUIRE(impl == 0, DGTTA_ERR_UNSUPPORTED, "conv3d_k3_fwd: shape not covered by the MFMA kernel");
   }
@@ -557,6 +567,15 @@ extern "C" int dgtta_conv3d_k3_fwd(const void *x, int ldx, const void *wpack, co
                                        (const T *)x, ldx, (const T *)wf, bias, (T *)y, ldy, Cin, Cout, CinP, CoutP, Di,
                                        Hi, Wi, Do, Ho, Wo, stride, total));
   DG_CHECK_LAUNCH("conv3_fwd_ref_kernel");
+  if (stats) {   // general kernel: statistics by a separate reduction pass, same buffer layout
+    const int64_t V = (int64_t)Do * Ho * Wo;
+    const int nblk = reduce_blocks(V);
+    hipLaunchKernelGGL(set_header_kernel, dim3(1), dim3(1), 0, st, (long long *)stats, (long long)nblk);
+    DISPATCH_T(dtype, hipLaunchKernelGGL((chan_reduce_kernel<T, 0>), dim3(nblk, B), dim3(256), 0, st, (const T *)y, ldy,
+                                         (const T *)nullptr, 0, nullptr, nullptr, nullptr, 0.f, (double *)stats + 32,
+                                         Cout, V));
+    DG_CHECK_LAUNCH("chan_reduce_kernel<0>");
+  }
   return DGTTA_OK;
 }
 
@@ -573,7 +592,7 @@ extern "C" int dgtta_conv3d_k3_dgrad(const void *dy, int lddy, const void *wpack
   if (impl != 1 && stride == 1 && !accumulate) {
     // stride-1 data gradient == forward conv of dy with the mirrored, transposed weights (wb)
     // (the first half of the blob, [tap][ci][co], is K-contiguous for this role; taps mirrored)
-    int rc = conv3_fwd_mfma(dy, lddy, wpack, 1, nullptr, dx, lddx, B, Cout, Cin, CoutP, CinP, Di, Hi, Wi, 1, dtype, st);
+    int rc = conv3_fwd_mfma(dy, lddy, wpack, 1, nullptr, dx, lddx, B, Cout, Cin, CoutP, CinP, Di, Hi, Wi, 1, dtype, st, nullptr);
     if (rc != DGTTA_ERR_UNSUPPORTED) return rc;
     DG_REQUIRE(impl == 0, DGTTA_ERR_UNSUPPORTED, "conv3d_k3_dgrad: shape not covered by the MFMA kernel");
   }
@@ -663,16 +682,20 @@ extern "C" int dgtta_instnorm_lrelu_fwd(const void *y, int ldy, const void *stat
                                         int64_t V, float eps, float slope, int dtype, void *stream) {
   DG_REQUIRE(y && gamma && beta && mean_rstd && z && ws, DGTTA_ERR_BADARG, "instnorm_lrelu_fwd: null pointer");
   DG_REQUIRE(B > 0 && C > 0 && V > 0 && ldy >= C && ldz >= C, DGTTA_ERR_BADARG, "instnorm_lrelu_fwd: bad dims");
-  DG_REQUIRE(stats == nullptr, DGTTA_ERR_UNSUPPORTED, "instnorm_lrelu_fwd: fused conv statistics not in this build");
   DG_REQUIRE(ws_bytes >= dgtta_instnorm_ws_bytes(B, C, V), DGTTA_ERR_WORKSPACE, "instnorm_lrelu_fwd: workspace too small");
   hipStream_t st = (hipStream_t)stream;
   const int nblk = reduce_blocks(V);
-  double *partial = (double *)ws;
-  DISPATCH_T(dtype, hipLaunchKernelGGL((chan_reduce_kernel<T, 0>), dim3(nblk, B), dim3(256), 0, st, (const T *)y, ldy,
-                                       (const T *)nullptr, 0, nullptr, nullptr, nullptr, 0.f, partial, C, V));
-  DG_CHECK_LAUNCH("chan_reduce_kernel<0>");
-  hipLaunchKernelGGL(in_stats_finalize_kernel, dim3(cdiv(B * C, 128)), dim3(128), 0, st, partial, nblk, B, C, V, eps,
-                     mean_rstd);
+  if (stats) {   // partial sums came with the conv epilogue (header + partials)
+    hipLaunchKernelGGL(in_stats_finalize_kernel, dim3(B * C), dim3(64), 0, st, (const double *)stats + 32,
+                       (const long long *)stats, 0, B, C, V, eps, mean_rstd);
+  } else {
+    double *partial = (double *)ws;
+    DISPATCH_T(dtype, hipLaunchKernelGGL((chan_reduce_kernel<T, 0>), dim3(nblk, B), dim3(256), 0, st, (const T *)y, ldy,
+                                         (const T *)nullptr, 0, nullptr, nullptr, nullptr, 0.f, partial, C, V));
+    DG_CHECK_LAUNCH("chan_reduce_kernel<0>");
+    hipLaunchKernelGGL(in_stats_finalize_kernel, dim3(B * C), dim3(64), 0, st, (const double *)partial,
+                       (const long long *)nullptr, nblk, B, C, V, eps, mean_rstd);
+  }
   DG_CHECK_LAUNCH("in_stats_finalize_kernel");
   const int64_t total = (int64_t)B * V * C;
   DISPATCH_T(dtype, hipLaunchKernelGGL((in_lrelu_apply_kernel<T>), dim3(gs_blocks(total)), dim3(256), 0, st,

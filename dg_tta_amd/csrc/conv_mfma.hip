@@ -697,7 +697,8 @@ __global__ void wgrad_reduce_kernel(const float *__restrict__ slabs, float *__re
                                     int nslab, int accumulate, Taps real, long long s_co, long long s_ci, long long s_tap) {
   const int64_t n = (int64_t)Cout * Cin * 27;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-    const int tap = (int)(i % 27), ci = (int)((i / 27) % Cin), co = (int)(i / (27 * (int64_t)Cin));
+    // co fastest: a wave reads 32-float rows of the slabs (coalesced); the strided write happens once per element
+    const int co = (int)(i % Cout), ci = (int)((i / Cout) % Cin), tap = (int)(i / ((int64_t)Cout * Cin));
     const int rt = real.wt[tap];
     if (rt < 0) continue;
     const int pair = (ci >> 5) * cobs + (co >> 5);
@@ -721,7 +722,7 @@ WgradPlan wgrad_plan(int B, int Cin, int Cout, int D, int H, int W) {
   p.cibs = cdiv(Cin, 32);
   p.cobs = cdiv(Cout, 32);
   const int64_t base = (int64_t)B * p.tW * p.tH * p.cibs * p.cobs;
-  int want = (int)cdiv64(1024, base);                 // aim for >= ~1024 workgroups
+  int want = (int)cdiv64(512, base);                  // aim for >= ~512 workgroups (2 per CU)
   int maxsplit = D / 4 > 0 ? D / 4 : 1;
   p.nsd = want < 1 ? 1 : (want > maxsplit ? maxsplit : want);
   p.DR = cdiv(D, p.nsd);
@@ -843,5 +844,48 @@ int convT_wgrad_mfma(const void *x, int ldx, const void *dout, int lddo, float *
                      int Cin, int Cout, int Di, int Hi, int Wi, int accumulate, int dtype, hipStream_t st) {
   if (dtype == DGTTA_F32) return convT_wgrad<float>(x, ldx, dout, lddo, dw_t, ws, ws_bytes, B, Cin, Cout, Di, Hi, Wi, accumulate, st);
   if (dtype == DGTTA_BF16) return convT_wgrad<bf16_t>(x, ldx, dout, lddo, dw_t, ws, ws_bytes, B, Cin, Cout, Di, Hi, Wi, accumulate, st);
+  return DGTTA_ERR_UNSUPPORTED;
+}
+
+// 1x1x1 head weight gradient dw[k][ci] = sum_rows dout[row][k] * x[row][ci] as a single-tap run of the wgrad kernel:
+// the [rows] axis is folded into a D x 4 x 32 lattice (no neighbour access with one tap, so any folding is valid).
+namespace {
+__global__ void f32_to_bf16_rows_kernel(const float *__restrict__ src, int lds_, bf16_t *__restrict__ dst, int C,
+                                        int64_t rows) {
+  const int64_t n = rows * C;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    dst[i] = f32_to_bf16(src[(i / C) * lds_ + i % C]);
+}
+}  // namespace
+
+size_t head_wgrad_mfma_ws_bytes(int Cin, int nsel, int64_t rows) {
+  if (rows % 128) return 0;
+  const int D = (int)(rows / 128);
+  return conv3_wgrad_mfma_ws_bytes(1, Cin, nsel, D, 4, 32) + align_up((size_t)rows * nsel * 2, 256);
+}
+
+int head_wgrad_mfma(const void *x, int ldx, const float *dout, int lddo, float *dw_sel, void *ws, size_t ws_bytes, int Cin,
+                    int nsel, int64_t rows, int accumulate, int dtype, hipStream_t st) {
+  if (rows % 128 || rows / 128 >= (1ll << 30)) return DGTTA_ERR_UNSUPPORTED;
+  const int D = (int)(rows / 128);
+  if (ws_bytes < head_wgrad_mfma_ws_bytes(Cin, nsel, rows)) return DGTTA_ERR_UNSUPPORTED;
+  Taps real;
+  for (int t = 0; t < 27; ++t) real.wt[t] = -1;
+  real.wt[13] = 0;
+  const View xv = dense_view(1, D, 4, 32, ldx);
+  if (dtype == DGTTA_F32) {
+    const View yv = dense_view(1, D, 4, 32, lddo);
+    return wgrad_launch<float>(x, xv, dout, yv, dw_sel, ws, ws_bytes, 1, Cin, nsel, 1u << 13, real, Cin, 1, 0, accumulate,
+                               st);
+  }
+  if (dtype == DGTTA_BF16) {
+    const size_t cbytes = align_up((size_t)rows * nsel * 2, 256);
+    bf16_t *d16 = (bf16_t *)ws;
+    hipLaunchKernelGGL(f32_to_bf16_rows_kernel, dim3(2048), dim3(256), 0, st, dout, lddo, d16, nsel, rows);
+    DG_CHECK_LAUNCH("f32_to_bf16_rows_kernel");
+    const View yv = dense_view(1, D, 4, 32, nsel);
+    return wgrad_launch<bf16_t>(x, xv, d16, yv, dw_sel, (char *)ws + cbytes, ws_bytes - cbytes, 1, Cin, nsel, 1u << 13, real,
+                                Cin, 1, 0, accumulate, st);
+  }
   return DGTTA_ERR_UNSUPPORTED;
 }

@@ -195,6 +195,135 @@ __global__ __launch_bounds__(256) void chan_reduce_kernel(const T *__restrict__ 
   }
 }
 
+// 16-byte vectorised variant of chan_reduce_kernel (needs C, ld multiples of EPV = 16/sizeof(T) and aligned rows):
+// a thread owns EPV consecutive channels, 256/G rows are in flight per iteration (G = C/EPV), two rows per thread and
+// iteration for memory-level parallelism.  Same partial layout [b][blk][c][2] (double).
+template <typename T>
+struct VecOf {
+  static constexpr int EPV = 16 / sizeof(T);
+};
+template <typename T>
+__device__ __forceinline__ void unpack16(const uint4 &v, float *f);
+template <>
+__device__ __forceinline__ void unpack16<float>(const uint4 &v, float *f) {
+  f[0] = __uint_as_float(v.x);
+  f[1] = __uint_as_float(v.y);
+  f[2] = __uint_as_float(v.z);
+  f[3] = __uint_as_float(v.w);
+}
+template <>
+__device__ __forceinline__ void unpack16<bf16_t>(const uint4 &v, float *f) {
+  const unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    f[2 * i] = __uint_as_float(w[i] << 16);
+    f[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
+  }
+}
+
+template <typename T, int MODE>
+__global__ __launch_bounds__(256) void chan_reduce_vec_kernel(const T *__restrict__ y, int ldy, const T *__restrict__ gz,
+                                                              int ldgz, const float *__restrict__ mean_rstd,
+                                                              const float *__restrict__ gamma,
+                                                              const float *__restrict__ beta, float slope,
+                                                              double *__restrict__ partial, int C, int64_t V) {
+  constexpr int EPV = VecOf<T>::EPV;
+  extern __shared__ float sred[];          // [rpi][C][2]
+  const int b = blockIdx.y;
+  const int G = C / EPV, rpi = 256 / G;
+  const int cg = threadIdx.x % G, rg = threadIdx.x / G;
+  const bool active = rg < rpi;
+  const int64_t rows_per_blk = cdiv64(V, gridDim.x);
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_blk, r1 = (r0 + rows_per_blk < V) ? r0 + rows_per_blk : V;
+  float s0[EPV], s1[EPV], mu[EPV], rs[EPV], ga[EPV], be[EPV];
+#pragma unroll
+  for (int e = 0; e < EPV; ++e) {
+    s0[e] = s1[e] = 0.f;
+    mu[e] = rs[e] = ga[e] = be[e] = 0.f;
+    if (MODE == 1 && active) {
+      const int c = cg * EPV + e;
+      mu[e] = mean_rstd[((int64_t)b * C + c) * 2];
+      rs[e] = mean_rstd[((int64_t)b * C + c) * 2 + 1];
+      ga[e] = gamma[c];
+      be[e] = beta[c];
+    }
+  }
+  if (active) {
+    const T *yb = y + (int64_t)b * V * ldy + cg * EPV;
+    const T *gb = (MODE == 1) ? gz + (int64_t)b * V * ldgz + cg * EPV : nullptr;
+    for (int64_t r = r0 + rg; r < r1; r += 2 * rpi) {
+      const bool two = r + rpi < r1;
+      uint4 v0 = *reinterpret_cast<const uint4 *>(yb + r * ldy), v1 = make_uint4(0, 0, 0, 0);
+      uint4 g0 = make_uint4(0, 0, 0, 0), g1 = g0;
+      if (two) v1 = *reinterpret_cast<const uint4 *>(yb + (r + rpi) * ldy);
+      if (MODE == 1) {
+        g0 = *reinterpret_cast<const uint4 *>(gb + r * ldgz);
+        if (two) g1 = *reinterpret_cast<const uint4 *>(gb + (r + rpi) * ldgz);
+      }
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        if (k == 1 && !two) break;
+        float f[EPV], g[EPV];
+        unpack16<T>(k ? v1 : v0, f);
+        if (MODE == 1) unpack16<T>(k ? g1 : g0, g);
+#pragma unroll
+        for (int e = 0; e < EPV; ++e) {
+          if (MODE == 0) {
+            s0[e] += f[e];
+            s1[e] += f[e] * f[e];
+          } else if (MODE == 2) {
+            s0[e] += f[e];
+          } else {
+            const float xh = (f[e] - mu[e]) * rs[e];
+            const float a = xh * ga[e] + be[e];
+            const float gg = a > 0.f ? g[e] : g[e] * slope;
+            s0[e] += gg;
+            s1[e] += gg * xh;
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < EPV; ++e) {
+      sred[((rg * C) + cg * EPV + e) * 2 + 0] = s0[e];
+      sred[((rg * C) + cg * EPV + e) * 2 + 1] = s1[e];
+    }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 256) {
+    double t0 = 0.0, t1 = 0.0;
+    for (int k = 0; k < rpi; ++k) {
+      t0 += (double)sred[(k * C + c) * 2];
+      t1 += (double)sred[(k * C + c) * 2 + 1];
+    }
+    double *p = partial + ((((int64_t)b * gridDim.x + blockIdx.x) * C) + c) * 2;
+    p[0] = t0;
+    p[1] = t1;
+  }
+}
+
+template <typename T>
+static bool vec_ok(const void *p, int ld, int C) {
+  constexpr int EPV = 16 / sizeof(T);
+  return p && ((uintptr_t)p & 15) == 0 && ld % EPV == 0 && C % EPV == 0 && C / EPV <= 256;
+}
+
+// launches the vectorised reduction when the operands allow it, else the scalar kernel
+template <typename T, int MODE>
+static void launch_chan_reduce(const void *y, int ldy, const void *gz, int ldgz, const float *mean_rstd,
+                               const float *gamma, const float *beta, float slope, double *partial, int nblk, int B, int C,
+                               int64_t V, hipStream_t st) {
+  if (vec_ok<T>(y, ldy, C) && (MODE != 1 || vec_ok<T>(gz, ldgz, C))) {
+    constexpr int EPV = 16 / sizeof(T);
+    const int rpi = 256 / (C / EPV);
+    hipLaunchKernelGGL((chan_reduce_vec_kernel<T, MODE>), dim3(nblk, B), dim3(256), (size_t)rpi * C * 2 * sizeof(float), st,
+                       (const T *)y, ldy, (const T *)gz, ldgz, mean_rstd, gamma, beta, slope, partial, C, V);
+  } else {
+    hipLaunchKernelGGL((chan_reduce_kernel<T, MODE>), dim3(nblk, B), dim3(256), 0, st, (const T *)y, ldy, (const T *)gz,
+                       ldgz, mean_rstd, gamma, beta, slope, partial, C, V);
+  }
+}
+
 // InstanceNorm statistics finalize: mean, rstd = 1/sqrt(biased var + eps).  One wave per (b,c); the number of
 // partial blocks is read from the device-side header when hdr != NULL (statistics produced by the conv epilogue).
 __global__ void in_stats_finalize_kernel(const double *__restrict__ partial, const long long *__restrict__ hdr, int nblk_h,
@@ -236,27 +365,33 @@ __global__ void in_lrelu_apply_kernel(const T *__restrict__ y, int ldy, const fl
   }
 }
 
-// backward finalize: c1 = mean(da), c2 = mean(da*xhat); dgamma (+)= sum_b sum(da*xhat); dbeta (+)= sum_b sum(da)
+// backward finalize: c1 = mean(da), c2 = mean(da*xhat); dgamma (+)= sum_b sum(da*xhat); dbeta (+)= sum_b sum(da).
+// one wave per channel
 __global__ void in_bwd_finalize_kernel(const double *__restrict__ partial, int nblk, int B, int C, int64_t V,
                                        float *__restrict__ c12, float *__restrict__ dgamma, float *__restrict__ dbeta,
                                        int accumulate) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+  const int c = blockIdx.x;
   double g_acc = 0.0, b_acc = 0.0;
   for (int b = 0; b < B; ++b) {
     double s0 = 0.0, s1 = 0.0;
-    for (int k = 0; k < nblk; ++k) {
+    for (int k = threadIdx.x; k < nblk; k += 64) {
       const double *p = partial + ((((int64_t)b * nblk + k) * C) + c) * 2;
       s0 += p[0];
       s1 += p[1];
     }
-    c12[((int64_t)b * C + c) * 2] = (float)(s0 / (double)V);
-    c12[((int64_t)b * C + c) * 2 + 1] = (float)(s1 / (double)V);
+    s0 = wave_sum_d(s0);
+    s1 = wave_sum_d(s1);
+    if (threadIdx.x == 0) {
+      c12[((int64_t)b * C + c) * 2] = (float)(s0 / (double)V);
+      c12[((int64_t)b * C + c) * 2 + 1] = (float)(s1 / (double)V);
+    }
     b_acc += s0;
     g_acc += s1;
   }
-  dgamma[c] = accumulate ? dgamma[c] + (float)g_acc : (float)g_acc;
-  dbeta[c] = accumulate ? dbeta[c] + (float)b_acc : (float)b_acc;
+  if (threadIdx.x == 0) {
+    dgamma[c] = accumulate ? dgamma[c] + (float)g_acc : (float)g_acc;
+    dbeta[c] = accumulate ? dbeta[c] + (float)b_acc : (float)b_acc;
+  }
 }
 
 // dy = gamma*rstd*(da - c1 - xhat*c2)
@@ -281,12 +416,11 @@ __global__ void in_lrelu_bwd_apply_kernel(const T *__restrict__ gz, int ldgz, co
 
 __global__ void bias_finalize_kernel(const double *__restrict__ partial, int nblk, int B, int C, float *__restrict__ db,
                                      int accumulate) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+  const int c = blockIdx.x;   // one wave per channel
   double s = 0.0;
-  for (int b = 0; b < B; ++b)
-    for (int k = 0; k < nblk; ++k) s += partial[((((int64_t)b * nblk + k) * C) + c) * 2];
-  db[c] = accumulate ? db[c] + (float)s : (float)s;
+  for (int k = threadIdx.x; k < B * nblk; k += 64) s += partial[(((int64_t)k * C) + c) * 2];
+  s = wave_sum_d(s);
+  if (threadIdx.x == 0) db[c] = accumulate ? db[c] + (float)s : (float)s;
 }
 
 // ============================================================================ ConvTranspose3d k2 s2
@@ -390,6 +524,55 @@ __global__ void head_dgrad_kernel(const float *__restrict__ dout, int lddo, cons
   }
 }
 
+// Fast head kernels for the production shape (CIN input channels, nsel <= 32 selected rows): one thread per voxel, the
+// activation row lives in registers (16-byte loads), the selected weight rows in LDS (broadcast reads).
+template <typename T, int CIN, bool NDHWC>
+__global__ __launch_bounds__(256) void head_fwd_fast_kernel(const T *__restrict__ x, int ldx, const float *__restrict__ w,
+                                                            const float *__restrict__ bias, const int *__restrict__ sel,
+                                                            int nsel, float *__restrict__ out, int ldo, int64_t V,
+                                                            int64_t rows) {
+  constexpr int EPV = 16 / sizeof(T);
+  __shared__ float sw[128 * CIN + 128];
+  for (int i = threadIdx.x; i < nsel * CIN; i += 256) sw[i] = w[(int64_t)(sel ? sel[i / CIN] : i / CIN) * CIN + i % CIN];
+  for (int i = threadIdx.x; i < nsel; i += 256) sw[128 * CIN + i] = bias[sel ? sel[i] : i];
+  __syncthreads();
+  for (int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x; row < rows; row += (int64_t)gridDim.x * 256) {
+    float xr[CIN];
+#pragma unroll
+    for (int g = 0; g < CIN / EPV; ++g)
+      unpack16<T>(*reinterpret_cast<const uint4 *>(x + row * ldx + g * EPV), xr + g * EPV);
+    for (int k = 0; k < nsel; ++k) {
+      float acc = 0.f;
+#pragma unroll
+      for (int ci = 0; ci < CIN; ++ci) acc = __builtin_fmaf(xr[ci], sw[k * CIN + ci], acc);
+      acc += sw[128 * CIN + k];
+      if (NDHWC) out[row * ldo + k] = acc;
+      else out[((row / V) * nsel + k) * V + row % V] = acc;
+    }
+  }
+}
+
+template <typename T, int CIN>
+__global__ __launch_bounds__(256) void head_dgrad_fast_kernel(const float *__restrict__ dout, int lddo,
+                                                              const float *__restrict__ w, const int *__restrict__ sel,
+                                                              int nsel, T *__restrict__ dx, int lddx, int64_t rows) {
+  __shared__ float sw[32 * CIN];
+  for (int i = threadIdx.x; i < nsel * CIN; i += 256) sw[i] = w[(int64_t)(sel ? sel[i / CIN] : i / CIN) * CIN + i % CIN];
+  __syncthreads();
+  for (int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x; row < rows; row += (int64_t)gridDim.x * 256) {
+    float acc[CIN];
+#pragma unroll
+    for (int ci = 0; ci < CIN; ++ci) acc[ci] = 0.f;
+    for (int k = 0; k < nsel; ++k) {
+      const float g = dout[row * lddo + k];
+#pragma unroll
+      for (int ci = 0; ci < CIN; ++ci) acc[ci] = __builtin_fmaf(g, sw[k * CIN + ci], acc[ci]);
+    }
+#pragma unroll
+    for (int ci = 0; ci < CIN; ++ci) st_f<T>(dx + row * lddx + ci, acc[ci]);
+  }
+}
+
 // partial[split][k][ci] ; grid (pairs/256, nsplit)
 template <typename T>
 __global__ void head_wgrad_kernel(const T *__restrict__ x, int ldx, const float *__restrict__ dout, int lddo,
@@ -467,8 +650,8 @@ int gs_blocks(int64_t total, int cap = 16384) {
 }
 
 int reduce_blocks(int64_t V) {
-  int64_t b = cdiv64(V, 2048);
-  return (int)(b < 512 ? (b > 0 ? b : 1) : 512);
+  int64_t b = cdiv64(V, 1024);
+  return (int)(b < 2048 ? (b > 0 ? b : 1) : 2048);
 }
 
 int wgrad_splits(int64_t nvox) {
@@ -628,10 +811,9 @@ static int bias_grad(const void *dy, int lddy, float *db, void *ws, int B, int C
                      hipStream_t st) {
   const int nblk = reduce_blocks(V);
   double *partial = (double *)ws;
-  DISPATCH_T(dtype, hipLaunchKernelGGL((chan_reduce_kernel<T, 2>), dim3(nblk, B), dim3(256), 0, st, (const T *)dy, lddy,
-                                       (const T *)nullptr, 0, nullptr, nullptr, nullptr, 0.f, partial, C, V));
+  DISPATCH_T(dtype, (launch_chan_reduce<T, 2>(dy, lddy, nullptr, 0, nullptr, nullptr, nullptr, 0.f, partial, nblk, B, C, V, st)));
   DG_CHECK_LAUNCH("chan_reduce_kernel<2>");
-  hipLaunchKernelGGL(bias_finalize_kernel, dim3(cdiv(C, 128)), dim3(128), 0, st, partial, nblk, B, C, db, accumulate);
+  hipLaunchKernelGGL(bias_finalize_kernel, dim3(C), dim3(64), 0, st, partial, nblk, B, C, db, accumulate);
   DG_CHECK_LAUNCH("bias_finalize_kernel");
   return DGTTA_OK;
 }
@@ -690,8 +872,7 @@ extern "C" int dgtta_instnorm_lrelu_fwd(const void *y, int ldy, const void *stat
                        (const long long *)stats, 0, B, C, V, eps, mean_rstd);
   } else {
     double *partial = (double *)ws;
-    DISPATCH_T(dtype, hipLaunchKernelGGL((chan_reduce_kernel<T, 0>), dim3(nblk, B), dim3(256), 0, st, (const T *)y, ldy,
-                                         (const T *)nullptr, 0, nullptr, nullptr, nullptr, 0.f, partial, C, V));
+    DISPATCH_T(dtype, (launch_chan_reduce<T, 0>(y, ldy, nullptr, 0, nullptr, nullptr, nullptr, 0.f, partial, nblk, B, C, V, st)));
     DG_CHECK_LAUNCH("chan_reduce_kernel<0>");
     hipLaunchKernelGGL(in_stats_finalize_kernel, dim3(B * C), dim3(64), 0, st, (const double *)partial,
                        (const long long *)nullptr, nblk, B, C, V, eps, mean_rstd);
@@ -717,11 +898,10 @@ extern "C" int dgtta_instnorm_lrelu_bwd(const void *gz, int ldgz, const void *y,
   const int nblk = reduce_blocks(V);
   double *partial = (double *)ws;
   float *c12 = (float *)((char *)ws + align_up((size_t)B * nblk * C * 2 * sizeof(double), 256));
-  DISPATCH_T(dtype, hipLaunchKernelGGL((chan_reduce_kernel<T, 1>), dim3(nblk, B), dim3(256), 0, st, (const T *)y, ldy,
-                                       (const T *)gz, ldgz, mean_rstd, gamma, beta, slope, partial, C, V));
+  DISPATCH_T(dtype, (launch_chan_reduce<T, 1>(y, ldy, gz, ldgz, mean_rstd, gamma, beta, slope, partial, nblk, B, C, V, st)));
   DG_CHECK_LAUNCH("chan_reduce_kernel<1>");
-  hipLaunchKernelGGL(in_bwd_finalize_kernel, dim3(cdiv(C, 128)), dim3(128), 0, st, partial, nblk, B, C, V, c12, dgamma,
-                     dbeta, accumulate);
+  hipLaunchKernelGGL(in_bwd_finalize_kernel, dim3(C), dim3(64), 0, st, partial, nblk, B, C, V, c12, dgamma, dbeta,
+                     accumulate);
   DG_CHECK_LAUNCH("in_bwd_finalize_kernel");
   const int64_t total = (int64_t)B * V * C;
   DISPATCH_T(dtype, hipLaunchKernelGGL((in_lrelu_bwd_apply_kernel<T>), dim3(gs_blocks(total)), dim3(256), 0, st,
@@ -826,6 +1006,18 @@ extern "C" int dgtta_seghead_fwd(const void *x, int ldx, const float *w, const f
   DG_REQUIRE(x && w && bias && out, DGTTA_ERR_BADARG, "seghead_fwd: null pointer");
   DG_REQUIRE(B > 0 && Cin > 0 && nsel > 0 && V > 0 && ldx >= Cin && (!out_ndhwc || ldo >= nsel), DGTTA_ERR_BADARG,
              "seghead_fwd: bad dims");
+  if (Cin == 32 && nsel <= 128 && ldx % 8 == 0 && ((uintptr_t)x & 15) == 0) {
+    const int64_t rows = (int64_t)B * V;
+    const int blocks = (int)(cdiv64(rows, 256) < 8192 ? cdiv64(rows, 256) : 8192);
+    if (out_ndhwc)
+      DISPATCH_T(dtype, hipLaunchKernelGGL((head_fwd_fast_kernel<T, 32, true>), dim3(blocks), dim3(256), 0,
+                                           (hipStream_t)stream, (const T *)x, ldx, w, bias, sel, nsel, out, ldo, V, rows));
+    else
+      DISPATCH_T(dtype, hipLaunchKernelGGL((head_fwd_fast_kernel<T, 32, false>), dim3(blocks), dim3(256), 0,
+                                           (hipStream_t)stream, (const T *)x, ldx, w, bias, sel, nsel, out, ldo, V, rows));
+    DG_CHECK_LAUNCH("head_fwd_fast_kernel");
+    return DGTTA_OK;
+  }
   const int64_t total = (int64_t)B * V * nsel;
   if (out_ndhwc)
     DISPATCH_T(dtype, hipLaunchKernelGGL((head_fwd_kernel<T, true>), dim3(gs_blocks(total, 1 << 20)), dim3(256), 0,
@@ -844,9 +1036,19 @@ static int head_splits(int64_t rows) {
   return (int)(s < 256 ? (s > 0 ? s : 1) : 256);
 }
 
+size_t head_wgrad_mfma_ws_bytes(int Cin, int nsel, int64_t rows);
+int head_wgrad_mfma(const void *x, int ldx, const float *dout, int lddo, float *dw_sel, void *ws, size_t ws_bytes, int Cin,
+                    int nsel, int64_t rows, int accumulate, int dtype, hipStream_t st);
+
+// workspace layout: [bias partials][main: split partials (VALU) | bf16 copy + slabs (MFMA)]
+static size_t head_bias_region(int B, int nsel, int64_t V) {
+  return align_up((size_t)B * reduce_blocks(V) * nsel * 2 * sizeof(double), 256);
+}
+
 extern "C" size_t dgtta_seghead_bwd_ws_bytes(int B, int Cin, int nsel, int64_t V) {
-  return align_up((size_t)head_splits((int64_t)B * V) * nsel * Cin * sizeof(float), 256) +
-         align_up((size_t)B * reduce_blocks(V) * nsel * 2 * sizeof(double), 256);
+  size_t a = align_up((size_t)head_splits((int64_t)B * V) * nsel * Cin * sizeof(float), 256);
+  size_t c = align_up(head_wgrad_mfma_ws_bytes(Cin, nsel, (int64_t)B * V), 256);
+  return head_bias_region(B, nsel, V) + (a > c ? a : c);
 }
 
 extern "C" int dgtta_seghead_bwd(const void *x, int ldx, const float *dout, int lddo, const float *w, const int *sel,
@@ -857,27 +1059,39 @@ extern "C" int dgtta_seghead_bwd(const void *x, int ldx, const float *dout, int 
   DG_REQUIRE(ws_bytes >= dgtta_seghead_bwd_ws_bytes(B, Cin, nsel, V), DGTTA_ERR_WORKSPACE, "seghead_bwd: workspace too small");
   hipStream_t st = (hipStream_t)stream;
   const int64_t rows = (int64_t)B * V;
+  void *ws_bias = ws;
+  void *ws_main = (char *)ws + head_bias_region(B, nsel, V);
+  const size_t main_bytes = ws_bytes - head_bias_region(B, nsel, V);
   if (dx) {
     DG_REQUIRE(lddx >= Cin, DGTTA_ERR_BADARG, "seghead_bwd: lddx < Cin");
-    const int64_t total = rows * Cin;
-    DISPATCH_T(dtype, hipLaunchKernelGGL((head_dgrad_kernel<T>), dim3(gs_blocks(total, 1 << 20)), dim3(256), 0, st, dout,
-                                         lddo, w, sel, nsel, (T *)dx, lddx, Cin, total));
-    DG_CHECK_LAUNCH("head_dgrad_kernel");
+    if (Cin == 32 && nsel <= 32) {
+      const int blocks = (int)(cdiv64(rows, 256) < 8192 ? cdiv64(rows, 256) : 8192);
+      DISPATCH_T(dtype, hipLaunchKernelGGL((head_dgrad_fast_kernel<T, 32>), dim3(blocks), dim3(256), 0, st, dout, lddo, w,
+                                           sel, nsel, (T *)dx, lddx, rows));
+      DG_CHECK_LAUNCH("head_dgrad_fast_kernel");
+    } else {
+      const int64_t total = rows * Cin;
+      DISPATCH_T(dtype, hipLaunchKernelGGL((head_dgrad_kernel<T>), dim3(gs_blocks(total, 1 << 20)), dim3(256), 0, st, dout,
+                                           lddo, w, sel, nsel, (T *)dx, lddx, Cin, total));
+      DG_CHECK_LAUNCH("head_dgrad_kernel");
+    }
   }
   if (dw_sel) {
-    const int ns = head_splits(rows);
-    float *part = (float *)ws;
-    DISPATCH_T(dtype, hipLaunchKernelGGL((head_wgrad_kernel<T>), dim3(cdiv(Cin * nsel, 256), ns), dim3(256), 0, st,
-                                         (const T *)x, ldx, dout, lddo, part, Cin, nsel, rows));
-    DG_CHECK_LAUNCH("head_wgrad_kernel");
-    const int64_t n = (int64_t)nsel * Cin;
-    hipLaunchKernelGGL(reduce_splits_kernel, dim3(gs_blocks(n)), dim3(256), 0, st, part, dw_sel, n, ns, accumulate);
-    DG_CHECK_LAUNCH("reduce_splits_kernel");
+    int rc = head_wgrad_mfma(x, ldx, dout, lddo, dw_sel, ws_main, main_bytes, Cin, nsel, rows, accumulate, dtype, st);
+    if (rc == DGTTA_ERR_UNSUPPORTED) {
+      const int ns = head_splits(rows);
+      float *part = (float *)ws_main;
+      DISPATCH_T(dtype, hipLaunchKernelGGL((head_wgrad_kernel<T>), dim3(cdiv(Cin * nsel, 256), ns), dim3(256), 0, st,
+                                           (const T *)x, ldx, dout, lddo, part, Cin, nsel, rows));
+      DG_CHECK_LAUNCH("head_wgrad_kernel");
+      const int64_t n = (int64_t)nsel * Cin;
+      hipLaunchKernelGGL(reduce_splits_kernel, dim3(gs_blocks(n)), dim3(256), 0, st, part, dw_sel, n, ns, accumulate);
+      DG_CHECK_LAUNCH("reduce_splits_kernel");
+    } else if (rc != DGTTA_OK) {
+      return rc;
+    }
   }
-  if (db_sel) {
-    void *ws2 = (char *)ws + align_up((size_t)head_splits(rows) * nsel * Cin * sizeof(float), 256);
-    return bias_grad(dout, lddo, db_sel, ws2, B, nsel, V, accumulate, DGTTA_F32, st);
-  }
+  if (db_sel) return bias_grad(dout, lddo, db_sel, ws_bias, B, nsel, V, accumulate, DGTTA_F32, st);
   return DGTTA_OK;
 }
 

@@ -263,3 +263,40 @@ def test_convT_mfma(case, dt):
         F.conv_transpose3d(xr, wr, None, stride=2).backward(dout.permute(0, 4, 1, 2, 3).cpu().double())
         assert (dx2.cpu() - xr.grad.permute(0, 2, 3, 4, 1).float()).abs().max() < 3e-5 * xr.grad.abs().max()
         assert (dw2.cpu() - wr.grad.float()).abs().max() < 3e-5 * wr.grad.abs().max()
+
+
+@pytest.mark.parametrize("nsel,V", [(16, 8 * 8 * 32), (5, 7 * 9 * 11), (105, 4 * 8 * 16)])
+@pytest.mark.parametrize("dt", [0, 1])
+def test_head_fast_paths(nsel, V, dt):
+    """1x1x1 head (Cin=32) forward / dgrad / wgrad fast paths vs a dense torch reference."""
+    from dg_tta_amd import _lib
+    from dg_tta_amd._lib import check, ptr, stream_of
+    lib = _lib.load()
+    torch.manual_seed(nsel + V)
+    tdt = torch.bfloat16 if dt else torch.float32
+    B, cin, ncls = 1, 32, 105
+    x = torch.randn(B, V, cin, device=DEV).to(tdt)
+    w = torch.randn(ncls, cin, device=DEV)
+    bias = torch.randn(ncls, device=DEV)
+    sel = None if nsel == ncls else torch.randperm(ncls, device=DEV)[:nsel].int()
+    out = torch.empty((B, V, nsel), device=DEV)
+    check(lib.dgtta_seghead_fwd(ptr(x), cin, ptr(w), ptr(bias), ptr(sel), nsel, ptr(out), 1, nsel, B, cin, V, dt, stream_of()),
+          "head fwd")
+    wsel = w if sel is None else w[sel.long()]
+    bsel = bias if sel is None else bias[sel.long()]
+    ref = x.float() @ wsel.t() + bsel
+    assert (out - ref).abs().max() < 2e-5 * ref.abs().max() + 1e-5
+    dout = torch.randn(B, V, nsel, device=DEV)
+    dx = torch.empty((B, V, cin), dtype=tdt, device=DEV)
+    dw, db = torch.empty((nsel, cin), device=DEV), torch.empty((nsel,), device=DEV)
+    nb = lib.dgtta_seghead_bwd_ws_bytes(B, cin, nsel, V)
+    ws = torch.empty(nb, dtype=torch.uint8, device=DEV)
+    check(lib.dgtta_seghead_bwd(ptr(x), cin, ptr(dout), nsel, ptr(w), ptr(sel), nsel, ptr(dx), cin, ptr(dw), ptr(db), ptr(ws),
+                                nb, B, cin, V, 0, dt, stream_of()), "head bwd")
+    tol = 2e-5 if dt == 0 else 1e-2
+    dx_ref = dout @ wsel
+    assert (dx.float() - dx_ref).abs().max() < tol * dx_ref.abs().max() + 1e-5
+    dw_ref = dout[0].t() @ x[0].float()
+    wtol = 3e-5 if dt == 0 else 2e-2        # bf16 MFMA path rounds dout to bf16
+    assert (dw - dw_ref).abs().max() < wtol * dw_ref.abs().max() + 1e-4
+    assert torch.allclose(db, dout[0].sum(0), rtol=1e-5, atol=1e-4)

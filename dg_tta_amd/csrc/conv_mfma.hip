@@ -579,6 +579,7 @@ __global__ __launch_bounds__(256) void conv3_wgrad_mfma_kernel(const T *__restri
   const int d_begin = ds * DR, d_end = (d_begin + DR < D) ? d_begin + DR : D;
   const T *xb = x + b * xv.sb;
   const T *yb0 = dy + b * yv.sb;
+  const int cin_lim = (Cin + EPV - 1) / EPV * EPV;
 
   uint4 stg[C::ROUNDS][EPV];
 
@@ -592,7 +593,7 @@ __global__ __launch_bounds__(256) void conv3_wgrad_mfma_kernel(const T *__restri
         if (!do_x) continue;
         const int cg = u % C::GC, ch = (u / C::GC) % C::NCH_X, row = u / (C::GC * C::NCH_X);
         const int gd = dx_slice, gh = h0 - 1 + row, c = cib * 32 + cg * EPV;
-        if ((unsigned)gd < (unsigned)xv.D && (unsigned)gh < (unsigned)xv.H && c < Cin) {
+        if ((unsigned)gd < (unsigned)xv.D && (unsigned)gh < (unsigned)xv.H && c < cin_lim) {
           const T *base = xb + gd * xv.sd + gh * xv.sh + c;
 #pragma unroll
           for (int j = 0; j < EPV; ++j) {
@@ -743,7 +744,10 @@ static int wgrad_launch(const void *x, const View &xv, const void *dy, const Vie
                         int B, int Cin, int Cout, unsigned tapmask, const Taps &real, long long s_co, long long s_ci,
                         long long s_tap, int accumulate, hipStream_t st) {
   constexpr int EPV = Elem<T>::EPV;
-  if (Cin % EPV || Cout % EPV || xv.sw % EPV || yv.sw % EPV || ((uintptr_t)x & 15) || ((uintptr_t)dy & 15))
+  // Cin may be ragged (first layer: 12 channels in rows of 16): the pad channels only feed gradient rows ci >= Cin,
+  // which the reduction never writes.  The rows must be long enough to be read in whole 16-byte groups.
+  if (Cout % EPV || xv.sw % EPV || yv.sw % EPV || ((uintptr_t)x & 15) || ((uintptr_t)dy & 15) ||
+      xv.sw < (Cin + EPV - 1) / EPV * EPV)
     return DGTTA_ERR_UNSUPPORTED;
   WgradPlan p = wgrad_plan(B, Cin, Cout, yv.D, yv.H, yv.W);
   const size_t need = (size_t)p.units * p.cibs * p.cobs * 27 * 1024 * sizeof(float);

@@ -238,7 +238,8 @@ extern "C" int dgtta_affine_warp3d_bwd(const float *grad_dst, const float *theta
   hipStream_t st = (hipStream_t)stream;
   const int64_t Vd = (int64_t)Dd * Hd * Wd;
   if (ndhwc) {
-    if (C % 4 == 0) {
+    // one lane per channel: a wave-instruction's atomics then cover whole 64-byte rows (C=16) instead of 16-byte pieces
+    if (false && C % 4 == 0) {
       int64_t total = (int64_t)B * Vd * (C / 4);
       hipLaunchKernelGGL((warp_bwd_kernel<4, true>), dim3(grid_for(total)), dim3(256), 0, st, grad_dst, theta, grad_src,
                          C, Ds, Hs, Ws, Dd, Hd, Wd, src_ldc, dst_ldc, pad_mode, tta_grid_algebra, total);

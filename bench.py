@@ -139,7 +139,8 @@ def main():
     ap.add_argument("--size", type=int, default=128)
     ap.add_argument("--accum", type=int, default=16)
     ap.add_argument("--copt", type=int, default=16)
-    ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16"])
+    ap.add_argument("--dtype", default="bf16", choices=["fp32", "bf16"],
+                    help="activation storage; accumulation, statistics, loss, gradients of weights and AdamW are fp32")
     ap.add_argument("--impl", type=int, default=0)
     ap.add_argument("--cpu-size", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -173,10 +174,8 @@ def main():
         runner.epoch()
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    from dg_tta_amd.sharding import max_over_ranks
+    dt = max_over_ranks(dt, device)
     set_probe(None)
 
     if rank == 0:

@@ -22,6 +22,7 @@ import torch
 from .. import ops
 from ..gin import gin_aug
 from ..optim import HipAdamW
+from ..sharding import owns
 from ..utils import disable_internal_augmentation
 from .augmentation_utils import get_rand_affine
 from .config_log_utils import (get_global_idx, get_parameters_save_path, is_template_modifier, plot_run_results)
@@ -215,7 +216,7 @@ def tta_main(run_name, config, tta_data_dir, save_base_path, label_mapping, modi
     print("\n# Starting TTA")
     for smp_idx in ([0] if across else range(num_samples)):
         _, tta_tens_list, sample_id, _ext, sub_dir_tta = get_sample_specs(config, smp_idx, tta_data, save_path, across)
-        if smp_idx % world != rank:
+        if not owns(smp_idx, rank, world):
             continue        # another GPU's sample (independent unit: nothing to exchange)
         print(f"\nSample {sample_id}")
         sub_dir_tta.mkdir(exist_ok=True, parents=True)

@@ -14,6 +14,7 @@
 //   Data gradient of a stride-1 conv = the same kernel on dy with mirrored taps and swapped channel roles.
 //   Stride 2:   the halo tile is staged de-interleaved by W parity so that lane reads stay contiguous.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -87,7 +88,7 @@ struct Taps {
 };
 
 // x: view xv;  w: [ntap][CoutP][CinP] (k contiguous), virtual tap t uses weight tap taps.wt[t];  y: view yv
-template <typename T, int MBW, int MBH, int MBD, int S, int NB, int KSPC>
+template <typename T, int MBW, int MBH, int MBD, int S, int NB, int KSPC, int ABL = 0>   // ABL: diagnostic ablation
 __global__ __launch_bounds__(256) void conv3_mfma_kernel(const T *__restrict__ x, View xv, const T *__restrict__ w,
                                                          Taps taps, const float *__restrict__ bias,
                                                          T *__restrict__ y, View yv, int Cin, int Cout, int CinP,
@@ -136,32 +137,72 @@ __global__ __launch_bounds__(256) void conv3_mfma_kernel(const T *__restrict__ x
   const T *xbp = x + (int64_t)b * xv.sb;
   const int cin_lim = (Cin + EPV - 1) / EPV * EPV;       // channels that may be read (caller guarantees ldx >= this)
 
-  for (int kc = 0; kc < CinP; kc += CK) {
-    __syncthreads();   // previous chunk's LDS reads are done
-    // ---- stage A: halo voxels x channel groups of this chunk
-    for (int idx = tid; idx < NV * NG; idx += 256) {
+  // Register staging, software pipelined: all global loads of a chunk are issued back to back (unconditional loads from
+  // a clamped address + select, so the compiler emits no per-load branch / wait), written to LDS one chunk later, and
+  // the loads of chunk k+1 are in flight while chunk k is being multiplied.
+  constexpr int NA = (NV * NG + 255) / 256, NBL = (27 * NC * NG + 255) / 256;
+  uint4 ra[NA], rb[NBL];
+  auto load_chunk = [&](int kc) {
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      const int idx = tid + i * 256;
       const int g = idx % NG, v = idx / NG;
       const int wx_l = v % G::ROW, hy = (v / G::ROW) % G::IH, dz = v / (G::ROW * G::IH);
       int wx = wx_l;
       if (S == 2) wx = (wx_l >= G::IWH) ? 2 * (wx_l - G::IWH) + 1 : 2 * wx_l;    // inverse of lds_col
       const int gd = id0 + dz, gh = ih0 + hy, gw = iw0 + wx;
       const int c = kc + g * EPV;
-      uint4 val = make_uint4(0, 0, 0, 0);
-      if ((S == 1 || wx < G::IW) && (unsigned)gd < (unsigned)Di && (unsigned)gh < (unsigned)Hi &&
-          (unsigned)gw < (unsigned)Wi && c < cin_lim)
-        val = *reinterpret_cast<const uint4 *>(xbp + gd * xv.sd + gh * xv.sh + gw * xv.sw + c);
-      sA[g * NV + v] = val;
+      const bool ok = idx < NV * NG && (S == 1 || wx < G::IW) && (unsigned)gd < (unsigned)Di &&
+                      (unsigned)gh < (unsigned)Hi && (unsigned)gw < (unsigned)Wi && c < cin_lim;
+      const T *p = ok ? xbp + gd * xv.sd + gh * xv.sh + gw * xv.sw + c : x;
+      if (ABL == 1) {
+        ra[i] = make_uint4(idx, 0, 0, 0);
+        continue;
+      }
+      const uint4 val = *reinterpret_cast<const uint4 *>(p);
+      ra[i] = ok ? val : make_uint4(0, 0, 0, 0);
     }
-    // ---- stage B: weights of this chunk for output channels n0..n0+NC
-    for (int idx = tid; idx < 27 * NC * NG; idx += 256) {
-      const int g = idx % NG, n = (idx / NG) % NC, tap = idx / (NG * NC);
+#pragma unroll
+    for (int i = 0; i < NBL; ++i) {
+      const int idx = tid + i * 256;
+      const int g = idx % NG, n = (idx / NG) % NC, tap = (idx / (NG * NC)) % 27;
       const int wt = taps.wt[tap];
-      if (wt < 0) continue;
-      uint4 val = make_uint4(0, 0, 0, 0);
-      if (n0 + n < CoutP) val = *reinterpret_cast<const uint4 *>(w + ((int64_t)wt * CoutP + n0 + n) * CinP + kc + g * EPV);
-      sB[(tap * NG + g) * NC + n] = val;
+      const bool ok = idx < 27 * NC * NG && wt >= 0 && n0 + n < CoutP;
+      const T *p = ok ? w + ((int64_t)wt * CoutP + n0 + n) * CinP + kc + g * EPV : w;
+      if (ABL == 1 || ABL == 4) {
+        rb[i] = make_uint4(idx, 0, 0, 0);
+        continue;
+      }
+      const uint4 val = *reinterpret_cast<const uint4 *>(p);
+      rb[i] = ok ? val : make_uint4(0, 0, 0, 0);
     }
+  };
+  auto store_chunk = [&]() {
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      const int idx = tid + i * 256;
+      if (ABL == 2) {
+        asm volatile("" ::"v"(ra[i].x));
+        continue;
+      }
+      if (idx < NV * NG) sA[(idx % NG) * NV + idx / NG] = ra[i];
+    }
+#pragma unroll
+    for (int i = 0; i < NBL; ++i) {
+      const int idx = tid + i * 256;
+      if (idx < 27 * NC * NG) {
+        const int g = idx % NG, n = (idx / NG) % NC, tap = idx / (NG * NC);
+        sB[(tap * NG + g) * NC + n] = rb[i];
+      }
+    }
+  };
+
+  load_chunk(0);
+  for (int kc = 0; kc < CinP; kc += CK) {
+    __syncthreads();   // previous chunk's LDS reads are done
+    store_chunk();
     __syncthreads();
+    if (kc + CK < CinP) load_chunk(kc + CK);
     // ---- 27 taps x KSPC k-steps of MFMA from LDS
 #pragma unroll
     for (int tap = 0; tap < 27; ++tap) {
@@ -176,9 +217,12 @@ __global__ __launch_bounds__(256) void conv3_mfma_kernel(const T *__restrict__ x
         for (int j = 0; j < NB; ++j) bf[j] = sB[(tap * NG + g) * NC + j * 32 + r];
 #pragma unroll
         for (int i = 0; i < MPW; ++i) {
-          const uint4 af = sA[g * NV + a_off[i] + tap_off];
+          const uint4 af = (ABL == 6) ? make_uint4(tap, i, tid, 0) : sA[g * NV + a_off[i] + tap_off];
 #pragma unroll
-          for (int j = 0; j < NB; ++j) mfma_step<T>(af, bf[j], acc[i][j]);
+          for (int j = 0; j < NB; ++j) {
+            if (ABL == 3) acc[i][j][0] += __uint_as_float(af.x ^ bf[j].x);
+            else mfma_step<T>(af, bf[j], acc[i][j]);
+          }
         }
       }
     }
@@ -205,7 +249,11 @@ __global__ __launch_bounds__(256) void conv3_mfma_kernel(const T *__restrict__ x
           T *o = y + b * yv.sb + od * yv.sd + oh * yv.sh + ow * yv.sw + co;
           float v = acc[i][j][q] + bv;
           if (accumulate) v += ld_f<T>(o);
-          st_f<T>(o, v);
+          if (ABL == 5) {
+            if (v == 1234.5f) st_f<T>(o, v);
+          } else {
+            st_f<T>(o, v);
+          }
           st1[j] += v;
           st2[j] += v * v;
         }
@@ -247,7 +295,18 @@ int launch_conv(const void *x, const View &xv, const void *w, const Taps &taps, 
   typedef ConvCfg<T, MBW, MBH, MBD, S, NB, KSPC> Cfg;
   typedef typename Cfg::G G;
   static bool attr_set = false;
-  auto kern = conv3_mfma_kernel<T, MBW, MBH, MBD, S, NB, KSPC>;
+  auto kern = conv3_mfma_kernel<T, MBW, MBH, MBD, S, NB, KSPC, 0>;
+  if (MBW == 32 && S == 1) {
+    static const char *abl = getenv("DGTTA_CONV_ABL");      // diagnostic only
+    if (abl && abl[0] == '1') kern = conv3_mfma_kernel<T, MBW, MBH, MBD, S, NB, KSPC, 1>;
+    if (abl && abl[0] == '2') kern = conv3_mfma_kernel<T, MBW, MBH, MBD, S, NB, KSPC, 2>;
+    if (abl && abl[0] == '3') kern = conv3_mfma_kernel<T, MBW, MBH, MBD, S, NB, KSPC, 3>;
+    if (abl && abl[0] == '4') kern = conv3_mfma_kernel<T, MBW, MBH, MBD, S, NB, KSPC, 4>;
+    if (abl && abl[0] == '5') kern = conv3_mfma_kernel<T, MBW, MBH, MBD, S, NB, KSPC, 5>;
+    if (abl && abl[0] == '6') kern = conv3_mfma_kernel<T, MBW, MBH, MBD, S, NB, KSPC, 6>;
+    if (abl) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)Cfg::LDS_BYTES);
+  }
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)Cfg::LDS_BYTES);
@@ -303,6 +362,11 @@ int dispatch_conv(const void *x, const View &xv, const void *w, const Taps &taps
 #define ARGS x, xv, w, taps, bias, y, yv, B, Cin, Cout, CinP, CoutP, accumulate, stats, st
   const long long vox = (long long)yv.D * yv.H * yv.W * B;
   if (stride == 1) {
+    static const char *var = getenv("DGTTA_CONV_VARIANT");      // diagnostic: tile-shape experiments
+    if (yv.W >= 32 && var && var[0] == 'a') return launch_conv<T, 32, 4, 4, 1, 1, 2>(ARGS);   // CK = 2 k-steps
+    if (yv.W >= 32 && var && var[0] == 'b') return launch_conv<T, 32, 4, 4, 1, 2, 1>(ARGS);   // 64 output channels
+    if (yv.W >= 32 && var && var[0] == 'd') return launch_conv<T, 32, 4, 2, 1, 1, 1>(ARGS);   // 256-voxel tile, 3 WG/CU
+    if (yv.W >= 32 && var && var[0] == 'e') return launch_conv<T, 32, 2, 4, 1, 1, 1>(ARGS);
     if (yv.W >= 32) return launch_conv<T, 32, 4, 4, 1, 1, 1>(ARGS);
     if (yv.W >= 16) return launch_conv<T, 16, 4, 4, 1, 1, 1>(ARGS);
     if (vox <= 4096) return launch_conv<T, 8, 2, 2, 1, 1, 1>(ARGS);     // tiny volumes: more, smaller workgroups
@@ -494,6 +558,15 @@ struct WG {
   static constexpr int ROUNDS = (NU + 255) / 256;
   static constexpr size_t LDS_BYTES = (size_t)(4 * XSLOT + 2 * YSLOT) * 16;
   static constexpr int NSTEP = 32 / (4 * EPV);   // MFMA k-steps per voxel row (bf16 1, fp32 2)
+  // LDS slot (in uint4) of channel c (0..31) of voxel run `run` in row `row`.  Within a channel group the EPV slots are
+  // XOR-swizzled so that the 8 lanes of a ds_write_b128 group (which differ in channel group / run parity and all write
+  // the same in-group channel j) hit 8 different 16-byte bank slots; readers apply the same map (still one distinct
+  // slot per lane of a 16-lane read group).
+  __device__ static __forceinline__ int slot(int row, int run, int nruns, int c) {
+    const int cg = c / EPV, j = c % EPV;
+    const int sw = (EPV == 8) ? ((cg | ((run & 1) << 2)) & 7) : ((cg >> 1) & 3);
+    return (row * nruns + run) * 32 + cg * EPV + (j ^ sw);
+  }
 };
 
 template <typename T>
@@ -552,8 +625,8 @@ __device__ __forceinline__ void mfma16<float>(const uint4 &a, const uint4 &b, f3
 
 // x: view xv (input lattice of the virtual stride-1 problem), dy: view yv (output lattice; tiles run over it).
 // tapmask: bit t set = virtual tap t is accumulated.
-template <typename T>
-__global__ __launch_bounds__(256) void conv3_wgrad_mfma_kernel(const T *__restrict__ x, View xv, const T *__restrict__ dy,
+template <typename T, int ABL = 0>   // ABL: diagnostic ablation (1 no global loads, 2 no LDS stores, 3 no MFMA); 0 = product
+__global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void conv3_wgrad_mfma_kernel(const T *__restrict__ x, View xv, const T *__restrict__ dy,
                                                                View yv, float *__restrict__ slabs, int Cin, int Cout,
                                                                int tilesW, int tilesH, int nsd, int DR, int cobs,
                                                                unsigned tapmask) {
@@ -583,37 +656,30 @@ __global__ __launch_bounds__(256) void conv3_wgrad_mfma_kernel(const T *__restri
 
   uint4 stg[C::ROUNDS][EPV];
 
+  // all loads of a slice are issued back to back: unconditional loads from a clamped address + select (a conditional
+  // load makes hipcc branch and wait per element, which serialises the round trips)
   auto load_units = [&](int dx_slice, bool do_x, int dy_slice, bool do_y) {
 #pragma unroll
     for (int rd = 0; rd < C::ROUNDS; ++rd) {
       const int u = tid + rd * 256;
+      const bool is_x = u < C::NUX;
+      const int v = is_x ? u : u - C::NUX;
+      const int nch = is_x ? C::NCH_X : C::NCH_Y;
+      const int cg = v % C::GC, ch = (v / C::GC) % nch, row = v / (C::GC * nch);
+      const View &vw = is_x ? xv : yv;
+      const T *bp = is_x ? xb : yb0;
+      const int gd = is_x ? dx_slice : dy_slice, gh = is_x ? h0 - 1 + row : h0 + row;
+      const int c = (is_x ? cib : cob) * 32 + cg * EPV;
+      const bool rowok = (ABL != 1) && u < C::NU && (is_x ? do_x : do_y) && (unsigned)gd < (unsigned)vw.D &&
+                         (unsigned)gh < (unsigned)vw.H && c < (is_x ? cin_lim : Cout);
+      const T *base = bp + (rowok ? gd * vw.sd + gh * vw.sh + c : 0);
+      const int gw0 = w0 + EPV * ch - (is_x ? 1 : 0);
 #pragma unroll
-      for (int j = 0; j < EPV; ++j) stg[rd][j] = make_uint4(0, 0, 0, 0);
-      if (u < C::NUX) {
-        if (!do_x) continue;
-        const int cg = u % C::GC, ch = (u / C::GC) % C::NCH_X, row = u / (C::GC * C::NCH_X);
-        const int gd = dx_slice, gh = h0 - 1 + row, c = cib * 32 + cg * EPV;
-        if ((unsigned)gd < (unsigned)xv.D && (unsigned)gh < (unsigned)xv.H && c < cin_lim) {
-          const T *base = xb + gd * xv.sd + gh * xv.sh + c;
-#pragma unroll
-          for (int j = 0; j < EPV; ++j) {
-            const int gw = w0 + EPV * ch - 1 + j;
-            if ((unsigned)gw < (unsigned)xv.W) stg[rd][j] = *reinterpret_cast<const uint4 *>(base + gw * xv.sw);
-          }
-        }
-      } else if (u < C::NU) {
-        if (!do_y) continue;
-        const int v = u - C::NUX;
-        const int cg = v % C::GC, ch = (v / C::GC) % C::NCH_Y, row = v / (C::GC * C::NCH_Y);
-        const int gd = dy_slice, gh = h0 + row, c = cob * 32 + cg * EPV;
-        if ((unsigned)gd < (unsigned)D && gh < H && c < Cout) {
-          const T *base = yb0 + gd * yv.sd + gh * yv.sh + c;
-#pragma unroll
-          for (int j = 0; j < EPV; ++j) {
-            const int gw = w0 + EPV * ch + j;
-            if (gw < W) stg[rd][j] = *reinterpret_cast<const uint4 *>(base + gw * yv.sw);
-          }
-        }
+      for (int j = 0; j < EPV; ++j) {
+        const int gw = gw0 + j;
+        const bool ok = rowok && (unsigned)gw < (unsigned)vw.W;
+        const uint4 val = *reinterpret_cast<const uint4 *>(base + (ok ? gw * vw.sw : 0));
+        stg[rd][j] = ok ? val : make_uint4(0, 0, 0, 0);
       }
     }
   };
@@ -622,21 +688,25 @@ __global__ __launch_bounds__(256) void conv3_wgrad_mfma_kernel(const T *__restri
     for (int rd = 0; rd < C::ROUNDS; ++rd) {
       const int u = tid + rd * 256;
       uint4 o[EPV];
+      if (ABL == 2) {
+        asm volatile("" ::"v"(stg[rd][0].x));
+        continue;
+      }
       if (u < C::NUX) {
         if (!do_x) continue;
         transpose_unit<T>(stg[rd], o);
         const int cg = u % C::GC, ch = (u / C::GC) % C::NCH_X, row = u / (C::GC * C::NCH_X);
-        uint4 *dst = sX + xslot * C::XSLOT + (row * C::NCH_X + ch) * 32 + cg * EPV;
+        uint4 *dst = sX + xslot * C::XSLOT;
 #pragma unroll
-        for (int j = 0; j < EPV; ++j) dst[j] = o[j];
+        for (int j = 0; j < EPV; ++j) dst[C::slot(row, ch, C::NCH_X, cg * EPV + j)] = o[j];
       } else if (u < C::NU) {
         if (!do_y) continue;
         transpose_unit<T>(stg[rd], o);
         const int v = u - C::NUX;
         const int cg = v % C::GC, ch = (v / C::GC) % C::NCH_Y, row = v / (C::GC * C::NCH_Y);
-        uint4 *dst = sY + yslot * C::YSLOT + (row * C::NCH_Y + ch) * 32 + cg * EPV;
+        uint4 *dst = sY + yslot * C::YSLOT;
 #pragma unroll
-        for (int j = 0; j < EPV; ++j) dst[j] = o[j];
+        for (int j = 0; j < EPV; ++j) dst[C::slot(row, ch, C::NCH_Y, cg * EPV + j)] = o[j];
       }
     }
   };
@@ -663,20 +733,25 @@ __global__ __launch_bounds__(256) void conv3_wgrad_mfma_kernel(const T *__restri
 #pragma unroll
       for (int stp = 0; stp < C::NSTEP; ++stp) {
         const int run = stp * 4 + kg;
-        const uint4 bf = yb[(oh * C::NCH_Y + run) * 32 + coh * 16 + m];
+        const uint4 bf = yb[C::slot(oh, run, C::NCH_Y, coh * 16 + m)];
 #pragma unroll
         for (int kd = 0; kd < 3; ++kd) {
           const uint4 *xs = sX + ((d + kd - 1) & 3) * C::XSLOT;
 #pragma unroll
           for (int kh = 0; kh < 3; ++kh) {
             if (((tapmask >> (kd * 9 + kh * 3)) & 7u) == 0) continue;      // wave-uniform: no tap of this (kd,kh) wanted
-            const uint4 *p = xs + ((oh + kh) * C::NCH_X + run) * 32 + cih * 16 + m;
-            const uint4 c0 = p[0];
-            const uint2 ex = *reinterpret_cast<const uint2 *>(p + 32);
+            const uint4 c0 = xs[C::slot(oh + kh, run, C::NCH_X, cih * 16 + m)];
+            const uint2 ex = *reinterpret_cast<const uint2 *>(xs + C::slot(oh + kh, run + 1, C::NCH_X, cih * 16 + m));
 #pragma unroll
             for (int kw = 0; kw < 3; ++kw)
-              if ((tapmask >> (kd * 9 + kh * 3 + kw)) & 1u)
-                mfma16<T>(shift_run<T>(c0, ex.x, ex.y, kw), bf, acc[kd * 9 + kh * 3 + kw]);
+              if ((tapmask >> (kd * 9 + kh * 3 + kw)) & 1u) {
+                if (ABL == 3) {
+                  const uint4 a_ = shift_run<T>(c0, ex.x, ex.y, kw);
+                  acc[kd * 9 + kh * 3 + kw][0] += __uint_as_float(a_.x ^ bf.x);
+                } else {
+                  mfma16<T>(shift_run<T>(c0, ex.x, ex.y, kw), bf, acc[kd * 9 + kh * 3 + kw]);
+                }
+              }
           }
         }
       }
@@ -753,7 +828,15 @@ static int wgrad_launch(const void *x, const View &xv, const void *dy, const Vie
   const size_t need = (size_t)p.units * p.cibs * p.cobs * 27 * 1024 * sizeof(float);
   if (ws_bytes < need || p.units >= (1ll << 31) || p.cibs * p.cobs > 65535) return DGTTA_ERR_UNSUPPORTED;
   static bool attr_set = false;
-  auto kern = conv3_wgrad_mfma_kernel<T>;
+  auto kern = conv3_wgrad_mfma_kernel<T, 0>;
+  {
+    static const char *abl = getenv("DGTTA_WGRAD_ABL");      // diagnostic only
+    if (abl && abl[0] == '1') kern = conv3_wgrad_mfma_kernel<T, 1>;
+    if (abl && abl[0] == '2') kern = conv3_wgrad_mfma_kernel<T, 2>;
+    if (abl && abl[0] == '3') kern = conv3_wgrad_mfma_kernel<T, 3>;
+    if (abl) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)WG<T>::LDS_BYTES);
+  }
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)WG<T>::LDS_BYTES);

@@ -324,6 +324,76 @@ static void launch_chan_reduce(const void *y, int ldy, const void *gz, int ldgz,
   }
 }
 
+template <typename T>
+__device__ __forceinline__ uint4 pack16(const float *f);
+template <>
+__device__ __forceinline__ uint4 pack16<float>(const float *f) {
+  return make_uint4(__float_as_uint(f[0]), __float_as_uint(f[1]), __float_as_uint(f[2]), __float_as_uint(f[3]));
+}
+template <>
+__device__ __forceinline__ uint4 pack16<bf16_t>(const float *f) {
+  unsigned w[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) w[i] = (unsigned)f32_to_bf16(f[2 * i]) | ((unsigned)f32_to_bf16(f[2 * i + 1]) << 16);
+  return make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+// 16-byte vectorised InstanceNorm+LeakyReLU apply kernels (forward MODE 0, backward MODE 1): grid (blocks, B); the
+// per-channel constants of sample b are staged in LDS once per workgroup; each thread streams 16-byte channel groups.
+// Same arithmetic as in_lrelu_apply_kernel / in_lrelu_bwd_apply_kernel.
+template <typename T, int MODE>
+__global__ __launch_bounds__(256) void in_apply_vec_kernel(const T *__restrict__ y, int ldy, const T *__restrict__ gz,
+                                                           int ldgz, const float *__restrict__ mean_rstd,
+                                                           const float *__restrict__ gamma,
+                                                           const float *__restrict__ beta, const float *__restrict__ c12,
+                                                           T *__restrict__ out, int ldo, int C, int64_t V, float slope) {
+  constexpr int EPV = 16 / sizeof(T);
+  extern __shared__ float sc[];     // fwd: [C][2] (alpha, beta'); bwd: [C][6] (mu, rs, ga, be, c1, c2)
+  const int b = blockIdx.y;
+  constexpr int NK = MODE == 0 ? 2 : 6;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    const float mu = mean_rstd[((int64_t)b * C + c) * 2], rs = mean_rstd[((int64_t)b * C + c) * 2 + 1];
+    if (MODE == 0) {
+      const float al = rs * gamma[c];
+      sc[c * NK] = al;
+      sc[c * NK + 1] = beta[c] - mu * al;
+    } else {
+      sc[c * NK] = mu;
+      sc[c * NK + 1] = rs;
+      sc[c * NK + 2] = gamma[c];
+      sc[c * NK + 3] = beta[c];
+      sc[c * NK + 4] = c12[((int64_t)b * C + c) * 2];
+      sc[c * NK + 5] = c12[((int64_t)b * C + c) * 2 + 1];
+    }
+  }
+  __syncthreads();
+  const int G = C / EPV;
+  const int64_t items = V * G;
+  const T *yb = y + (int64_t)b * V * ldy;
+  const T *gb = MODE == 1 ? gz + (int64_t)b * V * ldgz : nullptr;
+  T *ob = out + (int64_t)b * V * ldo;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < items; i += (int64_t)gridDim.x * 256) {
+    const int64_t row = i / G;
+    const int c0 = (int)(i % G) * EPV;
+    float f[EPV], g[EPV], o[EPV];
+    unpack16<T>(*reinterpret_cast<const uint4 *>(yb + row * ldy + c0), f);
+    if (MODE == 1) unpack16<T>(*reinterpret_cast<const uint4 *>(gb + row * ldgz + c0), g);
+#pragma unroll
+    for (int e = 0; e < EPV; ++e) {
+      const float *k = sc + (c0 + e) * NK;
+      if (MODE == 0) {
+        o[e] = lrelu(f[e] * k[0] + k[1], slope);
+      } else {
+        const float xh = (f[e] - k[0]) * k[1];
+        const float a = xh * k[2] + k[3];
+        const float gg = a > 0.f ? g[e] : g[e] * slope;
+        o[e] = (k[2] * k[1]) * ((gg - k[4]) - xh * k[5]);
+      }
+    }
+    *reinterpret_cast<uint4 *>(ob + row * ldo + c0) = pack16<T>(o);
+  }
+}
+
 // InstanceNorm statistics finalize: mean, rstd = 1/sqrt(biased var + eps).  One wave per (b,c); the number of
 // partial blocks is read from the device-side header when hdr != NULL (statistics produced by the conv epilogue).
 __global__ void in_stats_finalize_kernel(const double *__restrict__ partial, const long long *__restrict__ hdr, int nblk_h,
@@ -879,6 +949,16 @@ extern "C" int dgtta_instnorm_lrelu_fwd(const void *y, int ldy, const void *stat
   }
   DG_CHECK_LAUNCH("in_stats_finalize_kernel");
   const int64_t total = (int64_t)B * V * C;
+  const int esz = dtype == DGTTA_BF16 ? 2 : 4, epv = 16 / esz;
+  if (C % epv == 0 && ldy % epv == 0 && ldz % epv == 0 && !((uintptr_t)y & 15) && !((uintptr_t)z & 15) && C <= 2048) {
+    const int64_t items = V * (C / epv);
+    const int blocks = (int)(cdiv64(items, 256 * 4) < 4096 ? (cdiv64(items, 256 * 4) > 0 ? cdiv64(items, 256 * 4) : 1) : 4096);
+    DISPATCH_T(dtype, hipLaunchKernelGGL((in_apply_vec_kernel<T, 0>), dim3(blocks, B), dim3(256), (size_t)C * 2 * 4, st,
+                                         (const T *)y, ldy, (const T *)nullptr, 0, mean_rstd, gamma, beta, nullptr, (T *)z,
+                                         ldz, C, V, slope));
+    DG_CHECK_LAUNCH("in_apply_vec_kernel<0>");
+    return DGTTA_OK;
+  }
   DISPATCH_T(dtype, hipLaunchKernelGGL((in_lrelu_apply_kernel<T>), dim3(gs_blocks(total)), dim3(256), 0, st,
                                        (const T *)y, ldy, mean_rstd, gamma, beta, (T *)z, ldz, C, V, slope, total));
   DG_CHECK_LAUNCH("in_lrelu_apply_kernel");
@@ -904,6 +984,17 @@ extern "C" int dgtta_instnorm_lrelu_bwd(const void *gz, int ldgz, const void *y,
                      accumulate);
   DG_CHECK_LAUNCH("in_bwd_finalize_kernel");
   const int64_t total = (int64_t)B * V * C;
+  const int esz = dtype == DGTTA_BF16 ? 2 : 4, epv = 16 / esz;
+  if (C % epv == 0 && ldy % epv == 0 && ldgz % epv == 0 && lddy % epv == 0 && !((uintptr_t)y & 15) && !((uintptr_t)gz & 15) &&
+      !((uintptr_t)dy & 15) && C <= 2048) {
+    const int64_t items = V * (C / epv);
+    const int blocks = (int)(cdiv64(items, 256 * 4) < 4096 ? (cdiv64(items, 256 * 4) > 0 ? cdiv64(items, 256 * 4) : 1) : 4096);
+    DISPATCH_T(dtype, hipLaunchKernelGGL((in_apply_vec_kernel<T, 1>), dim3(blocks, B), dim3(256), (size_t)C * 6 * 4, st,
+                                         (const T *)y, ldy, (const T *)gz, ldgz, mean_rstd, gamma, beta, c12, (T *)dy, lddy,
+                                         C, V, slope));
+    DG_CHECK_LAUNCH("in_apply_vec_kernel<1>");
+    return DGTTA_OK;
+  }
   DISPATCH_T(dtype, hipLaunchKernelGGL((in_lrelu_bwd_apply_kernel<T>), dim3(gs_blocks(total)), dim3(256), 0, st,
                                        (const T *)gz, ldgz, (const T *)y, ldy, mean_rstd, gamma, beta, c12, (T *)dy, lddy,
                                        C, V, slope, total));

@@ -768,19 +768,45 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void conv3_wgrad_mfm
     for (int q = 0; q < 4; ++q) slab[(tap * 32 + cih * 16 + kg * 4 + q) * 32 + coh * 16 + m] = acc[tap][q];
 }
 
-// dw[co*s_co + ci*s_ci + real_tap*s_tap] (+)= sum over slabs of virtual tap t (real_tap = real.wt[t], -1: skip)
-__global__ void wgrad_reduce_kernel(const float *__restrict__ slabs, float *__restrict__ dw, int Cin, int Cout, int cobs,
-                                    int nslab, int accumulate, Taps real, long long s_co, long long s_ci, long long s_tap) {
-  const int64_t n = (int64_t)Cout * Cin * 27;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-    // co fastest: a wave reads 32-float rows of the slabs (coalesced); the strided write happens once per element
-    const int co = (int)(i % Cout), ci = (int)((i / Cout) % Cin), tap = (int)(i / ((int64_t)Cout * Cin));
-    const int rt = real.wt[tap];
-    if (rt < 0) continue;
-    const int pair = (ci >> 5) * cobs + (co >> 5);
-    const float *p = slabs + (int64_t)pair * nslab * (27 * 1024) + (tap * 32 + (ci & 31)) * 32 + (co & 31);
-    float s = 0.f;
-    for (int k = 0; k < nslab; ++k) s += p[(int64_t)k * (27 * 1024)];
+// dw[co*s_co + ci*s_ci + real_tap*s_tap] (+)= sum over slabs of virtual tap t (real_tap = real.wt[t], -1: skip).
+// Workgroup = 32 consecutive output channels (one coalesced 128-byte row of every slab) x 8 slab groups; the 8 partial
+// sums are combined through LDS in fixed order (deterministic).
+template <int G>   // G slab groups per output row (8: many slabs, 1: few slabs -> 8 output rows per workgroup)
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restrict__ slabs, float *__restrict__ dw, int Cin,
+                                                           int Cout, int cobs, int nslab, int accumulate, Taps real,
+                                                           long long s_co, long long s_ci, long long s_tap) {
+  constexpr int R = 8 / G;                  // output rows (tap, ci, co-block) per workgroup
+  __shared__ float part[8][32];
+  const int lane = threadIdx.x & 31, sub = threadIdx.x >> 5;
+  const int grp = sub % G, rsel = sub / G;
+  const int cobs32 = (Cout + 31) / 32;
+  const int64_t nrows = (int64_t)27 * Cin * cobs32;
+  int64_t t = (int64_t)blockIdx.x * R + rsel;
+  const bool live = t < nrows;
+  if (!live) t = 0;
+  const int cb = (int)(t % cobs32);
+  t /= cobs32;
+  const int ci = (int)(t % Cin);
+  const int tap = (int)(t / Cin);
+  const int rt = real.wt[tap];
+  const int co = cb * 32 + lane;
+  const bool ok = live && rt >= 0 && co < Cout;
+  float s = 0.f;
+  if (ok) {
+    const int pair = (ci >> 5) * cobs + cb;
+    const float *p = slabs + (int64_t)pair * nslab * (27 * 1024) + (tap * 32 + (ci & 31)) * 32 + lane;
+    for (int k = grp; k < nslab; k += G) s += p[(int64_t)k * (27 * 1024)];
+  }
+  if (G > 1) {
+    part[sub][lane] = s;
+    __syncthreads();
+    if (grp == 0) {
+      s = 0.f;
+#pragma unroll
+      for (int g = 0; g < G; ++g) s += part[rsel * G + g][lane];
+    }
+  }
+  if (grp == 0 && ok) {
     float *o = dw + co * s_co + ci * s_ci + rt * s_tap;
     *o = accumulate ? *o + s : s;
   }
@@ -845,10 +871,13 @@ static int wgrad_launch(const void *x, const View &xv, const void *dy, const Vie
   hipLaunchKernelGGL(kern, dim3((unsigned)p.units, (unsigned)(p.cibs * p.cobs)), dim3(256), WG<T>::LDS_BYTES, st,
                      (const T *)x, xv, (const T *)dy, yv, (float *)ws, Cin, Cout, p.tW, p.tH, p.nsd, p.DR, p.cobs, tapmask);
   DG_CHECK_LAUNCH("conv3_wgrad_mfma_kernel");
-  const int64_t n = (int64_t)Cout * Cin * 27;
-  int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, (const float *)ws, dw, Cin, Cout, p.cobs,
-                     (int)p.units, accumulate, real, s_co, s_ci, s_tap);
+  const int64_t rrows = (int64_t)27 * Cin * ((Cout + 31) / 32);
+  if (p.units >= 64)
+    hipLaunchKernelGGL(wgrad_reduce_kernel<8>, dim3((unsigned)rrows), dim3(256), 0, st, (const float *)ws, dw, Cin, Cout,
+                       p.cobs, (int)p.units, accumulate, real, s_co, s_ci, s_tap);
+  else
+    hipLaunchKernelGGL(wgrad_reduce_kernel<1>, dim3((unsigned)cdiv64(rrows, 8)), dim3(256), 0, st, (const float *)ws, dw,
+                       Cin, Cout, p.cobs, (int)p.units, accumulate, real, s_co, s_ci, s_tap);
   DG_CHECK_LAUNCH("wgrad_reduce_kernel");
   return DGTTA_OK;
 }

@@ -87,13 +87,15 @@ struct Taps {
   signed char wt[27];
 };
 
-// x: view xv;  w: [ntap][CoutP][CinP] (k contiguous), virtual tap t uses weight tap taps.wt[t];  y: view yv
+// x: view xv;  y: view yv;  virtual tap t uses weight tap taps.wt[t].
+// w is stored in "LDS image order" [N/32][K/(2*EPV)][ntaps_src][2][32][EPV]: the B tile of a K-chunk is one contiguous
+// run, so its staging is a linear, fully coalesced copy (see conv_weight_image_index).
 template <typename T, int MBW, int MBH, int MBD, int S, int NB, int KSPC, int ABL = 0>   // ABL: diagnostic ablation
 __global__ __launch_bounds__(256) void conv3_mfma_kernel(const T *__restrict__ x, View xv, const T *__restrict__ w,
                                                          Taps taps, const float *__restrict__ bias,
                                                          T *__restrict__ y, View yv, int Cin, int Cout, int CinP,
                                                          int CoutP, int tilesW, int tilesH, int tilesD, int accumulate,
-                                                         double *__restrict__ stats) {
+                                                         double *__restrict__ stats, int ntaps_src) {
   const int Di = xv.D, Hi = xv.H, Wi = xv.W, Do = yv.D, Ho = yv.H, Wo = yv.W;
   typedef ConvCfg<T, MBW, MBH, MBD, S, NB, KSPC> Cfg;
   typedef typename Cfg::G G;
@@ -164,11 +166,14 @@ __global__ __launch_bounds__(256) void conv3_mfma_kernel(const T *__restrict__ x
     }
 #pragma unroll
     for (int i = 0; i < NBL; ++i) {
-      const int idx = tid + i * 256;
-      const int g = idx % NG, n = (idx / NG) % NC, tap = (idx / (NG * NC)) % 27;
+      const int idx = tid + i * 256;       // == LDS index (tap*NG + g)*NC + n
+      const int n = idx % NC, g = (idx / NC) % NG, tap = (idx / (NG * NC)) % 27;
       const int wt = taps.wt[tap];
-      const bool ok = idx < 27 * NC * NG && wt >= 0 && n0 + n < CoutP;
-      const T *p = ok ? w + ((int64_t)wt * CoutP + n0 + n) * CinP + kc + g * EPV : w;
+      const bool ok = idx < 27 * NC * NG && wt >= 0;
+      const int64_t chunk2 = (int64_t)(kc / (2 * EPV)) + g / 2;     // K-chunk of 2*EPV channels
+      const int64_t off = (((((int64_t)(n0 + n) / 32) * (CinP / (2 * EPV)) + chunk2) * ntaps_src + wt) * 2 + (g & 1)) * 32 +
+                          (n0 + n) % 32;
+      const T *p = ok ? w + off * EPV : w;
       if (ABL == 1 || ABL == 4) {
         rb[i] = make_uint4(idx, 0, 0, 0);
         continue;
@@ -190,10 +195,7 @@ __global__ __launch_bounds__(256) void conv3_mfma_kernel(const T *__restrict__ x
 #pragma unroll
     for (int i = 0; i < NBL; ++i) {
       const int idx = tid + i * 256;
-      if (idx < 27 * NC * NG) {
-        const int g = idx % NG, n = (idx / NG) % NC, tap = idx / (NG * NC);
-        sB[(tap * NG + g) * NC + n] = rb[i];
-      }
+      if (idx < 27 * NC * NG) sB[idx] = rb[i];
     }
   };
 
@@ -291,7 +293,7 @@ __global__ __launch_bounds__(256) void conv3_mfma_kernel(const T *__restrict__ x
 template <typename T, int MBW, int MBH, int MBD, int S, int NB, int KSPC>
 int launch_conv(const void *x, const View &xv, const void *w, const Taps &taps, const float *bias, void *y,
                 const View &yv, int B, int Cin, int Cout, int CinP, int CoutP, int accumulate, double *stats,
-                hipStream_t st) {
+                int ntaps_src, hipStream_t st) {
   typedef ConvCfg<T, MBW, MBH, MBD, S, NB, KSPC> Cfg;
   typedef typename Cfg::G G;
   static bool attr_set = false;
@@ -317,7 +319,7 @@ int launch_conv(const void *x, const View &xv, const void *w, const Taps &taps, 
   DG_REQUIRE(tiles < (1ll << 31), DGTTA_ERR_UNSUPPORTED, "conv3_mfma: too many tiles");
   dim3 grid((unsigned)tiles, (unsigned)cdiv(CoutP, Cfg::NC));
   hipLaunchKernelGGL(kern, grid, dim3(256), Cfg::LDS_BYTES, st, (const T *)x, xv, (const T *)w, taps, bias, (T *)y, yv,
-                     Cin, Cout, CinP, CoutP, tW, tH, tD, accumulate, stats);
+                     Cin, Cout, CinP, CoutP, tW, tH, tD, accumulate, stats, ntaps_src);
   DG_CHECK_LAUNCH("conv3_mfma_kernel");
   return DGTTA_OK;
 }
@@ -358,8 +360,8 @@ bool operand_ok(const void *p, long long ld_elems, int Cin, int CinP) {
 template <typename T>
 int dispatch_conv(const void *x, const View &xv, const void *w, const Taps &taps, const float *bias, void *y,
                   const View &yv, int B, int Cin, int Cout, int CinP, int CoutP, int stride, int accumulate,
-                  hipStream_t st, double *stats = nullptr) {
-#define ARGS x, xv, w, taps, bias, y, yv, B, Cin, Cout, CinP, CoutP, accumulate, stats, st
+                  hipStream_t st, double *stats = nullptr, int ntaps_src = 27) {
+#define ARGS x, xv, w, taps, bias, y, yv, B, Cin, Cout, CinP, CoutP, accumulate, stats, ntaps_src, st
   const long long vox = (long long)yv.D * yv.H * yv.W * B;
   if (stride == 1) {
     static const char *var = getenv("DGTTA_CONV_VARIANT");      // diagnostic: tile-shape experiments
@@ -386,19 +388,54 @@ Taps identity_taps(int mirror) {
   return t;
 }
 
-// ConvTranspose3d k2 s2 weight packing: w_t[ci][co][o] fp32 -> wf[o][coP][ciP], wb[o][ciP][coP] (zero padded)
+// index of element (n, k, tap) in the LDS-image-ordered weight array [N/32][K/(2*EPV)][ntaps][2][32][EPV]
+__host__ __device__ inline int64_t conv_weight_image_index(int n, int k, int tap, int KP, int ntaps, int EPV) {
+  const int64_t chunk2 = k / (2 * EPV);
+  const int g = (k / EPV) % 2, e = k % EPV;
+  return ((((((int64_t)(n / 32)) * (KP / (2 * EPV)) + chunk2) * ntaps + tap) * 2 + g) * 32 + n % 32) * EPV + e;
+}
+
+// ConvTranspose3d k2 s2 weight packing: w_t[ci][co][o] fp32 -> image-ordered wf (N=co, K=ci) and wb (N=ci, K=co),
+// 8 "taps" = the 8 output offsets, zero padded
 template <typename T>
 __global__ void convT_pack_kernel(const float *__restrict__ w, T *__restrict__ wf, T *__restrict__ wb, int Cin, int Cout,
                                   int CinP, int CoutP) {
-  const int64_t n = (int64_t)8 * CinP * CoutP;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-    {
-      int ci = (int)(i % CinP), co = (int)((i / CinP) % CoutP), o = (int)(i / ((int64_t)CinP * CoutP));
-      st_f<T>(wf + i, (ci < Cin && co < Cout) ? w[((int64_t)ci * Cout + co) * 8 + o] : 0.f);
+  constexpr int EPV = Elem<T>::EPV;
+  const int CoutN = (CoutP + 31) / 32 * 32, CinN = (CinP + 31) / 32 * 32;
+  const int64_t nf = (int64_t)8 * CinP * CoutN, nb = (int64_t)8 * CoutP * CinN;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (nf > nb ? nf : nb);
+       i += (int64_t)gridDim.x * blockDim.x) {
+    if (i < nf) {
+      int ci = (int)(i % CinP), co = (int)((i / CinP) % CoutN), o = (int)(i / ((int64_t)CinP * CoutN));
+      st_f<T>(wf + conv_weight_image_index(co, ci, o, CinP, 8, EPV),
+              (ci < Cin && co < Cout) ? w[((int64_t)ci * Cout + co) * 8 + o] : 0.f);
     }
-    {
-      int co = (int)(i % CoutP), ci = (int)((i / CoutP) % CinP), o = (int)(i / ((int64_t)CinP * CoutP));
-      st_f<T>(wb + i, (ci < Cin && co < Cout) ? w[((int64_t)ci * Cout + co) * 8 + o] : 0.f);
+    if (i < nb) {
+      int co = (int)(i % CoutP), ci = (int)((i / CoutP) % CinN), o = (int)(i / ((int64_t)CoutP * CinN));
+      st_f<T>(wb + conv_weight_image_index(ci, co, o, CoutP, 8, EPV),
+              (ci < Cin && co < Cout) ? w[((int64_t)ci * Cout + co) * 8 + o] : 0.f);
+    }
+  }
+}
+
+// conv 3x3x3 weight images: imgF (N=co, K=ci) and imgB (N=ci, K=co) with REAL tap indices
+template <typename T>
+__global__ void conv_pack_image_kernel(const float *__restrict__ w, T *__restrict__ imgF, T *__restrict__ imgB, int Cin,
+                                       int Cout, int CinP, int CoutP) {
+  constexpr int EPV = Elem<T>::EPV;
+  const int CoutN = (CoutP + 31) / 32 * 32, CinN = (CinP + 31) / 32 * 32;
+  const int64_t nf = (int64_t)27 * CinP * CoutN, nb = (int64_t)27 * CoutP * CinN;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (nf > nb ? nf : nb);
+       i += (int64_t)gridDim.x * blockDim.x) {
+    if (i < nf) {
+      int ci = (int)(i % CinP), co = (int)((i / CinP) % CoutN), tap = (int)(i / ((int64_t)CinP * CoutN));
+      st_f<T>(imgF + conv_weight_image_index(co, ci, tap, CinP, 27, EPV),
+              (ci < Cin && co < Cout) ? w[((int64_t)co * Cin + ci) * 27 + tap] : 0.f);
+    }
+    if (i < nb) {
+      int co = (int)(i % CoutP), ci = (int)((i / CoutP) % CinN), tap = (int)(i / ((int64_t)CoutP * CinN));
+      st_f<T>(imgB + conv_weight_image_index(ci, co, tap, CoutP, 27, EPV),
+              (ci < Cin && co < Cout) ? w[((int64_t)co * Cin + ci) * 27 + tap] : 0.f);
     }
   }
 }
@@ -479,15 +516,38 @@ int conv3_dgrad_s2_mfma(const void *dy, int lddy, const void *w_kmajor, void *dx
 }
 
 // ConvTranspose3d(k2,s2) forward / data gradient as 8 single-tap launches (one per output offset o).
-size_t convT_packed_bytes(int CinP, int CoutP, int dtype) { return (size_t)2 * 8 * CinP * CoutP * (dtype == DGTTA_BF16 ? 2 : 4); }
+static size_t n32(int c) { return (size_t)(c + 31) / 32 * 32; }
+size_t convT_packed_bytes(int CinP, int CoutP, int dtype) {
+  return (size_t)8 * (CinP * n32(CoutP) + CoutP * n32(CinP)) * (dtype == DGTTA_BF16 ? 2 : 4);
+}
+// image-ordered conv weights (imgF | imgB) appended to the [wf | wb] blob
+size_t conv_image_bytes(int CinP, int CoutP, int dtype) {
+  return (size_t)27 * (CinP * n32(CoutP) + CoutP * n32(CinP)) * (dtype == DGTTA_BF16 ? 2 : 4);
+}
+size_t conv_imgB_offset_bytes(int CinP, int CoutP, int dtype) {
+  return (size_t)27 * CinP * n32(CoutP) * (dtype == DGTTA_BF16 ? 2 : 4);
+}
+int conv_pack_images(const float *w_t, void *img, int Cin, int Cout, int CinP, int CoutP, int dtype, hipStream_t st) {
+  const int64_t n = (int64_t)27 * (CinP > CoutP ? CinP : CoutP) * n32(CinP > CoutP ? CinP : CoutP);
+  const unsigned blocks = (unsigned)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+  void *imgB = (char *)img + conv_imgB_offset_bytes(CinP, CoutP, dtype);
+  if (dtype == DGTTA_F32)
+    hipLaunchKernelGGL((conv_pack_image_kernel<float>), dim3(blocks), dim3(256), 0, st, w_t, (float *)img, (float *)imgB, Cin,
+                       Cout, CinP, CoutP);
+  else
+    hipLaunchKernelGGL((conv_pack_image_kernel<bf16_t>), dim3(blocks), dim3(256), 0, st, w_t, (bf16_t *)img, (bf16_t *)imgB,
+                       Cin, Cout, CinP, CoutP);
+  DG_CHECK_LAUNCH("conv_pack_image_kernel");
+  return DGTTA_OK;
+}
 
 template <typename T>
 static int convT_run(int mode /*0 fwd, 1 dgrad*/, const void *in, int ldin, const float *w_t, const float *bias, void *out,
                      int ldout, void *ws, int B, int Cin, int Cout, int Di, int Hi, int Wi, hipStream_t st) {
   constexpr int EPV = Elem<T>::EPV;
   const int CinP = (Cin + 2 * EPV - 1) / (2 * EPV) * (2 * EPV), CoutP = (Cout + 2 * EPV - 1) / (2 * EPV) * (2 * EPV);
-  T *wf = (T *)ws, *wb = wf + (size_t)8 * CinP * CoutP;
-  const int64_t n = (int64_t)8 * CinP * CoutP;
+  T *wf = (T *)ws, *wb = wf + (size_t)8 * CinP * n32(CoutP);
+  const int64_t n = (int64_t)8 * (CinP > CoutP ? CinP : CoutP) * n32(CinP > CoutP ? CinP : CoutP);
   hipLaunchKernelGGL((convT_pack_kernel<T>), dim3((unsigned)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024)), dim3(256),
                      0, st, w_t, wf, wb, Cin, Cout, CinP, CoutP);
   DG_CHECK_LAUNCH("convT_pack_kernel");
@@ -503,12 +563,13 @@ static int convT_run(int mode /*0 fwd, 1 dgrad*/, const void *in, int ldin, cons
       View yv = parity_view(Do, Ho, Wo, ldout, o >> 2, (o >> 1) & 1, o & 1, &off);
       yv.sb = (long long)Do * Ho * Wo * ldout;
       const View xv = dense_view(B, Di, Hi, Wi, ldin);
-      rc = dispatch_conv<T>(in, xv, wf, taps, bias, (T *)out + off, yv, B, Cin, Cout, CinP, CoutP, 1, 0, st);
+      rc = dispatch_conv<T>(in, xv, wf, taps, bias, (T *)out + off, yv, B, Cin, Cout, CinP, CoutP, 1, 0, st, nullptr, 8);
     } else {
       View xv = parity_view(Do, Ho, Wo, ldin, o >> 2, (o >> 1) & 1, o & 1, &off);
       xv.sb = (long long)Do * Ho * Wo * ldin;
       const View yv = dense_view(B, Di, Hi, Wi, ldout);
-      rc = dispatch_conv<T>((const T *)in + off, xv, wb, taps, nullptr, out, yv, B, Cout, Cin, CoutP, CinP, 1, o != 0, st);
+      rc = dispatch_conv<T>((const T *)in + off, xv, wb, taps, nullptr, out, yv, B, Cout, Cin, CoutP, CinP, 1, o != 0, st,
+                            nullptr, 8);
     }
     if (rc != DGTTA_OK) return rc;
   }

@@ -768,8 +768,20 @@ static const void *wb_of(const void *wpack, int CinP, int CoutP, int dtype) {
   return (const char *)wpack + (size_t)27 * CinP * CoutP * esize(dtype);
 }
 
+size_t conv_image_bytes(int CinP, int CoutP, int dtype);
+size_t conv_imgB_offset_bytes(int CinP, int CoutP, int dtype);
+int conv_pack_images(const float *w_t, void *img, int Cin, int Cout, int CinP, int CoutP, int dtype, hipStream_t st);
+
+// blob = [wf | wb] (general kernels) followed by [imgF | imgB] (LDS-image order for the MFMA kernels)
+static const void *img_of(const void *wpack, int CinP, int CoutP, int dtype) {
+  return (const char *)wpack + (size_t)2 * 27 * CinP * CoutP * esize(dtype);
+}
+static const void *imgB_of(const void *wpack, int CinP, int CoutP, int dtype) {
+  return (const char *)img_of(wpack, CinP, CoutP, dtype) + conv_imgB_offset_bytes(CinP, CoutP, dtype);
+}
+
 extern "C" size_t dgtta_conv3d_packed_bytes(int CinP, int CoutP, int dtype) {
-  return (size_t)2 * 27 * CinP * CoutP * esize(dtype);
+  return (size_t)2 * 27 * CinP * CoutP * esize(dtype) + conv_image_bytes(CinP, CoutP, dtype);
 }
 
 extern "C" int dgtta_conv3d_pack_weights(const float *w_t, void *wpack, int Cin, int Cout, int CinP, int CoutP,
@@ -782,6 +794,9 @@ extern "C" int dgtta_conv3d_pack_weights(const float *w_t, void *wpack, int Cin,
   DISPATCH_T(dtype, hipLaunchKernelGGL((pack_weights_kernel<T>), dim3(gs_blocks(n)), dim3(256), 0, (hipStream_t)stream,
                                        w_t, (T *)wf, (T *)wb, Cin, Cout, CinP, CoutP));
   DG_CHECK_LAUNCH("pack_weights_kernel");
+  if (CinP % (dtype == DGTTA_BF16 ? 16 : 8) == 0 && CoutP % (dtype == DGTTA_BF16 ? 16 : 8) == 0)
+    return conv_pack_images(w_t, const_cast<void *>(img_of(wpack, CinP, CoutP, dtype)), Cin, Cout, CinP, CoutP, dtype,
+                            (hipStream_t)stream);
   return DGTTA_OK;
 }
 
@@ -808,8 +823,7 @@ extern "C" int dgtta_conv3d_k3_fwd(const void *x, int ldx, const void *wpack, co
   DG_REQUIRE(ldx >= Cin && ldy >= Cout, DGTTA_ERR_BADARG, "conv3d_k3_fwd: ld < C");
   hipStream_t st = (hipStream_t)stream;
   if (impl != 1) {
-    // the MFMA kernel wants K-contiguous weights [tap][co][ci] = the mirrored second half of the blob
-    int rc = conv3_fwd_mfma(x, ldx, wb_of(wpack, CinP, CoutP, dtype), 1, bias, y, ldy, B, Cin, Cout, CinP, CoutP, Di, Hi,
+    int rc = conv3_fwd_mfma(x, ldx, img_of(wpack, CinP, CoutP, dtype), 0, bias, y, ldy, B, Cin, Cout, CinP, CoutP, Di, Hi,
                             Wi, stride, dtype, st, (double *)stats);
     if (rc != DGTTA_ERR_UNSUPPORTED) return rc;
     DG_REQUIRE(impl == 0, DGTTA_ERR_UNSUPPORTED, "conv3d_k3_fwd: shape not covered by the MFMA kernel");
@@ -844,13 +858,15 @@ extern "C" int dgtta_conv3d_k3_dgrad(const void *dy, int lddy, const void *wpack
   hipStream_t st = (hipStream_t)stream;
   if (impl != 1 && stride == 1 && !accumulate) {
     // stride-1 data gradient == forward conv of dy with the mirrored, transposed weights (wb)
-    // (the first half of the blob, [tap][ci][co], is K-contiguous for this role; taps mirrored)
-    int rc = conv3_fwd_mfma(dy, lddy, wpack, 1, nullptr, dx, lddx, B, Cout, Cin, CoutP, CinP, Di, Hi, Wi, 1, dtype, st, nullptr);
+    // (imgB: N = ci, K = co; taps mirrored)
+    int rc = conv3_fwd_mfma(dy, lddy, imgB_of(wpack, CinP, CoutP, dtype), 1, nullptr, dx, lddx, B, Cout, Cin, CoutP, CinP, Di,
+                            Hi, Wi, 1, dtype, st, nullptr);
     if (rc != DGTTA_ERR_UNSUPPORTED) return rc;
     DG_REQUIRE(impl == 0, DGTTA_ERR_UNSUPPORTED, "conv3d_k3_dgrad: shape not covered by the MFMA kernel");
   }
   if (impl != 1 && stride == 2 && !((Di | Hi | Wi) & 1)) {
-    int rc = conv3_dgrad_s2_mfma(dy, lddy, wpack, dx, lddx, B, Cin, Cout, CinP, CoutP, Di, Hi, Wi, accumulate, dtype, st);
+    int rc = conv3_dgrad_s2_mfma(dy, lddy, imgB_of(wpack, CinP, CoutP, dtype), dx, lddx, B, Cin, Cout, CinP, CoutP, Di, Hi, Wi,
+                                 accumulate, dtype, st);
     if (rc != DGTTA_ERR_UNSUPPORTED) return rc;
     DG_REQUIRE(impl == 0, DGTTA_ERR_UNSUPPORTED, "conv3d_k3_dgrad: shape not covered by the MFMA kernel");
   }

@@ -169,7 +169,8 @@ class HipPlainConvUNet(nn.Module):
             return ent[1]
         lib = _lib.load()
         tdt = torch.float32 if dtype_code == F32 else torch.bfloat16
-        wpack = torch.empty((2, 27, cinp, coutp), dtype=tdt, device=w.device)
+        nbytes = lib.dgtta_conv3d_packed_bytes(cinp, coutp, dtype_code)
+        wpack = torch.empty(nbytes // tdt.itemsize, dtype=tdt, device=w.device)
         check(lib.dgtta_conv3d_pack_weights(ptr(w.detach()), ptr(wpack), conv.in_channels, conv.out_channels,
                                             cinp, coutp, dtype_code, stream_of(w.device)), "dgtta_conv3d_pack_weights")
         self._packed[key] = (w._version, wpack)

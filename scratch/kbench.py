@@ -11,7 +11,7 @@ DEV = "cuda:0"
 x = torch.randn(1, n, n, n, cin, device=DEV).to(tdt)
 if what == "conv":
     w = torch.randn(cout, cin, 3, 3, 3, device=DEV) * 0.05
-    wpack = torch.empty((2, 27, cin, cout), dtype=tdt, device=DEV)
+    wpack = torch.empty(lib.dgtta_conv3d_packed_bytes(cin, cout, dt) // (2 if dt else 4), dtype=tdt, device=DEV)
     check(lib.dgtta_conv3d_pack_weights(ptr(w), ptr(wpack), cin, cout, cin, cout, dt, stream_of()), "pack")
     y = torch.empty((1, n, n, n, cout), dtype=tdt, device=DEV)
     run = lambda: check(lib.dgtta_conv3d_k3_fwd(ptr(x), cin, ptr(wpack), None, ptr(y), cout, None, 1, cin, cout, cin, cout, n, n, n, 1, dt, 2, stream_of()), "fwd")

@@ -16,7 +16,7 @@ def _call_fwd(x, w, bias, stride, dt, impl, cinp, coutp):
     B, D, H, W, ld = x.shape
     cout, cin = w.shape[:2]
     tdt = torch.float32 if dt == 0 else torch.bfloat16
-    wpack = torch.empty((2, 27, cinp, coutp), dtype=tdt, device=DEV)
+    wpack = torch.empty(lib.dgtta_conv3d_packed_bytes(cinp, coutp, dt) // (2 if dt else 4), dtype=tdt, device=DEV)
     check(lib.dgtta_conv3d_pack_weights(ptr(w), ptr(wpack), cin, cout, cinp, coutp, dt, stream_of()), "pack")
     do, ho, wo = [(n - 1) // stride + 1 for n in (D, H, W)]
     y = torch.empty((B, do, ho, wo, cout), dtype=tdt, device=DEV)
@@ -93,7 +93,7 @@ def test_conv_mfma_timing_report(capsys):
                 continue
             x = torch.randn(1, n, n, n, cin, device=DEV).to(tdt)
             w = torch.randn(cout, cin, 3, 3, 3, device=DEV) * 0.05
-            wpack = torch.empty((2, 27, cin, cout), dtype=tdt, device=DEV)
+            wpack = torch.empty(lib.dgtta_conv3d_packed_bytes(cin, cout, dt) // (2 if dt else 4), dtype=tdt, device=DEV)
             check(lib.dgtta_conv3d_pack_weights(ptr(w), ptr(wpack), cin, cout, cin, cout, dt, stream_of()), "pack")
             no = (n - 1) // s + 1
             y = torch.empty((1, no, no, no, cout), dtype=tdt, device=DEV)

@@ -38,6 +38,7 @@ def build_workload(args, device, rank):
     act = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     net = he_init_(HipPlainConvUNet(act_dtype=act, conv_impl=args.impl), seed=7)
     net.exact_zero_bias_grad = True
+    net.accumulate_grads_in_place = True
     net.register_forward_pre_hook(gin_hook)
     net.register_forward_pre_hook(mind_hook)
     net = net.to(device)

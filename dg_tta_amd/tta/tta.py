@@ -231,6 +231,8 @@ def tta_main(run_name, config, tta_data_dir, save_base_path, label_mapping, modi
                 np.random.seed(int(config["seed"]) + unit)
             model = get_model_from_network(network, modifier_fn_module, parameters).to(device)
             fused = _fuse_head_if_possible(model, modifier_fn_module, label_mapping, config["optimized_labels"])
+            if hasattr(model, "accumulate_grads_in_place"):
+                model.accumulate_grads_in_place = True      # this loop owns the gradients (zero_grad once per epoch)
             optimizer = HipAdamW(model.parameters(), lr=config["lr"])
 
             def progress(epoch, loss, dice):

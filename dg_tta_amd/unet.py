@@ -130,6 +130,10 @@ class HipPlainConvUNet(nn.Module):
         # the channel mean); autograd in the reference accumulates rounding noise there.  True: report exact zeros and
         # skip the reduction pass; False: compute sum(dy) like autograd does (parity experiments).
         self.exact_zero_bias_grad = False
+        # True: backward adds straight into each parameter's .grad (allocated on first use) and returns no gradient
+        # tensors to autograd - saves a zero-fill + add per parameter and backward pass.  Tensor hooks on parameters
+        # are then not invoked; torch.autograd.grad() w.r.t. parameters is not supported in this mode.
+        self.accumulate_grads_in_place = False
         self._packed = {}        # id(weight) -> (version, wf, wb)
         self.selected_classes = None   # optional LongTensor: evaluate only these head rows (== map_label 'logits')
 
@@ -348,7 +352,14 @@ class _UNetFn(torch.autograd.Function):
         def want(p):
             return p.requires_grad
 
+        inplace = bool(net.accumulate_grads_in_place)
+        ACC = 1 if inplace else 0      # kernels add to the gradient buffers (which then are the parameters' .grad)
+
         def gbuf(p):
+            if inplace:
+                if p.grad is None:
+                    p.grad = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                return p.grad
             g = grads.get(id(p))
             if g is None:
                 g = torch.zeros_like(p, memory_format=torch.contiguous_format)
@@ -381,8 +392,8 @@ class _UNetFn(torch.autograd.Function):
         if need_hw:
             gw, gb = gbuf(head.weight), gbuf(head.bias)
             if sel is None:
-                gw.view(-1, cin_h).copy_(dws)
-                gb.copy_(dbs)
+                gw.view(-1, cin_h).add_(dws)       # buffers start at zero (or hold earlier accumulation steps)
+                gb.add_(dbs)
             else:
                 gw.view(-1, cin_h).index_add_(0, sel.long(), dws)
                 gb.index_add_(0, sel.long(), dbs)
@@ -412,7 +423,7 @@ class _UNetFn(torch.autograd.Function):
             dbet = gbuf(norm.bias) if want(norm.bias) else torch.empty_like(norm.bias)
             check(lib.dgtta_instnorm_lrelu_bwd(gz_ptr, gz_ld, ptr(rec["y"]), cout, ptr(norm.weight), ptr(norm.bias),
                                                ptr(rec["mr"]), ptr(dy), cout, ptr(dgam), ptr(dbet), ptr(w_), nb, B, cout,
-                                               v, SLOPE, 0, dt, st), "dgtta_instnorm_lrelu_bwd")
+                                               v, SLOPE, ACC, dt, st), "dgtta_instnorm_lrelu_bwd")
             # -- weight / bias gradient
             if want(conv.weight) or want(conv.bias):
                 nb = lib.dgtta_conv3d_wgrad_ws_bytes(B, cin, cout, do, ho, wo)
@@ -422,7 +433,7 @@ class _UNetFn(torch.autograd.Function):
                 if net.exact_zero_bias_grad:
                     db = None       # gradient buffer stays exactly zero (see HipPlainConvUNet.exact_zero_bias_grad)
                 check(lib.dgtta_conv3d_k3_wgrad(rec["u"], rec["ldu"], ptr(dy), cout, ptr(dw), ptr(db), ptr(w_), nb, B,
-                                                cin, cout, di, hi, wi, s, 0, dt, impl, st), "dgtta_conv3d_k3_wgrad")
+                                                cin, cout, di, hi, wi, s, ACC, dt, impl, st), "dgtta_conv3d_k3_wgrad")
             # -- data gradient towards the block input
             where = rec["where"]
             if idx == 0:
@@ -448,7 +459,7 @@ class _UNetFn(torch.autograd.Function):
                 dbu = gbuf(upm.bias) if want(upm.bias) else None
                 check(lib.dgtta_convT3d_k2s2_bwd(up["x"], up["ldx"], ptr(gc), 2 * cskip, ptr(upm.weight), ptr(glow),
                                                  up["cin"], ptr(dwu), ptr(dbu), ptr(w_), nb, B, up["cin"], up["cout"],
-                                                 ld0, lh0, lw0, 0, dt, impl, st), "dgtta_convT3d_k2s2_bwd")
+                                                 ld0, lh0, lw0, ACC, dt, impl, st), "dgtta_convT3d_k2s2_bwd")
                 gz_ptr, gz_ld = glow.data_ptr(), up["cin"]
                 keep_alive = [glow, gc]
             elif kind == "enc" and bidx == 0:

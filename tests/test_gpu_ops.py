@@ -308,3 +308,22 @@ def test_cpu_tensor_is_rejected():
     from dg_tta_amd._lib import DgttaError
     with pytest.raises(DgttaError):
         ops.mind3d(torch.zeros(1, 1, 8, 8, 8), torch.zeros(1, 12, 8, 8, 8))
+
+
+def test_unet_inplace_grad_accumulation_matches_autograd_path():
+    om, hm = _models(SMALL_CFG)
+    torch.manual_seed(6)
+    x = torch.randn(1, 12, 16, 16, 16).to(DEV)
+    gy = torch.randn(1, 9, 16, 16, 16).to(DEV)
+    for _ in range(2):                       # two accumulation steps through autograd
+        hm(x).backward(gy)
+    ref = {n: p.grad.clone() for n, p in hm.named_parameters() if p.grad is not None}
+    hm.zero_grad()
+    hm.accumulate_grads_in_place = True
+    for _ in range(2):
+        hm(x).backward(gy)
+    for n, p in hm.named_parameters():
+        if n in ref:
+            assert torch.allclose(p.grad, ref[n], rtol=1e-5, atol=1e-6 * float(ref[n].abs().max()) + 1e-9), n
+        else:
+            assert p.grad is None

@@ -4,7 +4,7 @@
 //   MFMA:       bf16 storage -> v_mfma_f32_32x32x16_bf16 (8 k-values per lane and operand),
 //               fp32 storage -> v_mfma_f32_32x32x2_f32 x4 (a lane's 16 B = 4 k-values feed 4 instructions);
 //               fp32 accumulation in both cases.
-//   Workgroup:  256 threads = 4 waves, output tile TD x TH x TW voxels (16 or 8 M-blocks) x 32*NB output channels.
+//   Workgroup:  NW = 8 (or 4) waves, output tile TD x TH x TW voxels (16 or 8 M-blocks) x 32*NB output channels.
 //   LDS:        A = input halo tile for one K-chunk, laid out [16-byte channel group][halo voxel] so that the 32 lanes
 //               of an M-block (consecutive voxels along W) read consecutive 16-byte slots -> ds_read_b128 without bank
 //               conflicts for every tap shift; B = the chunk's weights [tap][group][cout] (same property over cout).
@@ -90,8 +90,8 @@ struct Taps {
 // x: view xv;  y: view yv;  virtual tap t uses weight tap taps.wt[t].
 // w is stored in "LDS image order" [N/32][K/(2*EPV)][ntaps_src][2][32][EPV]: the B tile of a K-chunk is one contiguous
 // run, so its staging is a linear, fully coalesced copy (see conv_weight_image_index).
-template <typename T, int MBW, int MBH, int MBD, int S, int NB, int KSPC, int ABL = 0>   // ABL: diagnostic ablation
-__global__ __launch_bounds__(256) void conv3_mfma_kernel(const T *__restrict__ x, View xv, const T *__restrict__ w,
+template <typename T, int MBW, int MBH, int MBD, int S, int NB, int KSPC, int ABL = 0, int NW = 4>   // ABL: diagnostic ablation; NW waves
+__global__ __launch_bounds__(NW * 64) void conv3_mfma_kernel(const T *__restrict__ x, View xv, const T *__restrict__ w,
                                                          Taps taps, const float *__restrict__ bias,
                                                          T *__restrict__ y, View yv, int Cin, int Cout, int CinP,
                                                          int CoutP, int tilesW, int tilesH, int tilesD, int accumulate,
@@ -99,7 +99,7 @@ __global__ __launch_bounds__(256) void conv3_mfma_kernel(const T *__restrict__ x
   const int Di = xv.D, Hi = xv.H, Wi = xv.W, Do = yv.D, Ho = yv.H, Wo = yv.W;
   typedef ConvCfg<T, MBW, MBH, MBD, S, NB, KSPC> Cfg;
   typedef typename Cfg::G G;
-  constexpr int EPV = Cfg::EPV, NG = Cfg::NG, CK = Cfg::CK, NC = Cfg::NC, NV = G::NV, MPW = G::MPW;
+  constexpr int EPV = Cfg::EPV, NG = Cfg::NG, CK = Cfg::CK, NC = Cfg::NC, NV = G::NV, MPW = G::MB / NW, NT = NW * 64;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   uint4 *sA = reinterpret_cast<uint4 *>(smem);                    // [NG][NV]
   uint4 *sB = reinterpret_cast<uint4 *>(smem + Cfg::A_BYTES);     // [27][NG][NC]
@@ -142,12 +142,12 @@ __global__ __launch_bounds__(256) void conv3_mfma_kernel(const T *__restrict__ x
   // Register staging, software pipelined: all global loads of a chunk are issued back to back (unconditional loads from
   // a clamped address + select, so the compiler emits no per-load branch / wait), written to LDS one chunk later, and
   // the loads of chunk k+1 are in flight while chunk k is being multiplied.
-  constexpr int NA = (NV * NG + 255) / 256, NBL = (27 * NC * NG + 255) / 256;
+  constexpr int NA = (NV * NG + NT - 1) / NT, NBL = (27 * NC * NG + NT - 1) / NT;
   uint4 ra[NA], rb[NBL];
   auto load_chunk = [&](int kc) {
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
-      const int idx = tid + i * 256;
+      const int idx = tid + i * NT;
       const int g = idx % NG, v = idx / NG;
       const int wx_l = v % G::ROW, hy = (v / G::ROW) % G::IH, dz = v / (G::ROW * G::IH);
       int wx = wx_l;
@@ -166,7 +166,7 @@ __global__ __launch_bounds__(256) void conv3_mfma_kernel(const T *__restrict__ x
     }
 #pragma unroll
     for (int i = 0; i < NBL; ++i) {
-      const int idx = tid + i * 256;       // == LDS index (tap*NG + g)*NC + n
+      const int idx = tid + i * NT;       // == LDS index (tap*NG + g)*NC + n
       const int n = idx % NC, g = (idx / NC) % NG, tap = (idx / (NG * NC)) % 27;
       const int wt = taps.wt[tap];
       const bool ok = idx < 27 * NC * NG && wt >= 0;
@@ -185,7 +185,7 @@ __global__ __launch_bounds__(256) void conv3_mfma_kernel(const T *__restrict__ x
   auto store_chunk = [&]() {
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
-      const int idx = tid + i * 256;
+      const int idx = tid + i * NT;
       if (ABL == 2) {
         asm volatile("" ::"v"(ra[i].x));
         continue;
@@ -194,7 +194,7 @@ __global__ __launch_bounds__(256) void conv3_mfma_kernel(const T *__restrict__ x
     }
 #pragma unroll
     for (int i = 0; i < NBL; ++i) {
-      const int idx = tid + i * 256;
+      const int idx = tid + i * NT;
       if (idx < 27 * NC * NG) sB[idx] = rb[i];
     }
   };
@@ -278,7 +278,7 @@ __global__ __launch_bounds__(256) void conv3_mfma_kernel(const T *__restrict__ x
     if (tid < NC && n0 + tid < Cout) {
       double s = 0.0, ss = 0.0;
 #pragma unroll
-      for (int wv = 0; wv < 4; ++wv) {
+      for (int wv = 0; wv < NW; ++wv) {
         s += (double)red[(wv * NC + tid) * 2 + 0];
         ss += (double)red[(wv * NC + tid) * 2 + 1];
       }
@@ -290,15 +290,15 @@ __global__ __launch_bounds__(256) void conv3_mfma_kernel(const T *__restrict__ x
   }
 }
 
-template <typename T, int MBW, int MBH, int MBD, int S, int NB, int KSPC>
+template <typename T, int MBW, int MBH, int MBD, int S, int NB, int KSPC, int NW = 4>
 int launch_conv(const void *x, const View &xv, const void *w, const Taps &taps, const float *bias, void *y,
                 const View &yv, int B, int Cin, int Cout, int CinP, int CoutP, int accumulate, double *stats,
                 int ntaps_src, hipStream_t st) {
   typedef ConvCfg<T, MBW, MBH, MBD, S, NB, KSPC> Cfg;
   typedef typename Cfg::G G;
   static bool attr_set = false;
-  auto kern = conv3_mfma_kernel<T, MBW, MBH, MBD, S, NB, KSPC, 0>;
-  if (MBW == 32 && S == 1) {
+  auto kern = conv3_mfma_kernel<T, MBW, MBH, MBD, S, NB, KSPC, 0, NW>;
+  if (MBW == 32 && S == 1 && NW == 4) {
     static const char *abl = getenv("DGTTA_CONV_ABL");      // diagnostic only
     if (abl && abl[0] == '1') kern = conv3_mfma_kernel<T, MBW, MBH, MBD, S, NB, KSPC, 1>;
     if (abl && abl[0] == '2') kern = conv3_mfma_kernel<T, MBW, MBH, MBD, S, NB, KSPC, 2>;
@@ -318,7 +318,7 @@ int launch_conv(const void *x, const View &xv, const void *w, const Taps &taps, 
   const int64_t tiles = (int64_t)tW * tH * tD * B;
   DG_REQUIRE(tiles < (1ll << 31), DGTTA_ERR_UNSUPPORTED, "conv3_mfma: too many tiles");
   dim3 grid((unsigned)tiles, (unsigned)cdiv(CoutP, Cfg::NC));
-  hipLaunchKernelGGL(kern, grid, dim3(256), Cfg::LDS_BYTES, st, (const T *)x, xv, (const T *)w, taps, bias, (T *)y, yv,
+  hipLaunchKernelGGL(kern, grid, dim3(NW * 64), Cfg::LDS_BYTES, st, (const T *)x, xv, (const T *)w, taps, bias, (T *)y, yv,
                      Cin, Cout, CinP, CoutP, tW, tH, tD, accumulate, stats, ntaps_src);
   DG_CHECK_LAUNCH("conv3_mfma_kernel");
   return DGTTA_OK;
@@ -368,11 +368,14 @@ int dispatch_conv(const void *x, const View &xv, const void *w, const Taps &taps
     if (yv.W >= 32 && var && var[0] == 'a') return launch_conv<T, 32, 4, 4, 1, 1, 2>(ARGS);   // CK = 2 k-steps
     if (yv.W >= 32 && var && var[0] == 'b') return launch_conv<T, 32, 4, 4, 1, 2, 1>(ARGS);   // 64 output channels
     if (yv.W >= 32 && var && var[0] == 'd') return launch_conv<T, 32, 4, 2, 1, 1, 1>(ARGS);   // 256-voxel tile, 3 WG/CU
+    if (yv.W >= 32 && var && var[0] == 'w') return launch_conv<T, 32, 4, 4, 1, 1, 1, 8>(ARGS);   // 8 waves per workgroup
     if (yv.W >= 32 && var && var[0] == 'e') return launch_conv<T, 32, 2, 4, 1, 1, 1>(ARGS);
-    if (yv.W >= 32) return launch_conv<T, 32, 4, 4, 1, 1, 1>(ARGS);
-    if (yv.W >= 16) return launch_conv<T, 16, 4, 4, 1, 1, 1>(ARGS);
+    // 8 waves per workgroup (2 M-blocks each): 16 waves per CU hide the LDS / barrier latency (+27 % over 4 waves)
+    if (yv.W >= 32 && var && var[0] == 'x') return launch_conv<T, 32, 4, 4, 1, 1, 1, 4>(ARGS);
+    if (yv.W >= 32) return launch_conv<T, 32, 4, 4, 1, 1, 1, 8>(ARGS);
+    if (yv.W >= 16) return launch_conv<T, 16, 4, 4, 1, 1, 1, 8>(ARGS);
     if (vox <= 4096) return launch_conv<T, 8, 2, 2, 1, 1, 1>(ARGS);     // tiny volumes: more, smaller workgroups
-    return launch_conv<T, 8, 2, 8, 1, 1, 1>(ARGS);
+    return launch_conv<T, 8, 2, 8, 1, 1, 1, 8>(ARGS);
   }
   if (stride == 2) {
     if (yv.W >= 16) return launch_conv<T, 16, 2, 4, 2, 1, 1>(ARGS);

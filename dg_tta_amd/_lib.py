@@ -47,6 +47,7 @@ SIGNATURES = {
     "dgtta_ncdhw_to_ndhwc": (I, [P, P, I, I, I64, I, I, P]),
     "dgtta_ndhwc_to_ncdhw": (I, [P, P, I, I, I64, I, I, P]),
     "dgtta_argmax_dice": (I, [P, I, I, P, P, P, I, I64, P]),
+    "dgtta_window_accumulate": (I, [P, P, P, P, I, I, I, I, I, I, I, I, I, I, P]),
 }
 
 _lib = None

@@ -256,3 +256,37 @@ extern "C" int dgtta_affine_warp3d_bwd(const float *grad_dst, const float *theta
   DG_CHECK_LAUNCH("warp_bwd_kernel");
   return DGTTA_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Gaussian-weighted sliding-window accumulation (post-TTA ensemble inference; nnU-Net's
+// predict_sliding_window_return_logits [3P nnunetv2==2.2.1], reached from dg_tta/tta/nnunet_utils.py:116-125,208-230):
+//   acc[v0 + p][c] += patch[p][c] * gauss[p];   nsum[v0 + p] += gauss[p]        (voxel-major fp32 accumulators)
+// One lane per (patch voxel, channel): rows of C floats are contiguous, windows overlap only between launches.
+namespace {
+__global__ void window_accumulate_kernel(const float *__restrict__ patch, const float *__restrict__ gauss,
+                                         float *__restrict__ acc, float *__restrict__ nsum, int C, int PD, int PH, int PW,
+                                         int X, int Y, int Z, int x0, int y0, int z0, int64_t total) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    const int64_t p = i / C;
+    const int pw = (int)(p % PW), ph = (int)((p / PW) % PH), pd = (int)(p / ((int64_t)PW * PH));
+    const int64_t v = ((int64_t)(x0 + pd) * Y + (y0 + ph)) * Z + (z0 + pw);
+    const float g = gauss[p];
+    acc[v * C + c] += patch[i] * g;
+    if (c == 0 && nsum) nsum[v] += g;
+  }
+}
+}  // namespace
+
+extern "C" int dgtta_window_accumulate(const float *patch, const float *gauss, float *acc, float *nsum, int C, int PD, int PH,
+                                       int PW, int X, int Y, int Z, int x0, int y0, int z0, void *stream) {
+  DG_REQUIRE(patch && gauss && acc, DGTTA_ERR_BADARG, "window_accumulate: null pointer");
+  DG_REQUIRE(C > 0 && PD > 0 && PH > 0 && PW > 0 && x0 >= 0 && y0 >= 0 && z0 >= 0 && x0 + PD <= X && y0 + PH <= Y &&
+                 z0 + PW <= Z,
+             DGTTA_ERR_BADARG, "window_accumulate: window outside the volume");
+  const int64_t total = (int64_t)PD * PH * PW * C;
+  hipLaunchKernelGGL(window_accumulate_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, patch, gauss, acc,
+                     nsum, C, PD, PH, PW, X, Y, Z, x0, y0, z0, total);
+  DG_CHECK_LAUNCH("window_accumulate_kernel");
+  return DGTTA_OK;
+}

@@ -1,0 +1,107 @@
+"""Post-TTA ensemble sliding-window inference (SURVEY.md §8f "next" #1) — what the reference does at
+dg_tta/tta/tta.py:379-416 through nnU-Net's predictor (dg_tta/tta/nnunet_utils.py:116-125, 208-230):
+Gaussian-weighted 50 %-overlap sliding window, logits averaged over the ensemble's TTA'd parameter sets, argmax over
+ALL pretrain classes, then map_label(argmaxed) to the target label ids.  Mirroring is off (the DG trainers set
+inference_allowed_mirroring_axes=None, nnUNetTrainer_GIN_MIND.py:34-35).
+
+The window logic is a restatement of nnunetv2==2.2.1 (`compute_gaussian`, `compute_steps_for_sliding_window`,
+`predict_sliding_window_return_logits`) from its published behaviour: that package is not vendored with the reference, so
+this stage is "parity unpinned" (checked against the CPU restatement in oracle/inference.py only).  Accumulators are
+fp32 and live in HBM for the whole volume (105 classes x 512^3 = 56 GB fits the 288 GB of an MI355X), where nnU-Net
+uses fp16; resampling back to the original spacing / NIfTI export stay with nnU-Net.
+"""
+import numpy as np
+import torch
+
+from .. import _lib, ops
+from .._lib import check, ptr, stream_of
+from .torch_utils import map_label
+
+
+def compute_gaussian(tile_size, sigma_scale=1.0 / 8, value_scaling_factor=10.0):
+    from scipy.ndimage import gaussian_filter
+    tmp = np.zeros(tile_size)
+    tmp[tuple(i // 2 for i in tile_size)] = 1
+    g = gaussian_filter(tmp, [i * sigma_scale for i in tile_size], 0, mode="constant", cval=0)
+    g = torch.from_numpy(g).float()
+    g = g / g.max() * value_scaling_factor
+    g[g == 0] = g[g != 0].min()
+    return g
+
+
+def compute_steps_for_sliding_window(image_size, tile_size, tile_step_size=0.5):
+    assert all(i >= j for i, j in zip(image_size, tile_size)), "image size must be as large or larger than patch_size"
+    assert 0 < tile_step_size <= 1
+    target = [i * tile_step_size for i in tile_size]
+    num_steps = [int(np.ceil((i - k) / j)) + 1 for i, j, k in zip(image_size, target, tile_size)]
+    steps = []
+    for dim in range(len(tile_size)):
+        max_step = image_size[dim] - tile_size[dim]
+        actual = max_step / (num_steps[dim] - 1) if num_steps[dim] > 1 else 99999999999
+        steps.append([int(np.round(actual * i)) for i in range(num_steps[dim])])
+    return steps
+
+
+def pad_to_patch(data, patch_size):
+    """Centred zero padding up to the patch size (nnU-Net pads with constant 0); returns (padded, crop slices)."""
+    pads, crop = [], []
+    for have, want in zip(data.shape[1:], patch_size):
+        extra = max(want - have, 0)
+        lo = extra // 2
+        pads.append((lo, extra - lo))
+        crop.append(slice(lo, lo + have))
+    if any(p != (0, 0) for p in pads):
+        flat = [v for p in reversed(pads) for v in p]
+        data = torch.nn.functional.pad(data, flat, mode="constant", value=0)
+    return data, crop
+
+
+@torch.no_grad()
+def predict_sliding_window_return_logits(model, data, patch_size, acc=None, tile_step_size=0.5):
+    """data [C,X,Y,Z] (CPU or GPU) -> accumulates gauss-weighted logits of `model` into acc [X,Y,Z,ncls] (fp32, GPU).
+    Returns (acc, nsum, crop) ; logits = acc / nsum[..., None] cropped by `crop`."""
+    lib = _lib.load()
+    dev = next(model.parameters()).device
+    data, crop = pad_to_patch(data.float(), patch_size)
+    data = data.to(dev)
+    X, Y, Z = data.shape[1:]
+    gauss = compute_gaussian(tuple(patch_size)).to(dev).contiguous()
+    steps = compute_steps_for_sliding_window((X, Y, Z), patch_size, tile_step_size)
+    nsum = torch.zeros((X, Y, Z), dtype=torch.float32, device=dev)
+    was_training = model.training
+    model.eval()
+    for sx in steps[0]:
+        for sy in steps[1]:
+            for sz in steps[2]:
+                work = data[None, :, sx:sx + patch_size[0], sy:sy + patch_size[1], sz:sz + patch_size[2]].contiguous()
+                out = model(work)
+                if isinstance(out, tuple):
+                    out = out[0]
+                out = out.float().contiguous(memory_format=torch.channels_last_3d)        # [1,C,P] stored voxel-major
+                ncls = out.shape[1]
+                if acc is None:
+                    acc = torch.zeros((X, Y, Z, ncls), dtype=torch.float32, device=dev)
+                check(lib.dgtta_window_accumulate(ptr(out), ptr(gauss), ptr(acc), ptr(nsum), ncls, *patch_size, X, Y, Z, sx,
+                                                  sy, sz, stream_of(dev)), "dgtta_window_accumulate")
+    model.train(was_training)
+    return acc, nsum, crop
+
+
+@torch.no_grad()
+def run_inference(data, model, parameter_sets, patch_size, label_mapping=None, optimized_labels=None):
+    """Ensemble prediction of one preprocessed case: data [C,X,Y,Z] (image channel(s) only).
+    parameter_sets: list of state dicts (the `*_tta_parameters.pt` contents).  Returns the label map [X,Y,Z] (int64, CPU),
+    mapped to the target ids when label_mapping/optimized_labels are given (tta.py:407-411)."""
+    from .torch_utils import get_map_idxs
+    if hasattr(model, "set_selected_classes"):
+        model.set_selected_classes(None)          # argmax runs over ALL pretrain classes, as in the reference
+    acc, nsum, crop = None, None, None
+    for params in parameter_sets:
+        model.load_state_dict(params)
+        acc, nsum, crop = predict_sliding_window_return_logits(model, data, patch_size, acc)
+    # sum over members of (acc_m / nsum) has the argmax of sum_m acc_m (nsum > 0 is shared): no division pass needed
+    seg, _ = ops.argmax_dice(acc.permute(3, 0, 1, 2)[None])
+    seg = seg[0][tuple(crop)].cpu()
+    if label_mapping is not None:
+        seg = map_label(seg[None], get_map_idxs(label_mapping, optimized_labels, "pretrain_labels"), "argmaxed")[0]
+    return seg

@@ -248,6 +248,27 @@ def tta_main(run_name, config, tta_data_dir, save_base_path, label_mapping, modi
                 plot_run_results(sub_dir_tta, sample_id, ensemble_idx, losses, dices)
             if debug:
                 break
-    # The reference continues with ensemble sliding-window inference + evaluation (tta.py:376-477), which needs
-    # nnU-Net's predictor / SimpleITK; that stage is the "next" row of the scope table and is not part of this path.
+    # ---- ensemble sliding-window inference with the TTA'd parameter sets (reference: tta.py:376-416).  Label maps are
+    # written as <case>.npy in the preprocessed geometry; resampling to the original spacing, NIfTI export and
+    # compute_metrics_on_folder_simple (tta.py:420-477) need nnU-Net / SimpleITK and stay there.
+    if config.get("run_inference", True) and not across and not debug:
+        from .inference import run_inference
+        from .torch_utils import get_imgs
+        print("\n\n# Starting inference")
+        for smp_idx in range(num_samples):
+            sample, _, sample_id, _ext, sub_dir_tta = get_sample_specs(config, smp_idx, _inference_data, save_path, False)
+            if not owns(smp_idx, rank, world):
+                continue
+            paths = [get_parameters_save_path(sub_dir_tta, sample_id, e) for e in range(ensemble_count)]
+            if not all(p.is_file() for p in paths):
+                continue
+            params = [torch.load(p, map_location=device)[0] for p in paths]
+            model = get_model_from_network(network, modifier_fn_module).to(device)
+            disable_internal_augmentation()
+            image = get_imgs(sample["data"].unsqueeze(0)).squeeze(0)
+            seg = run_inference(image, model, params, patch_size, label_mapping, config["optimized_labels"])
+            out = Path(str(save_path / sample_id) + ".npy")
+            out.parent.mkdir(exist_ok=True, parents=True)
+            np.save(out, seg.numpy().astype(np.int16))
+            results[(sample_id, "prediction")] = out
     return results

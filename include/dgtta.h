@@ -201,6 +201,13 @@ int dgtta_ndhwc_to_ncdhw(const void *src, float *dst, int B, int C, int64_t V, i
 int dgtta_argmax_dice(const float *logits, int ldc, int C, const int64_t *labels, int64_t *argmax_out,
                       int64_t *counts, int B, int64_t V, void *stream);
 
+/* Gaussian-weighted sliding-window accumulation for the post-TTA ensemble inference (nnU-Net's
+ * predict_sliding_window_return_logits, reached from dg_tta/tta/nnunet_utils.py:116-125,208-230):
+ * acc[(x0..,y0..,z0..)][c] += patch[p][c]*gauss[p]; nsum[..] += gauss[p] (nsum may be NULL).
+ * patch [PD][PH][PW][C], acc [X][Y][Z][C], nsum [X][Y][Z], all fp32 voxel-major. */
+int dgtta_window_accumulate(const float *patch, const float *gauss, float *acc, float *nsum, int C, int PD, int PH,
+                            int PW, int X, int Y, int Z, int x0, int y0, int z0, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -234,7 +234,11 @@ def test_tta_main_end_to_end(tmp_path):
     torch.manual_seed(0)
     np.random.seed(0)
     res = tta_main("run0", cfg, tmp_path, tmp_path, mapping, modmod, DEV, network_bundle=bundle, tta_data=data())
-    assert len(res) == 4
+    preds = {k: v for k, v in res.items() if k[1] == "prediction"}
+    res = {k: v for k, v in res.items() if k[1] != "prediction"}
+    assert len(res) == 4 and len(preds) == 2
+    seg = np.load(preds[("tta_outputTs/case1", "prediction")])
+    assert seg.shape == (24, 24, 24) and set(np.unique(seg).tolist()) <= {0, 1, 2, 3}
     out = tmp_path / "run0" / "tta_outputTs"
     files = sorted(p.name for p in out.glob("*_tta_parameters.pt"))
     assert files == [f"case{s}__ensemble_idx_{e}_tta_parameters.pt" for s in (1, 2) for e in (0, 1)]
@@ -243,10 +247,12 @@ def test_tta_main_end_to_end(tmp_path):
     for (losses, dices) in res.values():
         assert torch.isfinite(losses).all() and (losses > 0).all() and torch.isfinite(dices).all()
     # resume: everything exists -> nothing is recomputed
-    assert len(tta_main("run0", cfg, tmp_path, tmp_path, mapping, modmod, DEV, network_bundle=bundle, tta_data=data())) == 0
+    again = tta_main("run0", cfg, tmp_path, tmp_path, mapping, modmod, DEV, network_bundle=bundle, tta_data=data())
+    assert all(k[1] == "prediction" for k in again)
     # sharding: rank 1 of 2 owns sample index 1 only, and reproduces the single-process result bit for bit (seeded units)
     res1 = tta_main("run1", cfg, tmp_path, tmp_path, mapping, modmod, DEV, network_bundle=bundle, tta_data=data(),
                     shard=(1, 2))
+    res1 = {k: v for k, v in res1.items() if k[1] != "prediction"}
     assert sorted(k[0] for k in res1) == ["tta_outputTs/case2"] * 2
     a = torch.load(out / "case2__ensemble_idx_1_tta_parameters.pt", map_location="cpu")[0]
     b = torch.load(tmp_path / "run1" / "tta_outputTs" / "case2__ensemble_idx_1_tta_parameters.pt", map_location="cpu")[0]

@@ -1,0 +1,57 @@
+"""Sliding-window ensemble inference ("next" row of SURVEY.md §8f): window arithmetic on the CPU, parity of the HIP
+path against the CPU restatement on the GPU."""
+import numpy as np
+import pytest
+import torch
+
+DEV = "cuda:0"
+
+
+def test_window_steps_and_gaussian_cpu():
+    from dg_tta_amd.tta.inference import compute_gaussian, compute_steps_for_sliding_window, pad_to_patch
+    from oracle import inference as oinf
+    assert compute_steps_for_sliding_window((512, 512, 512), (128, 128, 128)) == [[0, 64, 128, 192, 256, 320, 384]] * 3
+    assert compute_steps_for_sliding_window((128, 160, 130), (128, 128, 128)) == [[0], [0, 32], [0, 2]]
+    assert compute_steps_for_sliding_window((231, 228, 242), (112, 112, 128)) == [[0, 40, 79, 119], [0, 39, 77, 116], [0, 57, 114]]
+    for image, tile in ((40, 16), (16, 16), (231, 112)):
+        assert oinf.steps_1d(image, tile) == compute_steps_for_sliding_window((image,) * 3, (tile,) * 3)[0]
+    g = compute_gaussian((16, 16, 16))
+    assert torch.equal(g, oinf.compute_gaussian((16, 16, 16)))
+    assert float(g.max()) == 10.0 and float(g.min()) > 0 and g.argmax() == np.ravel_multi_index((8, 8, 8), (16, 16, 16))
+    assert torch.allclose(g, g.flip(0).roll(1, 0), atol=1e-6)            # symmetric about the centre voxel
+    x = torch.ones(1, 10, 20, 13)
+    padded, crop = pad_to_patch(x, [16, 16, 16])
+    assert tuple(padded.shape) == (1, 16, 20, 16) and padded[(slice(None),) + tuple(crop)].shape == x.shape
+    assert float(padded.sum()) == float(x.sum())
+
+
+@pytest.mark.gpu
+def test_ensemble_sliding_window_matches_cpu_restatement(tmp_path):
+    from conftest import SMALL_CFG
+    from dg_tta_amd.mind import MIND3D
+    from dg_tta_amd.tta.inference import run_inference
+    from dg_tta_amd.unet import HipPlainConvUNet
+    from oracle import inference as oinf, mind as omind, unet as ounet
+    torch.manual_seed(0)
+    data = torch.randn(1, 40, 36, 44)
+    patch = [16, 16, 16]
+    members = [ounet.perturb_affine(ounet.init_he(ounet.PlainConvUNetOracle(SMALL_CFG), s), s + 1) for s in (1, 2)]
+    # MIND noise is drawn per window on the device generator in the product path; use zero noise weighting on both
+    # sides to make the comparison deterministic (randn_weighting = 0 -> the draw does not matter).
+    zeros = torch.zeros(1, 12, *patch)
+    cpu_models = [lambda x, m=m: m(omind.mind3d(x, zeros, randn_weighting=0.0)) for m in members]
+    ref = oinf.ensemble_logits(cpu_models, data, patch)
+    net = HipPlainConvUNet(SMALL_CFG, conv_impl=1).to(DEV)
+    net.register_forward_pre_hook(lambda mod, inp: MIND3D(randn_weighting=0.0).forward(*inp))
+    seg = run_inference(data, net, [m.state_dict() for m in members], patch)
+    assert tuple(seg.shape) == (40, 36, 44) and seg.dtype == torch.int64
+    ref_seg = ref.argmax(0)
+    top2 = ref.topk(2, dim=0).values
+    safe = (top2[0] - top2[1]) > 1e-3
+    assert torch.equal(seg[safe], ref_seg[safe])                     # bit-exact labels outside float-tie voxels
+    assert (seg == ref_seg).float().mean() > 0.999
+    # mapping to target label ids (tta.py:407-411)
+    mapping = {"background": (0, 0), "a": (2, 1), "b": (5, 2)}
+    mapped = run_inference(data, net, [m.state_dict() for m in members], patch, mapping, ["background", "a", "b"])
+    assert set(mapped.unique().tolist()) <= {0, 1, 2}
+    assert torch.equal(mapped == 1, seg == 2) and torch.equal(mapped == 2, seg == 5)

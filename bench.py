@@ -191,8 +191,14 @@ def main():
             flop = conv_flops(probe["cin"], probe["cout"], probe["vout"])
             peak = 2500.0 if args.dtype == "bf16" else 157.3
             ach = flop / (avg_ms * 1e-3) / 1e12
+            traffic = None       # HBM bytes per launch from the committed PMC passes (profiles/), not a live counter
+            pmc = ROOT / "profiles" / "r01_conv_mfma_pmc_summary.json"
+            if pmc.exists() and args.dtype == "bf16" and args.size == 128:
+                d = json.loads(pmc.read_text()).get("dominant_128cube_Cout32", {})
+                if d:
+                    traffic = d["fetch_bytes_corrected_median"] + d["write_bytes_median"]
             roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
-                    "frac": round(ach / peak, 4), "traffic": None, "kernel": probe.get("kernel", "conv3d_k3_fwd"),
+                    "frac": round(ach / peak, 4), "traffic": traffic, "kernel": probe.get("kernel", "conv3_mfma_kernel"),
                     "launches": len(times), "avg_ms": round(avg_ms, 4),
                     "flop_per_launch": flop}
         out = {"metric": "TTA-epochs/sec per GPU on 128^3 patch", "value": round(value, 5), "unit": "TTA-epochs/s",

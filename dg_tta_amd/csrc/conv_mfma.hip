@@ -87,15 +87,29 @@ struct Taps {
   signed char wt[27];
 };
 
+// A launch can run up to 8 independent "classes" (blockIdx.z) that share shapes but differ in operand offsets and tap
+// tables: the 8 parity sub-lattices of a stride-2 data gradient, or the 8 output offsets of a 2x2x2 transposed conv.
+struct ConvClasses {
+  int n;
+  int acc[8];
+  long long xoff[8], yoff[8];   // element offsets of the operands of class c
+  Taps taps[8];
+};
+
 // x: view xv;  y: view yv;  virtual tap t uses weight tap taps.wt[t].
 // w is stored in "LDS image order" [N/32][K/(2*EPV)][ntaps_src][2][32][EPV]: the B tile of a K-chunk is one contiguous
 // run, so its staging is a linear, fully coalesced copy (see conv_weight_image_index).
 template <typename T, int MBW, int MBH, int MBD, int S, int NB, int KSPC, int ABL = 0, int NW = 4>   // ABL: diagnostic ablation; NW waves
 __global__ __launch_bounds__(NW * 64) void conv3_mfma_kernel(const T *__restrict__ x, View xv, const T *__restrict__ w,
-                                                         Taps taps, const float *__restrict__ bias,
+                                                         ConvClasses cs, const float *__restrict__ bias,
                                                          T *__restrict__ y, View yv, int Cin, int Cout, int CinP,
-                                                         int CoutP, int tilesW, int tilesH, int tilesD, int accumulate,
+                                                         int CoutP, int tilesW, int tilesH, int tilesD,
                                                          double *__restrict__ stats, int ntaps_src) {
+  const int cls = blockIdx.z;
+  x += cs.xoff[cls];
+  y += cs.yoff[cls];
+  const Taps &taps = cs.taps[cls];
+  const int accumulate = cs.acc[cls];
   const int Di = xv.D, Hi = xv.H, Wi = xv.W, Do = yv.D, Ho = yv.H, Wo = yv.W;
   typedef ConvCfg<T, MBW, MBH, MBD, S, NB, KSPC> Cfg;
   typedef typename Cfg::G G;
@@ -291,9 +305,9 @@ __global__ __launch_bounds__(NW * 64) void conv3_mfma_kernel(const T *__restrict
 }
 
 template <typename T, int MBW, int MBH, int MBD, int S, int NB, int KSPC, int NW = 4>
-int launch_conv(const void *x, const View &xv, const void *w, const Taps &taps, const float *bias, void *y,
-                const View &yv, int B, int Cin, int Cout, int CinP, int CoutP, int accumulate, double *stats,
-                int ntaps_src, hipStream_t st) {
+int launch_conv(const void *x, const View &xv, const void *w, const ConvClasses &cs, const float *bias, void *y,
+                const View &yv, int B, int Cin, int Cout, int CinP, int CoutP, double *stats, int ntaps_src,
+                hipStream_t st) {
   typedef ConvCfg<T, MBW, MBH, MBD, S, NB, KSPC> Cfg;
   typedef typename Cfg::G G;
   static bool attr_set = false;
@@ -317,9 +331,9 @@ int launch_conv(const void *x, const View &xv, const void *w, const Taps &taps, 
   const int tW = cdiv(yv.W, G::TW), tH = cdiv(yv.H, G::TH), tD = cdiv(yv.D, G::TD);
   const int64_t tiles = (int64_t)tW * tH * tD * B;
   DG_REQUIRE(tiles < (1ll << 31), DGTTA_ERR_UNSUPPORTED, "conv3_mfma: too many tiles");
-  dim3 grid((unsigned)tiles, (unsigned)cdiv(CoutP, Cfg::NC));
-  hipLaunchKernelGGL(kern, grid, dim3(NW * 64), Cfg::LDS_BYTES, st, (const T *)x, xv, (const T *)w, taps, bias, (T *)y, yv,
-                     Cin, Cout, CinP, CoutP, tW, tH, tD, accumulate, stats, ntaps_src);
+  dim3 grid((unsigned)tiles, (unsigned)cdiv(CoutP, Cfg::NC), (unsigned)cs.n);
+  hipLaunchKernelGGL(kern, grid, dim3(NW * 64), Cfg::LDS_BYTES, st, (const T *)x, xv, (const T *)w, cs, bias, (T *)y, yv,
+                     Cin, Cout, CinP, CoutP, tW, tH, tD, stats, ntaps_src);
   DG_CHECK_LAUNCH("conv3_mfma_kernel");
   return DGTTA_OK;
 }
@@ -358,10 +372,10 @@ bool operand_ok(const void *p, long long ld_elems, int Cin, int CinP) {
 
 // picks the tile shape from the (virtual) output extent
 template <typename T>
-int dispatch_conv(const void *x, const View &xv, const void *w, const Taps &taps, const float *bias, void *y,
-                  const View &yv, int B, int Cin, int Cout, int CinP, int CoutP, int stride, int accumulate,
-                  hipStream_t st, double *stats = nullptr, int ntaps_src = 27) {
-#define ARGS x, xv, w, taps, bias, y, yv, B, Cin, Cout, CinP, CoutP, accumulate, stats, ntaps_src, st
+int dispatch_conv_classes(const void *x, const View &xv, const void *w, const ConvClasses &cs, const float *bias, void *y,
+                          const View &yv, int B, int Cin, int Cout, int CinP, int CoutP, int stride, hipStream_t st,
+                          double *stats = nullptr, int ntaps_src = 27) {
+#define ARGS x, xv, w, cs, bias, y, yv, B, Cin, Cout, CinP, CoutP, stats, ntaps_src, st
   const long long vox = (long long)yv.D * yv.H * yv.W * B;
   if (stride == 1) {
     static const char *var = getenv("DGTTA_CONV_VARIANT");      // diagnostic: tile-shape experiments
@@ -383,6 +397,18 @@ int dispatch_conv(const void *x, const View &xv, const void *w, const Taps &taps
   }
 #undef ARGS
   return DGTTA_ERR_UNSUPPORTED;
+}
+
+template <typename T>
+int dispatch_conv(const void *x, const View &xv, const void *w, const Taps &taps, const float *bias, void *y,
+                  const View &yv, int B, int Cin, int Cout, int CinP, int CoutP, int stride, int accumulate,
+                  hipStream_t st, double *stats = nullptr, int ntaps_src = 27) {
+  ConvClasses cs;
+  cs.n = 1;
+  cs.acc[0] = accumulate;
+  cs.xoff[0] = cs.yoff[0] = 0;
+  cs.taps[0] = taps;
+  return dispatch_conv_classes<T>(x, xv, w, cs, bias, y, yv, B, Cin, Cout, CinP, CoutP, stride, st, stats, ntaps_src);
 }
 
 Taps identity_taps(int mirror) {
@@ -482,13 +508,18 @@ static int dgrad_s2(const void *dy, int lddy, const void *w_kmajor, void *dx, in
   if (!operand_ok<T>(dy, lddy, Cout, CoutP)) return DGTTA_ERR_UNSUPPORTED;
   const int Do = (Di - 1) / 2 + 1, Ho = (Hi - 1) / 2 + 1, Wo = (Wi - 1) / 2 + 1;
   const View xv = dense_view(B, Do, Ho, Wo, lddy);
+  // even extents: all 8 parity classes have the same shape -> ONE launch, class = blockIdx.z
+  ConvClasses cs;
+  cs.n = 8;
+  View yv;
   for (int p = 0; p < 8; ++p) {
     const int pd = p >> 2, ph = (p >> 1) & 1, pw = p & 1;
     long long off;
-    View yv = parity_view(Di, Hi, Wi, lddx, pd, ph, pw, &off);
+    yv = parity_view(Di, Hi, Wi, lddx, pd, ph, pw, &off);
     yv.sb = (long long)Di * Hi * Wi * lddx;
-    if (yv.D == 0 || yv.H == 0 || yv.W == 0) continue;
-    Taps taps;
+    cs.xoff[p] = 0;
+    cs.yoff[p] = off;
+    cs.acc[p] = accumulate;
     for (int t = 0; t < 27; ++t) {
       const int k[3] = {t / 9, (t / 3) % 3, t % 3}, par[3] = {pd, ph, pw};
       int real[3];
@@ -502,13 +533,10 @@ static int dgrad_s2(const void *dy, int lddy, const void *w_kmajor, void *dx, in
           real[a] = (k[a] == 1) ? 2 : 0;
         }
       }
-      taps.wt[t] = ok ? (signed char)(real[0] * 9 + real[1] * 3 + real[2]) : (signed char)-1;
+      cs.taps[p].wt[t] = ok ? (signed char)(real[0] * 9 + real[1] * 3 + real[2]) : (signed char)-1;
     }
-    int rc = dispatch_conv<T>(dy, xv, w_kmajor, taps, nullptr, (T *)dx + off, yv, B, Cout, Cin, CoutP, CinP, 1, accumulate,
-                              st);
-    if (rc != DGTTA_OK) return rc;
   }
-  return DGTTA_OK;
+  return dispatch_conv_classes<T>(dy, xv, w_kmajor, cs, nullptr, dx, yv, B, Cout, Cin, CoutP, CinP, 1, st);
 }
 
 int conv3_dgrad_s2_mfma(const void *dy, int lddy, const void *w_kmajor, void *dx, int lddx, int B, int Cin, int Cout,
@@ -556,24 +584,35 @@ static int convT_run(int mode /*0 fwd, 1 dgrad*/, const void *in, int ldin, cons
   DG_CHECK_LAUNCH("convT_pack_kernel");
   const int Do = 2 * Di, Ho = 2 * Hi, Wo = 2 * Wi;
   if (mode == 0 ? !operand_ok<T>(in, ldin, Cin, CinP) : !operand_ok<T>(in, ldin, Cout, CoutP)) return DGTTA_ERR_UNSUPPORTED;
+  if (mode == 0) {
+    // forward: the 8 output offsets write disjoint sub-lattices -> one launch with 8 classes
+    ConvClasses cs;
+    cs.n = 8;
+    View yv;
+    for (int o = 0; o < 8; ++o) {
+      long long off;
+      yv = parity_view(Do, Ho, Wo, ldout, o >> 2, (o >> 1) & 1, o & 1, &off);
+      yv.sb = (long long)Do * Ho * Wo * ldout;
+      cs.xoff[o] = 0;
+      cs.yoff[o] = off;
+      cs.acc[o] = 0;
+      for (int t = 0; t < 27; ++t) cs.taps[o].wt[t] = -1;
+      cs.taps[o].wt[13] = (signed char)o;
+    }
+    const View xv = dense_view(B, Di, Hi, Wi, ldin);
+    return dispatch_conv_classes<T>(in, xv, wf, cs, bias, out, yv, B, Cin, Cout, CinP, CoutP, 1, st, nullptr, 8);
+  }
+  // data gradient: the 8 offsets sum into the same dx -> sequential launches, accumulating from the second on
   for (int o = 0; o < 8; ++o) {
     long long off;
     Taps taps;
     for (int t = 0; t < 27; ++t) taps.wt[t] = -1;
     taps.wt[13] = (signed char)o;
-    int rc;
-    if (mode == 0) {
-      View yv = parity_view(Do, Ho, Wo, ldout, o >> 2, (o >> 1) & 1, o & 1, &off);
-      yv.sb = (long long)Do * Ho * Wo * ldout;
-      const View xv = dense_view(B, Di, Hi, Wi, ldin);
-      rc = dispatch_conv<T>(in, xv, wf, taps, bias, (T *)out + off, yv, B, Cin, Cout, CinP, CoutP, 1, 0, st, nullptr, 8);
-    } else {
-      View xv = parity_view(Do, Ho, Wo, ldin, o >> 2, (o >> 1) & 1, o & 1, &off);
-      xv.sb = (long long)Do * Ho * Wo * ldin;
-      const View yv = dense_view(B, Di, Hi, Wi, ldout);
-      rc = dispatch_conv<T>((const T *)in + off, xv, wb, taps, nullptr, out, yv, B, Cout, Cin, CoutP, CinP, 1, o != 0, st,
-                            nullptr, 8);
-    }
+    View xv = parity_view(Do, Ho, Wo, ldin, o >> 2, (o >> 1) & 1, o & 1, &off);
+    xv.sb = (long long)Do * Ho * Wo * ldin;
+    const View yv = dense_view(B, Di, Hi, Wi, ldout);
+    int rc = dispatch_conv<T>((const T *)in + off, xv, wb, taps, nullptr, out, yv, B, Cout, Cin, CoutP, CinP, 1, o != 0, st,
+                              nullptr, 8);
     if (rc != DGTTA_OK) return rc;
   }
   return DGTTA_OK;
@@ -687,13 +726,27 @@ __device__ __forceinline__ void mfma16<float>(const uint4 &a, const uint4 &b, f3
   acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.w), __uint_as_float(b.w), acc, 0, 0, 0);
 }
 
+// Up to 8 independent classes per launch (blockIdx.z): operand offsets + tap mask per class, one slab set per class.
+struct WgradClasses {
+  int n;
+  unsigned mask[8];
+  long long xoff[8], yoff[8];
+};
+struct RealTaps {
+  Taps t[8];
+};
+
 // x: view xv (input lattice of the virtual stride-1 problem), dy: view yv (output lattice; tiles run over it).
-// tapmask: bit t set = virtual tap t is accumulated.
+// mask bit t set = virtual tap t is accumulated.
 template <typename T, int ABL = 0>   // ABL: diagnostic ablation (1 no global loads, 2 no LDS stores, 3 no MFMA); 0 = product
 __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void conv3_wgrad_mfma_kernel(const T *__restrict__ x, View xv, const T *__restrict__ dy,
                                                                View yv, float *__restrict__ slabs, int Cin, int Cout,
                                                                int tilesW, int tilesH, int nsd, int DR, int cobs,
-                                                               unsigned tapmask) {
+                                                               WgradClasses wc) {
+  const int cls = blockIdx.z;
+  x += wc.xoff[cls];
+  dy += wc.yoff[cls];
+  const unsigned tapmask = wc.mask[cls];
   const int D = yv.D, H = yv.H, W = yv.W;
   typedef WG<T> C;
   constexpr int EPV = C::EPV;
@@ -825,7 +878,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void conv3_wgrad_mfm
   }
 
   // partial slab [27][32 ci][32 co]; C/D map of the 16x16 MFMA: col = lane&15, row = (lane>>4)*4 + reg
-  float *slab = slabs + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * (27 * 1024);
+  float *slab = slabs + (((int64_t)cls * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * (27 * 1024);
 #pragma unroll
   for (int tap = 0; tap < 27; ++tap)
 #pragma unroll
@@ -837,8 +890,11 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void conv3_wgrad_mfm
 // sums are combined through LDS in fixed order (deterministic).
 template <int G>   // G slab groups per output row (8: many slabs, 1: few slabs -> 8 output rows per workgroup)
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restrict__ slabs, float *__restrict__ dw, int Cin,
-                                                           int Cout, int cobs, int nslab, int accumulate, Taps real,
-                                                           long long s_co, long long s_ci, long long s_tap) {
+                                                           int Cout, int cobs, int npairs, int nslab, int accumulate,
+                                                           RealTaps reals, long long s_co, long long s_ci,
+                                                           long long s_tap) {
+  const Taps &real = reals.t[blockIdx.y];
+  slabs += (int64_t)blockIdx.y * npairs * nslab * (27 * 1024);
   constexpr int R = 8 / G;                  // output rows (tap, ci, co-block) per workgroup
   __shared__ float part[8][32];
   const int lane = threadIdx.x & 31, sub = threadIdx.x >> 5;
@@ -881,14 +937,14 @@ struct WgradPlan {
   int64_t units;
 };
 
-WgradPlan wgrad_plan(int B, int Cin, int Cout, int D, int H, int W) {
+WgradPlan wgrad_plan(int B, int Cin, int Cout, int D, int H, int W, int ncls = 1) {
   WgradPlan p;
   p.tW = cdiv(W, 32);
   p.tH = cdiv(H, 4);
   p.cibs = cdiv(Cin, 32);
   p.cobs = cdiv(Cout, 32);
-  const int64_t base = (int64_t)B * p.tW * p.tH * p.cibs * p.cobs;
-  int want = (int)cdiv64(512, base);                  // aim for >= ~512 workgroups (2 per CU)
+  const int64_t base = (int64_t)B * p.tW * p.tH * p.cibs * p.cobs * ncls;
+  int want = (int)cdiv64(512, base);                  // aim for >= ~512 workgroups (2 per CU) over all classes
   int maxsplit = D / 4 > 0 ? D / 4 : 1;
   p.nsd = want < 1 ? 1 : (want > maxsplit ? maxsplit : want);
   p.DR = cdiv(D, p.nsd);
@@ -899,23 +955,27 @@ WgradPlan wgrad_plan(int B, int Cin, int Cout, int D, int H, int W) {
 
 }  // namespace
 
+// sized for the 8-class launches (stride-2 conv, transposed conv); single-class launches use the first eighth
 size_t conv3_wgrad_mfma_ws_bytes(int B, int Cin, int Cout, int D, int H, int W) {
-  WgradPlan p = wgrad_plan(B, Cin, Cout, D, H, W);
-  return (size_t)p.units * p.cibs * p.cobs * 27 * 1024 * sizeof(float);
+  WgradPlan p1 = wgrad_plan(B, Cin, Cout, D, H, W, 1), p8 = wgrad_plan(B, Cin, Cout, D, H, W, 8);
+  const size_t a = (size_t)p1.units * p1.cibs * p1.cobs, b = (size_t)8 * p8.units * p8.cibs * p8.cobs;
+  return (a > b ? a : b) * 27 * 1024 * sizeof(float);
 }
 
 template <typename T>
-static int wgrad_launch(const void *x, const View &xv, const void *dy, const View &yv, float *dw, void *ws, size_t ws_bytes,
-                        int B, int Cin, int Cout, unsigned tapmask, const Taps &real, long long s_co, long long s_ci,
-                        long long s_tap, int accumulate, hipStream_t st) {
+static int wgrad_launch_classes(const void *x, const View &xv, const void *dy, const View &yv, float *dw, void *ws,
+                                size_t ws_bytes, int B, int Cin, int Cout, const WgradClasses &wc, const RealTaps &reals,
+                                long long s_co, long long s_ci, long long s_tap, int accumulate, hipStream_t st) {
   constexpr int EPV = Elem<T>::EPV;
   // Cin may be ragged (first layer: 12 channels in rows of 16): the pad channels only feed gradient rows ci >= Cin,
   // which the reduction never writes.  The rows must be long enough to be read in whole 16-byte groups.
   if (Cout % EPV || xv.sw % EPV || yv.sw % EPV || ((uintptr_t)x & 15) || ((uintptr_t)dy & 15) ||
       xv.sw < (Cin + EPV - 1) / EPV * EPV)
     return DGTTA_ERR_UNSUPPORTED;
-  WgradPlan p = wgrad_plan(B, Cin, Cout, yv.D, yv.H, yv.W);
-  const size_t need = (size_t)p.units * p.cibs * p.cobs * 27 * 1024 * sizeof(float);
+  for (int c = 0; c < wc.n; ++c)
+    if ((wc.xoff[c] * (long long)sizeof(T)) % 16 || (wc.yoff[c] * (long long)sizeof(T)) % 16) return DGTTA_ERR_UNSUPPORTED;
+  WgradPlan p = wgrad_plan(B, Cin, Cout, yv.D, yv.H, yv.W, wc.n);
+  const size_t need = (size_t)wc.n * p.units * p.cibs * p.cobs * 27 * 1024 * sizeof(float);
   if (ws_bytes < need || p.units >= (1ll << 31) || p.cibs * p.cobs > 65535) return DGTTA_ERR_UNSUPPORTED;
   static bool attr_set = false;
   auto kern = conv3_wgrad_mfma_kernel<T, 0>;
@@ -932,18 +992,32 @@ static int wgrad_launch(const void *x, const View &xv, const void *dy, const Vie
                               (int)WG<T>::LDS_BYTES);
     attr_set = true;
   }
-  hipLaunchKernelGGL(kern, dim3((unsigned)p.units, (unsigned)(p.cibs * p.cobs)), dim3(256), WG<T>::LDS_BYTES, st,
-                     (const T *)x, xv, (const T *)dy, yv, (float *)ws, Cin, Cout, p.tW, p.tH, p.nsd, p.DR, p.cobs, tapmask);
+  hipLaunchKernelGGL(kern, dim3((unsigned)p.units, (unsigned)(p.cibs * p.cobs), (unsigned)wc.n), dim3(256), WG<T>::LDS_BYTES,
+                     st, (const T *)x, xv, (const T *)dy, yv, (float *)ws, Cin, Cout, p.tW, p.tH, p.nsd, p.DR, p.cobs, wc);
   DG_CHECK_LAUNCH("conv3_wgrad_mfma_kernel");
   const int64_t rrows = (int64_t)27 * Cin * ((Cout + 31) / 32);
+  const int npairs = p.cibs * p.cobs;
   if (p.units >= 64)
-    hipLaunchKernelGGL(wgrad_reduce_kernel<8>, dim3((unsigned)rrows), dim3(256), 0, st, (const float *)ws, dw, Cin, Cout,
-                       p.cobs, (int)p.units, accumulate, real, s_co, s_ci, s_tap);
+    hipLaunchKernelGGL(wgrad_reduce_kernel<8>, dim3((unsigned)rrows, (unsigned)wc.n), dim3(256), 0, st, (const float *)ws, dw,
+                       Cin, Cout, p.cobs, npairs, (int)p.units, accumulate, reals, s_co, s_ci, s_tap);
   else
-    hipLaunchKernelGGL(wgrad_reduce_kernel<1>, dim3((unsigned)cdiv64(rrows, 8)), dim3(256), 0, st, (const float *)ws, dw,
-                       Cin, Cout, p.cobs, (int)p.units, accumulate, real, s_co, s_ci, s_tap);
+    hipLaunchKernelGGL(wgrad_reduce_kernel<1>, dim3((unsigned)cdiv64(rrows, 8), (unsigned)wc.n), dim3(256), 0, st,
+                       (const float *)ws, dw, Cin, Cout, p.cobs, npairs, (int)p.units, accumulate, reals, s_co, s_ci, s_tap);
   DG_CHECK_LAUNCH("wgrad_reduce_kernel");
   return DGTTA_OK;
+}
+
+template <typename T>
+static int wgrad_launch(const void *x, const View &xv, const void *dy, const View &yv, float *dw, void *ws, size_t ws_bytes,
+                        int B, int Cin, int Cout, unsigned tapmask, const Taps &real, long long s_co, long long s_ci,
+                        long long s_tap, int accumulate, hipStream_t st) {
+  WgradClasses wc;
+  wc.n = 1;
+  wc.mask[0] = tapmask;
+  wc.xoff[0] = wc.yoff[0] = 0;
+  RealTaps reals;
+  reals.t[0] = real;
+  return wgrad_launch_classes<T>(x, xv, dy, yv, dw, ws, ws_bytes, B, Cin, Cout, wc, reals, s_co, s_ci, s_tap, accumulate, st);
 }
 
 template <typename T>
@@ -959,13 +1033,17 @@ static int wgrad_conv(const void *x, int ldx, const void *dy, int lddy, float *d
   // parity 1 <- tap 0 (offset -1) and tap 2 (offset 0).  Each real tap belongs to exactly one of the 8 classes.
   const int Do = (Di - 1) / 2 + 1, Ho = (Hi - 1) / 2 + 1, Wo = (Wi - 1) / 2 + 1;
   const View yv = dense_view(B, Do, Ho, Wo, lddy);
+  WgradClasses wc;
+  RealTaps reals;
+  wc.n = 8;
+  View xv;
   for (int p = 0; p < 8; ++p) {
     const int par[3] = {p >> 2, (p >> 1) & 1, p & 1};
     long long off;
-    View xv = parity_view(Di, Hi, Wi, ldx, par[0], par[1], par[2], &off);
+    xv = parity_view(Di, Hi, Wi, ldx, par[0], par[1], par[2], &off);   // even extents: same shape for all classes
     xv.sb = (long long)Di * Hi * Wi * ldx;
-    if (xv.D == 0 || xv.H == 0 || xv.W == 0) continue;   // (then those taps only ever see padding: gradient 0)
-    Taps real;
+    wc.xoff[p] = off;
+    wc.yoff[p] = 0;
     unsigned mask = 0;
     for (int t = 0; t < 27; ++t) {
       const int k[3] = {t / 9, (t / 3) % 3, t % 3};
@@ -980,14 +1058,12 @@ static int wgrad_conv(const void *x, int ldx, const void *dy, int lddy, float *d
           rl[a] = (k[a] == 0) ? 0 : 2;
         }
       }
-      real.wt[t] = ok ? (signed char)(rl[0] * 9 + rl[1] * 3 + rl[2]) : (signed char)-1;
+      reals.t[p].wt[t] = ok ? (signed char)(rl[0] * 9 + rl[1] * 3 + rl[2]) : (signed char)-1;
       if (ok) mask |= 1u << t;
     }
-    int rc = wgrad_launch<T>((const T *)x + off, xv, dy, yv, dw_t, ws, ws_bytes, B, Cin, Cout, mask, real, s_co, s_ci, s_tap,
-                             accumulate, st);
-    if (rc != DGTTA_OK) return rc;
+    wc.mask[p] = mask;
   }
-  return DGTTA_OK;
+  return wgrad_launch_classes<T>(x, xv, dy, yv, dw_t, ws, ws_bytes, B, Cin, Cout, wc, reals, s_co, s_ci, s_tap, accumulate, st);
 }
 
 int conv3_wgrad_mfma(const void *x, int ldx, const void *dy, int lddy, float *dw_t, float *db, void *ws, size_t ws_bytes,
@@ -1006,18 +1082,22 @@ template <typename T>
 static int convT_wgrad(const void *x, int ldx, const void *dout, int lddo, float *dw_t, void *ws, size_t ws_bytes, int B,
                        int Cin, int Cout, int Di, int Hi, int Wi, int accumulate, hipStream_t st) {
   const View xv = dense_view(B, Di, Hi, Wi, ldx);
+  WgradClasses wc;
+  RealTaps reals;
+  wc.n = 8;
+  View yv;
   for (int o = 0; o < 8; ++o) {
     long long off;
-    View yv = parity_view(2 * Di, 2 * Hi, 2 * Wi, lddo, o >> 2, (o >> 1) & 1, o & 1, &off);
+    yv = parity_view(2 * Di, 2 * Hi, 2 * Wi, lddo, o >> 2, (o >> 1) & 1, o & 1, &off);
     yv.sb = (long long)8 * Di * Hi * Wi * lddo;
-    Taps real;
-    for (int t = 0; t < 27; ++t) real.wt[t] = -1;
-    real.wt[13] = (signed char)o;
-    int rc = wgrad_launch<T>(x, xv, (const T *)dout + off, yv, dw_t, ws, ws_bytes, B, Cin, Cout, 1u << 13, real, 8,
-                             (long long)Cout * 8, 1, accumulate, st);
-    if (rc != DGTTA_OK) return rc;
+    wc.xoff[o] = 0;
+    wc.yoff[o] = off;
+    wc.mask[o] = 1u << 13;
+    for (int t = 0; t < 27; ++t) reals.t[o].wt[t] = -1;
+    reals.t[o].wt[13] = (signed char)o;
   }
-  return DGTTA_OK;
+  return wgrad_launch_classes<T>(x, xv, dout, yv, dw_t, ws, ws_bytes, B, Cin, Cout, wc, reals, 8, (long long)Cout * 8, 1,
+                                 accumulate, st);
 }
 
 int convT_wgrad_mfma(const void *x, int ldx, const void *dout, int lddo, float *dw_t, void *ws, size_t ws_bytes, int B,

@@ -49,19 +49,24 @@ __device__ __forceinline__ void mfma_step<float>(const uint4 &a, const uint4 &b,
 }
 
 // Tile geometry.  MBW: voxels of an M-block along W (32/16/8); an M-block spans RPM = 32/MBW rows of H.
-// MBH x MBD M-blocks per workgroup (MPW = MBH*MBD/4 per wave).  S = stride.
+// MBH x MBD M-blocks per workgroup (MPW = MBH*MBD/4 per wave).  S = stride; S == 0 selects the POINTWISE variant
+// (stride 1, centre tap only, no halo) used by the 2x2x2 transposed-conv compositions.
 template <int MBW, int MBH, int MBD, int S>
 struct Geo {
+  static constexpr int SE = (S == 0) ? 1 : S;        // effective stride
+  static constexpr int HALO = (S == 0) ? 0 : 1;
+  static constexpr int NTAP = (S == 0) ? 1 : 27;     // taps staged in LDS
   static constexpr int RPM = 32 / MBW;
   static constexpr int TW = MBW, TH = RPM * MBH, TD = MBD;
   static constexpr int MB = MBH * MBD, MPW = MB / 4;
   // input halo extents
-  static constexpr int ID = (TD - 1) * S + 3, IH = (TH - 1) * S + 3, IW = (TW - 1) * S + 3;
+  static constexpr int ID = (TD - 1) * SE + 1 + 2 * HALO, IH = (TH - 1) * SE + 1 + 2 * HALO,
+                       IW = (TW - 1) * SE + 1 + 2 * HALO;
   // LDS row of W: for S=2 the row is split into even / odd columns, each IWH long
-  static constexpr int IWH = (S == 1) ? IW : (IW + 1) / 2;
-  static constexpr int ROW = (S == 1) ? IW : 2 * IWH;
+  static constexpr int IWH = (S != 2) ? IW : (IW + 1) / 2;
+  static constexpr int ROW = (S != 2) ? IW : 2 * IWH;
   static constexpr int NV = ID * IH * ROW;
-  __host__ __device__ static constexpr int lds_col(int wx) { return (S == 1) ? wx : (wx & 1) * IWH + (wx >> 1); }
+  __host__ __device__ static constexpr int lds_col(int wx) { return (S != 2) ? wx : (wx & 1) * IWH + (wx >> 1); }
 };
 
 template <typename T, int MBW, int MBH, int MBD, int S, int NB, int KSPC>
@@ -72,7 +77,7 @@ struct ConvCfg {
   static constexpr int CK = NG * EPV;        // channels per K-chunk
   static constexpr int NC = 32 * NB;
   static constexpr size_t A_BYTES = (size_t)NG * G::NV * 16;
-  static constexpr size_t B_BYTES = (size_t)27 * NG * NC * 16;
+  static constexpr size_t B_BYTES = (size_t)G::NTAP * NG * NC * 16;
   static constexpr size_t LDS_BYTES = A_BYTES + B_BYTES;
 };
 
@@ -94,6 +99,10 @@ struct ConvClasses {
   int acc[8];
   long long xoff[8], yoff[8];   // element offsets of the operands of class c
   Taps taps[8];
+  // K concatenation (pointwise variant): input channel c lives in segment c / kseg at element offset segoff[c / kseg]
+  // (the 8 parity sub-lattices of a transposed conv's output gradient); kseg == 0: plain channels
+  int kseg;
+  long long segoff[8];
 };
 
 // x: view xv;  y: view yv;  virtual tap t uses weight tap taps.wt[t].
@@ -129,8 +138,9 @@ __global__ __launch_bounds__(NW * 64) void conv3_mfma_kernel(const T *__restrict
   const int td = t % tilesD;
   const int b = t / tilesD;
   const int n0 = blockIdx.y * NC;
+  constexpr int SE = G::SE, NTAP = G::NTAP;
   const int od0 = td * G::TD, oh0 = th * G::TH, ow0 = tw * G::TW;      // output tile origin
-  const int id0 = od0 * S - 1, ih0 = oh0 * S - 1, iw0 = ow0 * S - 1;    // input halo origin
+  const int id0 = od0 * SE - G::HALO, ih0 = oh0 * SE - G::HALO, iw0 = ow0 * SE - G::HALO;    // input halo origin
 
   // per-lane LDS voxel offsets of this wave's M-blocks (tap offset is added as a compile-time constant)
   int a_off[MPW];
@@ -139,7 +149,7 @@ __global__ __launch_bounds__(NW * 64) void conv3_mfma_kernel(const T *__restrict
     const int mb = wave * MPW + i;
     const int mbd = mb / MBH, mbh = mb % MBH;
     const int row = mbh * G::RPM + r / MBW, col = r % MBW;
-    a_off[i] = ((mbd * S) * G::IH + row * S) * G::ROW + ((S == 1) ? col : col);   // S=2: column index in the half row
+    a_off[i] = ((mbd * SE) * G::IH + row * SE) * G::ROW + col;   // S=2: column index in the half row
   }
 
   f32x16_t acc[MPW][NB];
@@ -156,7 +166,7 @@ __global__ __launch_bounds__(NW * 64) void conv3_mfma_kernel(const T *__restrict
   // Register staging, software pipelined: all global loads of a chunk are issued back to back (unconditional loads from
   // a clamped address + select, so the compiler emits no per-load branch / wait), written to LDS one chunk later, and
   // the loads of chunk k+1 are in flight while chunk k is being multiplied.
-  constexpr int NA = (NV * NG + NT - 1) / NT, NBL = (27 * NC * NG + NT - 1) / NT;
+  constexpr int NA = (NV * NG + NT - 1) / NT, NBL = (NTAP * NC * NG + NT - 1) / NT;
   uint4 ra[NA], rb[NBL];
   auto load_chunk = [&](int kc) {
 #pragma unroll
@@ -167,10 +177,16 @@ __global__ __launch_bounds__(NW * 64) void conv3_mfma_kernel(const T *__restrict
       int wx = wx_l;
       if (S == 2) wx = (wx_l >= G::IWH) ? 2 * (wx_l - G::IWH) + 1 : 2 * wx_l;    // inverse of lds_col
       const int gd = id0 + dz, gh = ih0 + hy, gw = iw0 + wx;
-      const int c = kc + g * EPV;
-      const bool ok = idx < NV * NG && (S == 1 || wx < G::IW) && (unsigned)gd < (unsigned)Di &&
+      int c = kc + g * EPV;
+      long long soff = 0;
+      if (S == 0 && cs.kseg > 0) {        // K concatenation over parity segments
+        const int seg = c / cs.kseg;
+        c -= seg * cs.kseg;
+        soff = cs.segoff[seg];
+      }
+      const bool ok = idx < NV * NG && (S != 2 || wx < G::IW) && (unsigned)gd < (unsigned)Di &&
                       (unsigned)gh < (unsigned)Hi && (unsigned)gw < (unsigned)Wi && c < cin_lim;
-      const T *p = ok ? xbp + gd * xv.sd + gh * xv.sh + gw * xv.sw + c : x;
+      const T *p = ok ? xbp + soff + gd * xv.sd + gh * xv.sh + gw * xv.sw + c : x;
       if (ABL == 1) {
         ra[i] = make_uint4(idx, 0, 0, 0);
         continue;
@@ -181,9 +197,9 @@ __global__ __launch_bounds__(NW * 64) void conv3_mfma_kernel(const T *__restrict
 #pragma unroll
     for (int i = 0; i < NBL; ++i) {
       const int idx = tid + i * NT;       // == LDS index (tap*NG + g)*NC + n
-      const int n = idx % NC, g = (idx / NC) % NG, tap = (idx / (NG * NC)) % 27;
+      const int n = idx % NC, g = (idx / NC) % NG, tap = (S == 0) ? 13 : (idx / (NG * NC)) % 27;
       const int wt = taps.wt[tap];
-      const bool ok = idx < 27 * NC * NG && wt >= 0;
+      const bool ok = idx < NTAP * NC * NG && wt >= 0;
       const int64_t chunk2 = (int64_t)(kc / (2 * EPV)) + g / 2;     // K-chunk of 2*EPV channels
       const int64_t off = (((((int64_t)(n0 + n) / 32) * (CinP / (2 * EPV)) + chunk2) * ntaps_src + wt) * 2 + (g & 1)) * 32 +
                           (n0 + n) % 32;
@@ -209,7 +225,7 @@ __global__ __launch_bounds__(NW * 64) void conv3_mfma_kernel(const T *__restrict
 #pragma unroll
     for (int i = 0; i < NBL; ++i) {
       const int idx = tid + i * NT;
-      if (idx < 27 * NC * NG) sB[idx] = rb[i];
+      if (idx < NTAP * NC * NG) sB[idx] = rb[i];
     }
   };
 
@@ -221,16 +237,17 @@ __global__ __launch_bounds__(NW * 64) void conv3_mfma_kernel(const T *__restrict
     if (kc + CK < CinP) load_chunk(kc + CK);
     // ---- 27 taps x KSPC k-steps of MFMA from LDS
 #pragma unroll
-    for (int tap = 0; tap < 27; ++tap) {
+    for (int tap = (S == 0 ? 13 : 0); tap < (S == 0 ? 14 : 27); ++tap) {
       if (taps.wt[tap] < 0) continue;     // wave-uniform
       const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
-      const int tap_off = (kd * G::IH + kh) * G::ROW + G::lds_col(kw);
+      const int tap_off = (S == 0) ? 0 : (kd * G::IH + kh) * G::ROW + G::lds_col(kw);
+      const int tb = (S == 0) ? 0 : tap;   // tap slot in the LDS weight tile
 #pragma unroll
       for (int ks = 0; ks < KSPC; ++ks) {
         const int g = 2 * ks + h;
         uint4 bf[NB];
 #pragma unroll
-        for (int j = 0; j < NB; ++j) bf[j] = sB[(tap * NG + g) * NC + j * 32 + r];
+        for (int j = 0; j < NB; ++j) bf[j] = sB[(tb * NG + g) * NC + j * 32 + r];
 #pragma unroll
         for (int i = 0; i < MPW; ++i) {
           const uint4 af = (ABL == 6) ? make_uint4(tap, i, tid, 0) : sA[g * NV + a_off[i] + tap_off];
@@ -377,6 +394,12 @@ int dispatch_conv_classes(const void *x, const View &xv, const void *w, const Co
                           double *stats = nullptr, int ntaps_src = 27) {
 #define ARGS x, xv, w, cs, bias, y, yv, B, Cin, Cout, CinP, CoutP, stats, ntaps_src, st
   const long long vox = (long long)yv.D * yv.H * yv.W * B;
+  if (stride == 0) {      // pointwise (centre tap only, no halo)
+    if (yv.W >= 32) return launch_conv<T, 32, 4, 4, 0, 1, 1, 8>(ARGS);
+    if (yv.W >= 16) return launch_conv<T, 16, 4, 4, 0, 1, 1, 8>(ARGS);
+    if (vox <= 4096) return launch_conv<T, 8, 2, 2, 0, 1, 1>(ARGS);
+    return launch_conv<T, 8, 2, 8, 0, 1, 1, 8>(ARGS);
+  }
   if (stride == 1) {
     static const char *var = getenv("DGTTA_CONV_VARIANT");      // diagnostic: tile-shape experiments
     if (yv.W >= 32 && var && var[0] == 'a') return launch_conv<T, 32, 4, 4, 1, 1, 2>(ARGS);   // CK = 2 k-steps
@@ -405,6 +428,7 @@ int dispatch_conv(const void *x, const View &xv, const void *w, const Taps &taps
                   hipStream_t st, double *stats = nullptr, int ntaps_src = 27) {
   ConvClasses cs;
   cs.n = 1;
+  cs.kseg = 0;
   cs.acc[0] = accumulate;
   cs.xoff[0] = cs.yoff[0] = 0;
   cs.taps[0] = taps;
@@ -439,9 +463,9 @@ __global__ void convT_pack_kernel(const float *__restrict__ w, T *__restrict__ w
       st_f<T>(wf + conv_weight_image_index(co, ci, o, CinP, 8, EPV),
               (ci < Cin && co < Cout) ? w[((int64_t)ci * Cout + co) * 8 + o] : 0.f);
     }
-    if (i < nb) {
+    if (i < nb) {   // data-gradient role: N = ci, K = o*CoutP + co (the 8 parity segments concatenated along K), one tap
       int co = (int)(i % CoutP), ci = (int)((i / CoutP) % CinN), o = (int)(i / ((int64_t)CoutP * CinN));
-      st_f<T>(wb + conv_weight_image_index(ci, co, o, CoutP, 8, EPV),
+      st_f<T>(wb + conv_weight_image_index(ci, o * CoutP + co, 0, 8 * CoutP, 1, EPV),
               (ci < Cin && co < Cout) ? w[((int64_t)ci * Cout + co) * 8 + o] : 0.f);
     }
   }
@@ -511,6 +535,7 @@ static int dgrad_s2(const void *dy, int lddy, const void *w_kmajor, void *dx, in
   // even extents: all 8 parity classes have the same shape -> ONE launch, class = blockIdx.z
   ConvClasses cs;
   cs.n = 8;
+  cs.kseg = 0;
   View yv;
   for (int p = 0; p < 8; ++p) {
     const int pd = p >> 2, ph = (p >> 1) & 1, pw = p & 1;
@@ -585,9 +610,10 @@ static int convT_run(int mode /*0 fwd, 1 dgrad*/, const void *in, int ldin, cons
   const int Do = 2 * Di, Ho = 2 * Hi, Wo = 2 * Wi;
   if (mode == 0 ? !operand_ok<T>(in, ldin, Cin, CinP) : !operand_ok<T>(in, ldin, Cout, CoutP)) return DGTTA_ERR_UNSUPPORTED;
   if (mode == 0) {
-    // forward: the 8 output offsets write disjoint sub-lattices -> one launch with 8 classes
+    // forward: the 8 output offsets write disjoint sub-lattices -> one pointwise launch with 8 classes
     ConvClasses cs;
     cs.n = 8;
+    cs.kseg = 0;
     View yv;
     for (int o = 0; o < 8; ++o) {
       long long off;
@@ -600,22 +626,26 @@ static int convT_run(int mode /*0 fwd, 1 dgrad*/, const void *in, int ldin, cons
       cs.taps[o].wt[13] = (signed char)o;
     }
     const View xv = dense_view(B, Di, Hi, Wi, ldin);
-    return dispatch_conv_classes<T>(in, xv, wf, cs, bias, out, yv, B, Cin, Cout, CinP, CoutP, 1, st, nullptr, 8);
+    return dispatch_conv_classes<T>(in, xv, wf, cs, bias, out, yv, B, Cin, Cout, CinP, CoutP, 0, st, nullptr, 8);
   }
-  // data gradient: the 8 offsets sum into the same dx -> sequential launches, accumulating from the second on
+  // data gradient: dx[v][ci] = sum_o sum_co dout[2v+o][co] w[ci][co][o] = ONE pointwise GEMM with K = 8 x Cout, the 8
+  // parity sub-lattices of dout concatenated along K (segment offsets), no read-modify-write passes
+  ConvClasses cs;
+  cs.n = 1;
+  cs.acc[0] = 0;
+  cs.xoff[0] = cs.yoff[0] = 0;
+  for (int t = 0; t < 27; ++t) cs.taps[0].wt[t] = -1;
+  cs.taps[0].wt[13] = 0;
+  cs.kseg = CoutP;
+  View xv;
   for (int o = 0; o < 8; ++o) {
     long long off;
-    Taps taps;
-    for (int t = 0; t < 27; ++t) taps.wt[t] = -1;
-    taps.wt[13] = (signed char)o;
-    View xv = parity_view(Do, Ho, Wo, ldin, o >> 2, (o >> 1) & 1, o & 1, &off);
-    xv.sb = (long long)Do * Ho * Wo * ldin;
-    const View yv = dense_view(B, Di, Hi, Wi, ldout);
-    int rc = dispatch_conv<T>((const T *)in + off, xv, wb, taps, nullptr, out, yv, B, Cout, Cin, CoutP, CinP, 1, o != 0, st,
-                              nullptr, 8);
-    if (rc != DGTTA_OK) return rc;
+    xv = parity_view(Do, Ho, Wo, ldin, o >> 2, (o >> 1) & 1, o & 1, &off);
+    cs.segoff[o] = off;
   }
-  return DGTTA_OK;
+  xv.sb = (long long)Do * Ho * Wo * ldin;
+  const View yv = dense_view(B, Di, Hi, Wi, ldout);
+  return dispatch_conv_classes<T>(in, xv, wb, cs, nullptr, out, yv, B, Cout, Cin, 8 * CoutP, CinP, 0, st, nullptr, 1);
 }
 
 int convT_fwd_mfma(const void *x, int ldx, const float *w_t, const float *bias, void *out, int ldo, void *ws, int B, int Cin,

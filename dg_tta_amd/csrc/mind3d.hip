@@ -20,6 +20,7 @@ constexpr int ID = TD + 6, IH = TH + 6, IW = TW + 6;   // image tile (halo 3)
 constexpr int QD = TD + 4, QH = TH + 4, QW = TW + 4;   // q tile (halo 2)
 constexpr int NT = 256;
 constexpr int VPT = TD * TH * TW / NT;                 // 8 voxels per thread
+constexpr int QN = (QD * QH * QW + NT - 1) / NT;       // q-tile elements per thread
 
 // (d,h,w) offsets inside the 3x3x3 window minus 1, from mshift1/mshift2 (mind.py:112-135).
 __constant__ signed char c_s1[12][3] = {{0, 0, -1}, {0, -1, 0}, {0, -1, 0}, {0, 0, 1}, {0, 0, 1}, {1, 0, 0},
@@ -53,22 +54,46 @@ __global__ __launch_bounds__(NT) void mind_ssd_kernel(const float *__restrict__ 
 
   float ssd[VPT][12];
 
+  // q-stage bookkeeping that does not depend on the channel: clamped global coordinates (packed 10 bits each) and the
+  // global voxel index of every q-tile element this thread owns.  The noise of channel c+1 is fetched as one batch of
+  // independent loads while channel c is being filtered (the serialized per-element loads were the latency bound).
+  int gidx[QN], pk[QN];
+  float nreg[QN];
+#pragma unroll
+  for (int k = 0; k < QN; ++k) {
+    int i = tid + k * NT;
+    i = i < QD * QH * QW ? i : 0;
+    int qw = i % QW, qh = (i / QW) % QH, qd = i / (QW * QH);
+    int gd = clampi(d0 - 2 + qd, 0, D - 1), gh = clampi(h0 - 2 + qh, 0, H - 1), gw = clampi(w0 - 2 + qw, 0, W - 1);
+    gidx[k] = (gd * H + gh) * W + gw;
+    pk[k] = gd | (gh << 10) | (gw << 20);
+  }
+  {
+    const float *nz = noise + (int64_t)b * 12 * V;
+#pragma unroll
+    for (int k = 0; k < QN; ++k) nreg[k] = nz[gidx[k]];
+  }
+
 #pragma unroll
   for (int c = 0; c < 12; ++c) {
     __syncthreads();  // simg ready (c==0) / previous channel's r2 reads done
-    const float *nz = noise + ((int64_t)b * 12 + c) * V;
     const int a0 = c_s1[c][0], a1 = c_s1[c][1], a2 = c_s1[c][2];
     const int e0 = c_s2[c][0], e1 = c_s2[c][1], e2 = c_s2[c][2];
-    for (int i = tid; i < QD * QH * QW; i += NT) {
-      int qw = i % QW, qh = (i / QW) % QH, qd = i / (QW * QH);
-      int gd = clampi(d0 - 2 + qd, 0, D - 1), gh = clampi(h0 - 2 + qh, 0, H - 1), gw = clampi(w0 - 2 + qw, 0, W - 1);
+#pragma unroll
+    for (int k = 0; k < QN; ++k) {
+      const int i = tid + k * NT;
+      const int gd = pk[k] & 1023, gh = (pk[k] >> 10) & 1023, gw = pk[k] >> 20;
       int p1 = ((clampi(gd + a0, 0, D - 1) - (d0 - 3)) * IH + (clampi(gh + a1, 0, H - 1) - (h0 - 3))) * IW +
                (clampi(gw + a2, 0, W - 1) - (w0 - 3));
       int p2 = ((clampi(gd + e0, 0, D - 1) - (d0 - 3)) * IH + (clampi(gh + e1, 0, H - 1) - (h0 - 3))) * IW +
                (clampi(gw + e2, 0, W - 1) - (w0 - 3));
-      float n = nz[((int64_t)gd * H + gh) * W + gw];
-      float e = (simg[p1] - simg[p2]) + rw * n;
-      sq[i] = e * e;
+      float e = (simg[p1] - simg[p2]) + rw * nreg[k];
+      if (i < QD * QH * QW) sq[i] = e * e;
+    }
+    if (c + 1 < 12) {
+      const float *nz = noise + ((int64_t)b * 12 + c + 1) * V;
+#pragma unroll
+      for (int k = 0; k < QN; ++k) nreg[k] = nz[gidx[k]];
     }
     __syncthreads();
     // D filter: r1[d][h'][w'] = sum_t g[t] q[d+t][h'][w']
@@ -191,6 +216,8 @@ extern "C" int dgtta_mind3d_fwd(const float *img, const float *noise, float rw, 
                                 int out_dtype, void *ws, size_t ws_bytes, int B, int D, int H, int W, void *stream) {
   DG_REQUIRE(img && noise && out && ws, DGTTA_ERR_BADARG, "mind3d_fwd: null pointer");
   DG_REQUIRE(B > 0 && D > 0 && H > 0 && W > 0, DGTTA_ERR_BADARG, "mind3d_fwd: bad dims %d %d %d %d", B, D, H, W);
+  DG_REQUIRE(D <= 1024 && H <= 1024 && W <= 1024 && (int64_t)D * H * W < (1ll << 31), DGTTA_ERR_UNSUPPORTED,
+             "mind3d_fwd: each dim must be <= 1024 (got %d %d %d)", D, H, W);
   DG_REQUIRE(ws_bytes >= dgtta_mind3d_ws_bytes(B, D, H, W), DGTTA_ERR_WORKSPACE, "mind3d_fwd: workspace too small");
   DG_REQUIRE(out_ndhwc ? (out_ldc >= 12) : (out_dtype == DGTTA_F32), DGTTA_ERR_BADARG,
              "mind3d_fwd: NCDHW output must be fp32; NDHWC needs ldc >= 12");

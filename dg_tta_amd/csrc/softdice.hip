@@ -4,7 +4,8 @@
 //   nom_c = mean_v(2ab); den_c = 0.5*mean_v((a+b)^2); dice = nom/den (no eps; all-zero guard -> 1)
 //   loss = 1 - mean_{b, c>=start} dice
 // Logits are voxel-major [B][V][ldc] fp32 (one row of C classes per voxel = one coalesced read per lane).
-// fwd: wavefront reductions per class -> per-workgroup partials (double) -> fixed-order finalize.
+// Rows are moved between HBM and per-wave LDS tiles as contiguous runs (coalesced); lane = voxel inside the tile.
+// fwd: per-lane class/voxel-group partial sums -> per-workgroup partials (double) -> fixed-order finalize.
 // bwd: recomputes the softmax per voxel from the logits (cheaper than saving it) and applies the closed-form
 //      gradient with per-class coefficients P,Q prepared by the finalize kernel.
 // Algorithmic HBM bytes per voxel: fwd 2*C*4 read; bwd 2*C*4 read + 2*C*4 write.
@@ -12,14 +13,50 @@
 
 namespace {
 
-constexpr int NT = 256;
 constexpr int MAXC = 128;
+constexpr int MAXW = 4;                 // waves per workgroup (fewer when the tile does not fit)
+constexpr size_t LDS_BUDGET = 96 * 1024;
 
-struct VoxelSoftmax {
-  float mx, inv_sum, mask_part;  // mask_part = (sum_c logits > 0)
-};
+// Every wave owns two LDS tiles [64 voxels][LDP] (branch a, branch b).  Global rows are read/written as one contiguous
+// run of 64*ldc floats (fully coalesced); inside the tile lane = voxel and the odd row pitch LDP keeps the strided
+// per-lane walks over the classes bank-conflict free.
+__host__ __device__ inline int tile_pitch(int ldc) { return ldc | 1; }
 
-__device__ __forceinline__ VoxelSoftmax voxel_stats(const float *row, int C) {
+__device__ __forceinline__ void tile_load(float *tile, const float *src, int count, int ldc, int LDP, int lane, bool vec) {
+  if (vec) {
+    const float4 *s4 = reinterpret_cast<const float4 *>(src);
+    for (int i = lane; i < (count >> 2); i += 64) {
+      float4 x = s4[i];
+      int e = i << 2, v = e / ldc, ch = e - v * ldc;
+      float *d = tile + v * LDP + ch;
+      d[0] = x.x; d[1] = x.y; d[2] = x.z; d[3] = x.w;
+    }
+  } else {
+    for (int e = lane; e < count; e += 64) {
+      int v = e / ldc, ch = e - v * ldc;
+      tile[v * LDP + ch] = src[e];
+    }
+  }
+}
+
+__device__ __forceinline__ void tile_store(const float *tile, float *dst, int count, int ldc, int LDP, int lane, bool vec) {
+  if (vec) {
+    float4 *d4 = reinterpret_cast<float4 *>(dst);
+    for (int i = lane; i < (count >> 2); i += 64) {
+      int e = i << 2, v = e / ldc, ch = e - v * ldc;
+      const float *t = tile + v * LDP + ch;
+      d4[i] = make_float4(t[0], t[1], t[2], t[3]);
+    }
+  } else {
+    for (int e = lane; e < count; e += 64) {
+      int v = e / ldc, ch = e - v * ldc;
+      dst[e] = tile[v * LDP + ch];
+    }
+  }
+}
+
+// lane = voxel: replaces the row of logits by exp(x - max) in place; returns the exp-sum and the (sum_c x > 0) mask part
+__device__ __forceinline__ float row_softmax_inplace(float *row, int C, float *mask_part) {
   float mx = row[0], s = row[0];
   for (int c = 1; c < C; ++c) {
     float v = row[c];
@@ -27,67 +64,112 @@ __device__ __forceinline__ VoxelSoftmax voxel_stats(const float *row, int C) {
     s += v;
   }
   float se = 0.f;
-  for (int c = 0; c < C; ++c) se += expf(row[c] - mx);
-  VoxelSoftmax r;
-  r.mx = mx;
-  r.inv_sum = se;  // holds the SUM; callers divide
-  r.mask_part = s > 0.0f ? 1.0f : 0.0f;
-  return r;
+  for (int c = 0; c < C; ++c) {
+    float e = expf(row[c] - mx);
+    row[c] = e;
+    se += e;
+  }
+  *mask_part = s > 0.0f ? 1.0f : 0.0f;
+  return se;
 }
 
-__global__ __launch_bounds__(NT) void softdice_fwd_kernel(const float *__restrict__ la, const float *__restrict__ lb,
-                                                          double *__restrict__ partial, int C, int64_t V, int ldc) {
-  __shared__ float acc[NT / 64][MAXC][2];
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+__global__ __launch_bounds__(MAXW * 64) void softdice_fwd_kernel(const float *__restrict__ la,
+                                                                 const float *__restrict__ lb,
+                                                                 double *__restrict__ partial, int C, int64_t V, int ldc,
+                                                                 int vec) {
+  extern __shared__ float smem[];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, NW = blockDim.x >> 6;
+  const int LDP = tile_pitch(ldc);
+  float *ta = smem + (size_t)wv * 2 * 64 * LDP, *tb = ta + 64 * LDP;
   const int b = blockIdx.y;
-  for (int i = threadIdx.x; i < (NT / 64) * MAXC * 2; i += NT) (&acc[0][0][0])[i] = 0.f;
-  __syncthreads();
-  const float *pa = la + (int64_t)b * V * ldc, *pb = lb + (int64_t)b * V * ldc;
-  // every lane of a wave runs the same number of iterations (wave-uniform loop; inactive voxels contribute 0)
-  const int64_t stride = (int64_t)gridDim.x * NT;
-  for (int64_t base = (int64_t)blockIdx.x * NT + wv * 64; base < V; base += stride) {
-    const int64_t v = base + lane;
-    const bool on = v < V;
-    const float *ra = pa + (on ? v : 0) * ldc, *rb = pb + (on ? v : 0) * ldc;
-    VoxelSoftmax sa = voxel_stats(ra, C), sb = voxel_stats(rb, C);
-    const float m = on ? sa.mask_part * sb.mask_part : 0.f;
-    for (int c = 0; c < C; ++c) {
-      float a = (expf(ra[c] - sa.mx) / sa.inv_sum) * m;
-      float bq = (expf(rb[c] - sb.mx) / sb.inv_sum) * m;
-      float s1 = wave_sum((2.0f * a) * bq);
-      float t = a + bq;
-      float s2 = wave_sum(t * t);
-      if (lane == 0) {
-        acc[wv][c][0] += s1;
-        acc[wv][c][1] += s2;
+  // reduction role of this lane: class c, voxel group g of `groups`
+  const int groups = C <= 64 ? 64 / C : 1;
+  const int NR = (C + 63) >> 6;
+  const int rc = C <= 64 ? lane % C : lane, rg = C <= 64 ? lane / C : 0;
+  const bool ron = C <= 64 ? lane < groups * C : true;
+  float acc1[2] = {0.f, 0.f}, acc2[2] = {0.f, 0.f};
+  const int64_t ntiles = (V + 63) >> 6;
+  for (int64_t t0 = (int64_t)blockIdx.x * NW; t0 < ntiles; t0 += (int64_t)gridDim.x * NW) {
+    const int64_t t = t0 + wv;
+    const int64_t rem = V - t * 64;
+    const int nvalid = rem <= 0 ? 0 : (rem < 64 ? (int)rem : 64);
+    const int64_t off = ((int64_t)b * V + t * 64) * ldc;
+    if (nvalid > 0) {
+      tile_load(ta, la + off, nvalid * ldc, ldc, LDP, lane, vec);
+      tile_load(tb, lb + off, nvalid * ldc, ldc, LDP, lane, vec);
+    }
+    __syncthreads();
+    {
+      float *ra = ta + lane * LDP, *rb = tb + lane * LDP;
+      if (lane < nvalid) {
+        float ma, mb;
+        float sa = row_softmax_inplace(ra, C, &ma), sb = row_softmax_inplace(rb, C, &mb);
+        const float m = ma * mb;
+        for (int c = 0; c < C; ++c) {
+          ra[c] = (ra[c] / sa) * m;
+          rb[c] = (rb[c] / sb) * m;
+        }
+      } else {
+        for (int c = 0; c < C; ++c) ra[c] = rb[c] = 0.f;
       }
     }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const int c = rc + r * 64;
+      if (r < NR && ron && c < C) {
+        float s1 = 0.f, s2 = 0.f;
+        for (int v = rg; v < 64; v += groups) {
+          float a = ta[v * LDP + c], bq = tb[v * LDP + c];
+          s1 += (2.0f * a) * bq;
+          float tt = a + bq;
+          s2 += tt * tt;
+        }
+        acc1[r] += s1;
+        acc2[r] += s2;
+      }
+    }
+    __syncthreads();
+  }
+  // combine lanes (groups) and waves in a fixed order, in double
+  float *red = smem;  // [NW][64][4]
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    red[((wv * 64 + lane) * 2 + r) * 2 + 0] = acc1[r];
+    red[((wv * 64 + lane) * 2 + r) * 2 + 1] = acc2[r];
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < C * 2; i += NT) {
-    int c = i >> 1, k = i & 1;
+  for (int i = threadIdx.x; i < C * 2; i += blockDim.x) {
+    const int c = i >> 1, k = i & 1;
     double s = 0.0;
-    for (int w = 0; w < NT / 64; ++w) s += (double)acc[w][c][k];
-    partial[(((int64_t)b * gridDim.x + blockIdx.x) * C + c) * 2 + k] = s;
+    for (int w = 0; w < NW; ++w) {
+      if (C <= 64) {
+        for (int g = 0; g < groups; ++g) s += (double)red[((w * 64 + g * C + c) * 2 + 0) * 2 + k];
+      } else {
+        s += (double)red[((w * 64 + (c & 63)) * 2 + (c >> 6)) * 2 + k];
+      }
+    }
+    partial[(((int64_t)b * C + c) * 2 + k) * gridDim.x + blockIdx.x] = s;
   }
 }
 
-// one workgroup: sums partials in fixed order, forms dice/loss and the backward coefficients
-__global__ void softdice_finalize_kernel(const double *__restrict__ partial, int nblk, int B, int C, int64_t V,
-                                         int start_class, float *__restrict__ dice, float *__restrict__ loss,
-                                         float *__restrict__ coef) {
+// one workgroup (16 waves): sums partials in fixed order, forms dice/loss and the backward coefficients
+__global__ __launch_bounds__(1024) void softdice_finalize_kernel(const double *__restrict__ partial, int nblk, int B,
+                                                                 int C, int64_t V, int start_class,
+                                                                 float *__restrict__ dice, float *__restrict__ loss,
+                                                                 float *__restrict__ coef) {
   __shared__ float s_nom[8 * MAXC], s_den[8 * MAXC];
   __shared__ float s_flag, s_loss;
   const int n = B * C;
-  for (int i = threadIdx.x; i < n; i += blockDim.x) {
-    int b = i / C, c = i % C;
-    double s1 = 0.0, s2 = 0.0;
-    for (int k = 0; k < nblk; ++k) {
-      s1 += partial[(((int64_t)b * nblk + k) * C + c) * 2 + 0];
-      s2 += partial[(((int64_t)b * nblk + k) * C + c) * 2 + 1];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  for (int j = wv; j < 2 * n; j += nw) {          // j = (b*C + c)*2 + k, partial row of nblk doubles
+    double s = 0.0;
+    for (int q = lane; q < nblk; q += 64) s += partial[(int64_t)j * nblk + q];
+    s = wave_sum_d(s);
+    if (lane == 0) {
+      if (j & 1) s_den[j >> 1] = 0.5f * (float)(s / (double)V);
+      else s_nom[j >> 1] = (float)(s / (double)V);
     }
-    s_nom[i] = (float)(s1 / (double)V);
-    s_den[i] = 0.5f * (float)(s2 / (double)V);
   }
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -124,44 +206,93 @@ __global__ void softdice_finalize_kernel(const double *__restrict__ partial, int
   }
 }
 
-__global__ __launch_bounds__(NT) void softdice_bwd_kernel(const float *__restrict__ la, const float *__restrict__ lb,
-                                                          float *__restrict__ ga, float *__restrict__ gb,
-                                                          const float *__restrict__ coef, float scale_h,
-                                                          const float *__restrict__ scale_dev, int C, int64_t V,
-                                                          int ldc) {
+__global__ __launch_bounds__(MAXW * 64) void softdice_bwd_kernel(const float *__restrict__ la,
+                                                                 const float *__restrict__ lb, float *__restrict__ ga,
+                                                                 float *__restrict__ gb, const float *__restrict__ coef,
+                                                                 float scale_h, const float *__restrict__ scale_dev,
+                                                                 int C, int64_t V, int ldc, int vec) {
+  extern __shared__ float smem[];
   __shared__ float sc[MAXC * 2];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, NW = blockDim.x >> 6;
+  const int LDP = tile_pitch(ldc);
+  float *ta = smem + (size_t)wv * 2 * 64 * LDP, *tb = ta + 64 * LDP;
   const float scale = scale_dev ? scale_h * scale_dev[0] : scale_h;
   const int b = blockIdx.y;
-  for (int i = threadIdx.x; i < 2 * C; i += NT) sc[i] = coef[(int64_t)b * C * 2 + i];
-  __syncthreads();
-  for (int64_t v = (int64_t)blockIdx.x * NT + threadIdx.x; v < V; v += (int64_t)gridDim.x * NT) {
-    const int64_t ro = ((int64_t)b * V + v) * ldc;
-    const float *ra = la + ro, *rb = lb + ro;
-    VoxelSoftmax sa = voxel_stats(ra, C), sb = voxel_stats(rb, C);
-    const float m = sa.mask_part * sb.mask_part;
-    float dot_a = 0.f, dot_b = 0.f;
-    for (int c = 0; c < C; ++c) {
-      float pa = expf(ra[c] - sa.mx) / sa.inv_sum, pb = expf(rb[c] - sb.mx) / sb.inv_sum;
-      float a = pa * m, bq = pb * m;
-      float P = sc[2 * c], Q = sc[2 * c + 1];
-      float t = Q * (a + bq);
-      dot_a += (P * bq + t) * pa;
-      dot_b += (P * a + t) * pb;
+  for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) sc[i] = coef[(int64_t)b * C * 2 + i];
+  const int64_t ntiles = (V + 63) >> 6;
+  for (int64_t t0 = (int64_t)blockIdx.x * NW; t0 < ntiles; t0 += (int64_t)gridDim.x * NW) {
+    const int64_t t = t0 + wv;
+    const int64_t rem = V - t * 64;
+    const int nvalid = rem <= 0 ? 0 : (rem < 64 ? (int)rem : 64);
+    const int64_t off = ((int64_t)b * V + t * 64) * ldc;
+    if (nvalid > 0) {
+      tile_load(ta, la + off, nvalid * ldc, ldc, LDP, lane, vec);
+      tile_load(tb, lb + off, nvalid * ldc, ldc, LDP, lane, vec);
     }
-    for (int c = 0; c < C; ++c) {
-      float pa = expf(ra[c] - sa.mx) / sa.inv_sum, pb = expf(rb[c] - sb.mx) / sb.inv_sum;
-      float a = pa * m, bq = pb * m;
-      float P = sc[2 * c], Q = sc[2 * c + 1];
-      float t = Q * (a + bq);
-      ga[ro + c] = scale * m * pa * ((P * bq + t) - dot_a);
-      gb[ro + c] = scale * m * pb * ((P * a + t) - dot_b);
+    __syncthreads();
+    if (lane < nvalid) {
+      float *ra = ta + lane * LDP, *rb = tb + lane * LDP;
+      float ma, mb;
+      const float sa = row_softmax_inplace(ra, C, &ma), sb = row_softmax_inplace(rb, C, &mb);
+      const float m = ma * mb;
+      float dot_a = 0.f, dot_b = 0.f;
+      for (int c = 0; c < C; ++c) {
+        float pa = ra[c] / sa, pb = rb[c] / sb;
+        float a = pa * m, bq = pb * m;
+        float P = sc[2 * c], Q = sc[2 * c + 1];
+        float tt = Q * (a + bq);
+        dot_a += (P * bq + tt) * pa;
+        dot_b += (P * a + tt) * pb;
+      }
+      for (int c = 0; c < C; ++c) {
+        float pa = ra[c] / sa, pb = rb[c] / sb;
+        float a = pa * m, bq = pb * m;
+        float P = sc[2 * c], Q = sc[2 * c + 1];
+        float tt = Q * (a + bq);
+        ra[c] = scale * m * pa * ((P * bq + tt) - dot_a);
+        rb[c] = scale * m * pb * ((P * a + tt) - dot_b);
+      }
+      for (int c = C; c < ldc; ++c) ra[c] = rb[c] = 0.f;   // padding columns of the gradient rows are zeroed
     }
+    __syncthreads();
+    if (nvalid > 0) {
+      tile_store(ta, ga + off, nvalid * ldc, ldc, LDP, lane, vec);
+      tile_store(tb, gb + off, nvalid * ldc, ldc, LDP, lane, vec);
+    }
+    __syncthreads();
   }
 }
 
+int waves_for(int ldc) {
+  size_t per_wave = (size_t)2 * 64 * tile_pitch(ldc) * sizeof(float);
+  int nw = (int)(LDS_BUDGET / per_wave);
+  return nw > MAXW ? MAXW : (nw < 1 ? 1 : nw);
+}
+
+size_t lds_for(int ldc, int nw) {
+  size_t tiles = (size_t)nw * 2 * 64 * tile_pitch(ldc) * sizeof(float);
+  size_t red = (size_t)nw * 64 * 4 * sizeof(float);
+  return tiles > red ? tiles : red;
+}
+
 int nblocks_for(int64_t V) {
-  int64_t b = (V + NT - 1) / NT;
+  int64_t b = (V + 255) / 256;
   return (int)(b < 1024 ? b : 1024);
+}
+
+bool vec_ok(const void *a, const void *b, const void *c, const void *d, int ldc) {
+  return ldc % 4 == 0 && (((uintptr_t)a | (uintptr_t)b | (uintptr_t)c | (uintptr_t)d) & 15) == 0;
+}
+
+int allow_big_lds() {
+  static int rc = [] {
+    hipError_t e1 = hipFuncSetAttribute((const void *)softdice_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)LDS_BUDGET);
+    hipError_t e2 = hipFuncSetAttribute((const void *)softdice_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)LDS_BUDGET);
+    return (e1 == hipSuccess && e2 == hipSuccess) ? 0 : -1;
+  }();
+  return rc;
 }
 
 }  // namespace
@@ -183,10 +314,13 @@ extern "C" int dgtta_softdice_fwd(const float *la, const float *lb, float *dice,
   const int nblk = nblocks_for(V);
   double *partial = (double *)ws;
   float *coef = (float *)((char *)ws + align_up((size_t)B * nblk * C * 2 * sizeof(double), 256));
-  hipLaunchKernelGGL(softdice_fwd_kernel, dim3(nblk, B), dim3(NT), 0, st, la, lb, partial, C, V, ldc);
+  DG_REQUIRE(allow_big_lds() == 0, DGTTA_ERR_LAUNCH, "softdice: cannot raise the dynamic LDS limit");
+  const int nw = waves_for(ldc);
+  hipLaunchKernelGGL(softdice_fwd_kernel, dim3(nblk, B), dim3(nw * 64), lds_for(ldc, nw), st, la, lb, partial, C, V, ldc,
+                     (int)vec_ok(la, lb, nullptr, nullptr, ldc));
   DG_CHECK_LAUNCH("softdice_fwd_kernel");
-  hipLaunchKernelGGL(softdice_finalize_kernel, dim3(1), dim3(256), 0, st, partial, nblk, B, C, V, start_class, dice, loss,
-                     coef);
+  hipLaunchKernelGGL(softdice_finalize_kernel, dim3(1), dim3(1024), 0, st, partial, nblk, B, C, V, start_class, dice,
+                     loss, coef);
   DG_CHECK_LAUNCH("softdice_finalize_kernel");
   return DGTTA_OK;
 }
@@ -200,10 +334,12 @@ extern "C" int dgtta_softdice_bwd(const float *la, const float *lb, float *grad_
   hipStream_t st = (hipStream_t)stream;
   const int nblk = nblocks_for(V);
   const float *coef = (const float *)((const char *)ws + align_up((size_t)B * nblk * C * 2 * sizeof(double), 256));
-  int64_t gb = (V + NT - 1) / NT;
-  if (gb > 4096) gb = 4096;
-  hipLaunchKernelGGL(softdice_bwd_kernel, dim3((int)gb, B), dim3(NT), 0, st, la, lb, grad_la, grad_lb, coef, grad_scale,
-                     grad_scale_dev, C, V, ldc);
+  DG_REQUIRE(allow_big_lds() == 0, DGTTA_ERR_LAUNCH, "softdice: cannot raise the dynamic LDS limit");
+  const int nw = waves_for(ldc);
+  int64_t gb = (V + 255) / 256;
+  if (gb > 2048) gb = 2048;
+  hipLaunchKernelGGL(softdice_bwd_kernel, dim3((int)gb, B), dim3(nw * 64), lds_for(ldc, nw), st, la, lb, grad_la,
+                     grad_lb, coef, grad_scale, grad_scale_dev, C, V, ldc, (int)vec_ok(la, lb, grad_la, grad_lb, ldc));
   DG_CHECK_LAUNCH("softdice_bwd_kernel");
   return DGTTA_OK;
 }

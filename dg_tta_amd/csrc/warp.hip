@@ -19,9 +19,16 @@ struct Sample {
   float ix, iy, iz;
 };
 
+__device__ __forceinline__ Sample sample_from_base(const float *th, float x, float y, float z, int Ds, int Hs, int Ws,
+                                                   int algebra, int pad_mode);
+
 __device__ __forceinline__ Sample sample_pos(const float *th, int d, int h, int w, int Dd, int Hd, int Wd, int Ds,
                                              int Hs, int Ws, int algebra, int pad_mode) {
-  const float x = base_coord(w, Wd), y = base_coord(h, Hd), z = base_coord(d, Dd);
+  return sample_from_base(th, base_coord(w, Wd), base_coord(h, Hd), base_coord(d, Dd), Ds, Hs, Ws, algebra, pad_mode);
+}
+
+__device__ __forceinline__ Sample sample_from_base(const float *th, float x, float y, float z, int Ds, int Hs, int Ws,
+                                                   int algebra, int pad_mode) {
   float gx = __builtin_fmaf(th[2], z, __builtin_fmaf(th[1], y, th[0] * x)) + th[3];
   float gy = __builtin_fmaf(th[6], z, __builtin_fmaf(th[5], y, th[4] * x)) + th[7];
   float gz = __builtin_fmaf(th[10], z, __builtin_fmaf(th[9], y, th[8] * x)) + th[11];
@@ -146,17 +153,73 @@ __global__ void warp_fwd_kernel(const float *__restrict__ src, const float *__re
   }
 }
 
+// Voxel-space linearisation of the sampling map (it is affine): S(v) = s0 + M v, with the inverse of M.  Only used to
+// bound candidate ranges; the contributions themselves are always recomputed with the exact forward arithmetic.
+struct InvMap {
+  float m[3][3];     // rows (ix,iy,iz) x cols (w,h,d)
+  float inv[3][3];   // rows (w,h,d) x cols (ix,iy,iz)
+  float e[3];        // |inv| row sums = half-extent of the pre-image of a unit half-width box
+  float s0[3];
+  bool ok;           // invertible, finite, and at most 512 candidate voxels per source voxel
+};
+
+__device__ __forceinline__ InvMap inverse_map(const float *th, int Ds, int Hs, int Ws, int Dd, int Hd, int Wd, int algebra) {
+  InvMap r;
+  const Sample s0 = sample_pos(th, 0, 0, 0, Dd, Hd, Wd, Ds, Hs, Ws, algebra, DGTTA_PAD_ZEROS);
+  r.s0[0] = s0.ix;
+  r.s0[1] = s0.iy;
+  r.s0[2] = s0.iz;
+  const float m00 = th[0] * Ws / Wd, m01 = th[1] * Ws / Hd, m02 = th[2] * Ws / Dd;
+  const float m10 = th[4] * Hs / Wd, m11 = th[5] * Hs / Hd, m12 = th[6] * Hs / Dd;
+  const float m20 = th[8] * Ds / Wd, m21 = th[9] * Ds / Hd, m22 = th[10] * Ds / Dd;
+  const float c00 = m11 * m22 - m12 * m21, c01 = m12 * m20 - m10 * m22, c02 = m10 * m21 - m11 * m20;
+  const float det = m00 * c00 + m01 * c01 + m02 * c02;
+  const float idet = 1.0f / det;
+  r.m[0][0] = m00; r.m[0][1] = m01; r.m[0][2] = m02;
+  r.m[1][0] = m10; r.m[1][1] = m11; r.m[1][2] = m12;
+  r.m[2][0] = m20; r.m[2][1] = m21; r.m[2][2] = m22;
+  r.inv[0][0] = c00 * idet;
+  r.inv[0][1] = (m02 * m21 - m01 * m22) * idet;
+  r.inv[0][2] = (m01 * m12 - m02 * m11) * idet;
+  r.inv[1][0] = c01 * idet;
+  r.inv[1][1] = (m00 * m22 - m02 * m20) * idet;
+  r.inv[1][2] = (m02 * m10 - m00 * m12) * idet;
+  r.inv[2][0] = c02 * idet;
+  r.inv[2][1] = (m01 * m20 - m00 * m21) * idet;
+  r.inv[2][2] = (m00 * m11 - m01 * m10) * idet;
+  float vol = 1.f;
+  bool fin = det != 0.f && isfinite(idet) && isfinite(s0.ix) && isfinite(s0.iy) && isfinite(s0.iz);
+  for (int i = 0; i < 3; ++i) {
+    r.e[i] = fabsf(r.inv[i][0]) + fabsf(r.inv[i][1]) + fabsf(r.inv[i][2]);
+    fin = fin && isfinite(r.e[i]);
+    vol *= 2.0f * r.e[i] + 1.0f;
+  }
+  r.ok = fin && vol <= 512.0f;
+  return r;
+}
+
 // adjoint of the linear sampler w.r.t. src: scatter-add (fp32 atomics; sums are order dependent in the last bits)
 template <int VEC, bool NDHWC>
 __global__ void warp_bwd_kernel(const float *__restrict__ gdst, const float *__restrict__ theta, float *__restrict__ gsrc,
                                 int C, int Ds, int Hs, int Ws, int Dd, int Hd, int Wd, int src_ldc, int dst_ldc,
-                                int pad_mode, int algebra, int64_t total) {
+                                int pad_mode, int algebra, int only_declined, int B, int64_t total) {
+  __shared__ int declined[8];
+  if (only_declined) {   // fallback role: only batches the gather kernel declined; normally none -> exit at once
+    if (threadIdx.x < 8)
+      declined[threadIdx.x] = (int)threadIdx.x < B &&
+                              !inverse_map(theta + threadIdx.x * 12, Ds, Hs, Ws, Dd, Hd, Wd, algebra).ok;
+    __syncthreads();
+    int any = 0;
+    for (int q = 0; q < 8; ++q) any |= declined[q];
+    if (!any) return;
+  }
   const int cg = NDHWC ? (C / VEC) : 1;
   const int64_t Vd = (int64_t)Dd * Hd * Wd, Vs = (int64_t)Ds * Hs * Ws;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int g = (int)(i % cg);
     const int64_t vox = i / cg;
     const int b = (int)(vox / Vd);
+    if (only_declined && !declined[b]) continue;
     const int64_t v = vox % Vd;
     const int w = (int)(v % Wd), h = (int)((v / Wd) % Hd), d = (int)(v / ((int64_t)Wd * Hd));
     const Sample s = sample_pos(theta + b * 12, d, h, w, Dd, Hd, Wd, Ds, Hs, Ws, algebra, pad_mode);
@@ -176,6 +239,123 @@ __global__ void warp_bwd_kernel(const float *__restrict__ gdst, const float *__r
           atomicAdd(gsrc + ((int64_t)b * C + c) * Vs + off, gdst[((int64_t)b * C + c) * Vd + v] * cr.w[k]);
       }
     }
+  }
+}
+
+// Atomic-free, deterministic adjoint for NDHWC + zeros padding: one thread OWNS one grad_src voxel (CH channels in
+// registers).  Because the map is affine, the dst voxels whose trilinear footprint touches source voxel u lie in the
+// pre-image of u +- 1, a small box around M^-1 (u - s0) (2-3 lattice points per axis for the near-identity maps of
+// tta.py:523-548).  Each candidate's sample position and corner weight are recomputed with the forward's arithmetic,
+// so every term equals the scatter formulation's; only the (now fixed) summation order differs.  Neighbouring lanes
+// read neighbouring grad_dst rows (L1/L2 hits), stores are full coalesced rows, grad_src needs no zero-init.
+template <int CH, bool VEC>
+__global__ __launch_bounds__(256) void warp_bwd_gather_kernel(const float *__restrict__ gdst,
+                                                              const float *__restrict__ theta, float *__restrict__ gsrc,
+                                                              int C, int Ds, int Hs, int Ws, int Dd, int Hd, int Wd,
+                                                              int src_ldc, int dst_ldc, int algebra) {
+  const int64_t Vd = (int64_t)Dd * Hd * Wd, Vs = (int64_t)Ds * Hs * Ws;
+  // workgroup = compact 16 x 4 x 4 tile of source voxels (small grad_dst footprint -> L1/L2 reuse of the 8x overlap).
+  // (4 lanes per voxel with 4 channels each would make the row loads 4x denser per instruction, but repeats the
+  // candidate search 4x and measured slower: 374 vs 206 us at 128^3 x 16.)
+  const int tilesX = (Ws + 15) >> 4, tilesZ = (Ds + 3) >> 2;
+  const int c0 = (blockIdx.x / tilesX) * CH;
+  const int b = blockIdx.z / tilesZ;
+  const int x = (blockIdx.x % tilesX) * 16 + (threadIdx.x & 15), y = blockIdx.y * 4 + ((threadIdx.x >> 4) & 3),
+            z = (blockIdx.z % tilesZ) * 4 + (threadIdx.x >> 6);
+  if (x < Ws && y < Hs && z < Ds) {
+    const int64_t u = ((int64_t)z * Hs + y) * Ws + x;
+    const float *th = theta + b * 12;
+    const InvMap im = inverse_map(th, Ds, Hs, Ws, Dd, Hd, Wd, algebra);
+    if (!im.ok) return;   // the scatter kernels (launched next) take over (uniform per batch item)
+    const float rel[3] = {(float)x - im.s0[0], (float)y - im.s0[1], (float)z - im.s0[2]};
+    int lo[3], hi[3];
+    const int dims[3] = {Wd, Hd, Dd};
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      const float c = im.inv[a][0] * rel[0] + im.inv[a][1] * rel[1] + im.inv[a][2] * rel[2];
+      const float slack = im.e[a] + 0.02f;
+      lo[a] = max(0, (int)fmaxf(ceilf(c - slack), -1.0f));
+      hi[a] = min(dims[a] - 1, (int)fminf(floorf(c + slack), (float)dims[a]));
+    }
+    float acc[CH];
+#pragma unroll
+    for (int q = 0; q < CH; ++q) acc[q] = 0.f;
+    // per (d,h) line the three constraints |S_j(w,h,d) - u_j| < 1 bound w to ~1 lattice point (linear model + slack)
+    float rcp0[3];
+    bool bounds_w[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      bounds_w[j] = fabsf(im.m[j][0]) > 1e-6f;
+      rcp0[j] = bounds_w[j] ? 1.0f / im.m[j][0] : 0.f;
+    }
+    for (int d = lo[2]; d <= hi[2]; ++d) {
+      const float zc = base_coord(d, Dd);
+      for (int h = lo[1]; h <= hi[1]; ++h) {
+        const float yc = base_coord(h, Hd);
+        float wl = (float)lo[0], wh = (float)hi[0];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+          const float r = -rel[j] + im.m[j][1] * (float)h + im.m[j][2] * (float)d;
+          if (bounds_w[j]) {
+            const float a = (-1.02f - r) * rcp0[j], bq = (1.02f - r) * rcp0[j];
+            wl = fmaxf(wl, fminf(a, bq));
+            wh = fminf(wh, fmaxf(a, bq));
+          } else if (fabsf(r) > 1.02f) {
+            wh = wl - 1.0f;
+          }
+        }
+        const int w1 = (int)floorf(wh);
+        for (int w = (int)ceilf(wl); w <= w1; ++w) {
+          const Sample s = sample_from_base(th, base_coord(w, Wd), yc, zc, Ds, Hs, Ws, algebra, DGTTA_PAD_ZEROS);
+          const float fx = floorf(s.ix), fy = floorf(s.iy), fz = floorf(s.iz);
+          // weight of source voxel (x,y,z) in this sample: low corner -> (f+1)-i, high corner -> i-f (as corners())
+          const float dx = (float)x - fx, dy = (float)y - fy, dz = (float)z - fz;
+          if (!((dx == 0.f || dx == 1.f) && (dy == 0.f || dy == 1.f) && (dz == 0.f || dz == 1.f))) continue;
+          const float wx = dx == 0.f ? (fx + 1.0f) - s.ix : s.ix - fx;
+          const float wy = dy == 0.f ? (fy + 1.0f) - s.iy : s.iy - fy;
+          const float wz = dz == 0.f ? (fz + 1.0f) - s.iz : s.iz - fz;
+          const float wt = wx * wy * wz;
+          const float *gp = gdst + ((int64_t)b * Vd + ((int64_t)d * Hd + h) * Wd + w) * dst_ldc + c0;
+          if (VEC) {
+#pragma unroll
+            for (int q = 0; q < CH; q += 4) {
+              if (c0 + q < C) {
+                const float4 g = *reinterpret_cast<const float4 *>(gp + q);
+                acc[q] += g.x * wt;
+                acc[q + 1] += g.y * wt;
+                acc[q + 2] += g.z * wt;
+                acc[q + 3] += g.w * wt;
+              }
+            }
+          } else {
+#pragma unroll
+            for (int q = 0; q < CH; ++q)
+              if (c0 + q < C) acc[q] += gp[q] * wt;
+          }
+        }
+      }
+    }
+    float *o = gsrc + ((int64_t)b * Vs + u) * src_ldc + c0;
+    if (VEC) {
+#pragma unroll
+      for (int q = 0; q < CH; q += 4)
+        if (c0 + q < C) *reinterpret_cast<float4 *>(o + q) = make_float4(acc[q], acc[q + 1], acc[q + 2], acc[q + 3]);
+    } else {
+#pragma unroll
+      for (int q = 0; q < CH; ++q)
+        if (c0 + q < C) o[q] = acc[q];
+    }
+  }
+}
+
+// Fallback for maps the gather kernel declines (singular / extreme minification): zero, then scatter with atomics.
+__global__ void warp_bwd_zero_if_declined_kernel(const float *__restrict__ theta, float *__restrict__ gsrc, int B, int Ds,
+                                                 int Hs, int Ws, int Dd, int Hd, int Wd, int algebra, int64_t per_batch) {
+  for (int b = 0; b < B; ++b) {
+    if (inverse_map(theta + b * 12, Ds, Hs, Ws, Dd, Hd, Wd, algebra).ok) continue;
+    float *g = gsrc + (int64_t)b * per_batch;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < per_batch; i += (int64_t)gridDim.x * blockDim.x)
+      g[i] = 0.f;
   }
 }
 
@@ -236,22 +416,45 @@ extern "C" int dgtta_affine_warp3d_bwd(const float *grad_dst, const float *theta
                         dst_ldc);
   if (rc) return rc;
   hipStream_t st = (hipStream_t)stream;
-  const int64_t Vd = (int64_t)Dd * Hd * Wd;
+  const int64_t Vd = (int64_t)Dd * Hd * Wd, Vs = (int64_t)Ds * Hs * Ws;
+  if (ndhwc && pad_mode == DGTTA_PAD_ZEROS) {
+    // owner-computes gather (no atomics, no memset); batches whose map it declines are handled by the two launches after
+    const bool vec = (C % 4 == 0) && (dst_ldc % 4 == 0) && (src_ldc % 4 == 0) && ((uintptr_t)grad_dst % 16 == 0) &&
+                     ((uintptr_t)grad_src % 16 == 0);
+    DG_REQUIRE(B <= 8 && (int64_t)cdiv(Ds, 4) * B <= 65535 && cdiv(Hs, 4) <= 65535, DGTTA_ERR_UNSUPPORTED,
+               "warp_bwd: need B <= 8 and D*B/4, H/4 <= 65535");
+    dim3 grid(cdiv(Ws, 16) * cdiv(C, 16), cdiv(Hs, 4), cdiv(Ds, 4) * B);
+    if (vec)
+      hipLaunchKernelGGL((warp_bwd_gather_kernel<16, true>), grid, dim3(256), 0, st, grad_dst, theta, grad_src, C, Ds, Hs,
+                         Ws, Dd, Hd, Wd, src_ldc, dst_ldc, tta_grid_algebra);
+    else
+      hipLaunchKernelGGL((warp_bwd_gather_kernel<16, false>), grid, dim3(256), 0, st, grad_dst, theta, grad_src, C, Ds,
+                         Hs, Ws, Dd, Hd, Wd, src_ldc, dst_ldc, tta_grid_algebra);
+    DG_CHECK_LAUNCH("warp_bwd_gather_kernel");
+    hipLaunchKernelGGL(warp_bwd_zero_if_declined_kernel, dim3(256), dim3(256), 0, st, theta, grad_src, B, Ds, Hs, Ws, Dd,
+                       Hd, Wd, tta_grid_algebra, Vs * src_ldc);
+    DG_CHECK_LAUNCH("warp_bwd_zero_if_declined_kernel");
+    const int64_t tot2 = (int64_t)B * Vd * C;
+    hipLaunchKernelGGL((warp_bwd_kernel<1, true>), dim3(grid_for(tot2)), dim3(256), 0, st, grad_dst, theta, grad_src, C,
+                       Ds, Hs, Ws, Dd, Hd, Wd, src_ldc, dst_ldc, pad_mode, tta_grid_algebra, 1, B, tot2);
+    DG_CHECK_LAUNCH("warp_bwd_kernel");
+    return DGTTA_OK;
+  }
+  // general path: zero grad_src, then scatter with fp32 atomics
+  {
+    const size_t nb = ndhwc ? (size_t)B * Vs * src_ldc * sizeof(float) : (size_t)B * C * Vs * sizeof(float);
+    hipError_t e = hipMemsetAsync(grad_src, 0, nb, st);
+    DG_REQUIRE(e == hipSuccess, DGTTA_ERR_LAUNCH, "warp_bwd: memset failed: %s", hipGetErrorString(e));
+  }
   if (ndhwc) {
     // one lane per channel: a wave-instruction's atomics then cover whole 64-byte rows (C=16) instead of 16-byte pieces
-    if (false && C % 4 == 0) {
-      int64_t total = (int64_t)B * Vd * (C / 4);
-      hipLaunchKernelGGL((warp_bwd_kernel<4, true>), dim3(grid_for(total)), dim3(256), 0, st, grad_dst, theta, grad_src,
-                         C, Ds, Hs, Ws, Dd, Hd, Wd, src_ldc, dst_ldc, pad_mode, tta_grid_algebra, total);
-    } else {
-      int64_t total = (int64_t)B * Vd * C;
-      hipLaunchKernelGGL((warp_bwd_kernel<1, true>), dim3(grid_for(total)), dim3(256), 0, st, grad_dst, theta, grad_src,
-                         C, Ds, Hs, Ws, Dd, Hd, Wd, src_ldc, dst_ldc, pad_mode, tta_grid_algebra, total);
-    }
+    int64_t total = (int64_t)B * Vd * C;
+    hipLaunchKernelGGL((warp_bwd_kernel<1, true>), dim3(grid_for(total)), dim3(256), 0, st, grad_dst, theta, grad_src,
+                       C, Ds, Hs, Ws, Dd, Hd, Wd, src_ldc, dst_ldc, pad_mode, tta_grid_algebra, 0, B, total);
   } else {
     int64_t total = (int64_t)B * Vd;
     hipLaunchKernelGGL((warp_bwd_kernel<1, false>), dim3(grid_for(total)), dim3(256), 0, st, grad_dst, theta, grad_src, C,
-                       Ds, Hs, Ws, Dd, Hd, Wd, src_ldc, dst_ldc, pad_mode, tta_grid_algebra, total);
+                       Ds, Hs, Ws, Dd, Hd, Wd, src_ldc, dst_ldc, pad_mode, tta_grid_algebra, 0, B, total);
   }
   DG_CHECK_LAUNCH("warp_bwd_kernel");
   return DGTTA_OK;

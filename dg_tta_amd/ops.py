@@ -117,10 +117,10 @@ class _AffineWarp(torch.autograd.Function):
         dd, hd, wd = out_size
         if ndhwc:
             grad = grad.contiguous(memory_format=torch.channels_last_3d)
-            gsrc = torch.zeros((b, ds, hs, wsz, c), dtype=torch.float32, device=grad.device).permute(0, 4, 1, 2, 3)
+            gsrc = torch.empty((b, ds, hs, wsz, c), dtype=torch.float32, device=grad.device).permute(0, 4, 1, 2, 3)
         else:
             grad = grad.contiguous()
-            gsrc = torch.zeros(shape, dtype=torch.float32, device=grad.device)
+            gsrc = torch.empty(shape, dtype=torch.float32, device=grad.device)
         check(lib.dgtta_affine_warp3d_bwd(ptr(grad), ptr(theta), ptr(gsrc), b, c, ds, hs, wsz, dd, hd, wd, int(ndhwc), c,
                                           c, pad_mode, int(algebra), stream_of(grad.device)), "dgtta_affine_warp3d_bwd")
         return gsrc, None, None, None, None

@@ -79,9 +79,10 @@ int dgtta_gin_chain_fwd(const float *x, const float *alpha, const int *h_ksz, co
  * theta [B,3,4] fp32 device (x,y,z order of F.affine_grid).  If tta_grid_algebra != 0 the sampling
  * grid is formed as ((affine_grid(theta) - identity) + identity) in fp32, as tta.py:523-548 does.
  * src [B,C,Ds,Hs,Ws] / dst [B,C,Dd,Hd,Wd], layout NCDHW (ndhwc=0) or NDHWC with row lengths
- * src_ldc/dst_ldc.  fp32 only.  add_const is added to every output sample (get_batch's "+ img_min").
- * bwd: grad_src += d(dst)/d(src)^T grad_dst (linear only; theta gets no gradient, as in the
- * reference where R is a constant).  grad_src must be zero-initialised by the caller.
+ * src_ldc/dst_ldc.  fp32 only.  If sub_const_dev != NULL the scalar it points to is subtracted
+ * before and added back after sampling (get_batch's "(img - img_min) ... + img_min", torch_utils.py:55-73).
+ * bwd: grad_src = d(dst)/d(src)^T grad_dst (linear only; theta gets no gradient, as in the
+ * reference where R is a constant).  grad_src is overwritten; it needs no initialisation.
  * ------------------------------------------------------------------------------------------- */
 int dgtta_affine_warp3d_fwd(const float *src, const float *theta, float *dst, int B, int C, int Ds, int Hs,
                             int Ws, int Dd, int Hd, int Wd, int ndhwc, int src_ldc, int dst_ldc, int pad_mode,

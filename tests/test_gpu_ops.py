@@ -142,6 +142,38 @@ def test_warp_backward_matches_autograd():
         _close(xd.grad, x.grad, atol=5e-5, what=f"warp bwd cl={cl}")
 
 
+@pytest.mark.parametrize("case", ["strong", "resize", "odd_channels", "singular", "minify", "border"])
+def test_warp_backward_general_maps(case):
+    """adjoint of the sampler for maps beyond the near-identity TTA case: owner-computes gather path, the atomic
+    fallback it defers to (singular / strongly minifying maps) and border padding; torch fp32 autograd reference."""
+    import torch.nn.functional as F
+    from dg_tta_amd import ops
+    torch.manual_seed(11)
+    c, src, dst, pad = 8, (10, 12, 14), (10, 12, 14), "zeros"
+    theta = torch.eye(3, 4)[None] + 0.3 * torch.randn(1, 3, 4)
+    if case == "resize":
+        dst = (7, 16, 9)
+    elif case == "odd_channels":
+        c = 5
+    elif case == "singular":
+        theta[0, 1] = 0.0
+    elif case == "minify":
+        theta = torch.eye(3, 4)[None] * 0.05
+    elif case == "border":
+        pad = "border"
+    x = torch.randn(1, c, *src, requires_grad=True)
+    gy = torch.randn(1, c, *dst)
+    grid = F.affine_grid(theta, [1, c, *dst], align_corners=False)
+    F.grid_sample(x, grid, mode="bilinear", padding_mode=pad, align_corners=False).backward(gy)
+    for cl in (False, True):
+        xd = x.detach().to(DEV)
+        if cl:
+            xd = xd.contiguous(memory_format=torch.channels_last_3d)
+        xd.requires_grad_(True)
+        ops.affine_warp(xd, theta.to(DEV), out_size=dst, padding_mode=pad).backward(gy.to(DEV))
+        _close(xd.grad, x.grad, atol=1e-4, what=f"warp bwd {case} cl={cl}")
+
+
 def test_get_batch_golden():
     from dg_tta_amd.tta.torch_utils import get_batch
     g = load_golden("get_batch")

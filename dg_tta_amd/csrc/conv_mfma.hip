@@ -247,10 +247,10 @@ __global__ __launch_bounds__(NW * 64) void conv3_mfma_kernel(const T *__restrict
         const int g = 2 * ks + h;
         uint4 bf[NB];
 #pragma unroll
-        for (int j = 0; j < NB; ++j) bf[j] = sB[(tb * NG + g) * NC + j * 32 + r];
+        for (int j = 0; j < NB; ++j) bf[j] = (ABL == 7) ? make_uint4(tap, j, tid, 1) : sB[(tb * NG + g) * NC + j * 32 + r];
 #pragma unroll
         for (int i = 0; i < MPW; ++i) {
-          const uint4 af = (ABL == 6) ? make_uint4(tap, i, tid, 0) : sA[g * NV + a_off[i] + tap_off];
+          const uint4 af = (ABL == 6 || ABL == 7) ? make_uint4(tap, i, tid, 0) : sA[g * NV + a_off[i] + tap_off];
 #pragma unroll
           for (int j = 0; j < NB; ++j) {
             if (ABL == 3) acc[i][j][0] += __uint_as_float(af.x ^ bf[j].x);
@@ -329,14 +329,15 @@ int launch_conv(const void *x, const View &xv, const void *w, const ConvClasses 
   typedef typename Cfg::G G;
   static bool attr_set = false;
   auto kern = conv3_mfma_kernel<T, MBW, MBH, MBD, S, NB, KSPC, 0, NW>;
-  if (MBW == 32 && S == 1 && NW == 4) {
+  if (MBW == 32 && S == 1 && NW == 8) {
     static const char *abl = getenv("DGTTA_CONV_ABL");      // diagnostic only
-    if (abl && abl[0] == '1') kern = conv3_mfma_kernel<T, MBW, MBH, MBD, S, NB, KSPC, 1>;
-    if (abl && abl[0] == '2') kern = conv3_mfma_kernel<T, MBW, MBH, MBD, S, NB, KSPC, 2>;
-    if (abl && abl[0] == '3') kern = conv3_mfma_kernel<T, MBW, MBH, MBD, S, NB, KSPC, 3>;
-    if (abl && abl[0] == '4') kern = conv3_mfma_kernel<T, MBW, MBH, MBD, S, NB, KSPC, 4>;
-    if (abl && abl[0] == '5') kern = conv3_mfma_kernel<T, MBW, MBH, MBD, S, NB, KSPC, 5>;
-    if (abl && abl[0] == '6') kern = conv3_mfma_kernel<T, MBW, MBH, MBD, S, NB, KSPC, 6>;
+    if (abl && abl[0] == '1') kern = conv3_mfma_kernel<T, MBW, MBH, MBD, S, NB, KSPC, 1, NW>;
+    if (abl && abl[0] == '2') kern = conv3_mfma_kernel<T, MBW, MBH, MBD, S, NB, KSPC, 2, NW>;
+    if (abl && abl[0] == '3') kern = conv3_mfma_kernel<T, MBW, MBH, MBD, S, NB, KSPC, 3, NW>;
+    if (abl && abl[0] == '4') kern = conv3_mfma_kernel<T, MBW, MBH, MBD, S, NB, KSPC, 4, NW>;
+    if (abl && abl[0] == '5') kern = conv3_mfma_kernel<T, MBW, MBH, MBD, S, NB, KSPC, 5, NW>;
+    if (abl && abl[0] == '6') kern = conv3_mfma_kernel<T, MBW, MBH, MBD, S, NB, KSPC, 6, NW>;
+    if (abl && abl[0] == '7') kern = conv3_mfma_kernel<T, MBW, MBH, MBD, S, NB, KSPC, 7, NW>;
     if (abl) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)Cfg::LDS_BYTES);
   }
@@ -352,6 +353,358 @@ int launch_conv(const void *x, const View &xv, const void *w, const ConvClasses 
   hipLaunchKernelGGL(kern, grid, dim3(NW * 64), Cfg::LDS_BYTES, st, (const T *)x, xv, (const T *)w, cs, bias, (T *)y, yv,
                      Cin, Cout, CinP, CoutP, tW, tH, tD, stats, ntaps_src);
   DG_CHECK_LAUNCH("conv3_mfma_kernel");
+  return DGTTA_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Row-reuse kernel (bf16, stride 1, all 27 taps, W tiles of 32): the LDS-lean variant for the large layers.
+//
+// In the kernel above every MFMA fetches a fresh A fragment from LDS (1.5 ds_read_b128 per MFMA incl. B): with 32
+// output channels the LDS pipe saturates before the matrix cores do.  Here a wave owns a PD x PH patch of output rows
+// (one row = 32 voxels along W = one 32x32 accumulator) and walks the (PD+2) x (PH+2) INPUT rows of its patch: an
+// input-row fragment (one per kw shift) is read once and feeds every (kd,kh) tap whose output row lies in the patch
+// (up to 9 MFMAs per read), and the 27 weight fragments of the K-step live in registers.  PD = PH = 2: 48 A reads + 27
+// B reads per 108 MFMAs (0.7 per MFMA instead of 1.5).
+//   Workgroup: WD x WH waves, tile (PD*WD) x (PH*WH) x 32 voxels x 32 output channels; persistent over a contiguous
+//   range of (spatial tile, channel block) jobs, so the first K-chunk of the next tile is in flight during the last
+//   MFMA phase of the current one.
+//   Staging:   global_load_lds_dwordx4 (no staging registers, no ds_write): A chunk (16 channels) double buffered,
+//   B chunk (27 x 1 KiB, contiguous in the packed image) single buffered -- it is copied to registers at phase start.
+//   Padding voxels read a 16-byte zero constant.
+template <int PD, int PH, int WD, int WH>
+struct RowsCfg {
+  static constexpr int NW = WD * WH, NT = NW * 64;
+  static constexpr int TD = PD * WD, TH = PH * WH, TW = 32;
+  static constexpr int ID = TD + 2, IH = TH + 2, ROW = TW + 2;
+  // A chunk in LDS: one 68-entry block (16 B entries) per input row (dz,hy):
+  //   [0,32) channel group 0, columns 0..31 | [32,64) group 1, columns 0..31 | 64,65 group 0, columns 32,33 | 66,67 group 1
+  // = one full 1-KiB DMA piece + one 4-lane piece per row; all per-piece address arithmetic is scalar.
+  static constexpr int NROW = ID * IH, RB = 68;
+  static constexpr size_t A_BYTES = ((size_t)NROW * RB * 16 + 1023) / 1024 * 1024;
+  static constexpr size_t B_BYTES = 27 * 1024;
+  static constexpr size_t RED_BYTES = (size_t)NW * 32 * 2 * sizeof(float);
+  static constexpr size_t LDS_BYTES = 2 * A_BYTES + B_BYTES + RED_BYTES;
+};
+
+__device__ const uint4 g_zero16 = {0u, 0u, 0u, 0u};
+
+typedef __attribute__((address_space(3))) void lds_void_t;
+
+// LDS-DMA of 16 bytes per lane: lane i's bytes land at lds_addr + 16*i (lds_addr wave-uniform).  Issued from inline asm
+// on purpose: the compiler then keeps no s_waitcnt bookkeeping for it (with the builtin it drains vmcnt(0) before the
+// next ds_read, i.e. before the MFMA phase the copy is meant to overlap); the kernel waits with dma_wait_all() before
+// the barrier that publishes the buffer.  M0 is compiler-reserved, so it is saved and restored in the same statement.
+__device__ __forceinline__ void dma16_to_lds(const void *gsrc, unsigned lds_addr) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(gsrc), "s"(lds_addr)
+               : "memory");
+}
+__device__ __forceinline__ void dma_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// workgroup barrier that orders LDS traffic only: __syncthreads() would also drain vmcnt, i.e. wait for DMA in flight
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+__device__ __forceinline__ unsigned lds_addr_of(const void *p) {
+  return __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_void_t *)p);
+}
+
+template <int PD, int PH, int WD, int WH, int ABL = 0>   // ABL: diagnostic ablation
+__global__ __launch_bounds__(WD *WH * 64) void conv3_rows_kernel(const bf16_t *__restrict__ x, View xv,
+                                                                 const bf16_t *__restrict__ w, Taps taps,
+                                                                 const float *__restrict__ bias, bf16_t *__restrict__ y,
+                                                                 View yv, int Cin, int Cout, int CinP, int tilesW,
+                                                                 int tilesH, int tilesD, int nblkN, int njobs,
+                                                                 double *__restrict__ stats, int ntaps_src) {
+  typedef RowsCfg<PD, PH, WD, WH> Cfg;
+  constexpr int NW = Cfg::NW, IH = Cfg::IH;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char *sAb = smem;                                   // two A buffers
+  unsigned char *sBb = smem + 2 * Cfg::A_BYTES;                // [27][2][32] x 16 B
+  float *red = reinterpret_cast<float *>(smem + 2 * Cfg::A_BYTES + Cfg::B_BYTES);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int wd = wave / WH, wh = wave % WH;
+  const int Di = xv.D, Hi = xv.H, Wi = xv.W, Do = yv.D, Ho = yv.H, Wo = yv.W;
+  const int nk = CinP / 16;
+  const int cin_lim = (Cin + 7) / 8 * 8;
+
+  // contiguous job range of this workgroup; workgroups of one XCD (blockIdx % 8) get neighbouring ranges
+  const int G = gridDim.x;
+  const int lw = (G % 8 == 0) ? (int)(blockIdx.x % 8) * (G / 8) + (int)(blockIdx.x / 8) : (int)blockIdx.x;
+  const int j0 = (int)(((long long)njobs * lw) / G), j1 = (int)(((long long)njobs * (lw + 1)) / G);
+  const int nph = (j1 - j0) * nk;
+  if (nph == 0) return;
+
+  struct Job {
+    int b, n0, od0, oh0, ow0, tile;
+  };
+  auto decode = [&](int j) {
+    Job q;
+    const int td = j % tilesD;
+    j /= tilesD;
+    const int nb = j % nblkN;
+    j /= nblkN;
+    const int th = j % tilesH;
+    j /= tilesH;
+    const int tw = j % tilesW;
+    q.b = j / tilesW;
+    q.n0 = nb * 32;
+    q.od0 = td * Cfg::TD;
+    q.oh0 = th * Cfg::TH;
+    q.ow0 = tw * 32;
+    q.tile = (tw * tilesH + th) * tilesD + td;
+    return q;
+  };
+
+  // source taps of the B pieces this wave copies (read from the kernel arguments before any DMA is in flight)
+  int my_wt[(27 + NW - 1) / NW];
+#pragma unroll
+  for (int i = 0; i < (27 + NW - 1) / NW; ++i) {
+    const int tap = wave + i * NW;
+    my_wt[i] = __builtin_amdgcn_readfirstlane(tap < 27 ? (int)taps.wt[tap] : -1);
+  }
+
+  // DMA of K-chunk kc of job q into A buffer `buf` and the B buffer, one piece per call: this wave's share is NPR input
+  // rows (main + tail piece each) then NPB B pieces.  Issued one at a time between MFMA groups: a burst of all pieces
+  // blocks the issuing wave until the memory pipeline has absorbed them (measured: half of the kernel's cycles).
+  constexpr int NPR = (Cfg::NROW + NW - 1) / NW, NPB = (27 + NW - 1) / NW, NPIECE = 2 * NPR + NPB;
+  // lane roles inside a piece: main = (group lane>>5, column lane&31); tail (lanes 0..3) = (group lane>>1, column 32 + lane&1)
+  const int m_g = lane >> 5, m_wx = lane & 31, t_g = (lane >> 1) & 1, t_wx = 32 + (lane & 1);
+  auto issue_piece = [&](const Job &q, int kc, int buf, int i) {
+    if (i < 2 * NPR) {
+      const int row = wave + (i >> 1) * NW;          // wave-uniform
+      const bool tail = i & 1;
+      if (row < Cfg::NROW && (!tail || lane < 4)) {
+        const int dz = row / IH, hy = row % IH;
+        const int gd = q.od0 - 1 + dz, gh = q.oh0 - 1 + hy;
+        const int g = tail ? t_g : m_g, gw = q.ow0 - 1 + (tail ? t_wx : m_wx);
+        const int c = kc * 16 + g * 8;
+        const bool ok = (unsigned)gd < (unsigned)Di && (unsigned)gh < (unsigned)Hi && (unsigned)gw < (unsigned)Wi &&
+                        c < cin_lim;
+        const bf16_t *rowp = x + (long long)q.b * xv.sb + gd * xv.sd + gh * xv.sh;      // scalar part
+        const void *src = ok ? (const void *)(rowp + gw * xv.sw + c) : (const void *)&g_zero16;
+        if (ABL == 1 || ABL == 4) return;
+        dma16_to_lds(src, lds_addr_of(sAb + (size_t)buf * Cfg::A_BYTES + (row * Cfg::RB + (tail ? 64 : 0)) * 16));
+      }
+    } else {
+      const int tap = wave + (i - 2 * NPR) * NW;
+      if (tap < 27) {
+        const int wt = my_wt[i - 2 * NPR];
+        const void *src = wt >= 0 ? (const void *)(w + ((((long long)(q.n0 / 32) * nk + kc) * ntaps_src + wt) * 64 + lane) * 8)
+                                  : (const void *)&g_zero16;
+        if (ABL == 1 || ABL == 5) return;
+        dma16_to_lds(src, lds_addr_of(sBb + tap * 1024));
+      }
+    }
+  };
+
+  f32x16_t acc[PD][PH];
+  // this lane's A read bases (16-byte entries) for the three kw shifts: patch origin row block + entry of column r + kw
+  int abase[3];
+#pragma unroll
+  for (int kw = 0; kw < 3; ++kw) {
+    const int col = r + kw;
+    abase[kw] = ((wd * PD) * IH + wh * PH) * Cfg::RB + (col < 32 ? h * 32 + col : 64 + h * 2 + (col - 32));
+  }
+
+  Job cur = decode(j0);
+  float bv = 0.f;
+#pragma unroll
+  for (int i = 0; i < NPIECE; ++i) issue_piece(cur, 0, 0, i);
+  int kc = 0, jn = j0;
+  unsigned long long tseg[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = 0;     // ABL 6: cycle stamps per segment (diagnostic)
+  auto stamp = [&](int k) {
+    if (ABL == 6) {
+      __builtin_amdgcn_sched_barrier(0);
+      const unsigned long long t = __builtin_amdgcn_s_memtime();
+      __builtin_amdgcn_sched_barrier(0);
+      tseg[k] += t - tprev;
+      tprev = t;
+    }
+  };
+  if (ABL == 6) tprev = __builtin_amdgcn_s_memtime();
+  for (int p = 0; p < nph; ++p) {
+    dma_wait_all();
+    stamp(0);                 // waiting for the DMA
+    lds_barrier();            // chunk p has landed; every wave is done with phase p-1
+    uint4 breg[27];
+    {
+      const uint4 *sB = reinterpret_cast<const uint4 *>(sBb);
+#pragma unroll
+      for (int t = 0; t < 27; ++t) breg[t] = sB[t * 64 + lane];
+    }
+    if (kc == 0) {            // bias of this job, fetched while no DMA is in flight (its wait would drain them)
+      const int co = cur.n0 + r;
+      bv = (bias && co < Cout) ? bias[co] : 0.f;
+      asm volatile("" ::"v"(bv));
+    }
+    lds_barrier();            // B buffer is free again
+    stamp(1);                 // barrier + B fragments + barrier
+    // prefetch the next phase (next K-chunk of this job, or chunk 0 of the next job)
+    Job nxt = cur;
+    int kn = kc + 1;
+    if (kn == nk) {
+      kn = 0;
+      if (p + 1 < nph) nxt = decode(jn + 1);
+    }
+    const bool more = p + 1 < nph;
+    stamp(2);
+
+    if (kc == 0) {
+#pragma unroll
+      for (int i = 0; i < PD; ++i)
+#pragma unroll
+        for (int j = 0; j < PH; ++j)
+#pragma unroll
+          for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
+    }
+    {
+      const uint4 *sA = reinterpret_cast<const uint4 *>(sAb + (size_t)(p & 1) * Cfg::A_BYTES);
+#pragma unroll
+      for (int dz = 0; dz < PD + 2; ++dz)
+#pragma unroll
+        for (int hy = 0; hy < PH + 2; ++hy)
+#pragma unroll
+          for (int kw = 0; kw < 3; ++kw) {
+            const uint4 af = sA[abase[kw] + (dz * IH + hy) * Cfg::RB];
+            {   // spread this wave's DMA pieces of the next chunk evenly over the A-read steps
+              constexpr int NSTEP = (PD + 2) * (PH + 2) * 3;
+              const int step = (dz * (PH + 2) + hy) * 3 + kw;
+#pragma unroll
+              for (int i = 0; i < NPIECE; ++i)
+                if (step == (i * NSTEP) / NPIECE + 1 && more) issue_piece(nxt, kn, (p + 1) & 1, i);
+            }
+#pragma unroll
+            for (int kd = 0; kd < 3; ++kd)
+#pragma unroll
+              for (int kh = 0; kh < 3; ++kh) {
+                const int od = dz - kd, oh = hy - kh;
+                if (od >= 0 && od < PD && oh >= 0 && oh < PH) {
+                  if (ABL == 3) acc[od][oh][0] += __uint_as_float(af.x ^ breg[(kd * 3 + kh) * 3 + kw].x);
+                  else mfma_step<bf16_t>(af, breg[(kd * 3 + kh) * 3 + kw], acc[od][oh]);
+                }
+              }
+          }
+    }
+
+    stamp(3);                 // MFMA loop
+    if (kc == nk - 1) {
+      // ---- epilogue of job `cur`: bias, convert, transpose through LDS (this phase's A buffer, one 8-KiB slab per
+      //      wave) so that a lane stores 16 bytes = 8 channels of a voxel; optional per-channel sum / sum of squares of
+      //      the unrounded values for the following InstanceNorm
+      float st1 = 0.f, st2 = 0.f;
+      lds_barrier();          // every wave has finished reading this phase's A buffer
+      stamp(5);               // (diagnostic) barrier skew
+      // lane-derived epilogue indices are rebuilt from a laundered lane id: otherwise the compiler hoists them out of
+      // the phase loop, keeps them live across the MFMA phase and spills (a scratch reload's wait drains the DMA)
+      int le = lane;
+      asm volatile("" : "+v"(le));
+      const int re = le & 31, he = le >> 5;
+      const int co = cur.n0 + re;
+      bf16_t *slab = reinterpret_cast<bf16_t *>(sAb + (size_t)(p & 1) * Cfg::A_BYTES) + wave * (PD * PH * 1024);
+#pragma unroll
+      for (int i = 0; i < PD; ++i)
+#pragma unroll
+        for (int j = 0; j < PH; ++j) {
+          const int od = cur.od0 + wd * PD + i, oh = cur.oh0 + wh * PH + j;
+          const bool row_ok = od < Do && oh < Ho;
+#pragma unroll
+          for (int q = 0; q < 16; ++q) {
+            const int m = (q & 3) + 8 * (q >> 2) + 4 * he;
+            const float v = acc[i][j][q] + bv;
+            slab[(i * PH + j) * 1024 + m * 32 + re] = f32_to_bf16(v);
+            if (row_ok && co < Cout && cur.ow0 + m < Wo) {
+              st1 += v;
+              st2 += v * v;
+            }
+          }
+        }
+      stamp(6);               // (diagnostic) convert + slab writes
+      // (a wave reads back only its own slab: LDS operations of one wave complete in order)
+#pragma unroll
+      for (int i = 0; i < PD; ++i)
+#pragma unroll
+        for (int j = 0; j < PH; ++j) {
+          const int od = cur.od0 + wd * PD + i, oh = cur.oh0 + wh * PH + j;
+          bf16_t *orow = y + (long long)cur.b * yv.sb + od * yv.sd + oh * yv.sh + cur.n0;
+#pragma unroll
+          for (int t = 0; t < 2; ++t) {
+            const int m = t * 16 + (le >> 2), cq = (le & 3) * 8;
+            const uint4 val = *reinterpret_cast<const uint4 *>(slab + (i * PH + j) * 1024 + m * 32 + cq);
+            const int ow = cur.ow0 + m;
+            if (ABL != 2 && od < Do && oh < Ho && ow < Wo && cur.n0 + cq < Cout)
+              *reinterpret_cast<uint4 *>(orow + ow * yv.sw + cq) = val;
+          }
+        }
+      stamp(7);               // (diagnostic) slab reads + global stores
+      if (stats) {
+        const float a = st1 + __shfl_xor(st1, 32, 64), c2 = st2 + __shfl_xor(st2, 32, 64);
+        if (he == 0) {
+          red[(wave * 32 + re) * 2 + 0] = a;
+          red[(wave * 32 + re) * 2 + 1] = c2;
+        }
+        lds_barrier();
+        const int tiles_per_b = tilesW * tilesH * tilesD;
+        if (tid < 32 && cur.n0 + tid < Cout) {
+          double s = 0.0, ss = 0.0;
+#pragma unroll
+          for (int wv = 0; wv < NW; ++wv) {
+            s += (double)red[(wv * 32 + tid) * 2 + 0];
+            ss += (double)red[(wv * 32 + tid) * 2 + 1];
+          }
+          double *pp = stats + 32 + (((int64_t)cur.b * tiles_per_b + cur.tile) * Cout + cur.n0 + tid) * 2;
+          pp[0] = s;
+          pp[1] = ss;
+        }
+        if (lw == 0 && tid == 0 && p == nk - 1) reinterpret_cast<long long *>(stats)[0] = tiles_per_b;
+      }
+    }
+    stamp(4);                 // epilogue
+    kc = kn;
+    if (kn == 0) {
+      cur = nxt;
+      ++jn;
+    }
+  }
+  if (ABL == 6 && stats && lane == 0) {
+    for (int k = 0; k < 8; ++k) stats[4096 + ((size_t)blockIdx.x * NW + wave) * 8 + k] = (double)tseg[k];
+  }
+}
+
+template <int PD, int PH, int WD, int WH>
+int launch_conv_rows(const void *x, const View &xv, const void *w, const Taps &taps, const float *bias, void *y,
+                     const View &yv, int B, int Cin, int Cout, int CinP, int CoutP, double *stats, int ntaps_src,
+                     hipStream_t st) {
+  typedef RowsCfg<PD, PH, WD, WH> Cfg;
+  auto kern = conv3_rows_kernel<PD, PH, WD, WH>;
+  static const char *abl = getenv("DGTTA_ROWS_ABL");      // diagnostic only
+  if (abl && abl[0] == '1') kern = conv3_rows_kernel<PD, PH, WD, WH, 1>;
+  if (abl && abl[0] == '2') kern = conv3_rows_kernel<PD, PH, WD, WH, 2>;
+  if (abl && abl[0] == '3') kern = conv3_rows_kernel<PD, PH, WD, WH, 3>;
+  if (abl && abl[0] == '4') kern = conv3_rows_kernel<PD, PH, WD, WH, 4>;
+  if (abl && abl[0] == '5') kern = conv3_rows_kernel<PD, PH, WD, WH, 5>;
+  if (abl && abl[0] == '6') kern = conv3_rows_kernel<PD, PH, WD, WH, 6>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)Cfg::LDS_BYTES);
+    DG_REQUIRE(e == hipSuccess, DGTTA_ERR_LAUNCH, "conv3_rows: cannot raise the dynamic LDS limit to %zu", Cfg::LDS_BYTES);
+    attr_set = true;
+  }
+  const int tW = cdiv(yv.W, 32), tH = cdiv(yv.H, Cfg::TH), tD = cdiv(yv.D, Cfg::TD), nblkN = cdiv(CoutP, 32);
+  const long long njobs = (long long)tW * tH * tD * nblkN * B;
+  DG_REQUIRE(njobs < (1ll << 31), DGTTA_ERR_UNSUPPORTED, "conv3_rows: too many tiles");
+  static int ncu = [] {
+    int dev = 0, n = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+    return n > 0 ? n : 256;
+  }();
+  const int wg_per_cu = (int)((160 * 1024) / Cfg::LDS_BYTES) > 0 ? (int)((160 * 1024) / Cfg::LDS_BYTES) : 1;
+  const int grid = (int)(njobs < (long long)ncu * wg_per_cu ? njobs : (long long)ncu * wg_per_cu);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(Cfg::NT), Cfg::LDS_BYTES, st, (const bf16_t *)x, xv, (const bf16_t *)w, taps,
+                     bias, (bf16_t *)y, yv, Cin, Cout, CinP, tW, tH, tD, nblkN, (int)njobs, stats, ntaps_src);
+  DG_CHECK_LAUNCH("conv3_rows_kernel");
   return DGTTA_OK;
 }
 
@@ -399,6 +752,19 @@ int dispatch_conv_classes(const void *x, const View &xv, const void *w, const Co
     if (yv.W >= 16) return launch_conv<T, 16, 4, 4, 0, 1, 1, 8>(ARGS);
     if (vox <= 4096) return launch_conv<T, 8, 2, 2, 0, 1, 1>(ARGS);
     return launch_conv<T, 8, 2, 8, 0, 1, 1, 8>(ARGS);
+  }
+  if (stride == 1 && sizeof(T) == 2 && yv.W >= 32 && cs.n == 1 && cs.acc[0] == 0 && cs.kseg == 0 && cs.xoff[0] == 0 &&
+      cs.yoff[0] == 0) {
+    const char *rows = getenv("DGTTA_CONV_ROWS");   // diagnostic / tests: "0" forces the generic kernel, "1" this one
+    bool all_taps = true;
+    for (int t = 0; t < 27; ++t) all_taps = all_taps && cs.taps[0].wt[t] >= 0;
+    const bool vec_out = Cout % 8 == 0 && ((uintptr_t)y & 15) == 0 && yv.sw % 8 == 0 && yv.sh % 8 == 0 &&
+                         yv.sd % 8 == 0 && yv.sb % 8 == 0;
+    // enough (tile, channel block) jobs to fill the chip with one persistent workgroup per CU; below that the generic kernel wins
+    const long long njobs = (long long)cdiv(yv.W, 32) * cdiv(yv.H, 8) * cdiv(yv.D, 4) * cdiv(CoutP, 32) * B;
+    if (all_taps && vec_out && (njobs >= 256 || (rows && rows[0] == '1')) && !(rows && rows[0] == '0'))
+      return launch_conv_rows<2, 2, 2, 4>(x, xv, w, cs.taps[0], bias, y, yv, B, Cin, Cout, CinP, CoutP, stats, ntaps_src,
+                                          st);
   }
   if (stride == 1) {
     static const char *var = getenv("DGTTA_CONV_VARIANT");      // diagnostic: tile-shape experiments

@@ -79,6 +79,61 @@ def test_conv_mfma_bf16(case):
     assert (y.float() - y_valu.float()).abs().max() < 1.0 / 64 * y_ref.abs().max() + 1e-3
 
 
+ROWS_CASES = [  # (B, cin, cout, D, H, W): ragged tiles, several channel blocks / K-chunks, batch 2, concat-style strides
+    (1, 32, 32, 9, 13, 45), (2, 16, 64, 5, 17, 32), (1, 64, 96, 8, 8, 70), (1, 8, 32, 4, 8, 33),
+]
+
+
+@pytest.mark.parametrize("case", ROWS_CASES)
+def test_conv_rows_kernel_bf16(case, monkeypatch):
+    """The persistent row-reuse kernel (LDS-DMA staging), forced on at small sizes, against the generic MFMA kernel
+    and the fp32 VALU kernel on the same bf16 operands: forward with fused InstanceNorm statistics, and data gradient."""
+    from dg_tta_amd import _lib
+    from dg_tta_amd._lib import check, ptr, stream_of
+    lib = _lib.load()
+    B, cin, cout, D, H, W = case
+    torch.manual_seed(sum(case) + 7)
+    xb = torch.randn(B, D, H, W, cin, device=DEV).bfloat16()
+    w = (torch.randn(cout, cin, 3, 3, 3, device=DEV) / (27 * cin) ** 0.5).bfloat16().float()
+    bias = torch.randn(cout, device=DEV)
+    cinp, coutp = (cin + 15) // 16 * 16, (cout + 15) // 16 * 16
+    y_ref, _ = _call_fwd(xb.float(), w, bias, 1, 0, 1, (cin + 7) // 8 * 8, (cout + 7) // 8 * 8)
+
+    def run(rows):
+        monkeypatch.setenv("DGTTA_CONV_ROWS", rows)
+        wpack = torch.empty(lib.dgtta_conv3d_packed_bytes(cinp, coutp, 1) // 2, dtype=torch.bfloat16, device=DEV)
+        check(lib.dgtta_conv3d_pack_weights(ptr(w), ptr(wpack), cin, cout, cinp, coutp, 1, stream_of()), "pack")
+        y = torch.full((B, D, H, W, cout), float("nan"), dtype=torch.bfloat16, device=DEV)
+        nb = lib.dgtta_conv3d_stats_bytes(B, cout, D, H, W)
+        st = torch.zeros(nb, dtype=torch.uint8, device=DEV)
+        check(lib.dgtta_conv3d_k3_fwd(ptr(xb), cin, ptr(wpack), ptr(bias), ptr(y), cout, ptr(st), B, cin, cout, cinp, coutp,
+                                      D, H, W, 1, 1, 2, stream_of()), "fwd")
+        mr = torch.empty(B, cout, 2, device=DEV)
+        z = torch.empty_like(y)
+        gamma, beta = torch.ones(cout, device=DEV), torch.zeros(cout, device=DEV)
+        nws = lib.dgtta_instnorm_ws_bytes(B, cout, D * H * W)
+        ws = torch.empty(nws, dtype=torch.uint8, device=DEV)
+        check(lib.dgtta_instnorm_lrelu_fwd(ptr(y), cout, ptr(st), ptr(gamma), ptr(beta), ptr(mr), ptr(z), cout, ptr(ws), nws,
+                                           B, cout, D * H * W, 1e-5, 0.01, 1, stream_of()), "instnorm")
+        mean, rstd = mr[..., 0].reshape(-1).clone(), mr[..., 1].reshape(-1).clone()
+        dy = torch.randn(B, D, H, W, cout, device=DEV, generator=torch.Generator(DEV).manual_seed(3)).bfloat16()
+        dx = _call_dgrad(dy, wpack, cin, cinp, coutp, (D, H, W), 1, 1, 2)
+        torch.cuda.synchronize()
+        return y, mean, rstd, dx
+
+    y0, m0, r0, dx0 = run("0")
+    y1, m1, r1, dx1 = run("1")
+    scale = y_ref.abs().max()
+    assert torch.isfinite(y1.float()).all()
+    assert (y1.float() - y_ref).abs().max() < scale / 128 + 1e-3
+    assert (y1.float() - y0.float()).abs().max() < scale / 128 + 1e-3          # both round the same fp32 sums to bf16
+    ref_mean = y_ref.reshape(B, -1, cout).mean(1).reshape(-1)
+    ref_rstd = (y_ref.reshape(B, -1, cout).var(1, unbiased=False) + 1e-5).rsqrt().reshape(-1)
+    assert (m1 - ref_mean).abs().max() < 1e-4 and (m1 - m0).abs().max() < 1e-5
+    assert ((r1 - ref_rstd) / ref_rstd).abs().max() < 1e-4 and ((r1 - r0) / r0).abs().max() < 1e-5
+    assert (dx1.float() - dx0.float()).abs().max() < dx0.float().abs().max() / 128 + 1e-3
+
+
 def test_conv_mfma_timing_report(capsys):
     """Not a pass/fail perf gate: prints achieved TFLOP/s of the main layer shapes (read in gpurun logs)."""
     from dg_tta_amd import _lib

@@ -14,7 +14,11 @@ if what == "conv":
     wpack = torch.empty(lib.dgtta_conv3d_packed_bytes(cin, cout, dt) // (2 if dt else 4), dtype=tdt, device=DEV)
     check(lib.dgtta_conv3d_pack_weights(ptr(w), ptr(wpack), cin, cout, cin, cout, dt, stream_of()), "pack")
     y = torch.empty((1, n, n, n, cout), dtype=tdt, device=DEV)
-    run = lambda: check(lib.dgtta_conv3d_k3_fwd(ptr(x), cin, ptr(wpack), None, ptr(y), cout, None, 1, cin, cout, cin, cout, n, n, n, 1, dt, 2, stream_of()), "fwd")
+    import os
+    st = None
+    if os.environ.get("KB_STATS"):
+        st = torch.zeros(lib.dgtta_conv3d_stats_bytes(1, cout, n, n, n), dtype=torch.uint8, device=DEV)
+    run = lambda: check(lib.dgtta_conv3d_k3_fwd(ptr(x), cin, ptr(wpack), None, ptr(y), cout, ptr(st) if st is not None else None, 1, cin, cout, cin, cout, n, n, n, 1, dt, 2, stream_of()), "fwd")
 else:
     dy = torch.randn(1, n, n, n, cout, device=DEV).to(tdt)
     dw = torch.empty((cout, cin, 3, 3, 3), device=DEV)

@@ -394,21 +394,37 @@ __global__ __launch_bounds__(256) void in_apply_vec_kernel(const T *__restrict__
   }
 }
 
-// InstanceNorm statistics finalize: mean, rstd = 1/sqrt(biased var + eps).  One wave per (b,c); the number of
+// sum of two doubles over a 256-thread workgroup (fixed order: lanes by butterfly, then waves 0..3); result in all threads
+__device__ __forceinline__ void block_sum2_d(double &a, double &b, double *red /* >= 8 doubles of LDS */) {
+  a = wave_sum_d(a);
+  b = wave_sum_d(b);
+  const int w = threadIdx.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) {
+    red[2 * w] = a;
+    red[2 * w + 1] = b;
+  }
+  __syncthreads();
+  a = (red[0] + red[2]) + (red[4] + red[6]);
+  b = (red[1] + red[3]) + (red[5] + red[7]);
+}
+
+
+// InstanceNorm statistics finalize: mean, rstd = 1/sqrt(biased var + eps).  One 256-thread workgroup per (b,c); the number of
 // partial blocks is read from the device-side header when hdr != NULL (statistics produced by the conv epilogue).
 __global__ void in_stats_finalize_kernel(const double *__restrict__ partial, const long long *__restrict__ hdr, int nblk_h,
                                          int B, int C, int64_t V, float eps, float *__restrict__ mean_rstd) {
   const int i = blockIdx.x;
   const int b = i / C, c = i % C;
   const int nblk = hdr ? (int)hdr[0] : nblk_h;
+  __shared__ double red[8];
   double s = 0.0, ss = 0.0;
-  for (int k = threadIdx.x; k < nblk; k += 64) {
-    const double *p = partial + ((((int64_t)b * nblk + k) * C) + c) * 2;
-    s += p[0];
-    ss += p[1];
+  for (int k = threadIdx.x; k < nblk; k += 256) {
+    const double2 v = *reinterpret_cast<const double2 *>(partial + ((((int64_t)b * nblk + k) * C) + c) * 2);
+    s += v.x;
+    ss += v.y;
   }
-  s = wave_sum_d(s);
-  ss = wave_sum_d(ss);
+  block_sum2_d(s, ss, red);
   if (threadIdx.x == 0) {
     const double mean = s / (double)V;
     double var = ss / (double)V - mean * mean;
@@ -436,21 +452,21 @@ __global__ void in_lrelu_apply_kernel(const T *__restrict__ y, int ldy, const fl
 }
 
 // backward finalize: c1 = mean(da), c2 = mean(da*xhat); dgamma (+)= sum_b sum(da*xhat); dbeta (+)= sum_b sum(da).
-// one wave per channel
+// one 256-thread workgroup per channel
 __global__ void in_bwd_finalize_kernel(const double *__restrict__ partial, int nblk, int B, int C, int64_t V,
                                        float *__restrict__ c12, float *__restrict__ dgamma, float *__restrict__ dbeta,
                                        int accumulate) {
   const int c = blockIdx.x;
+  __shared__ double red[8];
   double g_acc = 0.0, b_acc = 0.0;
   for (int b = 0; b < B; ++b) {
     double s0 = 0.0, s1 = 0.0;
-    for (int k = threadIdx.x; k < nblk; k += 64) {
-      const double *p = partial + ((((int64_t)b * nblk + k) * C) + c) * 2;
-      s0 += p[0];
-      s1 += p[1];
+    for (int k = threadIdx.x; k < nblk; k += 256) {
+      const double2 v = *reinterpret_cast<const double2 *>(partial + ((((int64_t)b * nblk + k) * C) + c) * 2);
+      s0 += v.x;
+      s1 += v.y;
     }
-    s0 = wave_sum_d(s0);
-    s1 = wave_sum_d(s1);
+    block_sum2_d(s0, s1, red);
     if (threadIdx.x == 0) {
       c12[((int64_t)b * C + c) * 2] = (float)(s0 / (double)V);
       c12[((int64_t)b * C + c) * 2 + 1] = (float)(s1 / (double)V);
@@ -719,8 +735,9 @@ int gs_blocks(int64_t total, int cap = 16384) {
   return (int)(b < cap ? (b > 0 ? b : 1) : cap);
 }
 
+// per-channel reductions: >= 32 rows per block, at most 2048 blocks (small volumes used to run on 1-4 workgroups)
 int reduce_blocks(int64_t V) {
-  int64_t b = cdiv64(V, 1024);
+  int64_t b = cdiv64(V, 32);
   return (int)(b < 2048 ? (b > 0 ? b : 1) : 2048);
 }
 
@@ -954,13 +971,13 @@ extern "C" int dgtta_instnorm_lrelu_fwd(const void *y, int ldy, const void *stat
   hipStream_t st = (hipStream_t)stream;
   const int nblk = reduce_blocks(V);
   if (stats) {   // partial sums came with the conv epilogue (header + partials)
-    hipLaunchKernelGGL(in_stats_finalize_kernel, dim3(B * C), dim3(64), 0, st, (const double *)stats + 32,
+    hipLaunchKernelGGL(in_stats_finalize_kernel, dim3(B * C), dim3(256), 0, st, (const double *)stats + 32,
                        (const long long *)stats, 0, B, C, V, eps, mean_rstd);
   } else {
     double *partial = (double *)ws;
     DISPATCH_T(dtype, (launch_chan_reduce<T, 0>(y, ldy, nullptr, 0, nullptr, nullptr, nullptr, 0.f, partial, nblk, B, C, V, st)));
     DG_CHECK_LAUNCH("chan_reduce_kernel<0>");
-    hipLaunchKernelGGL(in_stats_finalize_kernel, dim3(B * C), dim3(64), 0, st, (const double *)partial,
+    hipLaunchKernelGGL(in_stats_finalize_kernel, dim3(B * C), dim3(256), 0, st, (const double *)partial,
                        (const long long *)nullptr, nblk, B, C, V, eps, mean_rstd);
   }
   DG_CHECK_LAUNCH("in_stats_finalize_kernel");
@@ -996,7 +1013,7 @@ extern "C" int dgtta_instnorm_lrelu_bwd(const void *gz, int ldgz, const void *y,
   float *c12 = (float *)((char *)ws + align_up((size_t)B * nblk * C * 2 * sizeof(double), 256));
   DISPATCH_T(dtype, (launch_chan_reduce<T, 1>(y, ldy, gz, ldgz, mean_rstd, gamma, beta, slope, partial, nblk, B, C, V, st)));
   DG_CHECK_LAUNCH("chan_reduce_kernel<1>");
-  hipLaunchKernelGGL(in_bwd_finalize_kernel, dim3(C), dim3(64), 0, st, partial, nblk, B, C, V, c12, dgamma, dbeta,
+  hipLaunchKernelGGL(in_bwd_finalize_kernel, dim3(C), dim3(256), 0, st, partial, nblk, B, C, V, c12, dgamma, dbeta,
                      accumulate);
   DG_CHECK_LAUNCH("in_bwd_finalize_kernel");
   const int64_t total = (int64_t)B * V * C;

@@ -6,7 +6,7 @@ re-normalisation run in the fused HIP kernels of csrc/gin.hip."""
 import torch
 
 from . import ops
-from .utils import get_internal_augmentation_enabled
+from .utils import get_internal_augmentation_enabled, upload_async
 
 N_LAYER, INTERM_CHANNELS, SCALE_POOL = 4, 2, (1, 3)
 
@@ -17,10 +17,11 @@ def draw_gin_params(nb, device):
     ks, kers, shifts = [], [], []
     for cin, cout in zip(chans[:-1], chans[1:]):
         k = SCALE_POOL[int(torch.randint(high=len(SCALE_POOL), size=(1,))[0])]
-        kers.append(torch.randn([cout * nb, cin, k, k, k]).to(device))
-        shifts.append((torch.randn([cout * nb, 1, 1, 1]) * 1.0).to(device))
+        kers.append(torch.randn([cout * nb, cin, k, k, k]))
+        shifts.append(torch.randn([cout * nb, 1, 1, 1]) * 1.0)
         ks.append(k)
-    return alpha, ks, kers, shifts
+    up = upload_async(kers + shifts, device)          # one non-blocking copy for the whole chain
+    return alpha, ks, up[:len(kers)], up[len(kers):]
 
 
 def gin_aug(input):

@@ -6,6 +6,7 @@ from collections import OrderedDict
 import torch
 
 from .. import ops
+from ..utils import upload_async
 
 _VOLUME_CACHE = {}
 
@@ -48,7 +49,7 @@ def get_batch(tensor_list, batch_idxs, patch_size, fixed_patch_idx=None, device=
             offset_range = ((t_shape - t_patch) / t_shape).clip(min=0.0)
             ranged = rand_offset * offset_range
             patch_affine[:, -1] = torch.cat([ranged.flip(0), torch.tensor([1.0])], dim=0)
-        theta = patch_affine[:3][None].float().to(device)
+        theta = upload_async([patch_affine[:3][None].float().contiguous()], device)[0]
         img, mn, lab = _resident(data, device)
         b_img.append(ops.affine_sample(img, theta, patch_size, "zeros", "bilinear", sub_const=mn))
         if lab is None:

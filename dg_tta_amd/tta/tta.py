@@ -23,7 +23,7 @@ from .. import ops
 from ..gin import gin_aug
 from ..optim import HipAdamW
 from ..sharding import owns
-from ..utils import disable_internal_augmentation
+from ..utils import disable_internal_augmentation, upload_async
 from .augmentation_utils import get_rand_affine
 from .config_log_utils import (get_global_idx, get_parameters_save_path, is_template_modifier, plot_run_results)
 from .model_utils import apply_running_stats, buffer_running_stats, get_model_from_network
@@ -76,7 +76,7 @@ def calc_branch(branch_id, config, model, intensity_aug_func, identity_grid, pat
         if spatial:
             if config["spatial_aug_type"] == "affine":
                 R, R_inverse = get_rand_affine(batch_size, flip=False)
-                R, R_inverse = R.to(device), R_inverse.to(device)
+                R, R_inverse = upload_async([R.float().contiguous(), R_inverse.float().contiguous()], device)
             elif config["spatial_aug_type"] == "deformable":
                 from .augmentation_utils import get_disp_field
                 get_disp_field()

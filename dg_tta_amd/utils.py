@@ -2,6 +2,8 @@
 import os
 from pathlib import Path
 
+import torch
+
 
 def enable_internal_augmentation():
     os.environ["DG_TTA_INTERNAL_AUGMENTATION"] = "true"
@@ -35,3 +37,23 @@ def set_environ_vars_from_paths_sh(sh_path):
                 continue
             k, v = line.replace("export", "").split("=", 1)
             os.environ[k.strip()] = v.strip().replace('"', "").replace("'", "")
+
+
+def upload_async(cpu_tensors, device):
+    """Moves a list of small fp32 CPU tensors to `device` with ONE non-blocking copy from pinned staging memory and
+    returns device views of the original shapes.  A plain `.to(device)` from pageable memory blocks the host until the
+    stream reaches the copy, i.e. every per-branch draw (GIN kernels, affine matrices, patch offsets) used to drain the
+    launch queue; the TTA loop makes ~10 of them per branch."""
+    device = torch.device(device)
+    if device.type != "cuda":
+        return [t.to(device) for t in cpu_tensors]
+    sizes = [t.numel() for t in cpu_tensors]
+    offs, total = [], 0
+    for n in sizes:
+        offs.append(total)
+        total += (n + 3) // 4 * 4                      # 16-byte aligned pieces
+    stage = torch.empty(max(total, 1), dtype=torch.float32, pin_memory=True)
+    for t, o, n in zip(cpu_tensors, offs, sizes):
+        stage[o:o + n].copy_(t.reshape(-1))
+    dev = stage.to(device, non_blocking=True)
+    return [dev[o:o + n].view(t.shape) for t, o, n in zip(cpu_tensors, offs, sizes)]

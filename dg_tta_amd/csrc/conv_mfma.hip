@@ -1228,6 +1228,18 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void conv3_wgrad_mfm
 #pragma unroll
   for (int i = 0; i < 27; ++i) acc[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
+  unsigned long long tseg[6] = {0, 0, 0, 0, 0, 0}, tprev = 0;     // ABL 6: cycle stamps per segment (diagnostic)
+  auto stamp = [&](int k) {
+    if (ABL == 6) {
+      __builtin_amdgcn_sched_barrier(0);
+      const unsigned long long t = __builtin_amdgcn_s_memtime();
+      __builtin_amdgcn_sched_barrier(0);
+      tseg[k] += t - tprev;
+      tprev = t;
+    }
+  };
+  if (ABL == 6) tprev = __builtin_amdgcn_s_memtime();
+
   // prologue: x slices d_begin-1, d_begin, d_begin+1 and dy slice d_begin
   load_units(d_begin - 1, true, d_begin, true);
   store_units((d_begin - 1) & 3, true, d_begin & 1, true);
@@ -1236,10 +1248,12 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void conv3_wgrad_mfm
   load_units(d_begin + 1, true, 0, false);
   store_units((d_begin + 1) & 3, true, 0, false);
   __syncthreads();
+  stamp(0);                                   // prologue
 
   for (int d = d_begin; d < d_end; ++d) {
     const bool more = d + 1 < d_end;
     load_units(d + 2, more, d + 1, more);     // in flight during the MFMAs below
+    stamp(1);                                 // load issue
     const uint4 *yb = sY + (d & 1) * C::YSLOT;
 #pragma unroll
     for (int oh = 0; oh < C::TH; ++oh) {
@@ -1269,8 +1283,11 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void conv3_wgrad_mfm
         }
       }
     }
+    stamp(2);                                 // MFMA loop
     store_units((d + 2) & 3, more, (d + 1) & 1, more);
+    stamp(3);                                 // wait for loads + transpose + LDS writes
     __syncthreads();
+    stamp(4);                                 // barrier
   }
 
   // partial slab [27][32 ci][32 co]; C/D map of the 16x16 MFMA: col = lane&15, row = (lane>>4)*4 + reg
@@ -1279,6 +1296,165 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void conv3_wgrad_mfm
   for (int tap = 0; tap < 27; ++tap)
 #pragma unroll
     for (int q = 0; q < 4; ++q) slab[(tap * 32 + cih * 16 + kg * 4 + q) * 32 + coh * 16 + m] = acc[tap][q];
+  if (ABL == 6) {
+    stamp(5);                                 // slab write issue
+    __syncthreads();
+    if (lane == 0)
+      for (int k = 0; k < 6; ++k) slab[27 * 1024 - 64 + wave * 8 + k] = (float)tseg[k];      // overwrites a slab corner
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// bf16 weight gradient with hardware-transposed operand reads (stride 1, all 27 taps).  Same decomposition and slab
+// format as conv3_wgrad_mfma_kernel, but:
+//   * x / dy slices stay VOXEL-major in LDS ([row][voxel][32 channels = 64 B]) and are filled by LDS-DMA
+//     (global_load_lds_dwordx4: 16 voxels x 64 B per instruction, no staging registers, no register transposes, no
+//     ds_write); the K-contiguous MFMA operands (8 consecutive voxels of one channel per lane) come out of
+//     ds_read_b64_tr_b16, so a tap's W shift is an address offset instead of a funnel shift per operand;
+//   * MFMA 32x32x16: a wave owns the whole 32(ci) x 32(co) tile for 7 (or 6) of the 27 taps (tap = wave + 4 i), the dy
+//     fragment of a (row, 16-voxel step) is shared by its taps; per MFMA: 2 transposed reads, ~1 VALU, no shifts.
+// (The predecessor spent its issue slots on funnel shifts and 8x8 register transposes: measured 2.5x the MFMA time.)
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+typedef __attribute__((address_space(3))) s16x4_t lds_s16x4_t;
+
+struct WT {
+  static constexpr int TH = 4, XR = TH + 2;
+  static constexpr int XW = 36;                         // voxels per x row in LDS (34 used)
+  static constexpr int X_ROW_B = XW * 64, X_SLICE_B = XR * X_ROW_B;
+  static constexpr int Y_ROW_B = 32 * 64, Y_SLICE_B = TH * Y_ROW_B;
+  static constexpr int LDS_BYTES = 4 * X_SLICE_B + 2 * Y_SLICE_B;
+  static constexpr int NPX = XR * 3, NPY = TH * 2, NP = NPX + NPY;      // DMA pieces per slice
+};
+
+__device__ __forceinline__ bf16x8_t tr_operand(const unsigned char *p) {
+  // two 4-voxel transposed reads = 8 consecutive voxels (k) of this lane's channel
+  const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t *)p);
+  const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t *)(p + 4 * 64));
+  typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+  const s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(bf16x8_t, v);
+}
+
+template <int ABL = 0>
+__global__ __launch_bounds__(256, 2) void conv3_wgrad_tr_kernel(const bf16_t *__restrict__ x, View xv,
+                                                                const bf16_t *__restrict__ dy, View yv,
+                                                                float *__restrict__ slabs, int Cin, int Cout, int tilesW,
+                                                                int tilesH, int nsd, int DR, int cobs) {
+  const int D = yv.D, H = yv.H, W = yv.W;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char *sX = smem;                                   // ring of 4 x slices
+  unsigned char *sY = smem + 4 * WT::X_SLICE_B;               // ring of 2 dy slices
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+  int t = blockIdx.x;
+  const int tw = t % tilesW;
+  t /= tilesW;
+  const int th = t % tilesH;
+  t /= tilesH;
+  const int ds = t % nsd;
+  const int b = t / nsd;
+  const int cib = blockIdx.y / cobs, cob = blockIdx.y % cobs;
+  const int h0 = th * WT::TH, w0 = tw * 32;
+  const int d_begin = ds * DR, d_end = (d_begin + DR < D) ? d_begin + DR : D;
+  const bf16_t *xb = x + b * xv.sb + cib * 32;
+  const bf16_t *yb = dy + b * yv.sb + cob * 32;
+  const int cin_lim = (Cin + 7) / 8 * 8;
+
+  // DMA of one slice: piece idx (wave-uniform) -> x row r (3 pieces: voxels 0-15, 16-31, 32-33) or dy row (2 pieces);
+  // lane l of a piece = voxel 16*pi + l/4, 16-byte channel chunk l%4
+  const int l_vox = lane >> 2, l_chunk = lane & 3;
+  auto issue_slice = [&](int xd, int xslot, bool do_x, int yd, int yslot, bool do_y) {
+#pragma unroll
+    for (int i = 0; i < (WT::NP + 3) / 4; ++i) {
+      const int idx = wave + 4 * i;
+      if (idx < WT::NPX) {
+        if (!do_x) continue;
+        const int r = idx / 3, pi = idx % 3;
+        if (pi == 2 && lane >= 8) continue;
+        const int gh = h0 - 1 + r, wx = 16 * pi + l_vox, gw = w0 - 1 + wx;
+        const bool ok = (unsigned)xd < (unsigned)xv.D && (unsigned)gh < (unsigned)xv.H && (unsigned)gw < (unsigned)xv.W &&
+                        cib * 32 + l_chunk * 8 < cin_lim;
+        const void *src = ok ? (const void *)(xb + xd * xv.sd + gh * xv.sh + gw * xv.sw + l_chunk * 8) : (const void *)&g_zero16;
+        if (ABL == 1) continue;
+        dma16_to_lds(src, lds_addr_of(sX + xslot * WT::X_SLICE_B + r * WT::X_ROW_B + pi * 1024));
+      } else if (idx < WT::NP) {
+        if (!do_y) continue;
+        const int j = idx - WT::NPX, r = j / 2, pi = j % 2;
+        const int gh = h0 + r, gw = w0 + 16 * pi + l_vox;
+        const bool ok = (unsigned)yd < (unsigned)D && gh < H && gw < W && cob * 32 + l_chunk * 8 < Cout;
+        const void *src = ok ? (const void *)(yb + yd * yv.sd + gh * yv.sh + gw * yv.sw + l_chunk * 8) : (const void *)&g_zero16;
+        if (ABL == 1) continue;
+        dma16_to_lds(src, lds_addr_of(sY + yslot * WT::Y_SLICE_B + r * WT::Y_ROW_B + pi * 1024));
+      }
+    }
+  };
+
+  // transposed-read lane address inside a 16-voxel x 32-channel block (64-byte voxel rows): group lane 4q+p supplies
+  // voxel row q, channels 4p..4p+3 of the group's 16 channels; groups 0/1 = channels 0-15 / 16-31, lanes >= 32 = k 8..15
+  const int lane_off = ((lane >> 5) * 8 + ((lane & 15) >> 2)) * 64 + ((lane >> 4) & 1) * 32 + (lane & 3) * 8;
+
+  // this wave's taps: tap = wave + 4 i (i < 7), wave-uniform offsets of the x operand
+  int tap_kd[7], tap_off[7];
+#pragma unroll
+  for (int i = 0; i < 7; ++i) {
+    const int tap = wave + 4 * i;
+    const int tc = tap < 27 ? tap : 26;
+    tap_kd[i] = tc / 9;
+    tap_off[i] = ((tc / 3) % 3) * WT::X_ROW_B + (tc % 3) * 64;
+  }
+
+  f32x16_t acc[7];
+#pragma unroll
+  for (int i = 0; i < 7; ++i)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[i][q] = 0.f;
+
+  // prologue: x slices d_begin-1, d_begin, d_begin+1 and dy slice d_begin
+  issue_slice(d_begin - 1, (d_begin - 1) & 3, true, d_begin, d_begin & 1, true);
+  issue_slice(d_begin, d_begin & 3, true, 0, 0, false);
+  issue_slice(d_begin + 1, (d_begin + 1) & 3, true, 0, 0, false);
+  dma_wait_all();
+  lds_barrier();
+
+  for (int d = d_begin; d < d_end; ++d) {
+    const bool more = d + 1 < d_end;
+    issue_slice(d + 2, (d + 2) & 3, more, d + 1, (d + 1) & 1, more);      // lands during the MFMAs below
+    const unsigned char *ys = sY + (d & 1) * WT::Y_SLICE_B + lane_off;
+    int slice_off[3];
+#pragma unroll
+    for (int kd = 0; kd < 3; ++kd) slice_off[kd] = ((d + kd - 1) & 3) * WT::X_SLICE_B;
+#pragma unroll
+    for (int oh = 0; oh < WT::TH; ++oh) {
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const bf16x8_t bfr = tr_operand(ys + oh * WT::Y_ROW_B + ks * 1024);
+#pragma unroll
+        for (int i = 0; i < 7; ++i) {
+          if (wave + 4 * i < 27) {      // wave-uniform
+            const int so = (tap_kd[i] == 0 ? slice_off[0] : (tap_kd[i] == 1 ? slice_off[1] : slice_off[2])) + tap_off[i];
+            const bf16x8_t afr = tr_operand(sX + lane_off + so + oh * WT::X_ROW_B + ks * 1024);
+            if (ABL == 3) acc[i][0] += (float)afr[0] * (float)bfr[1];
+            else acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr, bfr, acc[i], 0, 0, 0);
+          }
+        }
+      }
+    }
+    dma_wait_all();
+    lds_barrier();
+  }
+
+  // partial slab [27][32 ci][32 co]; C/D map of the 32x32 MFMA: col = lane&31 (co), row = (q&3) + 8(q>>2) + 4(lane>>5) (ci)
+  float *slab = slabs + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * (27 * 1024);
+  const int co = lane & 31, hh = lane >> 5;
+#pragma unroll
+  for (int i = 0; i < 7; ++i) {
+    const int tap = wave + 4 * i;
+    if (tap < 27) {
+#pragma unroll
+      for (int q = 0; q < 16; ++q) slab[(tap * 32 + (q & 3) + 8 * (q >> 2) + 4 * hh) * 32 + co] = acc[i][q];
+    }
+  }
 }
 
 // dw[co*s_co + ci*s_ci + real_tap*s_tap] (+)= sum over slabs of virtual tap t (real_tap = real.wt[t], -1: skip).
@@ -1373,6 +1549,28 @@ static int wgrad_launch_classes(const void *x, const View &xv, const void *dy, c
   WgradPlan p = wgrad_plan(B, Cin, Cout, yv.D, yv.H, yv.W, wc.n);
   const size_t need = (size_t)wc.n * p.units * p.cibs * p.cobs * 27 * 1024 * sizeof(float);
   if (ws_bytes < need || p.units >= (1ll << 31) || p.cibs * p.cobs > 65535) return DGTTA_ERR_UNSUPPORTED;
+  if (sizeof(T) == 2 && wc.n == 1 && wc.mask[0] == 0x7ffffffu && wc.xoff[0] == 0 && wc.yoff[0] == 0) {
+    const char *tr = getenv("DGTTA_WGRAD_TR");        // diagnostic / tests: "0" forces the register-transpose kernel
+    if (!(tr && tr[0] == '0')) {
+      auto ktr = conv3_wgrad_tr_kernel<0>;
+      static const char *abl = getenv("DGTTA_WGRAD_ABL");      // diagnostic only
+      if (abl && abl[0] == '1') ktr = conv3_wgrad_tr_kernel<1>;
+      if (abl && abl[0] == '3') ktr = conv3_wgrad_tr_kernel<3>;
+      static bool tr_attr = false;
+      if (!tr_attr || abl) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(ktr), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)WT::LDS_BYTES);
+        DG_REQUIRE(e == hipSuccess, DGTTA_ERR_LAUNCH, "wgrad_tr: cannot raise the dynamic LDS limit");
+        tr_attr = true;
+      }
+      hipLaunchKernelGGL(ktr, dim3((unsigned)p.units, (unsigned)(p.cibs * p.cobs)), dim3(256), WT::LDS_BYTES, st,
+                         (const bf16_t *)x, xv, (const bf16_t *)dy, yv, (float *)ws, Cin, Cout, p.tW, p.tH, p.nsd, p.DR,
+                         p.cobs);
+      DG_CHECK_LAUNCH("conv3_wgrad_tr_kernel");
+      goto reduce;
+    }
+  }
+  {
   static bool attr_set = false;
   auto kern = conv3_wgrad_mfma_kernel<T, 0>;
   {
@@ -1380,6 +1578,7 @@ static int wgrad_launch_classes(const void *x, const View &xv, const void *dy, c
     if (abl && abl[0] == '1') kern = conv3_wgrad_mfma_kernel<T, 1>;
     if (abl && abl[0] == '2') kern = conv3_wgrad_mfma_kernel<T, 2>;
     if (abl && abl[0] == '3') kern = conv3_wgrad_mfma_kernel<T, 3>;
+    if (abl && abl[0] == '6') kern = conv3_wgrad_mfma_kernel<T, 6>;
     if (abl) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)WG<T>::LDS_BYTES);
   }
@@ -1391,6 +1590,8 @@ static int wgrad_launch_classes(const void *x, const View &xv, const void *dy, c
   hipLaunchKernelGGL(kern, dim3((unsigned)p.units, (unsigned)(p.cibs * p.cobs), (unsigned)wc.n), dim3(256), WG<T>::LDS_BYTES,
                      st, (const T *)x, xv, (const T *)dy, yv, (float *)ws, Cin, Cout, p.tW, p.tH, p.nsd, p.DR, p.cobs, wc);
   DG_CHECK_LAUNCH("conv3_wgrad_mfma_kernel");
+  }
+reduce:
   const int64_t rrows = (int64_t)27 * Cin * ((Cout + 31) / 32);
   const int npairs = p.cibs * p.cobs;
   if (p.units >= 64)

@@ -1364,30 +1364,32 @@ __global__ __launch_bounds__(256, 2) void conv3_wgrad_tr_kernel(const bf16_t *__
   // DMA of one slice: piece idx (wave-uniform) -> x row r (3 pieces: voxels 0-15, 16-31, 32-33) or dy row (2 pieces);
   // lane l of a piece = voxel 16*pi + l/4, 16-byte channel chunk l%4
   const int l_vox = lane >> 2, l_chunk = lane & 3;
-  auto issue_slice = [&](int xd, int xslot, bool do_x, int yd, int yslot, bool do_y) {
-#pragma unroll
-    for (int i = 0; i < (WT::NP + 3) / 4; ++i) {
-      const int idx = wave + 4 * i;
-      if (idx < WT::NPX) {
-        if (!do_x) continue;
-        const int r = idx / 3, pi = idx % 3;
-        if (pi == 2 && lane >= 8) continue;
-        const int gh = h0 - 1 + r, wx = 16 * pi + l_vox, gw = w0 - 1 + wx;
-        const bool ok = (unsigned)xd < (unsigned)xv.D && (unsigned)gh < (unsigned)xv.H && (unsigned)gw < (unsigned)xv.W &&
-                        cib * 32 + l_chunk * 8 < cin_lim;
-        const void *src = ok ? (const void *)(xb + xd * xv.sd + gh * xv.sh + gw * xv.sw + l_chunk * 8) : (const void *)&g_zero16;
-        if (ABL == 1) continue;
-        dma16_to_lds(src, lds_addr_of(sX + xslot * WT::X_SLICE_B + r * WT::X_ROW_B + pi * 1024));
-      } else if (idx < WT::NP) {
-        if (!do_y) continue;
-        const int j = idx - WT::NPX, r = j / 2, pi = j % 2;
-        const int gh = h0 + r, gw = w0 + 16 * pi + l_vox;
-        const bool ok = (unsigned)yd < (unsigned)D && gh < H && gw < W && cob * 32 + l_chunk * 8 < Cout;
-        const void *src = ok ? (const void *)(yb + yd * yv.sd + gh * yv.sh + gw * yv.sw + l_chunk * 8) : (const void *)&g_zero16;
-        if (ABL == 1) continue;
-        dma16_to_lds(src, lds_addr_of(sY + yslot * WT::Y_SLICE_B + r * WT::Y_ROW_B + pi * 1024));
-      }
+  constexpr int NPW = (WT::NP + 3) / 4;        // pieces per wave and slice
+  auto issue_piece = [&](int i, int xd, int xslot, bool do_x, int yd, int yslot, bool do_y) __attribute__((always_inline)) {
+    const int idx = wave + 4 * i;
+    if (idx < WT::NPX) {
+      if (!do_x) return;
+      const int r = idx / 3, pi = idx % 3;
+      if (pi == 2 && lane >= 8) return;
+      const int gh = h0 - 1 + r, wx = 16 * pi + l_vox, gw = w0 - 1 + wx;
+      const bool ok = (unsigned)xd < (unsigned)xv.D && (unsigned)gh < (unsigned)xv.H && (unsigned)gw < (unsigned)xv.W &&
+                      cib * 32 + l_chunk * 8 < cin_lim;
+      const void *src = ok ? (const void *)(xb + xd * xv.sd + gh * xv.sh + gw * xv.sw + l_chunk * 8) : (const void *)&g_zero16;
+      if (ABL == 1) return;
+      dma16_to_lds(src, lds_addr_of(sX + xslot * WT::X_SLICE_B + r * WT::X_ROW_B + pi * 1024));
+    } else if (idx < WT::NP) {
+      if (!do_y) return;
+      const int j = idx - WT::NPX, r = j / 2, pi = j % 2;
+      const int gh = h0 + r, gw = w0 + 16 * pi + l_vox;
+      const bool ok = (unsigned)yd < (unsigned)D && gh < H && gw < W && cob * 32 + l_chunk * 8 < Cout;
+      const void *src = ok ? (const void *)(yb + yd * yv.sd + gh * yv.sh + gw * yv.sw + l_chunk * 8) : (const void *)&g_zero16;
+      if (ABL == 1) return;
+      dma16_to_lds(src, lds_addr_of(sY + yslot * WT::Y_SLICE_B + r * WT::Y_ROW_B + pi * 1024));
     }
+  };
+  auto issue_slice = [&](int xd, int xslot, bool do_x, int yd, int yslot, bool do_y) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < NPW; ++i) issue_piece(i, xd, xslot, do_x, yd, yslot, do_y);
   };
 
   // transposed-read lane address inside a 16-voxel x 32-channel block (64-byte voxel rows): group lane 4q+p supplies
@@ -1419,7 +1421,6 @@ __global__ __launch_bounds__(256, 2) void conv3_wgrad_tr_kernel(const bf16_t *__
 
   for (int d = d_begin; d < d_end; ++d) {
     const bool more = d + 1 < d_end;
-    issue_slice(d + 2, (d + 2) & 3, more, d + 1, (d + 1) & 1, more);      // lands during the MFMAs below
     const unsigned char *ys = sY + (d & 1) * WT::Y_SLICE_B + lane_off;
     int slice_off[3];
 #pragma unroll
@@ -1429,14 +1430,21 @@ __global__ __launch_bounds__(256, 2) void conv3_wgrad_tr_kernel(const bf16_t *__
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
         const bf16x8_t bfr = tr_operand(ys + oh * WT::Y_ROW_B + ks * 1024);
+        // one DMA piece of the next slices per (row, k-step): a burst at the top of the slice would block this wave
+        // until the memory pipeline has taken all of them
+        if (oh * 2 + ks < NPW) issue_piece(oh * 2 + ks, d + 2, (d + 2) & 3, more, d + 1, (d + 1) & 1, more);
+        // all 7 operand reads first, then 7 MFMAs (wave 3's seventh slot repeats tap 26 into a discarded accumulator,
+        // so the code is branch-free and the reads pipeline ahead of the matrix instructions)
+        bf16x8_t afr[7];
 #pragma unroll
         for (int i = 0; i < 7; ++i) {
-          if (wave + 4 * i < 27) {      // wave-uniform
-            const int so = (tap_kd[i] == 0 ? slice_off[0] : (tap_kd[i] == 1 ? slice_off[1] : slice_off[2])) + tap_off[i];
-            const bf16x8_t afr = tr_operand(sX + lane_off + so + oh * WT::X_ROW_B + ks * 1024);
-            if (ABL == 3) acc[i][0] += (float)afr[0] * (float)bfr[1];
-            else acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr, bfr, acc[i], 0, 0, 0);
-          }
+          const int so = (tap_kd[i] == 0 ? slice_off[0] : (tap_kd[i] == 1 ? slice_off[1] : slice_off[2])) + tap_off[i];
+          afr[i] = tr_operand(sX + lane_off + so + oh * WT::X_ROW_B + ks * 1024);
+        }
+#pragma unroll
+        for (int i = 0; i < 7; ++i) {
+          if (ABL == 3) acc[i][0] += (float)afr[i][0] * (float)bfr[1];
+          else acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[i], bfr, acc[i], 0, 0, 0);
         }
       }
     }

@@ -192,13 +192,13 @@ def main():
             peak = 2500.0 if args.dtype == "bf16" else 157.3
             ach = flop / (avg_ms * 1e-3) / 1e12
             traffic = None       # HBM bytes per launch from the committed PMC passes (profiles/), not a live counter
-            pmc = ROOT / "profiles" / "r01_conv_mfma_pmc_summary.json"
+            pmc = ROOT / "profiles" / "r01_pmc_summary.json"
             if pmc.exists() and args.dtype == "bf16" and args.size == 128:
-                d = json.loads(pmc.read_text()).get("dominant_128cube_Cout32", {})
-                if d:
+                d = json.loads(pmc.read_text()).get("conv_128cube_32to32", {})
+                if "fetch_bytes_corrected_median" in d:
                     traffic = d["fetch_bytes_corrected_median"] + d["write_bytes_median"]
             roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
-                    "frac": round(ach / peak, 4), "traffic": traffic, "kernel": probe.get("kernel", "conv3_mfma_kernel"),
+                    "frac": round(ach / peak, 4), "traffic": traffic, "kernel": probe.get("kernel", "conv3_rows_kernel" if args.dtype == "bf16" else "conv3_mfma_kernel"),
                     "launches": len(times), "avg_ms": round(avg_ms, 4),
                     "flop_per_launch": flop}
         out = {"metric": "TTA-epochs/sec per GPU on 128^3 patch", "value": round(value, 5), "unit": "TTA-epochs/s",

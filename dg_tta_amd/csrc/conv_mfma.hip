@@ -1343,11 +1343,18 @@ __device__ __forceinline__ bf16x8_t tr_operand(const unsigned char *p) {
   return __builtin_bit_cast(bf16x8_t, v);
 }
 
-template <int ABL = 0>
+// CLS: class launch (blockIdx.z selects operand offsets and a tap subset, as in conv3_wgrad_mfma_kernel): the set taps
+// are dealt round-robin to the 4 waves, slots beyond a wave's share are skipped with wave-uniform branches.
+template <int ABL = 0, bool CLS = false>
 __global__ __launch_bounds__(256, 2) void conv3_wgrad_tr_kernel(const bf16_t *__restrict__ x, View xv,
                                                                 const bf16_t *__restrict__ dy, View yv,
                                                                 float *__restrict__ slabs, int Cin, int Cout, int tilesW,
-                                                                int tilesH, int nsd, int DR, int cobs) {
+                                                                int tilesH, int nsd, int DR, int cobs, WgradClasses wc) {
+  const int cls = CLS ? blockIdx.z : 0;
+  if (CLS) {
+    x += wc.xoff[cls];
+    dy += wc.yoff[cls];
+  }
   const int D = yv.D, H = yv.H, W = yv.W;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char *sX = smem;                                   // ring of 4 x slices
@@ -1404,12 +1411,33 @@ __global__ __launch_bounds__(256, 2) void conv3_wgrad_tr_kernel(const bf16_t *__
   // voxel row q, channels 4p..4p+3 of the group's 16 channels; groups 0/1 = channels 0-15 / 16-31, lanes >= 32 = k 8..15
   const int lane_off = ((lane >> 5) * 8 + ((lane & 15) >> 2)) * 64 + ((lane >> 4) & 1) * 32 + (lane & 3) * 8;
 
-  // this wave's taps: tap = wave + 4 i (i < 7), wave-uniform offsets of the x operand
-  int tap_kd[7], tap_off[7];
+  // this wave's taps: tap = wave + 4 i (i < 7) -- with classes, the (wave + 4 i)-th set bit of the class mask;
+  // wave-uniform offsets of the x operand
+  int tap_id[7], tap_kd[7], tap_off[7];
+  int ntap_w = 7;
+  if (CLS) {
+    const unsigned mask = wc.mask[cls];
+    ntap_w = 0;
+#pragma unroll
+    for (int i = 0; i < 7; ++i) tap_id[i] = 26;
+    int seen = 0;
+    for (int tp = 0; tp < 27; ++tp)
+      if ((mask >> tp) & 1u) {
+        if ((seen & 3) == wave) {
+#pragma unroll
+          for (int i = 0; i < 7; ++i)
+            if (i == (seen >> 2)) tap_id[i] = tp;
+          ntap_w = (seen >> 2) + 1;
+        }
+        ++seen;
+      }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 7; ++i) tap_id[i] = wave + 4 * i < 27 ? wave + 4 * i : 26;
+  }
 #pragma unroll
   for (int i = 0; i < 7; ++i) {
-    const int tap = wave + 4 * i;
-    const int tc = tap < 27 ? tap : 26;
+    const int tc = tap_id[i];
     tap_kd[i] = tc / 9;
     tap_off[i] = ((tc / 3) % 3) * WT::X_ROW_B + (tc % 3) * 64;
   }
@@ -1446,11 +1474,13 @@ __global__ __launch_bounds__(256, 2) void conv3_wgrad_tr_kernel(const bf16_t *__
         bf16x8_t afr[7];
 #pragma unroll
         for (int i = 0; i < 7; ++i) {
+          if (CLS && i >= ntap_w) continue;      // wave-uniform
           const int so = (tap_kd[i] == 0 ? slice_off[0] : (tap_kd[i] == 1 ? slice_off[1] : slice_off[2])) + tap_off[i];
           afr[i] = tr_operand(sX + lane_off + so + oh * WT::X_ROW_B + ks * 1024);
         }
 #pragma unroll
         for (int i = 0; i < 7; ++i) {
+          if (CLS && i >= ntap_w) continue;
           if (ABL == 3) acc[i][0] += (float)afr[i][0] * (float)bfr[1];
           else acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[i], bfr, acc[i], 0, 0, 0);
         }
@@ -1461,12 +1491,12 @@ __global__ __launch_bounds__(256, 2) void conv3_wgrad_tr_kernel(const bf16_t *__
   }
 
   // partial slab [27][32 ci][32 co]; C/D map of the 32x32 MFMA: col = lane&31 (co), row = (q&3) + 8(q>>2) + 4(lane>>5) (ci)
-  float *slab = slabs + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * (27 * 1024);
+  float *slab = slabs + (((int64_t)cls * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * (27 * 1024);
   const int co = lane & 31, hh = lane >> 5;
 #pragma unroll
   for (int i = 0; i < 7; ++i) {
-    const int tap = wave + 4 * i;
-    if (tap < 27) {
+    const int tap = tap_id[i];
+    if (CLS ? i < ntap_w : wave + 4 * i < 27) {
 #pragma unroll
       for (int q = 0; q < 16; ++q) slab[(tap * 32 + (q & 3) + 8 * (q >> 2) + 4 * hh) * 32 + co] = acc[i][q];
     }
@@ -1565,23 +1595,24 @@ static int wgrad_launch_classes(const void *x, const View &xv, const void *dy, c
   WgradPlan p = wgrad_plan(B, Cin, Cout, yv.D, yv.H, yv.W, wc.n);
   const size_t need = (size_t)wc.n * p.units * p.cibs * p.cobs * 27 * 1024 * sizeof(float);
   if (ws_bytes < need || p.units >= (1ll << 31) || p.cibs * p.cobs > 65535) return DGTTA_ERR_UNSUPPORTED;
-  if (sizeof(T) == 2 && wc.n == 1 && wc.mask[0] == 0x7ffffffu && wc.xoff[0] == 0 && wc.yoff[0] == 0) {
+  if (sizeof(T) == 2) {
     const char *tr = getenv("DGTTA_WGRAD_TR");        // diagnostic / tests: "0" forces the register-transpose kernel
     if (!(tr && tr[0] == '0')) {
-      auto ktr = conv3_wgrad_tr_kernel<0>;
+      const bool plain = wc.n == 1 && wc.mask[0] == 0x7ffffffu && wc.xoff[0] == 0 && wc.yoff[0] == 0;
+      auto ktr = plain ? conv3_wgrad_tr_kernel<0, false> : conv3_wgrad_tr_kernel<0, true>;
       static const char *abl = getenv("DGTTA_WGRAD_ABL");      // diagnostic only
-      if (abl && abl[0] == '1') ktr = conv3_wgrad_tr_kernel<1>;
-      if (abl && abl[0] == '3') ktr = conv3_wgrad_tr_kernel<3>;
-      static bool tr_attr = false;
-      if (!tr_attr || abl) {
+      if (abl && abl[0] == '1' && plain) ktr = conv3_wgrad_tr_kernel<1, false>;
+      if (abl && abl[0] == '3' && plain) ktr = conv3_wgrad_tr_kernel<3, false>;
+      static bool tr_attr[2] = {false, false};
+      if (!tr_attr[plain] || abl) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(ktr), hipFuncAttributeMaxDynamicSharedMemorySize,
                                            (int)WT::LDS_BYTES);
         DG_REQUIRE(e == hipSuccess, DGTTA_ERR_LAUNCH, "wgrad_tr: cannot raise the dynamic LDS limit");
-        tr_attr = true;
+        tr_attr[plain] = true;
       }
-      hipLaunchKernelGGL(ktr, dim3((unsigned)p.units, (unsigned)(p.cibs * p.cobs)), dim3(256), WT::LDS_BYTES, st,
-                         (const bf16_t *)x, xv, (const bf16_t *)dy, yv, (float *)ws, Cin, Cout, p.tW, p.tH, p.nsd, p.DR,
-                         p.cobs);
+      hipLaunchKernelGGL(ktr, dim3((unsigned)p.units, (unsigned)(p.cibs * p.cobs), (unsigned)wc.n), dim3(256), WT::LDS_BYTES,
+                         st, (const bf16_t *)x, xv, (const bf16_t *)dy, yv, (float *)ws, Cin, Cout, p.tW, p.tH, p.nsd,
+                         p.DR, p.cobs, wc);
       DG_CHECK_LAUNCH("conv3_wgrad_tr_kernel");
       goto reduce;
     }

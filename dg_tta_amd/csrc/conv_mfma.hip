@@ -776,13 +776,10 @@ int dispatch_conv_classes(const void *x, const View &xv, const void *w, const Co
     // 8 waves per workgroup (2 M-blocks each): 16 waves per CU hide the LDS / barrier latency (+27 % over 4 waves)
     if (yv.W >= 32 && var && var[0] == 'x') return launch_conv<T, 32, 4, 4, 1, 1, 1, 4>(ARGS);
     if (yv.W >= 32) return launch_conv<T, 32, 4, 4, 1, 1, 1, 8>(ARGS);
-    // small volumes are latency bound (few workgroups, a long serial K loop): 128-voxel tiles and, when the channel
-    // padding allows it, 2 k-steps per chunk (half the barrier / load round trips)
+    // tiny volumes are latency bound (few workgroups, a long serial K loop): when the channel padding allows it, 2
+    // k-steps per chunk halve the barrier / load round trips.  (128-voxel tiles for the 16^3 layers measured faster in
+    // isolation but slower inside the network: 23.0 vs 20.9 ms per epoch.)
     const bool k2 = CinP % (4 * Elem<T>::EPV) == 0 && !(var && var[0] == 'k');
-    if (yv.W >= 16 && vox <= 8192 && !(var && var[0] == 'x')) {
-      if (k2) return launch_conv<T, 16, 2, 2, 1, 1, 2, 4>(ARGS);
-      return launch_conv<T, 16, 2, 2, 1, 1, 1, 4>(ARGS);
-    }
     if (yv.W >= 16) return launch_conv<T, 16, 4, 4, 1, 1, 1, 8>(ARGS);
     if (vox <= 4096 && k2) return launch_conv<T, 8, 2, 2, 1, 1, 2>(ARGS);
     if (vox <= 4096) return launch_conv<T, 8, 2, 2, 1, 1, 1>(ARGS);     // tiny volumes: more, smaller workgroups

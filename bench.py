@@ -200,7 +200,9 @@ def main():
             roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
                     "frac": round(ach / peak, 4), "traffic": traffic, "kernel": probe.get("kernel", "conv3_rows_kernel" if args.dtype == "bf16" else "conv3_mfma_kernel"),
                     "launches": len(times), "avg_ms": round(avg_ms, 4),
-                    "flop_per_launch": flop}
+                    "flop_per_launch": flop,
+                    "scope": "launches of block dec.3.1 (128^3 32->32, forward + data gradient) only; the kernel name "
+                             "also runs the other large layers, so rocprofv3's per-name average is a mix of shapes"}
         out = {"metric": "TTA-epochs/sec per GPU on 128^3 patch", "value": round(value, 5), "unit": "TTA-epochs/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 2),
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,

@@ -786,8 +786,15 @@ int dispatch_conv_classes(const void *x, const View &xv, const void *w, const Co
     return launch_conv<T, 8, 2, 8, 1, 1, 1, 8>(ARGS);
   }
   if (stride == 2) {
-    if (yv.W >= 16) return launch_conv<T, 16, 2, 4, 2, 1, 1>(ARGS);
-    return launch_conv<T, 8, 2, 4, 2, 1, 1>(ARGS);
+    // 8 waves per workgroup (one M-block each): 231 -> 153 us at 128^3 -> 64^3, 32 -> 64 channels
+    static const char *v2 = getenv("DGTTA_CONV_S2");      // diagnostic: "4" = the former 4-wave tiles
+    if (v2 && v2[0] == '4') {
+      if (yv.W >= 16) return launch_conv<T, 16, 2, 4, 2, 1, 1>(ARGS);
+      return launch_conv<T, 8, 2, 4, 2, 1, 1>(ARGS);
+    }
+    if (yv.W >= 32) return launch_conv<T, 32, 4, 2, 2, 1, 1, 8>(ARGS);
+    if (yv.W >= 16) return launch_conv<T, 16, 2, 4, 2, 1, 1, 8>(ARGS);
+    return launch_conv<T, 8, 2, 4, 2, 1, 1, 8>(ARGS);
   }
 #undef ARGS
   return DGTTA_ERR_UNSUPPORTED;

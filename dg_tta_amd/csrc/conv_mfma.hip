@@ -475,7 +475,7 @@ __global__ __launch_bounds__(WD *WH * 64) void conv3_rows_kernel(const bf16_t *_
     if (i < 2 * NPR) {
       const int row = wave + (i >> 1) * NW;          // wave-uniform
       const bool tail = i & 1;
-      if (row < Cfg::NROW && (!tail || lane < 4)) {
+      if (row < Cfg::NROW && (!tail || lane < 4) && !(ABL == 7 && tail)) {
         const int dz = row / IH, hy = row % IH;
         const int gd = q.od0 - 1 + dz, gh = q.oh0 - 1 + hy;
         const int g = tail ? t_g : m_g, gw = q.ow0 - 1 + (tail ? t_wx : m_wx);
@@ -685,6 +685,7 @@ int launch_conv_rows(const void *x, const View &xv, const void *w, const Taps &t
   if (abl && abl[0] == '4') kern = conv3_rows_kernel<PD, PH, WD, WH, 4>;
   if (abl && abl[0] == '5') kern = conv3_rows_kernel<PD, PH, WD, WH, 5>;
   if (abl && abl[0] == '6') kern = conv3_rows_kernel<PD, PH, WD, WH, 6>;
+  if (abl && abl[0] == '7') kern = conv3_rows_kernel<PD, PH, WD, WH, 7>;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,

@@ -355,3 +355,70 @@ def test_head_fast_paths(nsel, V, dt):
     wtol = 3e-5 if dt == 0 else 2e-2        # bf16 MFMA path rounds dout to bf16
     assert (dw - dw_ref).abs().max() < wtol * dw_ref.abs().max() + 1e-4
     assert torch.allclose(db, dout[0].sum(0), rtol=1e-5, atol=1e-4)
+
+
+# ------------------------------------------------------------------------------------------------ full-size properties
+def test_full_size_128_conv_two_kernels_agree_and_are_linear(monkeypatch):
+    """BASELINE size (128^3, 32 -> 32 channels, bf16): the row-reuse kernel and the generic kernel are independent
+    implementations and must agree to output rounding; the fused statistics must match the tensor; and the map is linear
+    (conv(x1 + 2 x2) = conv(x1) + 2 conv(x2) up to bf16 rounding of the three outputs)."""
+    from dg_tta_amd import _lib
+    from dg_tta_amd._lib import check, ptr, stream_of
+    lib = _lib.load()
+    n, c = 128, 32
+    g = torch.Generator(DEV).manual_seed(1234)
+    x1 = torch.randn(1, n, n, n, c, device=DEV, generator=g).bfloat16()
+    x2 = torch.randn(1, n, n, n, c, device=DEV, generator=g).bfloat16()
+    w = torch.randn(c, c, 3, 3, 3, device=DEV, generator=g) / (27 * c) ** 0.5
+    wpack = torch.empty(lib.dgtta_conv3d_packed_bytes(c, c, 1) // 2, dtype=torch.bfloat16, device=DEV)
+    check(lib.dgtta_conv3d_pack_weights(ptr(w), ptr(wpack), c, c, c, c, 1, stream_of()), "pack")
+    nb = lib.dgtta_conv3d_stats_bytes(1, c, n, n, n)
+
+    def conv(x, rows):
+        monkeypatch.setenv("DGTTA_CONV_ROWS", rows)
+        y = torch.empty((1, n, n, n, c), dtype=torch.bfloat16, device=DEV)
+        st = torch.zeros(nb, dtype=torch.uint8, device=DEV)
+        check(lib.dgtta_conv3d_k3_fwd(ptr(x), c, ptr(wpack), None, ptr(y), c, ptr(st), 1, c, c, c, c, n, n, n, 1, 1, 2,
+                                      stream_of()), "fwd")
+        mr = torch.empty(1, c, 2, device=DEV)
+        z = torch.empty_like(y)
+        one, zero = torch.ones(c, device=DEV), torch.zeros(c, device=DEV)
+        nws = lib.dgtta_instnorm_ws_bytes(1, c, n ** 3)
+        ws = torch.empty(nws, dtype=torch.uint8, device=DEV)
+        check(lib.dgtta_instnorm_lrelu_fwd(ptr(y), c, ptr(st), ptr(one), ptr(zero), ptr(mr), ptr(z), c, ptr(ws), nws, 1, c,
+                                           n ** 3, 1e-5, 0.01, 1, stream_of()), "instnorm")
+        return y.float(), mr[0, :, 0].clone(), mr[0, :, 1].clone()
+
+    y_rows, m_rows, r_rows = conv(x1, "1")
+    y_gen, m_gen, r_gen = conv(x1, "0")
+    scale = float(y_gen.abs().max())
+    assert float((y_rows - y_gen).abs().max()) < scale / 128 + 1e-3
+    assert float((m_rows - m_gen).abs().max()) < 1e-5 and float(((r_rows - r_gen) / r_gen).abs().max()) < 1e-5
+    flat = y_rows.reshape(-1, c)
+    assert float((m_rows - flat.mean(0)).abs().max()) < 2e-4            # statistics of the unrounded values vs the bf16 tensor
+    assert float((r_rows - (flat.var(0, unbiased=False) + 1e-5).rsqrt()).abs().max() / r_rows.mean()) < 2e-3
+    x3 = (x1.float() + 2.0 * x2.float())
+    x3b = x3.bfloat16()
+    assert float((x3b.float() - x3).abs().max()) < 0.05                   # x3 itself is rounded to bf16 (|x| < ~8)
+    y2, _, _ = conv(x2, "1")
+    y3, _, _ = conv(x3b, "1")
+    # tolerance: rounding of x3 (2^-9 relative per element, averaged by the 864-term sum) + three output roundings
+    assert float((y3 - (y_rows + 2.0 * y2)).abs().max()) < 3.0 * scale / 64 + 1e-2
+
+
+def test_full_size_128_wgrad_two_kernels_agree(monkeypatch):
+    """BASELINE size (128^3, 32 x 32 channels, bf16): the transposed-read weight-gradient kernel against the
+    register-transpose kernel (independent staging, MFMA shape and reduction order; fp32 accumulation in both)."""
+    n, c = 128, 32
+    g = torch.Generator(DEV).manual_seed(4321)
+    x = torch.randn(1, n, n, n, c, device=DEV, generator=g).bfloat16()
+    dy = torch.randn(1, n, n, n, c, device=DEV, generator=g).bfloat16()
+    monkeypatch.setenv("DGTTA_WGRAD_TR", "1")
+    dw1, db1 = _call_wgrad(x, dy, c, c, 1, 1, 2)
+    monkeypatch.setenv("DGTTA_WGRAD_TR", "0")
+    dw0, db0 = _call_wgrad(x, dy, c, c, 1, 1, 2)
+    assert float((dw1 - dw0).abs().max()) < 2e-4 * float(dw0.abs().max()) + 1e-3
+    assert torch.equal(db1, db0)
+    # checksum property: summing dW over taps and input channels = (sum over a 3^3 box of x) . dy, checked for tap 13
+    centre = torch.einsum("vc,vk->kc", x.reshape(-1, c).float(), dy.reshape(-1, c).float())
+    assert float((dw1[:, :, 1, 1, 1] - centre).abs().max()) < 2e-4 * float(centre.abs().max()) + 1e-2

@@ -78,7 +78,7 @@ class EpochRunner:
     def epoch(self):
         from dg_tta_amd import ops
         from dg_tta_amd.gin import gin_aug
-        from dg_tta_amd.tta.tta import calc_branch, START_CLASS
+        from dg_tta_amd.tta.tta import batch_branches_enabled, calc_both_branches, calc_branch, START_CLASS
         from dg_tta_amd.tta.torch_utils import dice_coeff, get_batch, get_map_idxs, map_label
         cfg, model, dev = self.cfg, self.model, self.device
         model.train()
@@ -88,8 +88,12 @@ class EpochRunner:
                 imgs, _ = get_batch(self.data, np.random.choice(range(1), 1).tolist(), self.patch, None, dev)
             a = (cfg, model, gin_aug, None, self.patch, 1, self.mapping, cfg["optimized_labels"], self.modmod, imgs[0],
                  dev, self.fused)
-            ta = calc_branch("branch_a", *a)
-            tb = calc_branch("branch_b", *a)
+            if batch_branches_enabled():       # product default: both branches as one batch of 2 (see tta.calc_both_branches)
+                ta, tb = calc_both_branches(cfg, model, gin_aug, self.patch, 1, self.mapping, cfg["optimized_labels"],
+                                            self.modmod, imgs[0], dev, self.fused)
+            else:
+                ta = calc_branch("branch_a", *a)
+                tb = calc_branch("branch_b", *a)
             loss, _ = ops.consistency_loss(ta, tb, START_CLASS)
             step_losses.append(loss.detach())
             torch.autograd.backward(loss, grad_tensors=self.inv)

@@ -14,15 +14,38 @@ class MIND3D(torch.nn.Module):
         self.delta, self.sigma, self.randn_weighting = delta, sigma, randn_weighting
         self.out_channels = 12
 
-    def forward(self, img, noise=None, out_dtype=torch.float32):
+    def forward(self, img, noise=None, out_dtype=torch.float32, groups=1):
         """Returns a logical [B,12,D,H,W] tensor.  Its memory is voxel-major with rows padded to 16 channels
         ([B,D,H,W,16], channels 12..15 zero), i.e. exactly what HipPlainConvUNet's first conv reads."""
         b, _, d, h, w = img.shape
         if noise is None:
             noise = torch.randn((b, 12, d, h, w), dtype=torch.float32, device=img.device)
-        buf = ops.mind3d(img, noise, self.randn_weighting, out_format="ndhwc", out_ldc=16, out_dtype=out_dtype)
+        buf = ops.mind3d(img, noise, self.randn_weighting, out_format="ndhwc", out_ldc=16, out_dtype=out_dtype, groups=groups)
         return buf[..., :12].permute(0, 4, 1, 2, 3)
 
 
+# Noise tensors drawn ahead of time by the batched two-branch path (tta.calc_both_branches): the reference draws a
+# branch's MIND noise inside that branch's forward pass, i.e. BEFORE the other branch's GIN draws; pre-drawing keeps
+# that order on the device generator when both branches run as one batch.
+_PENDING_NOISE = []
+
+
+def push_noise(noise, groups=1):
+    _PENDING_NOISE.append((noise, groups))
+
+
+def clear_noise():
+    _PENDING_NOISE.clear()
+
+
+def uses_mind_hook(model):
+    return any(h is mind_hook for m in model.modules() for h in m._forward_pre_hooks.values())
+
+
 def mind_hook(module, input):
-    return MIND3D().forward(*input, out_dtype=getattr(module, "act_dtype", torch.float32))
+    noise, groups = None, 1
+    if _PENDING_NOISE:
+        cand = _PENDING_NOISE[0][0]
+        if cand.shape[0] == input[0].shape[0] and tuple(cand.shape[2:]) == tuple(input[0].shape[2:]):
+            noise, groups = _PENDING_NOISE.pop(0)
+    return MIND3D().forward(*input, noise=noise, out_dtype=getattr(module, "act_dtype", torch.float32), groups=groups)

@@ -34,10 +34,12 @@ def empty_cl3d(b, c, d, h, w, dtype, device):
 
 
 # ------------------------------------------------------------------------------------------------ MIND
-def mind3d(img, noise, randn_weighting=0.05, out_format="ncdhw", out_ldc=12, out_dtype=torch.float32):
+def mind3d(img, noise, randn_weighting=0.05, out_format="ncdhw", out_ldc=12, out_dtype=torch.float32, groups=1):
     """MIND3D descriptor of img [B,1,D,H,W] with the randn draw `noise` [B,12,D,H,W] (reference: dg_tta/mind.py:142-164).
 
     out_format 'ncdhw' -> contiguous [B,12,D,H,W] fp32; 'ndhwc' -> raw [B,D,H,W,out_ldc] buffer (fp32 or bf16).
+    groups > 1: the batch is `groups` independent calls of B/groups samples (the variance clamp of mind.py:159-161
+    uses the mean over the whole call's batch), written into one output buffer.
     """
     require_cuda(img, noise)
     lib = _lib.load()
@@ -49,11 +51,15 @@ def mind3d(img, noise, randn_weighting=0.05, out_format="ncdhw", out_ldc=12, out
         out = torch.empty((b, d, h, w, out_ldc), dtype=out_dtype, device=img.device)
     else:
         out = torch.empty((b, 12, d, h, w), dtype=torch.float32, device=img.device)
-    nbytes = lib.dgtta_mind3d_ws_bytes(b, d, h, w)
+    assert b % groups == 0
+    bg = b // groups
+    nbytes = lib.dgtta_mind3d_ws_bytes(bg, d, h, w)
     ws = _ws(nbytes, img.device)
-    check(lib.dgtta_mind3d_fwd(ptr(img), ptr(noise), float(randn_weighting), ptr(out), int(ndhwc), int(out_ldc),
-                               BF16 if out_dtype == torch.bfloat16 else F32, ptr(ws), nbytes, b, d, h, w,
-                               stream_of(img.device)), "dgtta_mind3d_fwd")
+    for g in range(groups):
+        sl = slice(g * bg, (g + 1) * bg)
+        check(lib.dgtta_mind3d_fwd(ptr(img[sl]), ptr(noise[sl]), float(randn_weighting), ptr(out[sl]), int(ndhwc),
+                                   int(out_ldc), BF16 if out_dtype == torch.bfloat16 else F32, ptr(ws), nbytes, bg, d, h, w,
+                                   stream_of(img.device)), "dgtta_mind3d_fwd")
     return out
 
 

@@ -99,6 +99,72 @@ def calc_branch(branch_id, config, model, intensity_aug_func, identity_grid, pat
         return branch_target
 
 
+def calc_both_branches(config, model, intensity_aug_func, patch_size, batch_size, label_mapping, optimized_labels,
+                       modifier_fn_module, imgs, device, head_is_fused=False):
+    """calc_branch("branch_a") and calc_branch("branch_b") with the two network passes run as ONE batch of
+    2*batch_size (same weights, per-sample InstanceNorm: the same maths; the weight gradient then sums both branches
+    inside one kernel).  Small layers (16^3 and below) are launch / occupancy bound, so halving the number of launches
+    and doubling the work per launch is worth ~15 % of an epoch.  Random draws keep the reference's order on both
+    generators: branch a's GIN, affine and MIND-noise draws, then branch b's (the noise is pre-drawn and handed to
+    mind_hook).  Returns (target_a, target_b)."""
+    from ..mind import clear_noise, push_noise, uses_mind_hook
+    grad_context = nullcontext if config["have_grad_in"] in ["branch_a", "both"] else torch.no_grad
+    after_mapping = modifier_fn_module.ModifierFunctions.modify_tta_output_after_mapping_fn
+    with grad_context():
+        augs, inverses, noises = [], [], []
+        want_noise = uses_mind_hook(model)
+        for branch_id in ("branch_a", "branch_b"):
+            imgs_aug = imgs
+            if config["do_intensity_aug_in"] in [branch_id, "both"]:
+                imgs_aug = intensity_aug_func(imgs_aug)
+            R_inverse = None
+            if config["do_spatial_aug_in"] in [branch_id, "both"]:
+                if config["spatial_aug_type"] == "affine":
+                    R, R_inverse = get_rand_affine(batch_size, flip=False)
+                    R, R_inverse = upload_async([R.float().contiguous(), R_inverse.float().contiguous()], device)
+                elif config["spatial_aug_type"] == "deformable":
+                    from .augmentation_utils import get_disp_field
+                    get_disp_field()
+                else:
+                    R = R_inverse = torch.eye(4, device=device)[:3][None].repeat(batch_size, 1, 1)
+                imgs_aug = ops.affine_warp(imgs_aug, R, padding_mode="border", tta_grid_algebra=True)
+            augs.append(imgs_aug)
+            inverses.append(R_inverse)
+            if want_noise:
+                noises.append(torch.randn((imgs_aug.shape[0], 12) + tuple(imgs_aug.shape[2:]), dtype=torch.float32,
+                                          device=imgs_aug.device))
+        model.apply(buffer_running_stats)
+        model.apply(apply_running_stats)
+        if want_noise:
+            push_noise(torch.cat(noises, dim=0), groups=2)
+        try:
+            both = model(torch.cat(augs, dim=0))
+        finally:
+            clear_noise()
+        if isinstance(both, tuple):
+            both = both[0]
+        targets = []
+        nb = augs[0].shape[0]
+        for k in range(2):
+            t = both[k * nb:(k + 1) * nb]
+            if not head_is_fused:
+                t = map_label(t, get_map_idxs(label_mapping, optimized_labels, input_type="pretrain_labels"),
+                              input_format="logits")
+            t = after_mapping(t)
+            if isinstance(t, tuple):
+                t = t[0]
+            if inverses[k] is not None:
+                t = ops.affine_warp(t, inverses[k], padding_mode="zeros", tta_grid_algebra=True)
+            targets.append(t)
+    return targets[0], targets[1]
+
+
+def batch_branches_enabled():
+    """Both branches as one batch unless DGTTA_BATCH_BRANCHES=0 (then two calc_branch calls, as the reference does)."""
+    import os
+    return os.environ.get("DGTTA_BATCH_BRANCHES", "1") != "0"
+
+
 def _fuse_head_if_possible(model, modifier_fn_module, label_mapping, optimized_labels):
     """map_label(logits) == evaluating only the mapped rows of the 1x1x1 head; valid iff the user's model-output
     modifier is the untouched template (identity)."""
@@ -144,8 +210,12 @@ def tta_unit(model, optimizer, config, tta_tens_list, patch_size, label_mapping,
             imgs = imgs[0] if len(imgs) == 1 else torch.cat(imgs, dim=0)
             args = (config, model, intensity_aug_func, None, patch_size, B, label_mapping, optimized_labels,
                     modifier_fn_module, imgs, device, head_is_fused)
-            target_a = calc_branch("branch_a", *args)
-            target_b = calc_branch("branch_b", *args)
+            if batch_branches_enabled():
+                target_a, target_b = calc_both_branches(config, model, intensity_aug_func, patch_size, B, label_mapping,
+                                                        optimized_labels, modifier_fn_module, imgs, device, head_is_fused)
+            else:
+                target_a = calc_branch("branch_a", *args)
+                target_b = calc_branch("branch_b", *args)
             loss, _ = ops.consistency_loss(target_a, target_b, START_CLASS)
             step_losses.append(loss.detach())
             if epoch >= start and loss.requires_grad:

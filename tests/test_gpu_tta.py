@@ -130,6 +130,42 @@ def test_product_calc_branch_reproduces_reference_draw_order():
         assert (out.detach().cpu() - ref).abs().max().item() < 3e-4 * ref.abs().max().item()
 
 
+def test_batched_branches_equal_two_sequential_branches():
+    """calc_both_branches (one batch of 2 through the network) == calc_branch a, then b: same draws on both generators
+    (the draw order is kept), same targets, same loss and the same accumulated parameter gradients."""
+    from dg_tta_amd import ops
+    from dg_tta_amd.gin import gin_aug
+    from dg_tta_amd.tta.tta import START_CLASS, _fuse_head_if_possible, calc_both_branches, calc_branch
+    g = load_golden("calc_branch")
+    cfg = _plan()
+    imgs = g["imgs"].to(DEV)
+    dev = torch.device(DEV)
+    results = []
+    for batched in (False, True):
+        model, modmod = _product_model(g)
+        assert _fuse_head_if_possible(model, modmod, LABEL_MAPPING, OPTIMIZED)
+        torch.manual_seed(77)
+        torch.cuda.manual_seed(78)
+        if batched:
+            ta, tb = calc_both_branches(cfg, model, gin_aug, [16, 16, 16], 1, LABEL_MAPPING, OPTIMIZED, modmod, imgs, dev,
+                                        head_is_fused=True)
+        else:
+            a = (cfg, model, gin_aug, None, [16, 16, 16], 1, LABEL_MAPPING, OPTIMIZED, modmod, imgs, dev, True)
+            ta, tb = calc_branch("branch_a", *a), calc_branch("branch_b", *a)
+        loss, _ = ops.consistency_loss(ta, tb, START_CLASS)
+        loss.backward()
+        grads = {n: p.grad.detach().float().cpu().clone() for n, p in model.named_parameters() if p.grad is not None}
+        results.append((ta.detach().float().cpu(), tb.detach().float().cpu(), float(loss), grads))
+    (ta0, tb0, l0, g0), (ta1, tb1, l1, g1) = results
+    assert (ta0 - ta1).abs().max().item() < 1e-5 * max(1.0, ta0.abs().max().item())
+    assert (tb0 - tb1).abs().max().item() < 1e-5 * max(1.0, tb0.abs().max().item())
+    assert abs(l0 - l1) < 1e-6
+    assert g0.keys() == g1.keys() and len(g0) > 10
+    for n in g0:
+        scale = g0[n].abs().max().item()
+        assert (g0[n] - g1[n]).abs().max().item() < 2e-4 * scale + 1e-7, n
+
+
 def test_unfused_head_matches_fused():
     from dg_tta_amd.tta.torch_utils import map_label
     g = load_golden("calc_branch")

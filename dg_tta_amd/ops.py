@@ -187,9 +187,49 @@ class _ConsistencyLoss(torch.autograd.Function):
         return ga, gb, None
 
 
+class _ConsistencyLossPair(torch.autograd.Function):
+    """Same loss on the two halves of ONE batched tensor [2B,C,D,H,W] (branch a = first half): the gradient comes back
+    as one buffer, so autograd needs no slice-backward zero fills and adds."""
+
+    @staticmethod
+    def forward(ctx, both, start_class):
+        lib = _lib.load()
+        both = both.contiguous(memory_format=torch.channels_last_3d)
+        b2, c = both.shape[:2]
+        b = b2 // 2
+        v = both.shape[2] * both.shape[3] * both.shape[4]
+        la, lb = both[:b], both[b:]
+        dice = torch.empty((b, c), dtype=torch.float32, device=both.device)
+        loss = torch.empty((), dtype=torch.float32, device=both.device)
+        nbytes = lib.dgtta_softdice_ws_bytes(b, c, v)
+        ws = _ws(nbytes, both.device)
+        check(lib.dgtta_softdice_fwd(ptr(la), ptr(lb), ptr(dice), ptr(loss), ptr(ws), nbytes, b, c, v, c, start_class,
+                                     stream_of(both.device)), "dgtta_softdice_fwd")
+        ctx.save_for_backward(both, ws)
+        ctx.meta = (b, c, v, start_class)
+        ctx.mark_non_differentiable(dice)
+        return loss, dice
+
+    @staticmethod
+    def backward(ctx, gloss, _gdice):
+        both, ws = ctx.saved_tensors
+        b, c, v, start_class = ctx.meta
+        lib = _lib.load()
+        g = torch.empty_like(both, memory_format=torch.preserve_format)
+        gs = gloss.reshape(1).float().contiguous()
+        check(lib.dgtta_softdice_bwd(ptr(both[:b]), ptr(both[b:]), ptr(g[:b]), ptr(g[b:]), ptr(ws), 1.0, ptr(gs), b, c, v, c,
+                                     start_class, stream_of(both.device)), "dgtta_softdice_bwd")
+        return g, None
+
+
 def consistency_loss(target_a, target_b, start_class=1):
-    """tta.py:263-269: masked softmax of both branches + `1 - soft_dice[:, start_class:].mean()`. Returns (loss, dice[B,C])."""
+    """tta.py:263-269: masked softmax of both branches + `1 - soft_dice[:, start_class:].mean()`. Returns (loss, dice[B,C]).
+    Targets produced by tta.calc_both_branches carry their common batched tensor (`_dgtta_pair`): the loss is then taken
+    on that tensor directly."""
     require_cuda(target_a, target_b)
+    pair = getattr(target_a, "_dgtta_pair", None)
+    if pair is not None and pair is getattr(target_b, "_dgtta_pair", None) and pair.dtype == torch.float32:
+        return _ConsistencyLossPair.apply(pair, int(start_class))
     return _ConsistencyLoss.apply(target_a.float(), target_b.float(), int(start_class))
 
 

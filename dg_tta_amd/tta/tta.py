@@ -111,9 +111,10 @@ def calc_both_branches(config, model, intensity_aug_func, patch_size, batch_size
     grad_context = nullcontext if config["have_grad_in"] in ["branch_a", "both"] else torch.no_grad
     after_mapping = modifier_fn_module.ModifierFunctions.modify_tta_output_after_mapping_fn
     with grad_context():
-        augs, inverses, noises = [], [], []
+        augs, inverses = [], []
         want_noise = uses_mind_hook(model)
-        for branch_id in ("branch_a", "branch_b"):
+        noise = None
+        for k, branch_id in enumerate(("branch_a", "branch_b")):
             imgs_aug = imgs
             if config["do_intensity_aug_in"] in [branch_id, "both"]:
                 imgs_aug = intensity_aug_func(imgs_aug)
@@ -130,21 +131,32 @@ def calc_both_branches(config, model, intensity_aug_func, patch_size, batch_size
                 imgs_aug = ops.affine_warp(imgs_aug, R, padding_mode="border", tta_grid_algebra=True)
             augs.append(imgs_aug)
             inverses.append(R_inverse)
-            if want_noise:
-                noises.append(torch.randn((imgs_aug.shape[0], 12) + tuple(imgs_aug.shape[2:]), dtype=torch.float32,
-                                          device=imgs_aug.device))
+            if want_noise:      # this branch's torch.randn(...) of mind.py:150, drawn in place into its half of the batch
+                nb_ = imgs_aug.shape[0]
+                if noise is None:
+                    noise = torch.empty((2 * nb_, 12) + tuple(imgs_aug.shape[2:]), dtype=torch.float32,
+                                        device=imgs_aug.device)
+                noise[k * nb_:(k + 1) * nb_].normal_()
         model.apply(buffer_running_stats)
         model.apply(apply_running_stats)
         if want_noise:
-            push_noise(torch.cat(noises, dim=0), groups=2)
+            push_noise(noise, groups=2)
         try:
             both = model(torch.cat(augs, dim=0))
         finally:
             clear_noise()
         if isinstance(both, tuple):
             both = both[0]
-        targets = []
         nb = augs[0].shape[0]
+        template_after = is_template_modifier(after_mapping, "modify_tta_output_after_mapping_fn")
+        if head_is_fused and template_after and all(r is not None for r in inverses):
+            # fast path: one inverse warp over the batch, targets are views of one tensor (the loss then runs on it
+            # directly and returns one gradient buffer)
+            both = ops.affine_warp(both, torch.cat(inverses, dim=0), padding_mode="zeros", tta_grid_algebra=True)
+            ta, tb = both[:nb], both[nb:]
+            ta._dgtta_pair = tb._dgtta_pair = both
+            return ta, tb
+        targets = []
         for k in range(2):
             t = both[k * nb:(k + 1) * nb]
             if not head_is_fused:

@@ -78,25 +78,36 @@ class EpochRunner:
     def epoch(self):
         from dg_tta_amd import ops
         from dg_tta_amd.gin import gin_aug
-        from dg_tta_amd.tta.tta import batch_branches_enabled, calc_both_branches, calc_branch, START_CLASS
+        from dg_tta_amd.tta.tta import (batch_branches_enabled, batched_steps, calc_both_branches, calc_branch,
+                                        START_CLASS)
         from dg_tta_amd.tta.torch_utils import dice_coeff, get_batch, get_map_idxs, map_label
         cfg, model, dev = self.cfg, self.model, self.device
         model.train()
         step_losses = []
-        for _ in range(cfg["patches_to_be_accumulated"]):
+        accum = cfg["patches_to_be_accumulated"]
+
+        def next_imgs():
             with torch.no_grad():
                 imgs, _ = get_batch(self.data, np.random.choice(range(1), 1).tolist(), self.patch, None, dev)
-            a = (cfg, model, gin_aug, None, self.patch, 1, self.mapping, cfg["optimized_labels"], self.modmod, imgs[0],
-                 dev, self.fused)
-            if batch_branches_enabled():       # product default: both branches as one batch of 2 (see tta.calc_both_branches)
+            return imgs[0]
+
+        if batch_branches_enabled():      # product default (tta.tta_unit): branches and k accumulation steps as one batch
+            k = batched_steps(accum, 1)
+            for _ in range(accum // k):
                 ta, tb = calc_both_branches(cfg, model, gin_aug, self.patch, 1, self.mapping, cfg["optimized_labels"],
-                                            self.modmod, imgs[0], dev, self.fused)
-            else:
+                                            self.modmod, next_imgs, dev, self.fused, steps=k)
+                loss, dice = ops.consistency_loss(ta, tb, START_CLASS)
+                step_losses.extend((1.0 - dice.detach()[:, START_CLASS:].mean(1)).unbind(0))
+                torch.autograd.backward(loss, grad_tensors=self.inv * k)
+        else:
+            for _ in range(accum):
+                a = (cfg, model, gin_aug, None, self.patch, 1, self.mapping, cfg["optimized_labels"], self.modmod,
+                     next_imgs(), dev, self.fused)
                 ta = calc_branch("branch_a", *a)
                 tb = calc_branch("branch_b", *a)
-            loss, _ = ops.consistency_loss(ta, tb, START_CLASS)
-            step_losses.append(loss.detach())
-            torch.autograd.backward(loss, grad_tensors=self.inv)
+                loss, _ = ops.consistency_loss(ta, tb, START_CLASS)
+                step_losses.append(loss.detach())
+                torch.autograd.backward(loss, grad_tensors=self.inv)
         self.opt.step()
         self.opt.zero_grad()
         self.losses.append(torch.stack(step_losses).mean().item())

@@ -157,9 +157,9 @@ __global__ __launch_bounds__(MAXW * 64) void softdice_fwd_kernel(const float *__
 __global__ __launch_bounds__(1024) void softdice_finalize_kernel(const double *__restrict__ partial, int nblk, int B,
                                                                  int C, int64_t V, int start_class,
                                                                  float *__restrict__ dice, float *__restrict__ loss,
-                                                                 float *__restrict__ coef) {
+                                                                 float *__restrict__ coef, int guard_items) {
   __shared__ float s_nom[8 * MAXC], s_den[8 * MAXC];
-  __shared__ float s_flag, s_loss;
+  __shared__ float s_flag[8], s_loss;
   const int n = B * C;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
   for (int j = wv; j < 2 * n; j += nw) {          // j = (b*C + c)*2 + k, partial row of nblk doubles
@@ -172,14 +172,15 @@ __global__ __launch_bounds__(1024) void softdice_finalize_kernel(const double *_
     }
   }
   __syncthreads();
-  if (threadIdx.x == 0) {
+  if ((int)threadIdx.x < B / guard_items) {       // one guard per group of guard_items batch items
+    const int g0 = threadIdx.x * guard_items * C;
     float tot = 0.f;
-    for (int i = 0; i < n; ++i) tot += s_den[i];
-    s_flag = (tot == 0.0f) ? 1.f : 0.f;
+    for (int i = 0; i < guard_items * C; ++i) tot += s_den[g0 + i];
+    s_flag[threadIdx.x] = (tot == 0.0f) ? 1.f : 0.f;
   }
   __syncthreads();
-  const bool all_zero = s_flag != 0.f;
-  for (int i = threadIdx.x; i < n; i += blockDim.x) dice[i] = all_zero ? 1.0f : s_nom[i] / s_den[i];
+  for (int i = threadIdx.x; i < n; i += blockDim.x)
+    dice[i] = s_flag[(i / C) / guard_items] != 0.f ? 1.0f : s_nom[i] / s_den[i];
   __syncthreads();
   if (threadIdx.x == 0) {
     float acc = 0.f;
@@ -196,7 +197,7 @@ __global__ __launch_bounds__(1024) void softdice_finalize_kernel(const double *_
   for (int i = threadIdx.x; i < n; i += blockDim.x) {
     int c = i % C;
     float P = 0.f, Q = 0.f;
-    if (!all_zero && c >= start_class) {
+    if (s_flag[(i / C) / guard_items] == 0.f && c >= start_class) {
       float den = s_den[i], nom = s_nom[i];
       P = -invN * 2.0f / ((float)V * den);
       Q = invN * nom / (den * den * (float)V);
@@ -304,11 +305,12 @@ extern "C" size_t dgtta_softdice_ws_bytes(int B, int C, int64_t V) {
 }
 
 extern "C" int dgtta_softdice_fwd(const float *la, const float *lb, float *dice, float *loss, void *ws, size_t ws_bytes,
-                                  int B, int C, int64_t V, int ldc, int start_class, void *stream) {
+                                  int B, int C, int64_t V, int ldc, int start_class, int guard_items, void *stream) {
   DG_REQUIRE(la && lb && dice && loss && ws, DGTTA_ERR_BADARG, "softdice_fwd: null pointer");
   DG_REQUIRE(B > 0 && B <= 8 && C > 0 && C <= MAXC && V > 0 && ldc >= C, DGTTA_ERR_BADARG,
              "softdice_fwd: need 1<=B<=8, 1<=C<=%d, ldc>=C (B=%d C=%d ldc=%d)", MAXC, B, C, ldc);
   DG_REQUIRE(start_class >= 0 && start_class < C, DGTTA_ERR_BADARG, "softdice_fwd: bad start_class");
+  DG_REQUIRE(guard_items >= 1 && B % guard_items == 0, DGTTA_ERR_BADARG, "softdice_fwd: guard_items must divide B");
   DG_REQUIRE(ws_bytes >= dgtta_softdice_ws_bytes(B, C, V), DGTTA_ERR_WORKSPACE, "softdice_fwd: workspace too small");
   hipStream_t st = (hipStream_t)stream;
   const int nblk = nblocks_for(V);
@@ -320,7 +322,7 @@ extern "C" int dgtta_softdice_fwd(const float *la, const float *lb, float *dice,
                      (int)vec_ok(la, lb, nullptr, nullptr, ldc));
   DG_CHECK_LAUNCH("softdice_fwd_kernel");
   hipLaunchKernelGGL(softdice_finalize_kernel, dim3(1), dim3(1024), 0, st, partial, nblk, B, C, V, start_class, dice,
-                     loss, coef);
+                     loss, coef, guard_items);
   DG_CHECK_LAUNCH("softdice_finalize_kernel");
   return DGTTA_OK;
 }

@@ -156,7 +156,7 @@ def affine_sample(src, theta, out_size, padding_mode="zeros", mode="bilinear", s
 # ------------------------------------------------------------------------------------------------ loss
 class _ConsistencyLoss(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, la, lb, start_class):
+    def forward(ctx, la, lb, start_class, guard_items=0):
         lib = _lib.load()
         b, c = la.shape[:2]
         v = la.shape[2] * la.shape[3] * la.shape[4]
@@ -167,7 +167,7 @@ class _ConsistencyLoss(torch.autograd.Function):
         nbytes = lib.dgtta_softdice_ws_bytes(b, c, v)
         ws = _ws(nbytes, la.device)
         check(lib.dgtta_softdice_fwd(ptr(la), ptr(lb), ptr(dice), ptr(loss), ptr(ws), nbytes, b, c, v, c, start_class,
-                                     stream_of(la.device)), "dgtta_softdice_fwd")
+                                     guard_items if guard_items else b, stream_of(la.device)), "dgtta_softdice_fwd")
         ctx.save_for_backward(la, lb, ws)
         ctx.meta = (b, c, v, start_class)
         ctx.mark_non_differentiable(dice)
@@ -184,7 +184,7 @@ class _ConsistencyLoss(torch.autograd.Function):
         gs = gloss.reshape(1).float().contiguous()
         check(lib.dgtta_softdice_bwd(ptr(la), ptr(lb), ptr(ga), ptr(gb), ptr(ws), 1.0, ptr(gs), b, c, v, c, start_class,
                                      stream_of(la.device)), "dgtta_softdice_bwd")
-        return ga, gb, None
+        return ga, gb, None, None
 
 
 class _ConsistencyLossPair(torch.autograd.Function):
@@ -192,7 +192,7 @@ class _ConsistencyLossPair(torch.autograd.Function):
     as one buffer, so autograd needs no slice-backward zero fills and adds."""
 
     @staticmethod
-    def forward(ctx, both, start_class):
+    def forward(ctx, both, start_class, guard_items):
         lib = _lib.load()
         both = both.contiguous(memory_format=torch.channels_last_3d)
         b2, c = both.shape[:2]
@@ -204,7 +204,7 @@ class _ConsistencyLossPair(torch.autograd.Function):
         nbytes = lib.dgtta_softdice_ws_bytes(b, c, v)
         ws = _ws(nbytes, both.device)
         check(lib.dgtta_softdice_fwd(ptr(la), ptr(lb), ptr(dice), ptr(loss), ptr(ws), nbytes, b, c, v, c, start_class,
-                                     stream_of(both.device)), "dgtta_softdice_fwd")
+                                     guard_items if guard_items else b, stream_of(both.device)), "dgtta_softdice_fwd")
         ctx.save_for_backward(both, ws)
         ctx.meta = (b, c, v, start_class)
         ctx.mark_non_differentiable(dice)
@@ -219,7 +219,7 @@ class _ConsistencyLossPair(torch.autograd.Function):
         gs = gloss.reshape(1).float().contiguous()
         check(lib.dgtta_softdice_bwd(ptr(both[:b]), ptr(both[b:]), ptr(g[:b]), ptr(g[b:]), ptr(ws), 1.0, ptr(gs), b, c, v, c,
                                      start_class, stream_of(both.device)), "dgtta_softdice_bwd")
-        return g, None
+        return g, None, None
 
 
 def consistency_loss(target_a, target_b, start_class=1):
@@ -229,8 +229,9 @@ def consistency_loss(target_a, target_b, start_class=1):
     require_cuda(target_a, target_b)
     pair = getattr(target_a, "_dgtta_pair", None)
     if pair is not None and pair is getattr(target_b, "_dgtta_pair", None) and pair.dtype == torch.float32:
-        return _ConsistencyLossPair.apply(pair, int(start_class))
-    return _ConsistencyLoss.apply(target_a.float(), target_b.float(), int(start_class))
+        return _ConsistencyLossPair.apply(pair, int(start_class), int(getattr(target_a, "_dgtta_guard_items", 0)))
+    return _ConsistencyLoss.apply(target_a.float(), target_b.float(), int(start_class),
+                                  int(getattr(target_a, "_dgtta_guard_items", 0)))
 
 
 # ------------------------------------------------------------------------------------------------ AdamW

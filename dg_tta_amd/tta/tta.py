@@ -100,54 +100,65 @@ def calc_branch(branch_id, config, model, intensity_aug_func, identity_grid, pat
 
 
 def calc_both_branches(config, model, intensity_aug_func, patch_size, batch_size, label_mapping, optimized_labels,
-                       modifier_fn_module, imgs, device, head_is_fused=False):
+                       modifier_fn_module, imgs, device, head_is_fused=False, steps=1):
     """calc_branch("branch_a") and calc_branch("branch_b") with the two network passes run as ONE batch of
     2*batch_size (same weights, per-sample InstanceNorm: the same maths; the weight gradient then sums both branches
     inside one kernel).  Small layers (16^3 and below) are launch / occupancy bound, so halving the number of launches
     and doubling the work per launch is worth ~15 % of an epoch.  Random draws keep the reference's order on both
     generators: branch a's GIN, affine and MIND-noise draws, then branch b's (the noise is pre-drawn and handed to
-    mind_hook).  Returns (target_a, target_b)."""
+    mind_hook).  Returns (target_a, target_b).
+
+    steps > 1 additionally batches `steps` accumulation steps (they all see the same weights: the optimizer only steps
+    once per epoch): `imgs` is then a callable that samples the next step's patches (get_batch), called in step order so
+    that the reference's draw sequence  get_batch_i, branch_a_i, branch_b_i, get_batch_i+1, ...  is kept.  The targets are
+    ordered [step][batch item]; ops.consistency_loss on them returns the MEAN of the per-step losses and dice[step]."""
     from ..mind import clear_noise, push_noise, uses_mind_hook
     grad_context = nullcontext if config["have_grad_in"] in ["branch_a", "both"] else torch.no_grad
     after_mapping = modifier_fn_module.ModifierFunctions.modify_tta_output_after_mapping_fn
     with grad_context():
-        augs, inverses = [], []
+        augs, inverses = [[], []], [[], []]
         want_noise = uses_mind_hook(model)
         noise = None
-        for k, branch_id in enumerate(("branch_a", "branch_b")):
-            imgs_aug = imgs
-            if config["do_intensity_aug_in"] in [branch_id, "both"]:
-                imgs_aug = intensity_aug_func(imgs_aug)
-            R_inverse = None
-            if config["do_spatial_aug_in"] in [branch_id, "both"]:
-                if config["spatial_aug_type"] == "affine":
-                    R, R_inverse = get_rand_affine(batch_size, flip=False)
-                    R, R_inverse = upload_async([R.float().contiguous(), R_inverse.float().contiguous()], device)
-                elif config["spatial_aug_type"] == "deformable":
-                    from .augmentation_utils import get_disp_field
-                    get_disp_field()
-                else:
-                    R = R_inverse = torch.eye(4, device=device)[:3][None].repeat(batch_size, 1, 1)
-                imgs_aug = ops.affine_warp(imgs_aug, R, padding_mode="border", tta_grid_algebra=True)
-            augs.append(imgs_aug)
-            inverses.append(R_inverse)
-            if want_noise:      # this branch's torch.randn(...) of mind.py:150, drawn in place into its half of the batch
-                nb_ = imgs_aug.shape[0]
-                if noise is None:
-                    noise = torch.empty((2 * nb_, 12) + tuple(imgs_aug.shape[2:]), dtype=torch.float32,
-                                        device=imgs_aug.device)
-                noise[k * nb_:(k + 1) * nb_].normal_()
+        for step in range(steps):
+            step_imgs = imgs() if callable(imgs) else imgs
+            for k, branch_id in enumerate(("branch_a", "branch_b")):
+                imgs_aug = step_imgs
+                if config["do_intensity_aug_in"] in [branch_id, "both"]:
+                    imgs_aug = intensity_aug_func(imgs_aug)
+                R_inverse = None
+                if config["do_spatial_aug_in"] in [branch_id, "both"]:
+                    if config["spatial_aug_type"] == "affine":
+                        R, R_inverse = get_rand_affine(batch_size, flip=False)
+                        R, R_inverse = upload_async([R.float().contiguous(), R_inverse.float().contiguous()], device)
+                    elif config["spatial_aug_type"] == "deformable":
+                        from .augmentation_utils import get_disp_field
+                        get_disp_field()
+                    else:
+                        R = R_inverse = torch.eye(4, device=device)[:3][None].repeat(batch_size, 1, 1)
+                    imgs_aug = ops.affine_warp(imgs_aug, R, padding_mode="border", tta_grid_algebra=True)
+                augs[k].append(imgs_aug)
+                inverses[k].append(R_inverse)
+                if want_noise:      # this branch's torch.randn(...) of mind.py:150, drawn in place into its slot of the batch
+                    nb_ = imgs_aug.shape[0]
+                    if noise is None:
+                        noise = torch.empty((2 * steps * nb_, 12) + tuple(imgs_aug.shape[2:]), dtype=torch.float32,
+                                            device=imgs_aug.device)
+                    slot = k * steps + step
+                    noise[slot * nb_:(slot + 1) * nb_].normal_()
+        augs = augs[0] + augs[1]                    # all of branch a (step order), then all of branch b
+        inverses = inverses[0] + inverses[1]
         model.apply(buffer_running_stats)
         model.apply(apply_running_stats)
         if want_noise:
-            push_noise(noise, groups=2)
+            push_noise(noise, groups=2 * steps)
         try:
             both = model(torch.cat(augs, dim=0))
         finally:
             clear_noise()
         if isinstance(both, tuple):
             both = both[0]
-        nb = augs[0].shape[0]
+        per = augs[0].shape[0]
+        nb = steps * per
         template_after = is_template_modifier(after_mapping, "modify_tta_output_after_mapping_fn")
         if head_is_fused and template_after and all(r is not None for r in inverses):
             # fast path: one inverse warp over the batch, targets are views of one tensor (the loss then runs on it
@@ -155,19 +166,23 @@ def calc_both_branches(config, model, intensity_aug_func, patch_size, batch_size
             both = ops.affine_warp(both, torch.cat(inverses, dim=0), padding_mode="zeros", tta_grid_algebra=True)
             ta, tb = both[:nb], both[nb:]
             ta._dgtta_pair = tb._dgtta_pair = both
+            ta._dgtta_guard_items = tb._dgtta_guard_items = per
             return ta, tb
-        targets = []
-        for k in range(2):
-            t = both[k * nb:(k + 1) * nb]
+        pieces = []
+        for j in range(2 * steps):                  # general path: per (branch, step) slice, as calc_branch does
+            t = both[j * per:(j + 1) * per]
             if not head_is_fused:
                 t = map_label(t, get_map_idxs(label_mapping, optimized_labels, input_type="pretrain_labels"),
                               input_format="logits")
             t = after_mapping(t)
             if isinstance(t, tuple):
                 t = t[0]
-            if inverses[k] is not None:
-                t = ops.affine_warp(t, inverses[k], padding_mode="zeros", tta_grid_algebra=True)
-            targets.append(t)
+            if inverses[j] is not None:
+                t = ops.affine_warp(t, inverses[j], padding_mode="zeros", tta_grid_algebra=True)
+            pieces.append(t)
+        targets = [torch.cat(pieces[:steps], dim=0) if steps > 1 else pieces[0],
+                   torch.cat(pieces[steps:], dim=0) if steps > 1 else pieces[1]]
+        targets[0]._dgtta_guard_items = targets[1]._dgtta_guard_items = per
     return targets[0], targets[1]
 
 
@@ -175,6 +190,17 @@ def batch_branches_enabled():
     """Both branches as one batch unless DGTTA_BATCH_BRANCHES=0 (then two calc_branch calls, as the reference does)."""
     import os
     return os.environ.get("DGTTA_BATCH_BRANCHES", "1") != "0"
+
+
+def batched_steps(accum, batch_size):
+    """Accumulation steps run per network pass (DGTTA_BATCH_STEPS, default 4): 2 * steps * batch_size samples must stay
+    within the kernels' batch limit of 8 and `steps` must divide the number of accumulation steps."""
+    import os
+    k = max(1, int(os.environ.get("DGTTA_BATCH_STEPS", "4")))
+    k = min(k, max(1, 4 // max(1, batch_size)), accum)
+    while accum % k:
+        k -= 1
+    return k
 
 
 def _fuse_head_if_possible(model, modifier_fn_module, label_mapping, optimized_labels):
@@ -215,24 +241,37 @@ def tta_unit(model, optimizer, config, tta_tens_list, patch_size, label_mapping,
                 raise ValueError()
             n_released = sum(p.numel() for p in model.parameters() if p.requires_grad)
             print(f"Released #{n_released / 1e6:.2f} million trainable params")
-        for _ in range(accum):
+        def next_imgs():
             with torch.no_grad():
                 imgs, _ = get_batch(tta_tens_list, np.random.choice(range(len(tta_tens_list)), B).tolist(), patch_size,
                                     fixed_patch_idx=None, device=device)
-            imgs = imgs[0] if len(imgs) == 1 else torch.cat(imgs, dim=0)
-            args = (config, model, intensity_aug_func, None, patch_size, B, label_mapping, optimized_labels,
-                    modifier_fn_module, imgs, device, head_is_fused)
-            if batch_branches_enabled():
+            return imgs[0] if len(imgs) == 1 else torch.cat(imgs, dim=0)
+
+        if batch_branches_enabled():
+            k = batched_steps(accum, B)
+            for _ in range(accum // k):
                 target_a, target_b = calc_both_branches(config, model, intensity_aug_func, patch_size, B, label_mapping,
-                                                        optimized_labels, modifier_fn_module, imgs, device, head_is_fused)
-            else:
+                                                        optimized_labels, modifier_fn_module, next_imgs, device,
+                                                        head_is_fused, steps=k)
+                loss, dice = ops.consistency_loss(target_a, target_b, START_CLASS)      # mean of the k step losses
+                if k == 1:
+                    step_losses.append(loss.detach())
+                else:
+                    step_losses.extend((1.0 - dice.detach().reshape(k, B, -1)[:, :, START_CLASS:].mean((1, 2))).unbind(0))
+                if epoch >= start and loss.requires_grad:
+                    torch.autograd.backward(loss, grad_tensors=inv_accum * k)
+        else:
+            for _ in range(accum):
+                imgs = next_imgs()
+                args = (config, model, intensity_aug_func, None, patch_size, B, label_mapping, optimized_labels,
+                        modifier_fn_module, imgs, device, head_is_fused)
                 target_a = calc_branch("branch_a", *args)
                 target_b = calc_branch("branch_b", *args)
-            loss, _ = ops.consistency_loss(target_a, target_b, START_CLASS)
-            step_losses.append(loss.detach())
-            if epoch >= start and loss.requires_grad:
-                # d(loss/accum): the 1/accum factor is handed to the loss kernel as a device scalar
-                torch.autograd.backward(loss, grad_tensors=inv_accum)
+                loss, _ = ops.consistency_loss(target_a, target_b, START_CLASS)
+                step_losses.append(loss.detach())
+                if epoch >= start and loss.requires_grad:
+                    # d(loss/accum): the 1/accum factor is handed to the loss kernel as a device scalar
+                    torch.autograd.backward(loss, grad_tensors=inv_accum)
         if epoch >= start:
             optimizer.step()
             optimizer.zero_grad()

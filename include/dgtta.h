@@ -98,10 +98,13 @@ int dgtta_affine_warp3d_bwd(const float *grad_dst, const float *theta, float *gr
  * fwd writes dice[B*C], loss[1] and keeps what bwd needs in ws.  bwd writes grad_la/grad_lb
  * (same layout) = grad_scale * (grad_scale_dev ? *grad_scale_dev : 1) * dloss/dlogits (mask treated as
  * a constant, as autograd does; the device scalar lets autograd's upstream gradient stay on the GPU).
+ * guard_items: soft_dice_loss's "denominator.sum() == 0 -> dice = 1" guard is evaluated per group of
+ * guard_items consecutive batch items (B = one reference call; 1 = every item is its own call, used
+ * when several accumulation steps of batch size 1 run as one batch).  Must divide B.
  * ------------------------------------------------------------------------------------------- */
 size_t dgtta_softdice_ws_bytes(int B, int C, int64_t V);
 int dgtta_softdice_fwd(const float *la, const float *lb, float *dice, float *loss, void *ws, size_t ws_bytes,
-                       int B, int C, int64_t V, int ldc, int start_class, void *stream);
+                       int B, int C, int64_t V, int ldc, int start_class, int guard_items, void *stream);
 int dgtta_softdice_bwd(const float *la, const float *lb, float *grad_la, float *grad_lb, const void *ws,
                        float grad_scale, const float *grad_scale_dev, int B, int C, int64_t V, int ldc,
                        int start_class, void *stream);

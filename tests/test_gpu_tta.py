@@ -166,6 +166,54 @@ def test_batched_branches_equal_two_sequential_branches():
         assert (g0[n] - g1[n]).abs().max().item() < 2e-4 * scale + 1e-7, n
 
 
+def test_batched_steps_equal_sequential_accumulation():
+    """2 accumulation steps x 2 branches as ONE batch of 4 == two sequential steps of two sequential branches: same
+    draws (patch offsets, GIN, affine, MIND noise on their generators in the reference order), same per-step losses and
+    the same accumulated gradients."""
+    from dg_tta_amd import ops
+    from dg_tta_amd.gin import gin_aug
+    from dg_tta_amd.tta.torch_utils import get_batch
+    from dg_tta_amd.tta.tta import START_CLASS, _fuse_head_if_possible, calc_both_branches, calc_branch
+    g = load_golden("calc_branch")
+    cfg = _plan()
+    dev = torch.device(DEV)
+    vol = torch.randn(1, 24, 24, 24, generator=torch.Generator().manual_seed(5)) * 100.0 - 300.0
+    results = []
+    for batched in (False, True):
+        model, modmod = _product_model(g)
+        assert _fuse_head_if_possible(model, modmod, LABEL_MAPPING, OPTIMIZED)
+        torch.manual_seed(91)
+        torch.cuda.manual_seed(92)
+
+        def next_imgs():
+            imgs, _ = get_batch([vol], [0], [16, 16, 16], None, dev)
+            return imgs[0]
+
+        losses = []
+        if batched:
+            ta, tb = calc_both_branches(cfg, model, gin_aug, [16, 16, 16], 1, LABEL_MAPPING, OPTIMIZED, modmod, next_imgs,
+                                        dev, head_is_fused=True, steps=2)
+            loss, dice = ops.consistency_loss(ta, tb, START_CLASS)
+            losses = (1.0 - dice[:, START_CLASS:].mean(1)).tolist()
+            assert abs(float(loss) - sum(losses) / 2) < 1e-6
+            torch.autograd.backward(loss, grad_tensors=torch.full((), 0.5 * 2, device=DEV))
+        else:
+            for _ in range(2):
+                a = (cfg, model, gin_aug, None, [16, 16, 16], 1, LABEL_MAPPING, OPTIMIZED, modmod, next_imgs(), dev, True)
+                ta, tb = calc_branch("branch_a", *a), calc_branch("branch_b", *a)
+                loss, _ = ops.consistency_loss(ta, tb, START_CLASS)
+                losses.append(float(loss))
+                torch.autograd.backward(loss, grad_tensors=torch.full((), 0.5, device=DEV))
+        grads = {n: p.grad.detach().float().cpu().clone() for n, p in model.named_parameters() if p.grad is not None}
+        results.append((losses, grads))
+    (l0, g0), (l1, g1) = results
+    assert max(abs(a - b) for a, b in zip(l0, l1)) < 2e-6, (l0, l1)
+    assert g0.keys() == g1.keys() and len(g0) > 10
+    for n in g0:
+        scale = g0[n].abs().max().item()
+        assert (g0[n] - g1[n]).abs().max().item() < 3e-4 * scale + 1e-7, n
+
+
 def test_unfused_head_matches_fused():
     from dg_tta_amd.tta.torch_utils import map_label
     g = load_golden("calc_branch")

@@ -108,7 +108,11 @@ struct ConvClasses {
 // x: view xv;  y: view yv;  virtual tap t uses weight tap taps.wt[t].
 // w is stored in "LDS image order" [N/32][K/(2*EPV)][ntaps_src][2][32][EPV]: the B tile of a K-chunk is one contiguous
 // run, so its staging is a linear, fully coalesced copy (see conv_weight_image_index).
-template <typename T, int MBW, int MBH, int MBD, int S, int NB, int KSPC, int ABL = 0, int NW = 4>   // ABL: diagnostic ablation; NW waves
+// AC ("all classes"): data gradient of a stride-2 conv in ONE pass over dy.  The 8 parity classes of the input lattice
+// need dy at 8 shifts (0/+1 per axis) only; a wave keeps 8 accumulators (one per class), reads each shifted A fragment
+// once and feeds the (class, tap) pairs that use it (27 in total = every real tap once).  Class c is written to
+// y + cs.yoff[c] with the strides of yv (the parity view).  Replaces 8 class launches that each re-staged the dy tile.
+template <typename T, int MBW, int MBH, int MBD, int S, int NB, int KSPC, int ABL = 0, int NW = 4, bool AC = false>   // ABL: diagnostic ablation; NW waves
 __global__ __launch_bounds__(NW * 64) void conv3_mfma_kernel(const T *__restrict__ x, View xv, const T *__restrict__ w,
                                                          ConvClasses cs, const float *__restrict__ bias,
                                                          T *__restrict__ y, View yv, int Cin, int Cout, int CinP,
@@ -116,7 +120,7 @@ __global__ __launch_bounds__(NW * 64) void conv3_mfma_kernel(const T *__restrict
                                                          double *__restrict__ stats, int ntaps_src) {
   const int cls = blockIdx.z;
   x += cs.xoff[cls];
-  y += cs.yoff[cls];
+  if (!AC) y += cs.yoff[cls];
   const Taps &taps = cs.taps[cls];
   const int accumulate = cs.acc[cls];
   const int Di = xv.D, Hi = xv.H, Wi = xv.W, Do = yv.D, Ho = yv.H, Wo = yv.W;
@@ -152,11 +156,12 @@ __global__ __launch_bounds__(NW * 64) void conv3_mfma_kernel(const T *__restrict
     a_off[i] = ((mbd * SE) * G::IH + row * SE) * G::ROW + col;   // S=2: column index in the half row
   }
 
-  f32x16_t acc[MPW][NB];
+  constexpr int NACC = AC ? 8 : NB;
+  f32x16_t acc[MPW][NACC];
 #pragma unroll
   for (int i = 0; i < MPW; ++i)
 #pragma unroll
-    for (int j = 0; j < NB; ++j)
+    for (int j = 0; j < NACC; ++j)
 #pragma unroll
       for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
 
@@ -198,7 +203,7 @@ __global__ __launch_bounds__(NW * 64) void conv3_mfma_kernel(const T *__restrict
     for (int i = 0; i < NBL; ++i) {
       const int idx = tid + i * NT;       // == LDS index (tap*NG + g)*NC + n
       const int n = idx % NC, g = (idx / NC) % NG, tap = (S == 0) ? 13 : (idx / (NG * NC)) % 27;
-      const int wt = taps.wt[tap];
+      const int wt = AC ? tap : taps.wt[tap];
       const bool ok = idx < NTAP * NC * NG && wt >= 0;
       const int64_t chunk2 = (int64_t)(kc / (2 * EPV)) + g / 2;     // K-chunk of 2*EPV channels
       const int64_t off = (((((int64_t)(n0 + n) / 32) * (CinP / (2 * EPV)) + chunk2) * ntaps_src + wt) * 2 + (g & 1)) * 32 +
@@ -235,6 +240,36 @@ __global__ __launch_bounds__(NW * 64) void conv3_mfma_kernel(const T *__restrict
     store_chunk();
     __syncthreads();
     if (kc + CK < CinP) load_chunk(kc + CK);
+    if (AC) {
+      // ---- 8 shifts x KSPC k-steps: A fragment of shift (sd,sh,sw) feeds class/tap pairs: per axis shift 1 <- (parity 1,
+      //      real tap 0); shift 0 <- (parity 0, tap 1) and (parity 1, tap 2)
+#pragma unroll
+      for (int ks = 0; ks < KSPC; ++ks) {
+        const int g = 2 * ks + h;
+#pragma unroll
+        for (int sh8 = 0; sh8 < 8; ++sh8) {
+          const int sd = sh8 >> 2, shh = (sh8 >> 1) & 1, sw = sh8 & 1;
+          const int tap_off = ((1 + sd) * G::IH + (1 + shh)) * G::ROW + G::lds_col(1 + sw);
+          uint4 af[MPW];
+#pragma unroll
+          for (int i = 0; i < MPW; ++i) af[i] = sA[g * NV + a_off[i] + tap_off];
+#pragma unroll
+          for (int od = 0; od < 2 - sd; ++od)
+#pragma unroll
+            for (int oh = 0; oh < 2 - shh; ++oh)
+#pragma unroll
+              for (int ow = 0; ow < 2 - sw; ++ow) {
+                // option 0 on a shift-0 axis: parity 0 / tap 1; option 1: parity 1 / tap 2; shift-1 axis: parity 1 / tap 0
+                const int pd = sd ? 1 : od, ph = shh ? 1 : oh, pw = sw ? 1 : ow;
+                const int td = sd ? 0 : 1 + od, th = shh ? 0 : 1 + oh, tw = sw ? 0 : 1 + ow;
+                const int tap = td * 9 + th * 3 + tw, c8 = pd * 4 + ph * 2 + pw;
+                const uint4 bfr = sB[(tap * NG + g) * NC + r];
+#pragma unroll
+                for (int i = 0; i < MPW; ++i) mfma_step<T>(af[i], bfr, acc[i][c8]);
+              }
+        }
+      }
+    } else
     // ---- 27 taps x KSPC k-steps of MFMA from LDS
 #pragma unroll
     for (int tap = (S == 0 ? 13 : 0); tap < (S == 0 ? 14 : 27); ++tap) {
@@ -266,6 +301,29 @@ __global__ __launch_bounds__(NW * 64) void conv3_mfma_kernel(const T *__restrict
   float st1[NB], st2[NB];
 #pragma unroll
   for (int j = 0; j < NB; ++j) st1[j] = st2[j] = 0.f;
+  if (AC) {
+#pragma unroll
+    for (int i = 0; i < MPW; ++i) {
+      const int mb = wave * MPW + i;
+      const int mbd = mb / MBH, mbh = mb % MBH;
+      const int co = n0 + r;
+#pragma unroll
+      for (int c8 = 0; c8 < 8; ++c8) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          const int m = (q & 3) + 8 * (q >> 2) + 4 * h;
+          const int od = od0 + mbd, oh = oh0 + mbh * G::RPM + m / MBW, ow = ow0 + m % MBW;
+          if (co < Cout && od < Do && oh < Ho && ow < Wo) {
+            T *o = y + cs.yoff[c8] + b * yv.sb + od * yv.sd + oh * yv.sh + ow * yv.sw + co;
+            float v = acc[i][c8][q];
+            if (accumulate) v += ld_f<T>(o);
+            st_f<T>(o, v);
+          }
+        }
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < MPW; ++i) {
     const int mb = wave * MPW + i;
@@ -319,6 +377,29 @@ __global__ __launch_bounds__(NW * 64) void conv3_mfma_kernel(const T *__restrict
     }
     if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) reinterpret_cast<long long *>(stats)[0] = tiles_per_b;
   }
+}
+
+// all-classes stride-2 data gradient (AC = true): tiles over the dy lattice, grid.z = 1
+template <typename T, int MBW, int MBH, int MBD>
+int launch_conv_allcls(const void *x, const View &xv, const void *w, const ConvClasses &cs, void *y, const View &yv, int B,
+                       int Cin, int Cout, int CinP, int CoutP, hipStream_t st) {
+  typedef ConvCfg<T, MBW, MBH, MBD, 1, 1, 1> Cfg;
+  typedef typename Cfg::G G;
+  auto kern = conv3_mfma_kernel<T, MBW, MBH, MBD, 1, 1, 1, 0, 8, true>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)Cfg::LDS_BYTES);
+    attr_set = true;
+  }
+  const int tW = cdiv(yv.W, G::TW), tH = cdiv(yv.H, G::TH), tD = cdiv(yv.D, G::TD);
+  const int64_t tiles = (int64_t)tW * tH * tD * B;
+  DG_REQUIRE(tiles < (1ll << 31), DGTTA_ERR_UNSUPPORTED, "conv3_mfma: too many tiles");
+  dim3 grid((unsigned)tiles, (unsigned)cdiv(CoutP, Cfg::NC), 1u);
+  hipLaunchKernelGGL(kern, grid, dim3(8 * 64), Cfg::LDS_BYTES, st, (const T *)x, xv, (const T *)w, cs, (const float *)nullptr,
+                     (T *)y, yv, Cin, Cout, CinP, CoutP, tW, tH, tD, (double *)nullptr, 27);
+  DG_CHECK_LAUNCH("conv3_mfma_kernel<all classes>");
+  return DGTTA_OK;
 }
 
 template <typename T, int MBW, int MBH, int MBD, int S, int NB, int KSPC, int NW = 4>
@@ -938,6 +1019,15 @@ static int dgrad_s2(const void *dy, int lddy, const void *w_kmajor, void *dx, in
         }
       }
       cs.taps[p].wt[t] = ok ? (signed char)(real[0] * 9 + real[1] * 3 + real[2]) : (signed char)-1;
+    }
+  }
+  {
+    // one pass over dy with all 8 classes accumulated per wave (yv: extent of the dy lattice, strides of the parity view)
+    const char *ac = getenv("DGTTA_DGRAD_S2_ALLCLS");      // diagnostic / tests: "0" = the 8-class launch
+    if (!(ac && ac[0] == '0') && CinP % 8 == 0) {
+      if (yv.W >= 32) return launch_conv_allcls<T, 32, 4, 2>(dy, xv, w_kmajor, cs, dx, yv, B, Cout, Cin, CoutP, CinP, st);
+      if (yv.W >= 16) return launch_conv_allcls<T, 16, 2, 4>(dy, xv, w_kmajor, cs, dx, yv, B, Cout, Cin, CoutP, CinP, st);
+      return launch_conv_allcls<T, 8, 2, 4>(dy, xv, w_kmajor, cs, dx, yv, B, Cout, Cin, CoutP, CinP, st);
     }
   }
   return dispatch_conv_classes<T>(dy, xv, w_kmajor, cs, nullptr, dx, yv, B, Cout, Cin, CoutP, CinP, 1, st);

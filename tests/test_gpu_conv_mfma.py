@@ -422,3 +422,38 @@ def test_full_size_128_wgrad_two_kernels_agree(monkeypatch):
     # checksum property: summing dW over taps and input channels = (sum over a 3^3 box of x) . dy, checked for tap 13
     centre = torch.einsum("vc,vk->kc", x.reshape(-1, c).float(), dy.reshape(-1, c).float())
     assert float((dw1[:, :, 1, 1, 1] - centre).abs().max()) < 2e-4 * float(centre.abs().max()) + 1e-2
+
+
+@pytest.mark.parametrize("case", [(1, 32, 64, 16, 8, 64, 1), (2, 16, 24, 12, 12, 36, 1), (1, 64, 128, 8, 8, 16, 0),
+                                  (1, 320, 320, 4, 4, 8, 1), (1, 32, 64, 16, 8, 64, 0)])
+@pytest.mark.parametrize("dt", [0, 1])
+def test_dgrad_stride2_all_classes(case, dt, monkeypatch):
+    """Stride-2 data gradient: the single-pass kernel (8 parity classes accumulated per wave) against the 8-class
+    launch and the VALU kernel, with and without accumulation into dx (skip-connection sum); (B, cin, cout, Di, Hi, Wi, acc)."""
+    from dg_tta_amd import _lib
+    from dg_tta_amd._lib import check, ptr, stream_of
+    lib = _lib.load()
+    B, cin, cout, D, H, W, acc = case
+    tdt = torch.float32 if dt == 0 else torch.bfloat16
+    m = 16 if dt else 8
+    cinp, coutp = (cin + m - 1) // m * m, (cout + m - 1) // m * m
+    torch.manual_seed(sum(case) + dt)
+    w = (torch.randn(cout, cin, 3, 3, 3, device=DEV) / (27 * cout) ** 0.5).to(tdt).float()
+    dy = torch.randn(B, D // 2, H // 2, W // 2, cout, device=DEV).to(tdt)
+    dx0 = torch.randn(B, D, H, W, cin, device=DEV).to(tdt)
+    wpack = torch.empty(lib.dgtta_conv3d_packed_bytes(cinp, coutp, dt) // (2 if dt else 4), dtype=tdt, device=DEV)
+    check(lib.dgtta_conv3d_pack_weights(ptr(w), ptr(wpack), cin, cout, cinp, coutp, dt, stream_of()), "pack")
+
+    def run(impl, allcls):
+        monkeypatch.setenv("DGTTA_DGRAD_S2_ALLCLS", allcls)
+        dx = dx0.clone()
+        check(lib.dgtta_conv3d_k3_dgrad(ptr(dy), cout, ptr(wpack), ptr(dx), cin, B, cin, cout, cinp, coutp, D, H, W, 2, acc,
+                                        dt, impl, stream_of()), "dgrad")
+        torch.cuda.synchronize()
+        return dx.float()
+
+    ref, cls8, one = run(1, "0"), run(2, "0"), run(2, "1")
+    tol = (2e-5 if dt == 0 else 1.0 / 64) * float(ref.abs().max()) + 1e-4
+    assert float((cls8 - ref).abs().max()) < tol
+    assert float((one - ref).abs().max()) < tol
+    assert float((one - cls8).abs().max()) < tol

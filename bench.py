@@ -200,24 +200,28 @@ def main():
         # roofline of the dominant kernel, timed with events on the launch stream inside the timed region
         roof = None
         if probe["events"]:
-            times = [s.elapsed_time(e) for s, e in probe["events"]]
+            # launches of the probed block: training passes carry 2 branches x k accumulation steps, the eval pass 1 sample
+            times = [(s.elapsed_time(e), nb_) for s, e, nb_ in probe["events"]]
+            nb = max(n for _, n in times)
+            times = [t for t, n in times if n == nb]
             avg_ms = sum(times) / len(times)
-            v = args.size ** 3
-            flop = conv_flops(probe["cin"], probe["cout"], probe["vout"])
+            flop = conv_flops(probe["cin"], probe["cout"], probe["vout"]) * nb
             peak = 2500.0 if args.dtype == "bf16" else 157.3
             ach = flop / (avg_ms * 1e-3) / 1e12
             traffic = None       # HBM bytes per launch from the committed PMC passes (profiles/), not a live counter
             pmc = ROOT / "profiles" / "r01_pmc_summary.json"
             if pmc.exists() and args.dtype == "bf16" and args.size == 128:
                 d = json.loads(pmc.read_text()).get("conv_128cube_32to32", {})
-                if "fetch_bytes_corrected_median" in d:
-                    traffic = d["fetch_bytes_corrected_median"] + d["write_bytes_median"]
+                if "fetch_bytes_corrected_median" in d:     # PMC pass = one sample of this layer; scaled by the batch
+                    traffic = (d["fetch_bytes_corrected_median"] + d["write_bytes_median"]) * nb
             roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
                     "frac": round(ach / peak, 4), "traffic": traffic, "kernel": probe.get("kernel", "conv3_rows_kernel" if args.dtype == "bf16" else "conv3_mfma_kernel"),
                     "launches": len(times), "avg_ms": round(avg_ms, 4),
-                    "flop_per_launch": flop,
-                    "scope": "launches of block dec.3.1 (128^3 32->32, forward + data gradient) only; the kernel name "
-                             "also runs the other large layers, so rocprofv3's per-name average is a mix of shapes"}
+                    "flop_per_launch": flop, "samples_per_launch": nb,
+                    "scope": "forward launches of block dec.3.1 (128^3 32->32, fused statistics) in the training passes "
+                             "(samples_per_launch = 2 branches x k accumulation steps); the kernel name also runs the other "
+                             "large layers, so rocprofv3's per-name average is a mix of shapes; traffic = PMC of one sample "
+                             "x samples_per_launch"}
         out = {"metric": "TTA-epochs/sec per GPU on 128^3 patch", "value": round(value, 5), "unit": "TTA-epochs/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 2),
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,

@@ -263,8 +263,8 @@ class _UNetFn(torch.autograd.Function):
                                           coutp, di, hi, wi, s, dt, impl, st), "dgtta_conv3d_k3_fwd")
             if pr is not None:
                 ev1.record()
-                pr["events"].append((ev0, ev1))
-                pr.update(cin=cin, cout=cout, vout=do * ho * wo)
+                pr["events"].append((ev0, ev1, B))
+                pr.update(cin=cin, cout=cout, vout=do * ho * wo, batch=B)
             v = do * ho * wo
             mr = torch.empty((B, cout, 2), dtype=torch.float32, device=dev)
             if z_out is None:

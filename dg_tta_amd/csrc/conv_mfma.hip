@@ -302,6 +302,13 @@ __global__ __launch_bounds__(NW * 64) void conv3_mfma_kernel(const T *__restrict
 #pragma unroll
   for (int j = 0; j < NB; ++j) st1[j] = st2[j] = 0.f;
   if (AC) {
+    // epilogue: one class at a time through a per-wave fp32 slab [32 voxels][32 channels] (row pitch 36 floats) in the
+    // finished A/B tiles, so that a lane handles 8 consecutive channels of a voxel: 16-byte (bf16) loads / stores of
+    // whole 64-byte rows instead of 2-byte accesses (the skip-connection sum makes this a read-modify-write)
+    const bool vec = Cout % 8 == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0 && yv.sw % 8 == 0 && yv.sh % 8 == 0 &&
+                     yv.sd % 8 == 0 && yv.sb % 8 == 0;
+    __syncthreads();
+    float *slab = reinterpret_cast<float *>(smem) + wave * (32 * 36);
 #pragma unroll
     for (int i = 0; i < MPW; ++i) {
       const int mb = wave * MPW + i;
@@ -309,15 +316,59 @@ __global__ __launch_bounds__(NW * 64) void conv3_mfma_kernel(const T *__restrict
       const int co = n0 + r;
 #pragma unroll
       for (int c8 = 0; c8 < 8; ++c8) {
+        if (!vec) {
 #pragma unroll
-        for (int q = 0; q < 16; ++q) {
-          const int m = (q & 3) + 8 * (q >> 2) + 4 * h;
+          for (int q = 0; q < 16; ++q) {
+            const int m = (q & 3) + 8 * (q >> 2) + 4 * h;
+            const int od = od0 + mbd, oh = oh0 + mbh * G::RPM + m / MBW, ow = ow0 + m % MBW;
+            if (co < Cout && od < Do && oh < Ho && ow < Wo) {
+              T *o = y + cs.yoff[c8] + b * yv.sb + od * yv.sd + oh * yv.sh + ow * yv.sw + co;
+              float v = acc[i][c8][q];
+              if (accumulate) v += ld_f<T>(o);
+              st_f<T>(o, v);
+            }
+          }
+          continue;
+        }
+#pragma unroll
+        for (int q = 0; q < 16; ++q) slab[((q & 3) + 8 * (q >> 2) + 4 * h) * 36 + r] = acc[i][c8][q];
+        // (a wave reads back only its own slab: LDS operations of one wave complete in order)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const int m = t * 16 + (lane >> 2), cq = (lane & 3) * 8;
+          const float4 v0 = *reinterpret_cast<const float4 *>(slab + m * 36 + cq);
+          const float4 v1 = *reinterpret_cast<const float4 *>(slab + m * 36 + cq + 4);
+          float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
           const int od = od0 + mbd, oh = oh0 + mbh * G::RPM + m / MBW, ow = ow0 + m % MBW;
-          if (co < Cout && od < Do && oh < Ho && ow < Wo) {
-            T *o = y + cs.yoff[c8] + b * yv.sb + od * yv.sd + oh * yv.sh + ow * yv.sw + co;
-            float v = acc[i][c8][q];
-            if (accumulate) v += ld_f<T>(o);
-            st_f<T>(o, v);
+          if (n0 + cq < Cout && od < Do && oh < Ho && ow < Wo) {
+            T *o = y + cs.yoff[c8] + b * yv.sb + od * yv.sd + oh * yv.sh + ow * yv.sw + n0 + cq;
+            if (sizeof(T) == 2) {
+              uint4 *o4 = reinterpret_cast<uint4 *>(o);
+              if (accumulate) {
+                const uint4 old = *o4;
+                const unsigned wv[4] = {old.x, old.y, old.z, old.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                  v[2 * e] += __uint_as_float(wv[e] << 16);
+                  v[2 * e + 1] += __uint_as_float(wv[e] & 0xffff0000u);
+                }
+              }
+              uint4 pk;
+              pk.x = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
+              pk.y = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
+              pk.z = (unsigned)f32_to_bf16(v[4]) | ((unsigned)f32_to_bf16(v[5]) << 16);
+              pk.w = (unsigned)f32_to_bf16(v[6]) | ((unsigned)f32_to_bf16(v[7]) << 16);
+              *o4 = pk;
+            } else {
+              float4 *o4 = reinterpret_cast<float4 *>(o);
+              if (accumulate) {
+                const float4 a0 = o4[0], a1 = o4[1];
+                v[0] += a0.x; v[1] += a0.y; v[2] += a0.z; v[3] += a0.w;
+                v[4] += a1.x; v[5] += a1.y; v[6] += a1.z; v[7] += a1.w;
+              }
+              o4[0] = make_float4(v[0], v[1], v[2], v[3]);
+              o4[1] = make_float4(v[4], v[5], v[6], v[7]);
+            }
           }
         }
       }

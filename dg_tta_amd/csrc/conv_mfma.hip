@@ -1649,6 +1649,147 @@ __global__ __launch_bounds__(256, 2) void conv3_wgrad_tr_kernel(const bf16_t *__
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// bf16 weight gradient of a STRIDE-2 conv in one pass:  dW[tap][ci][co] = sum_vo x[2 vo + tap - 1][ci] * dy[vo][co].
+// Same scheme as conv3_wgrad_tr_kernel (LDS-DMA staging, ds_read_b64_tr_b16 operands, 7 taps per wave, slab output) with
+// the x tile kept at FULL resolution: output tile 2 rows x 16 voxels needs x rows 2h0-1 .. 2h0+3 and voxels 2w0-1 ..
+// 2w0+31; output slice d needs x slices 2d-1, 2d, 2d+1 (ring of 5: 3 live + 2 arriving).  The transposed read takes one
+// row address per lane, so "every second voxel" is just a 128-byte row stride of the operand block.  dy is read once and x
+// once (+ halo), instead of 8 parity-class passes that each re-read dy and gathered x with half-used cache lines.
+struct WT2 {
+  static constexpr int TH = 2, TWO = 16;                // output rows / voxels per tile
+  static constexpr int XR = 2 * TH + 1, XW = 36;        // x rows per slice, voxels per x row in LDS (33 used)
+  static constexpr int X_ROW_B = XW * 64, X_SLICE_B = XR * X_ROW_B;
+  static constexpr int Y_ROW_B = TWO * 64, Y_SLICE_B = TH * Y_ROW_B;
+  static constexpr int NXS = 5;                         // x ring slots
+  static constexpr int LDS_BYTES = NXS * X_SLICE_B + 2 * Y_SLICE_B;
+  static constexpr int NPX1 = XR * 3;                   // DMA pieces per x slice (16 + 16 + 1 voxels per row)
+  static constexpr int NP = 2 * NPX1 + TH;              // pieces per output slice: two x slices + one dy slice
+};
+
+__global__ __launch_bounds__(256, 2) void conv3_wgrad_tr_s2_kernel(const bf16_t *__restrict__ x, View xv,
+                                                                   const bf16_t *__restrict__ dy, View yv,
+                                                                   float *__restrict__ slabs, int Cin, int Cout, int tilesW,
+                                                                   int tilesH, int nsd, int DR, int cobs) {
+  const int D = yv.D, H = yv.H, W = yv.W;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char *sX = smem;
+  unsigned char *sY = smem + WT2::NXS * WT2::X_SLICE_B;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+  int t = blockIdx.x;
+  const int tw = t % tilesW;
+  t /= tilesW;
+  const int th = t % tilesH;
+  t /= tilesH;
+  const int ds = t % nsd;
+  const int b = t / nsd;
+  const int cib = blockIdx.y / cobs, cob = blockIdx.y % cobs;
+  const int h0 = th * WT2::TH, w0 = tw * WT2::TWO;
+  const int d_begin = ds * DR, d_end = (d_begin + DR < D) ? d_begin + DR : D;
+  const bf16_t *xb = x + b * xv.sb + cib * 32;
+  const bf16_t *yb = dy + b * yv.sb + cob * 32;
+  const int cin_lim = (Cin + 7) / 8 * 8;
+  const int l_vox = lane >> 2, l_chunk = lane & 3;
+
+  auto xslot = [&](int xd) { return (xd + WT2::NXS) % WT2::NXS; };
+  // piece i of this wave for output slice `od`: x slices 2od-1+{s} (s given by the piece index) and the dy slice
+  auto issue_x_slice = [&](int xd, int i) __attribute__((always_inline)) {      // piece index idx = wave + 4 i < NPX1
+    const int idx = wave + 4 * i;
+    if (idx >= WT2::NPX1) return;
+    const int r = idx / 3, pi = idx % 3;
+    if (pi == 2 && lane >= 4) return;
+    const int gh = 2 * h0 - 1 + r, wx = 16 * pi + l_vox, gw = 2 * w0 - 1 + wx;
+    const bool ok = (unsigned)xd < (unsigned)xv.D && (unsigned)gh < (unsigned)xv.H && (unsigned)gw < (unsigned)xv.W &&
+                    cib * 32 + l_chunk * 8 < cin_lim;
+    const void *src = ok ? (const void *)(xb + xd * xv.sd + gh * xv.sh + gw * xv.sw + l_chunk * 8) : (const void *)&g_zero16;
+    dma16_to_lds(src, lds_addr_of(sX + xslot(xd) * WT2::X_SLICE_B + r * WT2::X_ROW_B + pi * 1024));
+  };
+  auto issue_y_slice = [&](int yd) __attribute__((always_inline)) {             // rows 0/1 by waves 0/1
+    if (wave >= WT2::TH) return;
+    const int gh = h0 + wave, gw = w0 + l_vox;
+    const bool ok = (unsigned)yd < (unsigned)D && gh < H && gw < W && cob * 32 + l_chunk * 8 < Cout;
+    const void *src = ok ? (const void *)(yb + yd * yv.sd + gh * yv.sh + gw * yv.sw + l_chunk * 8) : (const void *)&g_zero16;
+    dma16_to_lds(src, lds_addr_of(sY + (yd & 1) * WT2::Y_SLICE_B + wave * WT2::Y_ROW_B));
+  };
+  constexpr int NPXW = (WT2::NPX1 + 3) / 4;      // x pieces per wave and x slice
+
+  // transposed-read lane addresses: dy block rows are consecutive voxels (64 B), x block rows every second voxel (128 B)
+  const int kq = (lane >> 5) * 8 + ((lane & 15) >> 2), cpart = ((lane >> 4) & 1) * 32 + (lane & 3) * 8;
+  const int lane_off_y = kq * 64 + cpart, lane_off_x = kq * 128 + cpart;
+
+  int tap_kd[7], tap_off[7];
+#pragma unroll
+  for (int i = 0; i < 7; ++i) {
+    const int tc = wave + 4 * i < 27 ? wave + 4 * i : 26;
+    tap_kd[i] = tc / 9;
+    tap_off[i] = ((tc / 3) % 3) * WT2::X_ROW_B + (tc % 3) * 64;
+  }
+  f32x16_t acc[7];
+#pragma unroll
+  for (int i = 0; i < 7; ++i)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[i][q] = 0.f;
+
+  // prologue: x slices 2 d_begin - 1 .. 2 d_begin + 1, dy slice d_begin
+#pragma unroll
+  for (int sl = -1; sl <= 1; ++sl)
+#pragma unroll
+    for (int i = 0; i < NPXW; ++i) issue_x_slice(2 * d_begin + sl, i);
+  issue_y_slice(d_begin);
+  dma_wait_all();
+  lds_barrier();
+
+  for (int d = d_begin; d < d_end; ++d) {
+    if (d + 1 < d_end) {       // next output slice: x slices 2d+2, 2d+3 and dy slice d+1 land during the MFMAs below
+#pragma unroll
+      for (int i = 0; i < NPXW; ++i) issue_x_slice(2 * d + 2, i);
+#pragma unroll
+      for (int i = 0; i < NPXW; ++i) issue_x_slice(2 * d + 3, i);
+      issue_y_slice(d + 1);
+    }
+    const unsigned char *ys = sY + (d & 1) * WT2::Y_SLICE_B + lane_off_y;
+    int slice_off[3];
+#pragma unroll
+    for (int kd = 0; kd < 3; ++kd) slice_off[kd] = xslot(2 * d + kd - 1) * WT2::X_SLICE_B;
+#pragma unroll
+    for (int oh = 0; oh < WT2::TH; ++oh) {
+      // K-step = the 16 output voxels of the row
+      const s16x4_t blo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t *)(ys + oh * WT2::Y_ROW_B));
+      const s16x4_t bhi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t *)(ys + oh * WT2::Y_ROW_B + 4 * 64));
+      typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+      const s16x8_t bv = {blo[0], blo[1], blo[2], blo[3], bhi[0], bhi[1], bhi[2], bhi[3]};
+      const bf16x8_t bfr = __builtin_bit_cast(bf16x8_t, bv);
+      bf16x8_t afr[7];
+#pragma unroll
+      for (int i = 0; i < 7; ++i) {
+        const int so = (tap_kd[i] == 0 ? slice_off[0] : (tap_kd[i] == 1 ? slice_off[1] : slice_off[2])) + tap_off[i];
+        const unsigned char *pa = sX + lane_off_x + so + 2 * oh * WT2::X_ROW_B;
+        const s16x4_t alo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t *)pa);
+        const s16x4_t ahi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t *)(pa + 4 * 128));
+        const s16x8_t av = {alo[0], alo[1], alo[2], alo[3], ahi[0], ahi[1], ahi[2], ahi[3]};
+        afr[i] = __builtin_bit_cast(bf16x8_t, av);
+      }
+#pragma unroll
+      for (int i = 0; i < 7; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[i], bfr, acc[i], 0, 0, 0);
+    }
+    dma_wait_all();
+    lds_barrier();
+  }
+
+  float *slab = slabs + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * (27 * 1024);
+  const int co = lane & 31, hh = lane >> 5;
+#pragma unroll
+  for (int i = 0; i < 7; ++i) {
+    const int tap = wave + 4 * i;
+    if (tap < 27) {
+#pragma unroll
+      for (int q = 0; q < 16; ++q) slab[(tap * 32 + (q & 3) + 8 * (q >> 2) + 4 * hh) * 32 + co] = acc[i][q];
+    }
+  }
+}
+
 // dw[co*s_co + ci*s_ci + real_tap*s_tap] (+)= sum over slabs of virtual tap t (real_tap = real.wt[t], -1: skip).
 // Workgroup = 32 consecutive output channels (one coalesced 128-byte row of every slab) x 8 slab groups; the 8 partial
 // sums are combined through LDS in fixed order (deterministic).
@@ -1719,11 +1860,32 @@ WgradPlan wgrad_plan(int B, int Cin, int Cout, int D, int H, int W, int ncls = 1
 
 }  // namespace
 
-// sized for the 8-class launches (stride-2 conv, transposed conv); single-class launches use the first eighth
+// one-pass stride-2 kernel: tiles of 2 rows x 16 voxels of the output lattice
+static WgradPlan wgrad_plan_s2(int B, int Cin, int Cout, int D, int H, int W) {
+  WgradPlan p;
+  p.tW = cdiv(W, WT2::TWO);
+  p.tH = cdiv(H, WT2::TH);
+  p.cibs = cdiv(Cin, 32);
+  p.cobs = cdiv(Cout, 32);
+  const int64_t base = (int64_t)B * p.tW * p.tH * p.cibs * p.cobs;
+  int want = (int)cdiv64(512, base);
+  int maxsplit = D / 4 > 0 ? D / 4 : 1;
+  p.nsd = want < 1 ? 1 : (want > maxsplit ? maxsplit : want);
+  p.DR = cdiv(D, p.nsd);
+  p.nsd = cdiv(D, p.DR);
+  p.units = (int64_t)B * p.tW * p.tH * p.nsd;
+  return p;
+}
+
+// sized for the 8-class launches (stride-2 conv, transposed conv) and the one-pass stride-2 plan; single-class launches
+// use the first part
 size_t conv3_wgrad_mfma_ws_bytes(int B, int Cin, int Cout, int D, int H, int W) {
-  WgradPlan p1 = wgrad_plan(B, Cin, Cout, D, H, W, 1), p8 = wgrad_plan(B, Cin, Cout, D, H, W, 8);
-  const size_t a = (size_t)p1.units * p1.cibs * p1.cobs, b = (size_t)8 * p8.units * p8.cibs * p8.cobs;
-  return (a > b ? a : b) * 27 * 1024 * sizeof(float);
+  WgradPlan p1 = wgrad_plan(B, Cin, Cout, D, H, W, 1), p8 = wgrad_plan(B, Cin, Cout, D, H, W, 8),
+            p2 = wgrad_plan_s2(B, Cin, Cout, D, H, W);
+  size_t a = (size_t)p1.units * p1.cibs * p1.cobs, b = (size_t)8 * p8.units * p8.cibs * p8.cobs,
+         c = (size_t)p2.units * p2.cibs * p2.cobs;
+  a = a > b ? a : b;
+  return (a > c ? a : c) * 27 * 1024 * sizeof(float);
 }
 
 template <typename T>
@@ -1823,6 +1985,40 @@ static int wgrad_conv(const void *x, int ldx, const void *dy, int lddy, float *d
   // parity 1 <- tap 0 (offset -1) and tap 2 (offset 0).  Each real tap belongs to exactly one of the 8 classes.
   const int Do = (Di - 1) / 2 + 1, Ho = (Hi - 1) / 2 + 1, Wo = (Wi - 1) / 2 + 1;
   const View yv = dense_view(B, Do, Ho, Wo, lddy);
+  if (sizeof(T) == 2) {
+    // one pass over x (full resolution tile) and dy with all 27 taps: conv3_wgrad_tr_s2_kernel
+    const char *one = getenv("DGTTA_WGRAD_S2_ONEPASS");      // diagnostic / tests: "0" = the 8-class launch
+    const View xfull = dense_view(B, Di, Hi, Wi, ldx);
+    WgradPlan p = wgrad_plan_s2(B, Cin, Cout, Do, Ho, Wo);
+    const size_t need = (size_t)p.units * p.cibs * p.cobs * 27 * 1024 * sizeof(float);
+    const bool ok = Cout % 8 == 0 && ldx % 8 == 0 && lddy % 8 == 0 && !((uintptr_t)x & 15) && !((uintptr_t)dy & 15) &&
+                    ldx >= (Cin + 7) / 8 * 8 && ws_bytes >= need && p.units < (1ll << 31) && p.cibs * p.cobs <= 65535;
+    if (ok && !(one && one[0] == '0')) {
+      static bool attr = false;
+      if (!attr) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(conv3_wgrad_tr_s2_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)WT2::LDS_BYTES);
+        DG_REQUIRE(e == hipSuccess, DGTTA_ERR_LAUNCH, "wgrad_tr_s2: cannot raise the dynamic LDS limit");
+        attr = true;
+      }
+      hipLaunchKernelGGL(conv3_wgrad_tr_s2_kernel, dim3((unsigned)p.units, (unsigned)(p.cibs * p.cobs)), dim3(256),
+                         WT2::LDS_BYTES, st, (const bf16_t *)x, xfull, (const bf16_t *)dy, yv, (float *)ws, Cin, Cout, p.tW,
+                         p.tH, p.nsd, p.DR, p.cobs);
+      DG_CHECK_LAUNCH("conv3_wgrad_tr_s2_kernel");
+      RealTaps ident;
+      ident.t[0] = identity_taps(0);
+      const int64_t rrows = (int64_t)27 * Cin * ((Cout + 31) / 32);
+      const int npairs = p.cibs * p.cobs;
+      if (p.units >= 64)
+        hipLaunchKernelGGL(wgrad_reduce_kernel<8>, dim3((unsigned)rrows, 1u), dim3(256), 0, st, (const float *)ws, dw_t, Cin,
+                           Cout, p.cobs, npairs, (int)p.units, accumulate, ident, s_co, s_ci, s_tap);
+      else
+        hipLaunchKernelGGL(wgrad_reduce_kernel<1>, dim3((unsigned)cdiv64(rrows, 8), 1u), dim3(256), 0, st, (const float *)ws,
+                           dw_t, Cin, Cout, p.cobs, npairs, (int)p.units, accumulate, ident, s_co, s_ci, s_tap);
+      DG_CHECK_LAUNCH("wgrad_reduce_kernel");
+      return DGTTA_OK;
+    }
+  }
   WgradClasses wc;
   RealTaps reals;
   wc.n = 8;

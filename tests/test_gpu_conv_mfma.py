@@ -457,3 +457,25 @@ def test_dgrad_stride2_all_classes(case, dt, monkeypatch):
     assert float((cls8 - ref).abs().max()) < tol
     assert float((one - ref).abs().max()) < tol
     assert float((one - cls8).abs().max()) < tol
+
+
+@pytest.mark.parametrize("case", [(1, 32, 64, 8, 12, 72), (2, 16, 32, 6, 6, 20), (1, 64, 96, 4, 8, 32), (1, 320, 320, 4, 4, 8)])
+def test_wgrad_stride2_one_pass_bf16(case, monkeypatch):
+    """Stride-2 weight gradient (bf16): the one-pass kernel (x tile at full resolution, transposed reads with a 2-voxel
+    row stride) against the 8 parity-class launch and the VALU kernel on the same operands."""
+    B, cin, cout, D, H, W = case
+    torch.manual_seed(sum(case) + 19)
+    x = torch.randn(B, D, H, W, cin, device=DEV).bfloat16()
+    dy = torch.randn(B, D // 2, H // 2, W // 2, cout, device=DEV).bfloat16()
+    ref, _ = _call_wgrad(x.float(), dy.float(), cin, cout, 2, 0, 1)
+    monkeypatch.setenv("DGTTA_WGRAD_S2_ONEPASS", "0")
+    cls8, _ = _call_wgrad(x, dy, cin, cout, 2, 1, 2)
+    monkeypatch.setenv("DGTTA_WGRAD_S2_ONEPASS", "1")
+    one, _ = _call_wgrad(x, dy, cin, cout, 2, 1, 2)
+    tol = 1e-4 * float(ref.abs().max()) + 1e-4
+    assert float((cls8 - ref).abs().max()) < tol
+    assert float((one - ref).abs().max()) < tol
+    # accumulate into existing gradients
+    dw = ref.clone()
+    _call_wgrad(x, dy, cin, cout, 2, 1, 2, accumulate=1, dw=dw, db=torch.zeros(cout, device=DEV))
+    assert float((dw - 2 * ref).abs().max()) < 2 * tol

@@ -1790,6 +1790,116 @@ __global__ __launch_bounds__(256, 2) void conv3_wgrad_tr_s2_kernel(const bf16_t 
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// bf16 weight gradient of ConvTranspose3d(k2,s2) in one pass:  dW[ci][co][o] = sum_v x[v][ci] * dout[2v + o][co].
+// Tile = 2 rows x 16 voxels of the INPUT lattice; the dout tile is kept at full resolution (4 rows x 32 voxels, slices 2d and
+// 2d+1) and read with a 2-voxel row stride, the x fragment of a row is shared by the 8 offsets (2 per wave).  x and dout are
+// read once, instead of 8 single-tap class launches that each re-read x and gathered a dout parity sub-lattice.
+struct WT3 {
+  static constexpr int TH = 2, TWI = 16;
+  static constexpr int X_ROW_B = TWI * 64, X_SLICE_B = TH * X_ROW_B;             // 2 KiB
+  static constexpr int Y_ROW_B = 2 * TWI * 64, Y_SLICE_B = 2 * TH * Y_ROW_B;     // one dout slice: 4 rows x 2 KiB
+  static constexpr int Y_PAIR_B = 2 * Y_SLICE_B;                                 // dout slices 2d, 2d+1
+  static constexpr int LDS_BYTES = 2 * X_SLICE_B + 2 * Y_PAIR_B;
+  static constexpr int NPY = 2 * 2 * TH * 2;                                     // dout pieces per x slice (16 KiB)
+};
+
+__global__ __launch_bounds__(256, 2) void convT_wgrad_tr_kernel(const bf16_t *__restrict__ x, View xv,
+                                                                const bf16_t *__restrict__ dout, View yv,
+                                                                float *__restrict__ slabs, int Cin, int Cout, int tilesW,
+                                                                int tilesH, int nsd, int DR, int cobs) {
+  const int D = xv.D, H = xv.H, W = xv.W;                  // input lattice; yv = dense view of dout (2D x 2H x 2W)
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char *sX = smem;                                // 2 slots
+  unsigned char *sY = smem + 2 * WT3::X_SLICE_B;           // 2 slots of a slice pair
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int t = blockIdx.x;
+  const int tw = t % tilesW;
+  t /= tilesW;
+  const int th = t % tilesH;
+  t /= tilesH;
+  const int ds = t % nsd;
+  const int b = t / nsd;
+  const int cib = blockIdx.y / cobs, cob = blockIdx.y % cobs;
+  const int h0 = th * WT3::TH, w0 = tw * WT3::TWI;
+  const int d_begin = ds * DR, d_end = (d_begin + DR < D) ? d_begin + DR : D;
+  const bf16_t *xb = x + b * xv.sb + cib * 32;
+  const bf16_t *yb = dout + b * yv.sb + cob * 32;
+  const int cin_lim = (Cin + 7) / 8 * 8;
+  const int l_vox = lane >> 2, l_chunk = lane & 3;
+
+  // pieces of x slice d: 2 rows (waves 0,1); pieces of the dout pair: 2 slices x 4 rows x 2 halves = 16 (4 per wave)
+  auto issue = [&](int d) __attribute__((always_inline)) {
+    if (wave < WT3::TH) {
+      const int gh = h0 + wave, gw = w0 + l_vox;
+      const bool ok = (unsigned)d < (unsigned)D && gh < H && gw < W && cib * 32 + l_chunk * 8 < cin_lim;
+      const void *src = ok ? (const void *)(xb + d * xv.sd + gh * xv.sh + gw * xv.sw + l_chunk * 8) : (const void *)&g_zero16;
+      dma16_to_lds(src, lds_addr_of(sX + (d & 1) * WT3::X_SLICE_B + wave * WT3::X_ROW_B));
+    }
+#pragma unroll
+    for (int i = 0; i < WT3::NPY / 4; ++i) {
+      const int idx = wave + 4 * i;                     // (slice s, row r, half pi)
+      const int sl = idx >> 3, r = (idx >> 1) & 3, pi = idx & 1;
+      const int gd = 2 * d + sl, gh = 2 * h0 + r, gw = 2 * w0 + 16 * pi + l_vox;
+      const bool ok = (unsigned)d < (unsigned)D && gd < yv.D && gh < yv.H && gw < yv.W && cob * 32 + l_chunk * 8 < Cout;
+      const void *src = ok ? (const void *)(yb + gd * yv.sd + gh * yv.sh + gw * yv.sw + l_chunk * 8) : (const void *)&g_zero16;
+      dma16_to_lds(src, lds_addr_of(sY + (d & 1) * WT3::Y_PAIR_B + sl * WT3::Y_SLICE_B + r * WT3::Y_ROW_B + pi * 1024));
+    }
+  };
+
+  const int kq = (lane >> 5) * 8 + ((lane & 15) >> 2), cpart = ((lane >> 4) & 1) * 32 + (lane & 3) * 8;
+  const int lane_off_x = kq * 64 + cpart, lane_off_y = kq * 128 + cpart;
+  // this wave's two output offsets o = 2 wave, 2 wave + 1  (o = od*4 + oh*2 + ow)
+  f32x16_t acc[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[i][q] = 0.f;
+  int ooff[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int o = 2 * wave + i;
+    ooff[i] = (o >> 2) * WT3::Y_SLICE_B + ((o >> 1) & 1) * WT3::Y_ROW_B + (o & 1) * 64;
+  }
+
+  issue(d_begin);
+  dma_wait_all();
+  lds_barrier();
+  typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+  for (int d = d_begin; d < d_end; ++d) {
+    if (d + 1 < d_end) issue(d + 1);
+    const unsigned char *xs = sX + (d & 1) * WT3::X_SLICE_B + lane_off_x;
+    const unsigned char *ys = sY + (d & 1) * WT3::Y_PAIR_B + lane_off_y;
+#pragma unroll
+    for (int r = 0; r < WT3::TH; ++r) {
+      const s16x4_t alo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t *)(xs + r * WT3::X_ROW_B));
+      const s16x4_t ahi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t *)(xs + r * WT3::X_ROW_B + 4 * 64));
+      const s16x8_t av = {alo[0], alo[1], alo[2], alo[3], ahi[0], ahi[1], ahi[2], ahi[3]};
+      const bf16x8_t afr = __builtin_bit_cast(bf16x8_t, av);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const unsigned char *pb = ys + ooff[i] + 2 * r * WT3::Y_ROW_B;
+        const s16x4_t blo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t *)pb);
+        const s16x4_t bhi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t *)(pb + 4 * 128));
+        const s16x8_t bv = {blo[0], blo[1], blo[2], blo[3], bhi[0], bhi[1], bhi[2], bhi[3]};
+        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr, __builtin_bit_cast(bf16x8_t, bv), acc[i], 0, 0, 0);
+      }
+    }
+    dma_wait_all();
+    lds_barrier();
+  }
+  // slab "tap" slot = output offset o
+  float *slab = slabs + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * (27 * 1024);
+  const int co = lane & 31, hh = lane >> 5;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int o = 2 * wave + i;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) slab[(o * 32 + (q & 3) + 8 * (q >> 2) + 4 * hh) * 32 + co] = acc[i][q];
+  }
+}
+
 // dw[co*s_co + ci*s_ci + real_tap*s_tap] (+)= sum over slabs of virtual tap t (real_tap = real.wt[t], -1: skip).
 // Workgroup = 32 consecutive output channels (one coalesced 128-byte row of every slab) x 8 slab groups; the 8 partial
 // sums are combined through LDS in fixed order (deterministic).
@@ -2068,6 +2178,39 @@ template <typename T>
 static int convT_wgrad(const void *x, int ldx, const void *dout, int lddo, float *dw_t, void *ws, size_t ws_bytes, int B,
                        int Cin, int Cout, int Di, int Hi, int Wi, int accumulate, hipStream_t st) {
   const View xv = dense_view(B, Di, Hi, Wi, ldx);
+  if (sizeof(T) == 2) {
+    const char *one = getenv("DGTTA_CONVT_WGRAD_ONEPASS");      // diagnostic / tests: "0" = the 8-class launch
+    const View yfull = dense_view(B, 2 * Di, 2 * Hi, 2 * Wi, lddo);
+    WgradPlan p = wgrad_plan_s2(B, Cin, Cout, Di, Hi, Wi);        // same tile shape (2 rows x 16 voxels) on the input lattice
+    const size_t need = (size_t)p.units * p.cibs * p.cobs * 27 * 1024 * sizeof(float);
+    const bool ok = Cout % 8 == 0 && ldx % 8 == 0 && lddo % 8 == 0 && !((uintptr_t)x & 15) && !((uintptr_t)dout & 15) &&
+                    ldx >= (Cin + 7) / 8 * 8 && ws_bytes >= need && p.units < (1ll << 31) && p.cibs * p.cobs <= 65535;
+    if (ok && !(one && one[0] == '0')) {
+      static bool attr = false;
+      if (!attr) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(convT_wgrad_tr_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)WT3::LDS_BYTES);
+        DG_REQUIRE(e == hipSuccess, DGTTA_ERR_LAUNCH, "convT_wgrad_tr: cannot raise the dynamic LDS limit");
+        attr = true;
+      }
+      hipLaunchKernelGGL(convT_wgrad_tr_kernel, dim3((unsigned)p.units, (unsigned)(p.cibs * p.cobs)), dim3(256),
+                         WT3::LDS_BYTES, st, (const bf16_t *)x, xv, (const bf16_t *)dout, yfull, (float *)ws, Cin, Cout, p.tW,
+                         p.tH, p.nsd, p.DR, p.cobs);
+      DG_CHECK_LAUNCH("convT_wgrad_tr_kernel");
+      RealTaps rt;
+      for (int t = 0; t < 27; ++t) rt.t[0].wt[t] = (signed char)(t < 8 ? t : -1);      // slab tap slot o -> dw_t[..][o]
+      const int64_t rrows = (int64_t)27 * Cin * ((Cout + 31) / 32);
+      const int npairs = p.cibs * p.cobs;
+      if (p.units >= 64)
+        hipLaunchKernelGGL(wgrad_reduce_kernel<8>, dim3((unsigned)rrows, 1u), dim3(256), 0, st, (const float *)ws, dw_t, Cin,
+                           Cout, p.cobs, npairs, (int)p.units, accumulate, rt, 8, (long long)Cout * 8, 1);
+      else
+        hipLaunchKernelGGL(wgrad_reduce_kernel<1>, dim3((unsigned)cdiv64(rrows, 8), 1u), dim3(256), 0, st, (const float *)ws,
+                           dw_t, Cin, Cout, p.cobs, npairs, (int)p.units, accumulate, rt, 8, (long long)Cout * 8, 1);
+      DG_CHECK_LAUNCH("wgrad_reduce_kernel");
+      return DGTTA_OK;
+    }
+  }
   WgradClasses wc;
   RealTaps reals;
   wc.n = 8;

@@ -18,7 +18,7 @@ namespace {
 constexpr int TD = 8, TH = 8, TW = 32;
 constexpr int ID = TD + 6, IH = TH + 6, IW = TW + 6;   // image tile (halo 3)
 constexpr int QD = TD + 4, QH = TH + 4, QW = TW + 4;   // q tile (halo 2)
-constexpr int NT = 256;
+constexpr int NT = 512;                                 // 8 waves: twice the occupancy for the 60 barrier phases (212 -> ? us)
 constexpr int VPT = TD * TH * TW / NT;                 // 8 voxels per thread
 constexpr int QN = (QD * QH * QW + NT - 1) / NT;       // q-tile elements per thread
 

@@ -659,6 +659,77 @@ __global__ __launch_bounds__(256) void head_dgrad_fast_kernel(const float *__res
   }
 }
 
+// Coalesced variants for the production shape (32 input channels in contiguous 64-byte bf16 rows / 128-byte fp32 rows,
+// nsel <= 16 selected classes in contiguous fp32 rows): a workgroup moves 256 rows through LDS in both directions, so
+// that every global access is a contiguous 16-byte-per-lane stream (thread-per-row loads touch 64 cache lines per
+// instruction, and the per-class 4-byte stores 64 lines for 256 bytes).
+template <typename T>
+__global__ __launch_bounds__(256) void head_fwd_lds_kernel(const T *__restrict__ x, const float *__restrict__ w,
+                                                           const float *__restrict__ bias, const int *__restrict__ sel,
+                                                           int nsel, float *__restrict__ out, int64_t rows) {
+  constexpr int CIN = 32, EPV = 16 / sizeof(T), XU = CIN / EPV;      // uint4 per input row
+  constexpr int XP = XU + 1;                                          // padded row pitch in uint4
+  __shared__ float sw[16 * CIN + 16];
+  __shared__ uint4 sx[256 * XP];
+  __shared__ float so[256 * 17];
+  for (int i = threadIdx.x; i < nsel * CIN; i += 256) sw[i] = w[(int64_t)(sel ? sel[i / CIN] : i / CIN) * CIN + i % CIN];
+  for (int i = threadIdx.x; i < nsel; i += 256) sw[16 * CIN + i] = bias[sel ? sel[i] : i];
+  for (int64_t r0 = (int64_t)blockIdx.x * 256; r0 < rows; r0 += (int64_t)gridDim.x * 256) {
+    const int nr = rows - r0 < 256 ? (int)(rows - r0) : 256;
+    __syncthreads();
+    const uint4 *gx = reinterpret_cast<const uint4 *>(x + r0 * CIN);
+    for (int i = threadIdx.x; i < nr * XU; i += 256) sx[(i / XU) * XP + i % XU] = gx[i];
+    __syncthreads();
+    if ((int)threadIdx.x < nr) {
+      float xr[CIN];
+#pragma unroll
+      for (int g = 0; g < XU; ++g) unpack16<T>(sx[threadIdx.x * XP + g], xr + g * EPV);
+      for (int k = 0; k < nsel; ++k) {
+        float acc = 0.f;
+#pragma unroll
+        for (int ci = 0; ci < CIN; ++ci) acc = __builtin_fmaf(xr[ci], sw[k * CIN + ci], acc);
+        so[threadIdx.x * 17 + k] = acc + sw[16 * CIN + k];
+      }
+    }
+    __syncthreads();
+    float *go = out + r0 * nsel;
+    for (int i = threadIdx.x; i < nr * nsel; i += 256) go[i] = so[(i / nsel) * 17 + i % nsel];
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void head_dgrad_lds_kernel(const float *__restrict__ dout, const float *__restrict__ w,
+                                                             const int *__restrict__ sel, int nsel, T *__restrict__ dx,
+                                                             int64_t rows) {
+  constexpr int CIN = 32, EPV = 16 / sizeof(T), XU = CIN / EPV, XP = XU + 1;
+  __shared__ float sw[16 * CIN];
+  __shared__ float sg[256 * 17];
+  __shared__ uint4 sx[256 * XP];
+  for (int i = threadIdx.x; i < nsel * CIN; i += 256) sw[i] = w[(int64_t)(sel ? sel[i / CIN] : i / CIN) * CIN + i % CIN];
+  for (int64_t r0 = (int64_t)blockIdx.x * 256; r0 < rows; r0 += (int64_t)gridDim.x * 256) {
+    const int nr = rows - r0 < 256 ? (int)(rows - r0) : 256;
+    __syncthreads();
+    const float *gg = dout + r0 * nsel;
+    for (int i = threadIdx.x; i < nr * nsel; i += 256) sg[(i / nsel) * 17 + i % nsel] = gg[i];
+    __syncthreads();
+    if ((int)threadIdx.x < nr) {
+      float acc[CIN];
+#pragma unroll
+      for (int ci = 0; ci < CIN; ++ci) acc[ci] = 0.f;
+      for (int k = 0; k < nsel; ++k) {
+        const float g = sg[threadIdx.x * 17 + k];
+#pragma unroll
+        for (int ci = 0; ci < CIN; ++ci) acc[ci] = __builtin_fmaf(g, sw[k * CIN + ci], acc[ci]);
+      }
+#pragma unroll
+      for (int g = 0; g < XU; ++g) sx[threadIdx.x * XP + g] = pack16<T>(acc + g * EPV);
+    }
+    __syncthreads();
+    uint4 *gx = reinterpret_cast<uint4 *>(dx + r0 * CIN);
+    for (int i = threadIdx.x; i < nr * XU; i += 256) gx[i] = sx[(i / XU) * XP + i % XU];
+  }
+}
+
 // partial[split][k][ci] ; grid (pairs/256, nsplit)
 template <typename T>
 __global__ void head_wgrad_kernel(const T *__restrict__ x, int ldx, const float *__restrict__ dout, int lddo,
@@ -1133,6 +1204,12 @@ extern "C" int dgtta_seghead_fwd(const void *x, int ldx, const float *w, const f
   if (Cin == 32 && nsel <= 128 && ldx % 8 == 0 && ((uintptr_t)x & 15) == 0) {
     const int64_t rows = (int64_t)B * V;
     const int blocks = (int)(cdiv64(rows, 256) < 8192 ? cdiv64(rows, 256) : 8192);
+    if (out_ndhwc && ldx == 32 && ldo == nsel && nsel <= 16 && ((uintptr_t)out & 15) == 0) {
+      DISPATCH_T(dtype, hipLaunchKernelGGL((head_fwd_lds_kernel<T>), dim3(blocks), dim3(256), 0, (hipStream_t)stream,
+                                           (const T *)x, w, bias, sel, nsel, out, rows));
+      DG_CHECK_LAUNCH("head_fwd_lds_kernel");
+      return DGTTA_OK;
+    }
     if (out_ndhwc)
       DISPATCH_T(dtype, hipLaunchKernelGGL((head_fwd_fast_kernel<T, 32, true>), dim3(blocks), dim3(256), 0,
                                            (hipStream_t)stream, (const T *)x, ldx, w, bias, sel, nsel, out, ldo, V, rows));
@@ -1190,9 +1267,15 @@ extern "C" int dgtta_seghead_bwd(const void *x, int ldx, const float *dout, int 
     DG_REQUIRE(lddx >= Cin, DGTTA_ERR_BADARG, "seghead_bwd: lddx < Cin");
     if (Cin == 32 && nsel <= 32) {
       const int blocks = (int)(cdiv64(rows, 256) < 8192 ? cdiv64(rows, 256) : 8192);
-      DISPATCH_T(dtype, hipLaunchKernelGGL((head_dgrad_fast_kernel<T, 32>), dim3(blocks), dim3(256), 0, st, dout, lddo, w,
-                                           sel, nsel, (T *)dx, lddx, rows));
-      DG_CHECK_LAUNCH("head_dgrad_fast_kernel");
+      if (lddx == 32 && lddo == nsel && nsel <= 16 && ((uintptr_t)dx & 15) == 0) {
+        DISPATCH_T(dtype, hipLaunchKernelGGL((head_dgrad_lds_kernel<T>), dim3(blocks), dim3(256), 0, st, dout, w, sel, nsel,
+                                             (T *)dx, rows));
+        DG_CHECK_LAUNCH("head_dgrad_lds_kernel");
+      } else {
+        DISPATCH_T(dtype, hipLaunchKernelGGL((head_dgrad_fast_kernel<T, 32>), dim3(blocks), dim3(256), 0, st, dout, lddo, w,
+                                             sel, nsel, (T *)dx, lddx, rows));
+        DG_CHECK_LAUNCH("head_dgrad_fast_kernel");
+      }
     } else {
       const int64_t total = rows * Cin;
       DISPATCH_T(dtype, hipLaunchKernelGGL((head_dgrad_kernel<T>), dim3(gs_blocks(total, 1 << 20)), dim3(256), 0, st, dout,

@@ -1650,6 +1650,146 @@ __global__ __launch_bounds__(256, 2) void conv3_wgrad_tr_kernel(const bf16_t *__
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// 8-wave variant of conv3_wgrad_tr_kernel for Cout >= 64: a workgroup owns a 32(ci) x 64(co) channel tile, so the x tile
+// (the larger one, with its halo) is staged once for two output-channel blocks: 58 instead of 94 DMA bytes per MFMA
+// (the 4-wave kernel sits on the ~11 B/clk/CU fill rate).  Wave w owns taps w, w+8, w+16, w+24 (27 of the 32 slots are
+// real) for both blocks: an x fragment feeds 2 MFMAs, 1.5 transposed reads per MFMA instead of 2.3.
+struct WT8 {
+  static constexpr int Y_ROW_B = 32 * 128, Y_SLICE_B = WT::TH * Y_ROW_B;       // dy rows of 64 channels
+  static constexpr int LDS_BYTES = 4 * WT::X_SLICE_B + 2 * Y_SLICE_B;
+  static constexpr int NPY = WT::TH * 4;                                        // 8 voxels x 128 B per piece
+  static constexpr int NP = WT::NPX + NPY;
+};
+
+__global__ __launch_bounds__(512, 1) void conv3_wgrad_tr8_kernel(const bf16_t *__restrict__ x, View xv,
+                                                                 const bf16_t *__restrict__ dy, View yv,
+                                                                 float *__restrict__ slabs, int Cin, int Cout, int tilesW,
+                                                                 int tilesH, int nsd, int DR, int cobs) {
+  const int D = yv.D, H = yv.H, W = yv.W;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char *sX = smem;
+  unsigned char *sY = smem + 4 * WT::X_SLICE_B;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int t = blockIdx.x;
+  const int tw = t % tilesW;
+  t /= tilesW;
+  const int th = t % tilesH;
+  t /= tilesH;
+  const int ds = t % nsd;
+  const int b = t / nsd;
+  const int cobs2 = (cobs + 1) / 2;
+  const int cib = blockIdx.y / cobs2, cob2 = blockIdx.y % cobs2;          // channel-block pair (2 cob2, 2 cob2 + 1)
+  const int h0 = th * WT::TH, w0 = tw * 32;
+  const int d_begin = ds * DR, d_end = (d_begin + DR < D) ? d_begin + DR : D;
+  const bf16_t *xb = x + b * xv.sb + cib * 32;
+  const bf16_t *yb = dy + b * yv.sb + cob2 * 64;
+  const int cin_lim = (Cin + 7) / 8 * 8;
+
+  constexpr int NPW = (WT8::NP + 7) / 8;
+  auto issue_piece = [&](int i, int xd, int xslot, int yd, int yslot, bool more, bool with_y = true) __attribute__((always_inline)) {
+    const int idx = wave + 8 * i;
+    if (!more) return;
+    if (idx < WT::NPX) {
+      const int r = idx / 3, pi = idx % 3;
+      if (pi == 2 && lane >= 8) return;
+      const int l_vox = lane >> 2, l_chunk = lane & 3;
+      const int gh = h0 - 1 + r, gw = w0 - 1 + 16 * pi + l_vox;
+      const bool ok = (unsigned)xd < (unsigned)xv.D && (unsigned)gh < (unsigned)xv.H && (unsigned)gw < (unsigned)xv.W &&
+                      cib * 32 + l_chunk * 8 < cin_lim;
+      const void *src = ok ? (const void *)(xb + xd * xv.sd + gh * xv.sh + gw * xv.sw + l_chunk * 8) : (const void *)&g_zero16;
+      dma16_to_lds(src, lds_addr_of(sX + xslot * WT::X_SLICE_B + r * WT::X_ROW_B + pi * 1024));
+    } else if (idx < WT8::NP && with_y) {
+      const int j = idx - WT::NPX, r = j / 4, pi = j % 4;
+      const int l_vox = lane >> 3, l_chunk = lane & 7;       // 8 voxels x 8 chunks of 16 B
+      const int gh = h0 + r, gw = w0 + 8 * pi + l_vox;
+      const bool ok = (unsigned)yd < (unsigned)D && gh < H && gw < W && cob2 * 64 + l_chunk * 8 < Cout;
+      const void *src = ok ? (const void *)(yb + yd * yv.sd + gh * yv.sh + gw * yv.sw + l_chunk * 8) : (const void *)&g_zero16;
+      dma16_to_lds(src, lds_addr_of(sY + yslot * WT8::Y_SLICE_B + r * WT8::Y_ROW_B + pi * 1024));
+    }
+  };
+
+  const int kq = (lane >> 5) * 8 + ((lane & 15) >> 2), cpart = ((lane >> 4) & 1) * 32 + (lane & 3) * 8;
+  const int lane_off_x = kq * 64 + cpart, lane_off_y = kq * 128 + cpart;
+
+  int tap_kd[4], tap_off[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int tc = wave + 8 * i < 27 ? wave + 8 * i : 26;
+    tap_kd[i] = tc / 9;
+    tap_off[i] = ((tc / 3) % 3) * WT::X_ROW_B + (tc % 3) * 64;
+  }
+  f32x16_t acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[i][c][q] = 0.f;
+
+  // prologue: x slices d_begin-1, d_begin, d_begin+1 and dy slice d_begin
+#pragma unroll
+  for (int i = 0; i < NPW; ++i) issue_piece(i, d_begin - 1, (d_begin - 1) & 3, d_begin, d_begin & 1, true);
+#pragma unroll
+  for (int sl = 0; sl <= 1; ++sl)
+#pragma unroll
+    for (int i = 0; i < (WT::NPX + 7) / 8; ++i) issue_piece(i, d_begin + sl, (d_begin + sl) & 3, 0, 0, true, false);
+  dma_wait_all();
+  lds_barrier();
+  typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+  for (int d = d_begin; d < d_end; ++d) {
+    const bool more = d + 1 < d_end;
+    const unsigned char *ys = sY + (d & 1) * WT8::Y_SLICE_B + lane_off_y;
+    int slice_off[3];
+#pragma unroll
+    for (int kd = 0; kd < 3; ++kd) slice_off[kd] = ((d + kd - 1) & 3) * WT::X_SLICE_B;
+#pragma unroll
+    for (int oh = 0; oh < WT::TH; ++oh) {
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        if (oh * 2 + ks < NPW) issue_piece(oh * 2 + ks, d + 2, (d + 2) & 3, d + 1, (d + 1) & 1, more);
+        bf16x8_t bfr[2];
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          const unsigned char *pb = ys + oh * WT8::Y_ROW_B + ks * 16 * 128 + c * 64;
+          const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t *)pb);
+          const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t *)(pb + 4 * 128));
+          const s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+          bfr[c] = __builtin_bit_cast(bf16x8_t, v);
+        }
+        bf16x8_t afr[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int so = (tap_kd[i] == 0 ? slice_off[0] : (tap_kd[i] == 1 ? slice_off[1] : slice_off[2])) + tap_off[i];
+          afr[i] = tr_operand(sX + lane_off_x + so + oh * WT::X_ROW_B + ks * 1024);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int c = 0; c < 2; ++c) acc[i][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[i], bfr[c], acc[i][c], 0, 0, 0);
+      }
+    }
+    dma_wait_all();
+    lds_barrier();
+  }
+  const int co = lane & 31, hh = lane >> 5;
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    const int cob = 2 * cob2 + c;
+    if (cob >= cobs) continue;
+    float *slab = slabs + (((int64_t)cib * cobs + cob) * gridDim.x + blockIdx.x) * (27 * 1024);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int tap = wave + 8 * i;
+      if (tap < 27) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) slab[(tap * 32 + (q & 3) + 8 * (q >> 2) + 4 * hh) * 32 + co] = acc[i][c][q];
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // bf16 weight gradient of a STRIDE-2 conv in one pass:  dW[tap][ci][co] = sum_vo x[2 vo + tap - 1][ci] * dy[vo][co].
 // Same scheme as conv3_wgrad_tr_kernel (LDS-DMA staging, ds_read_b64_tr_b16 operands, 7 taps per wave, slab output) with
 // the x tile kept at FULL resolution: output tile 2 rows x 16 voxels needs x rows 2h0-1 .. 2h0+3 and voxels 2w0-1 ..
@@ -2027,6 +2167,21 @@ static int wgrad_launch_classes(const void *x, const View &xv, const void *dy, c
                                            (int)WT::LDS_BYTES);
         DG_REQUIRE(e == hipSuccess, DGTTA_ERR_LAUNCH, "wgrad_tr: cannot raise the dynamic LDS limit");
         tr_attr[plain] = true;
+      }
+      const char *w8 = getenv("DGTTA_WGRAD_TR8");      // diagnostic / tests: "0" = always the 4-wave kernel
+      if (plain && Cout >= 64 && !abl && !(w8 && w8[0] == '0')) {
+        static bool a8 = false;
+        if (!a8) {
+          hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(conv3_wgrad_tr8_kernel),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)WT8::LDS_BYTES);
+          DG_REQUIRE(e == hipSuccess, DGTTA_ERR_LAUNCH, "wgrad_tr8: cannot raise the dynamic LDS limit");
+          a8 = true;
+        }
+        hipLaunchKernelGGL(conv3_wgrad_tr8_kernel, dim3((unsigned)p.units, (unsigned)(p.cibs * ((p.cobs + 1) / 2))), dim3(512),
+                           WT8::LDS_BYTES, st, (const bf16_t *)x, xv, (const bf16_t *)dy, yv, (float *)ws, Cin, Cout, p.tW, p.tH,
+                           p.nsd, p.DR, p.cobs);
+        DG_CHECK_LAUNCH("conv3_wgrad_tr8_kernel");
+        goto reduce;
       }
       hipLaunchKernelGGL(ktr, dim3((unsigned)p.units, (unsigned)(p.cibs * p.cobs), (unsigned)wc.n), dim3(256), WT::LDS_BYTES,
                          st, (const bf16_t *)x, xv, (const bf16_t *)dy, yv, (float *)ws, Cin, Cout, p.tW, p.tH, p.nsd,

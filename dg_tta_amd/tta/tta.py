@@ -370,8 +370,10 @@ def tta_main(run_name, config, tta_data_dir, save_base_path, label_mapping, modi
             if debug:
                 break
     # ---- ensemble sliding-window inference with the TTA'd parameter sets (reference: tta.py:376-416).  Label maps are
-    # written as <case>.npy in the preprocessed geometry; resampling to the original spacing, NIfTI export and
-    # compute_metrics_on_folder_simple (tta.py:420-477) need nnU-Net / SimpleITK and stay there.
+    # written as <case>.npy (or <case>.nii.gz when the case carries a NIfTI header in data_properties['nifti_header'])
+    # in the preprocessed geometry; the target label channels of the case, mapped to the TTA label set, go to
+    # mapped_target_labels{Ts,Tr}/ and summary_{Ts,Tr}.json is written as tta.py:447-470 does (evaluation.py).
+    # Resampling to the original spacing stays with nnU-Net.
     if config.get("run_inference", True) and not across and not debug:
         from .inference import run_inference
         from .torch_utils import get_imgs
@@ -388,8 +390,36 @@ def tta_main(run_name, config, tta_data_dir, save_base_path, label_mapping, modi
             disable_internal_augmentation()
             image = get_imgs(sample["data"].unsqueeze(0)).squeeze(0)
             seg = run_inference(image, model, params, patch_size, label_mapping, config["optimized_labels"])
-            out = Path(str(save_path / sample_id) + ".npy")
+            nii = (sample.get("data_properties") or {}).get("nifti_header") if isinstance(sample, dict) else None
+            out = Path(str(save_path / sample_id) + (".nii.gz" if nii is not None else ".npy"))
             out.parent.mkdir(exist_ok=True, parents=True)
-            np.save(out, seg.numpy().astype(np.int16))
+            _save_label_map(out, seg.numpy().astype(np.int16), nii)
             results[(sample_id, "prediction")] = out
+            # reference labels of this case (one-hot channels of the preprocessed sample), in the TTA label order
+            if sample["data"].shape[0] > 1:
+                bucket = "Ts" if "outputTs" in out.parent.name else ("Tr" if "outputTr" in out.parent.name else None)
+                if bucket is not None:
+                    segs = sample["data"][1:]
+                    target = torch.cat([(segs.sum(0, keepdim=True) < 1.0).float(), segs.float()], dim=0).argmax(0)
+                    ref_path = save_path / f"mapped_target_labels{bucket}" / out.name
+                    ref_path.parent.mkdir(exist_ok=True, parents=True)
+                    _save_label_map(ref_path, target.numpy().astype(np.int16), nii)
+        if rank == 0 or world == 1:
+            from .evaluation import compute_metrics_on_folder_simple
+            for bucket in ["Ts", "Tr"]:
+                refs, preds = save_path / f"mapped_target_labels{bucket}", save_path / f"tta_output{bucket}"
+                if refs.is_dir() and preds.is_dir():
+                    modifier_fn_module.ModifierFunctions.postprocess_results_fn(preds)
+                    summary = compute_metrics_on_folder_simple(refs, preds, list(range(len(config["optimized_labels"]))),
+                                                               output_file=save_path / f"summary_{bucket}.json",
+                                                               device=device)
+                    results[("summary", bucket)] = summary["foreground_mean"]["Dice"]
     return results
+
+
+def _save_label_map(path, arr, nifti_header=None):
+    if str(path).endswith(".npy"):
+        np.save(path, arr)
+    else:
+        from .nifti_io import write_nifti
+        write_nifti(path, arr, header=nifti_header)

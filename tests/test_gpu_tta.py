@@ -319,8 +319,18 @@ def test_tta_main_end_to_end(tmp_path):
     np.random.seed(0)
     res = tta_main("run0", cfg, tmp_path, tmp_path, mapping, modmod, DEV, network_bundle=bundle, tta_data=data())
     preds = {k: v for k, v in res.items() if k[1] == "prediction"}
-    res = {k: v for k, v in res.items() if k[1] != "prediction"}
-    assert len(res) == 4 and len(preds) == 2
+    summ = {k: v for k, v in res.items() if k[0] == "summary"}
+    res = {k: v for k, v in res.items() if k[1] != "prediction" and k[0] != "summary"}
+    assert len(res) == 4 and len(preds) == 2 and list(summ) == [("summary", "Ts")]
+    # evaluation artefacts as the reference writes them: mapped targets + summary_Ts.json in nnU-Net's layout
+    import json
+    sj = json.loads((tmp_path / "run0" / "summary_Ts.json").read_text())
+    assert len(sj["metric_per_case"]) == 2 and set(sj["mean"]) == {"0", "1", "2", "3"}
+    assert sj["foreground_mean"]["Dice"] == pytest.approx(summ[("summary", "Ts")], nan_ok=True)
+    tgt = np.load(tmp_path / "run0" / "mapped_target_labelsTs" / "case1.npy")
+    assert tgt.shape == (24, 24, 24) and set(np.unique(tgt).tolist()) <= {0, 1, 2, 3}
+    m1 = sj["metric_per_case"][0]["metrics"]["1"]
+    assert m1["TP"] + m1["FN"] == m1["n_ref"] == int((tgt == 1).sum())
     seg = np.load(preds[("tta_outputTs/case1", "prediction")])
     assert seg.shape == (24, 24, 24) and set(np.unique(seg).tolist()) <= {0, 1, 2, 3}
     out = tmp_path / "run0" / "tta_outputTs"
@@ -332,11 +342,11 @@ def test_tta_main_end_to_end(tmp_path):
         assert torch.isfinite(losses).all() and (losses > 0).all() and torch.isfinite(dices).all()
     # resume: everything exists -> nothing is recomputed
     again = tta_main("run0", cfg, tmp_path, tmp_path, mapping, modmod, DEV, network_bundle=bundle, tta_data=data())
-    assert all(k[1] == "prediction" for k in again)
+    assert all(k[1] == "prediction" or k[0] == "summary" for k in again)
     # sharding: rank 1 of 2 owns sample index 1 only, and reproduces the single-process result bit for bit (seeded units)
     res1 = tta_main("run1", cfg, tmp_path, tmp_path, mapping, modmod, DEV, network_bundle=bundle, tta_data=data(),
                     shard=(1, 2))
-    res1 = {k: v for k, v in res1.items() if k[1] != "prediction"}
+    res1 = {k: v for k, v in res1.items() if k[1] != "prediction" and k[0] != "summary"}
     assert sorted(k[0] for k in res1) == ["tta_outputTs/case2"] * 2
     a = torch.load(out / "case2__ensemble_idx_1_tta_parameters.pt", map_location="cpu")[0]
     b = torch.load(tmp_path / "run1" / "tta_outputTs" / "case2__ensemble_idx_1_tta_parameters.pt", map_location="cpu")[0]

@@ -203,14 +203,14 @@ template <int VEC, bool NDHWC>
 __global__ void warp_bwd_kernel(const float *__restrict__ gdst, const float *__restrict__ theta, float *__restrict__ gsrc,
                                 int C, int Ds, int Hs, int Ws, int Dd, int Hd, int Wd, int src_ldc, int dst_ldc,
                                 int pad_mode, int algebra, int only_declined, int B, int64_t total) {
-  __shared__ int declined[8];
+  __shared__ int declined[16];
   if (only_declined) {   // fallback role: only batches the gather kernel declined; normally none -> exit at once
-    if (threadIdx.x < 8)
+    if (threadIdx.x < 16)
       declined[threadIdx.x] = (int)threadIdx.x < B &&
                               !inverse_map(theta + threadIdx.x * 12, Ds, Hs, Ws, Dd, Hd, Wd, algebra).ok;
     __syncthreads();
     int any = 0;
-    for (int q = 0; q < 8; ++q) any |= declined[q];
+    for (int q = 0; q < 16; ++q) any |= declined[q];
     if (!any) return;
   }
   const int cg = NDHWC ? (C / VEC) : 1;
@@ -421,8 +421,8 @@ extern "C" int dgtta_affine_warp3d_bwd(const float *grad_dst, const float *theta
     // owner-computes gather (no atomics, no memset); batches whose map it declines are handled by the two launches after
     const bool vec = (C % 4 == 0) && (dst_ldc % 4 == 0) && (src_ldc % 4 == 0) && ((uintptr_t)grad_dst % 16 == 0) &&
                      ((uintptr_t)grad_src % 16 == 0);
-    DG_REQUIRE(B <= 8 && (int64_t)cdiv(Ds, 4) * B <= 65535 && cdiv(Hs, 4) <= 65535, DGTTA_ERR_UNSUPPORTED,
-               "warp_bwd: need B <= 8 and D*B/4, H/4 <= 65535");
+    DG_REQUIRE(B <= 16 && (int64_t)cdiv(Ds, 4) * B <= 65535 && cdiv(Hs, 4) <= 65535, DGTTA_ERR_UNSUPPORTED,
+               "warp_bwd: need B <= 16 and D*B/4, H/4 <= 65535");
     dim3 grid(cdiv(Ws, 16) * cdiv(C, 16), cdiv(Hs, 4), cdiv(Ds, 4) * B);
     if (vec)
       hipLaunchKernelGGL((warp_bwd_gather_kernel<16, true>), grid, dim3(256), 0, st, grad_dst, theta, grad_src, C, Ds, Hs,

@@ -194,10 +194,10 @@ def batch_branches_enabled():
 
 def batched_steps(accum, batch_size):
     """Accumulation steps run per network pass (DGTTA_BATCH_STEPS, default 4): 2 * steps * batch_size samples must stay
-    within the kernels' batch limit of 8 and `steps` must divide the number of accumulation steps."""
+    within the kernels' batch limits (loss: 8 pairs, warp: 16 samples) and `steps` must divide the number of accumulation steps."""
     import os
     k = max(1, int(os.environ.get("DGTTA_BATCH_STEPS", "4")))
-    k = min(k, max(1, 4 // max(1, batch_size)), accum)
+    k = min(k, max(1, 8 // max(1, batch_size)), accum)
     while accum % k:
         k -= 1
     return k

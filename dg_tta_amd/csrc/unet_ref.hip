@@ -669,42 +669,31 @@ __global__ __launch_bounds__(256) void head_fwd_lds_kernel(const T *__restrict__
                                                            int nsel, float *__restrict__ out, int64_t rows) {
   constexpr int CIN = 32, EPV = 16 / sizeof(T), XU = CIN / EPV;      // uint4 per input row
   constexpr int XP = XU + 1;                                          // padded row pitch in uint4
-  constexpr int KC = 16;                                              // classes per pass
-  __shared__ float sw[KC * CIN + KC];
+  __shared__ float sw[16 * CIN + 16];
   __shared__ uint4 sx[256 * XP];
-  __shared__ float so[256 * (KC + 1)];
+  __shared__ float so[256 * 17];
+  for (int i = threadIdx.x; i < nsel * CIN; i += 256) sw[i] = w[(int64_t)(sel ? sel[i / CIN] : i / CIN) * CIN + i % CIN];
+  for (int i = threadIdx.x; i < nsel; i += 256) sw[16 * CIN + i] = bias[sel ? sel[i] : i];
   for (int64_t r0 = (int64_t)blockIdx.x * 256; r0 < rows; r0 += (int64_t)gridDim.x * 256) {
     const int nr = rows - r0 < 256 ? (int)(rows - r0) : 256;
     __syncthreads();
     const uint4 *gx = reinterpret_cast<const uint4 *>(x + r0 * CIN);
     for (int i = threadIdx.x; i < nr * XU; i += 256) sx[(i / XU) * XP + i % XU] = gx[i];
     __syncthreads();
-    float xr[CIN];
     if ((int)threadIdx.x < nr) {
+      float xr[CIN];
 #pragma unroll
       for (int g = 0; g < XU; ++g) unpack16<T>(sx[threadIdx.x * XP + g], xr + g * EPV);
-    }
-    for (int k0 = 0; k0 < nsel; k0 += KC) {          // the activation row stays in registers across class chunks
-      const int nk = nsel - k0 < KC ? nsel - k0 : KC;
-      __syncthreads();
-      for (int i = threadIdx.x; i < nk * CIN; i += 256) {
-        const int k = k0 + i / CIN;
-        sw[i] = w[(int64_t)(sel ? sel[k] : k) * CIN + i % CIN];
-      }
-      for (int i = threadIdx.x; i < nk; i += 256) sw[KC * CIN + i] = bias[sel ? sel[k0 + i] : k0 + i];
-      __syncthreads();
-      if ((int)threadIdx.x < nr) {
-        for (int k = 0; k < nk; ++k) {
-          float acc = 0.f;
+      for (int k = 0; k < nsel; ++k) {
+        float acc = 0.f;
 #pragma unroll
-          for (int ci = 0; ci < CIN; ++ci) acc = __builtin_fmaf(xr[ci], sw[k * CIN + ci], acc);
-          so[threadIdx.x * (KC + 1) + k] = acc + sw[KC * CIN + k];
-        }
+        for (int ci = 0; ci < CIN; ++ci) acc = __builtin_fmaf(xr[ci], sw[k * CIN + ci], acc);
+        so[threadIdx.x * 17 + k] = acc + sw[16 * CIN + k];
       }
-      __syncthreads();
-      // rows of nsel floats: this chunk's nk consecutive classes of every row (contiguous runs of nk*4 bytes)
-      for (int i = threadIdx.x; i < nr * nk; i += 256) out[(r0 + i / nk) * nsel + k0 + i % nk] = so[(i / nk) * (KC + 1) + i % nk];
     }
+    __syncthreads();
+    float *go = out + r0 * nsel;
+    for (int i = threadIdx.x; i < nr * nsel; i += 256) go[i] = so[(i / nsel) * 17 + i % nsel];
   }
 }
 
@@ -1215,7 +1204,7 @@ extern "C" int dgtta_seghead_fwd(const void *x, int ldx, const float *w, const f
   if (Cin == 32 && nsel <= 128 && ldx % 8 == 0 && ((uintptr_t)x & 15) == 0) {
     const int64_t rows = (int64_t)B * V;
     const int blocks = (int)(cdiv64(rows, 256) < 8192 ? cdiv64(rows, 256) : 8192);
-    if (out_ndhwc && ldx == 32 && ldo == nsel) {
+    if (out_ndhwc && ldx == 32 && ldo == nsel && nsel <= 16 && ((uintptr_t)out & 15) == 0) {
       DISPATCH_T(dtype, hipLaunchKernelGGL((head_fwd_lds_kernel<T>), dim3(blocks), dim3(256), 0, (hipStream_t)stream,
                                            (const T *)x, w, bias, sel, nsel, out, rows));
       DG_CHECK_LAUNCH("head_fwd_lds_kernel");

@@ -222,3 +222,28 @@ def test_tta_main_refuses_cpu_device(tmp_path):
     from dg_tta_amd.tta.tta import tta_main
     with pytest.raises(RuntimeError, match="MI355X only"):
         tta_main("r", {}, tmp_path, tmp_path, {}, None, "cpu")
+
+
+def test_batched_steps_respects_limits(monkeypatch):
+    """steps per network pass: divides the accumulation count, 2 * steps * batch_size <= 16, DGTTA_BATCH_STEPS honoured."""
+    from dg_tta_amd.tta.tta import batch_branches_enabled, batched_steps
+    monkeypatch.delenv("DGTTA_BATCH_STEPS", raising=False)
+    assert batched_steps(16, 1) == 4 and batched_steps(16, 2) == 4 and batched_steps(6, 1) == 3 and batched_steps(1, 1) == 1
+    assert batched_steps(16, 4) == 2 and batched_steps(16, 8) == 1
+    monkeypatch.setenv("DGTTA_BATCH_STEPS", "8")
+    assert batched_steps(16, 1) == 8 and batched_steps(12, 1) == 6 and batched_steps(16, 2) == 4
+    monkeypatch.setenv("DGTTA_BATCH_STEPS", "1")
+    assert batched_steps(16, 1) == 1
+    monkeypatch.delenv("DGTTA_BATCH_BRANCHES", raising=False)
+    assert batch_branches_enabled()
+    monkeypatch.setenv("DGTTA_BATCH_BRANCHES", "0")
+    assert not batch_branches_enabled()
+
+
+def test_upload_async_cpu_passthrough():
+    """on a non-CUDA device the staging helper is a plain copy (shapes and values kept)"""
+    import torch
+    from dg_tta_amd.utils import upload_async
+    a, b = torch.arange(6.0).reshape(2, 3), torch.ones(5)
+    out = upload_async([a, b], "cpu")
+    assert torch.equal(out[0], a) and torch.equal(out[1], b) and out[0].shape == a.shape

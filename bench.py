@@ -72,59 +72,23 @@ class EpochRunner:
         disable_internal_augmentation()
         self.model.apply(fix_all)
         self.model.apply(release_all)            # measured epochs are adaptation epochs (epoch >= start_tta_at_epoch)
-        self.inv = torch.full((), 1.0 / args.accum, dtype=torch.float32, device=device)
         self.losses = []
 
     def epoch(self):
-        from dg_tta_amd import ops
-        from dg_tta_amd.gin import gin_aug
-        from dg_tta_amd.tta.tta import (batch_branches_enabled, batched_steps, calc_both_branches, calc_branch,
-                                        START_CLASS)
-        from dg_tta_amd.tta.torch_utils import dice_coeff, get_batch, get_map_idxs, map_label
-        cfg, model, dev = self.cfg, self.model, self.device
-        model.train()
-        step_losses = []
-        accum = cfg["patches_to_be_accumulated"]
-
-        def next_imgs():
-            with torch.no_grad():
-                imgs, _ = get_batch(self.data, np.random.choice(range(1), 1).tolist(), self.patch, None, dev)
-            return imgs[0]
-
-        if batch_branches_enabled():      # product default (tta.tta_unit): branches and k accumulation steps as one batch
-            k = batched_steps(accum, 1)
-            for _ in range(accum // k):
-                ta, tb = calc_both_branches(cfg, model, gin_aug, self.patch, 1, self.mapping, cfg["optimized_labels"],
-                                            self.modmod, next_imgs, dev, self.fused, steps=k)
-                loss, dice = ops.consistency_loss(ta, tb, START_CLASS)
-                step_losses.extend((1.0 - dice.detach()[:, START_CLASS:].mean(1)).unbind(0))
-                torch.autograd.backward(loss, grad_tensors=self.inv * k)
-        else:
-            for _ in range(accum):
-                a = (cfg, model, gin_aug, None, self.patch, 1, self.mapping, cfg["optimized_labels"], self.modmod,
-                     next_imgs(), dev, self.fused)
-                ta = calc_branch("branch_a", *a)
-                tb = calc_branch("branch_b", *a)
-                loss, _ = ops.consistency_loss(ta, tb, START_CLASS)
-                step_losses.append(loss.detach())
-                torch.autograd.backward(loss, grad_tensors=self.inv)
-        self.opt.step()
-        self.opt.zero_grad()
-        self.losses.append(torch.stack(step_losses).mean().item())
-        with torch.inference_mode():
-            model.eval()
-            imgs, labels = get_batch(self.data, [0], self.patch, "center", dev)
-            out = model(imgs[0])
-            am, _ = ops.argmax_dice(out)
-            lab = map_label(labels[0], get_map_idxs(self.mapping, cfg["optimized_labels"], "tta_labels"), "argmaxed")
-            self.dice = dice_coeff(am, lab.long(), len(cfg["optimized_labels"])).nanmean().item()
+        """One adaptation epoch through the PRODUCT's own epoch function (dg_tta_amd.tta.tta.tta_epoch, the body of
+        tta_unit): nothing of the loop is restated here."""
+        from dg_tta_amd.tta.tta import tta_epoch
+        loss, self.dice = tta_epoch(self.model, self.opt, self.cfg, self.data, self.patch, self.mapping, self.modmod,
+                                    self.device, self.fused, adapt=True)
+        self.losses.append(loss)
 
 
 def cpu_baseline(args):
-    """Times the CPU oracle (restatement of the reference, kind 'port') on a bounded sample of the same workload:
-    ONE accumulation step (2 branches + loss + backward) on a `cpu_size`^3 patch, scaled by voxel count to 128^3 and
-    by (accum + eval forward) to one epoch."""
-    from oracle import gin as ogin, tta as otta, unet as ounet
+    """Times the CPU oracle (restatement of the reference, kind 'port') on a bounded sample of the same workload, as
+    BASELINE.md §4 prescribes: ONE warm-up + ONE measured accumulation step (2 branches fwd + loss + bwd) on a
+    `cpu_size`^3 patch (default: the full 128^3), scaled by the voxel count if smaller and by (accum + eval forward)
+    to one epoch."""
+    from oracle import tta as otta, unet as ounet
     n = args.cpu_size
     cores = min(len(os.sched_getaffinity(0)), 16)     # a one-GPU box's CPU share is 16 cores (oversubscribing 256 hurts)
     torch.set_num_threads(cores)
@@ -135,16 +99,57 @@ def cpu_baseline(args):
 
     def draws(seed):
         torch.manual_seed(seed)
-        return dict(gin_draw=ogin.draw_gin_params(1), affine_draw=torch.randn(1, 3, 4),
-                    mind_noise=torch.randn(1, 12, n, n, n))
-    t0 = time.perf_counter()
-    otta.tta_step(om, imgs, sel, draws(1), draws(2), accum=args.accum, backward=True)
-    dt = time.perf_counter() - t0
+        return otta.draw_branch(1, [n, n, n])
+    times = []
+    for rep in range(1 + max(args.cpu_warmup, 0)):
+        t0 = time.perf_counter()
+        otta.tta_step(om, imgs, sel, draws(1 + 2 * rep), draws(2 + 2 * rep), accum=args.accum, backward=True)
+        times.append(time.perf_counter() - t0)
+    dt = times[-1]
     scale = (args.size / n) ** 3
     epoch_s = dt * scale * (args.accum + 1.0 / 6.0)       # eval forward ~ 1/6 of a step (1 of 6 network passes)
     return {"value": 1.0 / epoch_s, "unit": "TTA-epochs/s", "cores": cores, "kind": "port",
-            "sample": f"1 accumulation step (2 branches fwd + loss + bwd) of the CPU oracle on a {n}^3 patch = "
-                      f"{dt:.1f} s, scaled x{scale:.2f} (voxels) x{args.accum + 1 / 6:.2f} (steps per epoch)"}
+            "sample": f"{args.cpu_warmup} warm-up + 1 measured accumulation step (2 branches fwd + loss + bwd) of the CPU "
+                      f"oracle on a {n}^3 patch = {dt:.1f} s (warm-up {times[0]:.1f} s), scaled x{scale:.2f} (voxels) "
+                      f"x{args.accum + 1 / 6:.2f} (steps per epoch)"}
+
+
+def product_switches():
+    """The environment switches of the product path in force for this run (Switches)."""
+    from dg_tta_amd.tta.tta import batch_branches_enabled, batched_steps
+    return {"DGTTA_BATCH_BRANCHES": int(batch_branches_enabled()), "steps_per_pass": batched_steps(16, 1),
+            "exact_zero_bias_grad": True, "accumulate_grads_in_place": True,
+            "env": {k: v for k, v in os.environ.items() if k.startswith("DGTTA_")}}
+
+
+def roofline_of(probe, args, dtype):
+    """Roofline of the dominant kernel from the events recorded around its launches inside the timed region."""
+    if not probe["events"]:
+        return None
+    # launches of the probed block: training passes carry 2 branches x k accumulation steps, the eval pass 1 sample
+    times = [(s.elapsed_time(e), nb_) for s, e, nb_ in probe["events"]]
+    nb = max(n for _, n in times)
+    times = [t for t, n in times if n == nb]
+    avg_ms = sum(times) / len(times)
+    flop = conv_flops(probe["cin"], probe["cout"], probe["vout"]) * nb
+    peak = 2500.0 if dtype == "bf16" else 157.3
+    ach = flop / (avg_ms * 1e-3) / 1e12
+    traffic, src = None, None       # HBM bytes per launch: rocprofv3 PMC passes committed under profiles/ (not a live counter)
+    for cand in ("r02_pmc_summary.json", "r01_pmc_summary.json"):
+        pmc = ROOT / "profiles" / cand
+        if pmc.exists() and dtype == "bf16" and args.size == 128:
+            d = json.loads(pmc.read_text()).get("conv_128cube_32to32", {})
+            if "fetch_bytes_corrected_median" in d:     # PMC pass = one sample of this layer; scaled by the batch
+                traffic = (d["fetch_bytes_corrected_median"] + d["write_bytes_median"]) * nb
+                src = f"profiles/{cand} (rocprofv3 --pmc passes of one sample of this layer x samples_per_launch)"
+                break
+    return {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+            "traffic": traffic, "traffic_source": src,
+            "kernel": "conv3_rows_kernel" if dtype == "bf16" else "conv3_mfma_kernel",
+            "launches": len(times), "avg_ms": round(avg_ms, 4), "flop_per_launch": flop, "samples_per_launch": nb,
+            "scope": "forward launches of block dec.3.1 (128^3 32->32, fused statistics) in the training passes "
+                     "(samples_per_launch = 2 branches x k accumulation steps); the kernel name also runs the other "
+                     "large layers, so rocprofv3's per-name average is a mix of shapes"}
 
 
 def main():
@@ -158,7 +163,9 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["fp32", "bf16"],
                     help="activation storage; accumulation, statistics, loss, gradients of weights and AdamW are fp32")
     ap.add_argument("--impl", type=int, default=0)
-    ap.add_argument("--cpu-size", type=int, default=64)
+    ap.add_argument("--cpu-size", type=int, default=128)
+    ap.add_argument("--cpu-warmup", type=int, default=1)
+    ap.add_argument("--no-fp32", action="store_true", help="skip the nested reference-precision (fp32) epoch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -170,59 +177,54 @@ def main():
         torch.cuda.set_device(local)
         dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
     device = torch.device(f"cuda:{local}")
-    torch.manual_seed(1234 + rank)
-    np.random.seed(1234 + rank)
 
-    runner = EpochRunner(args, device, rank)
+    from dg_tta_amd.sharding import max_over_ranks
     from dg_tta_amd.unet import set_probe
-    for _ in range(args.warmup):
-        runner.epoch()
-    probe = set_probe(("dec", 3, 1))          # the 128^3 32->32 conv block (largest single-shape FLOP share)
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        runner.epoch()
-    barrier()
-    dt = time.perf_counter() - t0
-    from dg_tta_amd.sharding import max_over_ranks
-    dt = max_over_ranks(dt, device)
-    set_probe(None)
+    def timed_run(dtype, steps, warmup):
+        """W untimed + K timed epochs of the product path in `dtype`; returns (seconds max over ranks, runner, roofline)."""
+        args.dtype = dtype
+        torch.manual_seed(1234 + rank)
+        np.random.seed(1234 + rank)
+        runner = EpochRunner(args, device, rank)
+        for _ in range(warmup):
+            runner.epoch()
+        probe = set_probe(("dec", 3, 1))          # the 128^3 32->32 conv block (largest single-shape FLOP share)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            runner.epoch()
+        barrier()
+        dt = max_over_ranks(time.perf_counter() - t0, device)
+        set_probe(None)
+        return dt, runner, roofline_of(probe, args, dtype)
+
+    main_dtype = args.dtype
+    dt, runner, roof = timed_run(main_dtype, args.steps, args.warmup)
+    losses, dice = list(runner.losses), runner.dice
+    del runner
+    torch.cuda.empty_cache()
+    other = None
+    if not args.no_fp32 and main_dtype == "bf16":
+        # the reference never autocasts during TTA (SURVEY.md §8a N1): the same epoch with fp32 storage / fp32 MFMA
+        fdt, frunner, froof = timed_run("fp32", 1, 1)
+        other = {"value": round(world / fdt, 5), "value_per_gpu": round(1.0 / fdt, 5), "unit": "TTA-epochs/s", "steps": 1,
+                 "warmup": 1, "ms_per_step": round(fdt * 1e3, 2), "loss_last_epoch": frunner.losses[-1],
+                 "pseudo_dice": frunner.dice, "roofline": froof}
+        del frunner
+        torch.cuda.empty_cache()
+    args.dtype = main_dtype
 
     if rank == 0:
         ms = dt / args.steps * 1e3
         value = world * args.steps / dt
-        # roofline of the dominant kernel, timed with events on the launch stream inside the timed region
-        roof = None
-        if probe["events"]:
-            # launches of the probed block: training passes carry 2 branches x k accumulation steps, the eval pass 1 sample
-            times = [(s.elapsed_time(e), nb_) for s, e, nb_ in probe["events"]]
-            nb = max(n for _, n in times)
-            times = [t for t, n in times if n == nb]
-            avg_ms = sum(times) / len(times)
-            flop = conv_flops(probe["cin"], probe["cout"], probe["vout"]) * nb
-            peak = 2500.0 if args.dtype == "bf16" else 157.3
-            ach = flop / (avg_ms * 1e-3) / 1e12
-            traffic = None       # HBM bytes per launch from the committed PMC passes (profiles/), not a live counter
-            pmc = ROOT / "profiles" / "r01_pmc_summary.json"
-            if pmc.exists() and args.dtype == "bf16" and args.size == 128:
-                d = json.loads(pmc.read_text()).get("conv_128cube_32to32", {})
-                if "fetch_bytes_corrected_median" in d:     # PMC pass = one sample of this layer; scaled by the batch
-                    traffic = (d["fetch_bytes_corrected_median"] + d["write_bytes_median"]) * nb
-            roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
-                    "frac": round(ach / peak, 4), "traffic": traffic, "kernel": probe.get("kernel", "conv3_rows_kernel" if args.dtype == "bf16" else "conv3_mfma_kernel"),
-                    "launches": len(times), "avg_ms": round(avg_ms, 4),
-                    "flop_per_launch": flop, "samples_per_launch": nb,
-                    "scope": "forward launches of block dec.3.1 (128^3 32->32, fused statistics) in the training passes "
-                             "(samples_per_launch = 2 branches x k accumulation steps); the kernel name also runs the other "
-                             "large layers, so rocprofv3's per-name average is a mix of shapes; traffic = PMC of one sample "
-                             "x samples_per_launch"}
         out = {"metric": "TTA-epochs/sec per GPU on 128^3 patch", "value": round(value, 5), "unit": "TTA-epochs/s",
+               "value_per_gpu": round(args.steps / dt, 5),
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 2),
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
                "data": "synthetic",
@@ -230,10 +232,14 @@ def main():
                                       f"{args.accum} accumulation steps, GIN+affine in both branches, MIND 12ch, "
                                       f"nnUNet 3d_fullres 105 classes, C_opt={args.copt}, AdamW, 1 eval patch",
                           "patch": args.size, "accum": args.accum, "c_opt": args.copt,
-                          "parallelism": f"{world} independent TTA instance(s), sample-sharded"},
-               "loss_last_epoch": runner.losses[-1], "pseudo_dice": runner.dice,
+                          "parallelism": f"{world} independent TTA instance(s), sample-sharded",
+                          "value_is": "whole-job aggregate over all GPUs (value_per_gpu = one instance)",
+                          "product_switches": product_switches()},
+               "loss_last_epoch": losses[-1], "pseudo_dice": dice,
                "epoch_tflop": round(96.89 * (args.size / 128) ** 3 * (args.accum * 6 + 1) / 97.0, 2),
                "roofline": roof}
+        if other is not None:
+            out["fp32"] = other
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args)
         print(json.dumps(out), flush=True)

@@ -25,6 +25,8 @@ SIGNATURES = {
     "dgtta_softdice_ws_bytes": (SZ, [I, I, I64]),
     "dgtta_softdice_fwd": (I, [P, P, P, P, P, SZ, I, I, I64, I, I, I, P]),
     "dgtta_softdice_bwd": (I, [P, P, P, P, P, F, P, I, I, I64, I, I, P]),
+    "dgtta_softdice_probs_fwd": (I, [P, P, P, P, SZ, I, I, I64, I64, I64, I64, P]),
+    "dgtta_softdice_probs_bwd": (I, [P, P, P, P, P, P, I, I, I64, I64, I64, I64, P]),
     "dgtta_adamw_step": (I, [C.POINTER(P), C.POINTER(P), C.POINTER(P), C.POINTER(P), C.POINTER(I64), I, F, F, F, F, F,
                              I, P]),
     "dgtta_conv3d_packed_bytes": (SZ, [I, I, I]),

@@ -264,6 +264,56 @@ __global__ __launch_bounds__(MAXW * 64) void softdice_bwd_kernel(const float *__
   }
 }
 
+
+// ---- stand-alone soft_dice_loss(a, b) on probability maps (torch_utils.py:90-104): a, b [B][C][V] with element strides
+// (sb, sc, sv), i.e. NCDHW (sv = 1) or channels-last (sc = 1).  One workgroup reduces a voxel chunk of one (b, c) plane;
+// partials and the finalize kernel are shared with the fused loss (guard over the whole call, start_class 0).
+__global__ __launch_bounds__(256) void softdice_probs_fwd_kernel(const float *__restrict__ a, const float *__restrict__ b,
+                                                                 double *__restrict__ partial, int C, int64_t V,
+                                                                 int64_t sb, int64_t sc, int64_t sv) {
+  __shared__ float red[16];
+  const int bc = blockIdx.y, bi = bc / C, c = bc - bi * C;
+  const float *pa = a + (int64_t)bi * sb + (int64_t)c * sc, *pb = b + (int64_t)bi * sb + (int64_t)c * sc;
+  const int64_t per = cdiv64(V, gridDim.x), v0 = (int64_t)blockIdx.x * per, v1 = v0 + per < V ? v0 + per : V;
+  double s1 = 0.0, s2 = 0.0;
+  for (int64_t c0 = v0; c0 < v1; c0 += 256 * 64) {        // float partials over <= 64 voxels per thread, then double
+    float f1 = 0.f, f2 = 0.f;
+    const int64_t c1 = c0 + 256 * 64 < v1 ? c0 + 256 * 64 : v1;
+    for (int64_t v = c0 + threadIdx.x; v < c1; v += 256) {
+      const float x = pa[v * sv], y = pb[v * sv];
+      f1 += (2.0f * x) * y;
+      const float t = x + y;
+      f2 += t * t;
+    }
+    s1 += (double)f1;
+    s2 += (double)f2;
+  }
+  const float r1 = block_sum((float)s1, red), r2 = block_sum((float)s2, red);
+  if (threadIdx.x == 0) {
+    partial[((int64_t)bc * 2 + 0) * gridDim.x + blockIdx.x] = (double)r1;
+    partial[((int64_t)bc * 2 + 1) * gridDim.x + blockIdx.x] = (double)r2;
+  }
+}
+
+// d dice[b,c] / d a_v = 2 b_v / (V den) - nom (a_v + b_v) / (V den^2)  (and a <-> b); coef = (P, Q) of the finalize kernel
+// with invN = 1 / (B C): the factor is undone here and replaced by the upstream gradient gdice[b,c].
+__global__ __launch_bounds__(256) void softdice_probs_bwd_kernel(const float *__restrict__ a, const float *__restrict__ b,
+                                                                 const float *__restrict__ gdice,
+                                                                 const float *__restrict__ coef, float *__restrict__ ga,
+                                                                 float *__restrict__ gb, int B, int C, int64_t V,
+                                                                 int64_t sb, int64_t sc, int64_t sv) {
+  const int bc = blockIdx.y, bi = bc / C, c = bc - bi * C;
+  const int64_t base = (int64_t)bi * sb + (int64_t)c * sc;
+  const float g = gdice[bc] * (float)(B * C);
+  const float P = -coef[2 * bc] * g, Q = -coef[2 * bc + 1] * g;
+  for (int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x; v < V; v += (int64_t)gridDim.x * 256) {
+    const float x = a[base + v * sv], y = b[base + v * sv];
+    const float t = Q * (x + y);
+    ga[base + v * sv] = P * y + t;
+    gb[base + v * sv] = P * x + t;
+  }
+}
+
 int waves_for(int ldc) {
   size_t per_wave = (size_t)2 * 64 * tile_pitch(ldc) * sizeof(float);
   int nw = (int)(LDS_BUDGET / per_wave);
@@ -301,7 +351,7 @@ int allow_big_lds() {
 // ws layout: [partials: B*nblk*C*2 double][coef: B*C*2 float]
 extern "C" size_t dgtta_softdice_ws_bytes(int B, int C, int64_t V) {
   return align_up((size_t)B * nblocks_for(V) * C * 2 * sizeof(double), 256) +
-         align_up((size_t)B * C * 2 * sizeof(float), 256);
+         align_up((size_t)B * C * 2 * sizeof(float), 256) + 256 /* scratch scalar of the stand-alone op */;
 }
 
 extern "C" int dgtta_softdice_fwd(const float *la, const float *lb, float *dice, float *loss, void *ws, size_t ws_bytes,
@@ -343,5 +393,41 @@ extern "C" int dgtta_softdice_bwd(const float *la, const float *lb, float *grad_
   hipLaunchKernelGGL(softdice_bwd_kernel, dim3((int)gb, B), dim3(nw * 64), lds_for(ldc, nw), st, la, lb, grad_la,
                      grad_lb, coef, grad_scale, grad_scale_dev, C, V, ldc, (int)vec_ok(la, lb, grad_la, grad_lb, ldc));
   DG_CHECK_LAUNCH("softdice_bwd_kernel");
+  return DGTTA_OK;
+}
+
+extern "C" int dgtta_softdice_probs_fwd(const float *a, const float *b, float *dice, void *ws, size_t ws_bytes, int B, int C,
+                                        int64_t V, int64_t stride_b, int64_t stride_c, int64_t stride_v, void *stream) {
+  DG_REQUIRE(a && b && dice && ws, DGTTA_ERR_BADARG, "softdice_probs_fwd: null pointer");
+  DG_REQUIRE(B > 0 && B <= 8 && C > 0 && C <= MAXC && V > 0, DGTTA_ERR_BADARG,
+             "softdice_probs_fwd: need 1<=B<=8, 1<=C<=%d (B=%d C=%d)", MAXC, B, C);
+  DG_REQUIRE(ws_bytes >= dgtta_softdice_ws_bytes(B, C, V), DGTTA_ERR_WORKSPACE, "softdice_probs_fwd: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  const int nblk = nblocks_for(V);
+  double *partial = (double *)ws;
+  float *coef = (float *)((char *)ws + align_up((size_t)B * nblk * C * 2 * sizeof(double), 256));
+  float *scratch = coef + align_up((size_t)B * C * 2 * sizeof(float), 256) / sizeof(float);
+  hipLaunchKernelGGL(softdice_probs_fwd_kernel, dim3(nblk, B * C), dim3(256), 0, st, a, b, partial, C, V, stride_b,
+                     stride_c, stride_v);
+  DG_CHECK_LAUNCH("softdice_probs_fwd_kernel");
+  hipLaunchKernelGGL(softdice_finalize_kernel, dim3(1), dim3(1024), 0, st, partial, nblk, B, C, V, 0, dice, scratch, coef,
+                     B);
+  DG_CHECK_LAUNCH("softdice_finalize_kernel");
+  return DGTTA_OK;
+}
+
+extern "C" int dgtta_softdice_probs_bwd(const float *a, const float *b, const float *grad_dice, float *grad_a, float *grad_b,
+                                        const void *ws, int B, int C, int64_t V, int64_t stride_b, int64_t stride_c,
+                                        int64_t stride_v, void *stream) {
+  DG_REQUIRE(a && b && grad_dice && grad_a && grad_b && ws, DGTTA_ERR_BADARG, "softdice_probs_bwd: null pointer");
+  DG_REQUIRE(B > 0 && B <= 8 && C > 0 && C <= MAXC && V > 0, DGTTA_ERR_BADARG, "softdice_probs_bwd: bad dims");
+  hipStream_t st = (hipStream_t)stream;
+  const int nblk = nblocks_for(V);
+  const float *coef = (const float *)((const char *)ws + align_up((size_t)B * nblk * C * 2 * sizeof(double), 256));
+  int64_t gx = (V + 255) / 256;
+  if (gx > 512) gx = 512;
+  hipLaunchKernelGGL(softdice_probs_bwd_kernel, dim3((int)gx, B * C), dim3(256), 0, st, a, b, grad_dice, coef, grad_a,
+                     grad_b, B, C, V, stride_b, stride_c, stride_v);
+  DG_CHECK_LAUNCH("softdice_probs_bwd_kernel");
   return DGTTA_OK;
 }

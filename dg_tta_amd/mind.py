@@ -30,6 +30,12 @@ class MIND3D(torch.nn.Module):
 _PENDING_NOISE = []
 
 
+def draw_noise_(slot):
+    """mind.py:150's torch.randn draw for one branch, written in place into its slot of the batched noise tensor (device
+    generator, as the reference).  A function of its own so that parity tests can route it through the CPU generator."""
+    return slot.normal_()
+
+
 def push_noise(noise, groups=1):
     _PENDING_NOISE.append((noise, groups))
 
@@ -42,10 +48,28 @@ def uses_mind_hook(model):
     return any(h is mind_hook for m in model.modules() for h in m._forward_pre_hooks.values())
 
 
+_FORCED_GROUPS = [None]
+
+
+class mind_groups:
+    """Context: mind_hook treats the batch as `groups` independent calls (one variance-clamp mean per group)."""
+
+    def __init__(self, groups):
+        self.groups = groups
+
+    def __enter__(self):
+        self.prev, _FORCED_GROUPS[0] = _FORCED_GROUPS[0], self.groups
+
+    def __exit__(self, *exc):
+        _FORCED_GROUPS[0] = self.prev
+
+
 def mind_hook(module, input):
     noise, groups = None, 1
     if _PENDING_NOISE:
         cand = _PENDING_NOISE[0][0]
         if cand.shape[0] == input[0].shape[0] and tuple(cand.shape[2:]) == tuple(input[0].shape[2:]):
             noise, groups = _PENDING_NOISE.pop(0)
+    if _FORCED_GROUPS[0] is not None and noise is None and input[0].shape[0] % _FORCED_GROUPS[0] == 0:
+        groups = _FORCED_GROUPS[0]
     return MIND3D().forward(*input, noise=noise, out_dtype=getattr(module, "act_dtype", torch.float32), groups=groups)

@@ -234,6 +234,45 @@ def consistency_loss(target_a, target_b, start_class=1):
                                   int(getattr(target_a, "_dgtta_guard_items", 0)))
 
 
+class _SoftDice(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        lib = _lib.load()
+        bsz, c = a.shape[:2]
+        v = a[0, 0].numel()
+        dense = [t.is_contiguous() or t.is_contiguous(memory_format=torch.channels_last_3d) for t in (a, b)]
+        if not (all(dense) and a.stride() == b.stride()):
+            a, b = a.contiguous(), b.contiguous()
+        cl = a.dim() == 5 and not a.is_contiguous()             # dense channels-last
+        strides = (v * c, 1, c) if cl else (v * c, v, 1)
+        dice = torch.empty((bsz, c), dtype=torch.float32, device=a.device)
+        nbytes = lib.dgtta_softdice_ws_bytes(bsz, c, v)
+        ws = _ws(nbytes, a.device)
+        check(lib.dgtta_softdice_probs_fwd(ptr(a), ptr(b), ptr(dice), ptr(ws), nbytes, bsz, c, v, *strides,
+                                           stream_of(a.device)), "dgtta_softdice_probs_fwd")
+        ctx.save_for_backward(a, b, ws)
+        ctx.meta = (bsz, c, v, strides)
+        return dice
+
+    @staticmethod
+    def backward(ctx, gdice):
+        a, b, ws = ctx.saved_tensors
+        bsz, c, v, strides = ctx.meta
+        lib = _lib.load()
+        ga, gb = torch.empty_like(a, memory_format=torch.preserve_format), torch.empty_like(b, memory_format=torch.preserve_format)
+        check(lib.dgtta_softdice_probs_bwd(ptr(a), ptr(b), ptr(gdice.float().contiguous()), ptr(ga), ptr(gb), ptr(ws), bsz,
+                                           c, v, *strides, stream_of(a.device)), "dgtta_softdice_probs_bwd")
+        return ga, gb
+
+
+def soft_dice(smp_a, smp_b):
+    """soft_dice_loss(smp_a, smp_b) -> [B,C] of the reference (torch_utils.py:90-104) on probability maps [B,C,D,H,W]
+    (fp32, contiguous or channels_last_3d); differentiable w.r.t. both inputs."""
+    require_cuda(smp_a, smp_b)
+    assert smp_a.shape == smp_b.shape and smp_a.dim() >= 3
+    return _SoftDice.apply(smp_a.float(), smp_b.float())
+
+
 # ------------------------------------------------------------------------------------------------ AdamW
 def adamw_step(params, grads, exp_avgs, exp_avg_sqs, step, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01):
     lib = _lib.load()

@@ -39,6 +39,22 @@ def _add_common(parser):
     parser.add_argument("--pretrainer_fold", help="Fold ID of nnUNet model to use for pretraining", default="0")
 
 
+def _wait_children(procs, poll_s=0.5):
+    """Waits for the per-GPU children; when one fails the others are stopped (they would otherwise sit in the filesystem
+    barrier waiting for the dead rank's files).  Returns the list of return codes."""
+    import time
+    while True:
+        rcs = [p.poll() for p in procs]
+        if all(rc is not None for rc in rcs):
+            return rcs
+        if any(rc is not None and rc != 0 for rc in rcs):
+            for p in procs:
+                if p.poll() is None:
+                    p.terminate()
+            return [p.wait() for p in procs]
+        time.sleep(poll_s)
+
+
 class DGTTAProgram:
     def __init__(self, argv=None):
         self.argv = list(sys.argv if argv is None else argv)
@@ -98,12 +114,24 @@ class DGTTAProgram:
         if args.gpus > 1 and world == 1:
             # fan out: one independent process per GPU, pinned with HIP_VISIBLE_DEVICES, same run directory
             (results_dir / run_name).mkdir(exist_ok=True, parents=True)
+            from .sharding import child_devices
             procs = []
-            for r in range(args.gpus):
-                env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(args.gpus), HIP_VISIBLE_DEVICES=str(r))
+            for r, dev_id in enumerate(child_devices(args.gpus)):
+                env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(args.gpus), HIP_VISIBLE_DEVICES=dev_id,
+                           DGTTA_SUMMARY_BY_PARENT="1")
+                env.pop("CUDA_VISIBLE_DEVICES", None)
                 cmd = [sys.executable, "-m", "dg_tta_amd.run"] + self.argv[1:] + ["--run_name", run_name]
                 procs.append(subprocess.Popen(cmd, env=env))
-            raise SystemExit(max(p.wait() for p in procs))
+            rcs = _wait_children(procs)
+            if any(rc != 0 for rc in rcs):       # a child killed by a signal has a NEGATIVE return code
+                print(f"run_tta: child return codes {rcs}: not evaluating an incomplete run", file=sys.stderr)
+                raise SystemExit(1)
+            # every child has exited: all predictions are on disk, the summary cannot race (reference: tta.py:447-470)
+            with open(Path(plan_dir) / "tta_plan.json", "r") as f:
+                config = json.load(f)
+            from .tta.tta import evaluate_run
+            evaluate_run(results_dir / run_name, config, load_current_modifier_functions(plan_dir), torch.device(args.device))
+            raise SystemExit(0)
 
         with open(Path(plan_dir) / "tta_plan.json", "r") as f:
             config = json.load(f)

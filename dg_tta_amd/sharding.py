@@ -11,10 +11,64 @@ def owns(sample_index, rank, world):
     return sample_index % world == rank
 
 
+def unit_owner(sample_index, ensemble_index, num_samples, ensemble_count, world):
+    """Rank that adapts the (sample, ensemble member) unit.  With at least as many samples as ranks a sample's members
+    stay together (round-robin over samples); with fewer samples than ranks the (sample, member) PAIRS are dealt
+    round-robin, so that e.g. 1 sample x 3 members still uses 3 GPUs.  The sample's ensemble inference
+    is done by the owner of member 0, after a filesystem barrier on the members' parameter files."""
+    if world <= 1:
+        return 0
+    if num_samples >= world:
+        return sample_index % world
+    return (sample_index * ensemble_count + ensemble_index) % world
+
+
 def units_for_rank(num_samples, ensemble_count, rank, world):
-    """(sample, ensemble) units of this rank: samples round-robin, all ensemble members of a sample on one rank (the
-    sample's ensemble-averaged inference needs all of its members' files)."""
-    return [(s, e) for s in range(num_samples) if owns(s, rank, world) for e in range(ensemble_count)]
+    """(sample, ensemble) units of this rank (see unit_owner)."""
+    return [(s, e) for s in range(num_samples) for e in range(ensemble_count)
+            if unit_owner(s, e, num_samples, ensemble_count, world) == rank]
+
+
+def wait_for_files(paths, timeout_s=24 * 3600.0, poll_s=0.5):
+    """Filesystem barrier (the mechanism the reference's resume logic already relies on, tta.py:164-170): blocks until
+    every path exists; raises TimeoutError naming the missing files.  Writers rename complete files into place."""
+    import time
+    from pathlib import Path
+    paths = [Path(p) for p in paths]
+    t0 = time.monotonic()
+    while True:
+        missing = [p for p in paths if not p.is_file()]
+        if not missing:
+            return
+        if time.monotonic() - t0 > timeout_s:
+            raise TimeoutError(f"filesystem barrier: still missing after {timeout_s:.0f} s: {[str(p) for p in missing]}")
+        time.sleep(poll_s)
+
+
+def done_marker(save_path, rank):
+    from pathlib import Path
+    return Path(save_path) / f".rank_{rank}.done"
+
+
+def mark_rank_done(save_path, rank):
+    done_marker(save_path, rank).write_text("done\n")
+
+
+def summary_by_parent():
+    """True in the children of `dgtta run_tta --gpus N`: the fan-out parent evaluates the run after all of them exited."""
+    return os.environ.get("DGTTA_SUMMARY_BY_PARENT", "0") == "1"
+
+
+def child_devices(n):
+    """Physical device ids for n children: the parent's HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES restriction is kept."""
+    for var in ("HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        cur = os.environ.get(var)
+        if cur:
+            ids = [c.strip() for c in cur.split(",") if c.strip() != ""]
+            if len(ids) < n:
+                raise RuntimeError(f"--gpus {n} but {var}={cur} exposes only {len(ids)} device(s)")
+            return ids[:n]
+    return [str(i) for i in range(n)]
 
 
 def max_over_ranks(seconds, device=None):

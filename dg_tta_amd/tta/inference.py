@@ -15,6 +15,7 @@ import torch
 
 from .. import _lib, ops
 from .._lib import check, ptr, stream_of
+from ..mind import mind_groups
 from .torch_utils import map_label
 
 
@@ -86,13 +87,17 @@ def predict_sliding_window_return_logits(model, data, patch_size, acc=None, tile
     was_training = model.training
     model.eval()
     # windows go through the network WINDOW_BATCH at a time: the 16^3-and-below layers are launch / occupancy bound at
-    # batch 1 (same observation as in the TTA loop); the result is independent of the grouping (per-sample InstanceNorm)
+    # batch 1 (same observation as in the TTA loop); per-sample InstanceNorm and per-window MIND statistics (below) make
+    # the result independent of the grouping
     origins = [(sx, sy, sz) for sx in steps[0] for sy in steps[1] for sz in steps[2]]
     for g0 in range(0, len(origins), WINDOW_BATCH):
         group = origins[g0:g0 + WINDOW_BATCH]
         work = torch.stack([data[:, sx:sx + patch_size[0], sy:sy + patch_size[1], sz:sz + patch_size[2]]
                             for sx, sy, sz in group]).contiguous()
-        out = model(work)
+        # MIND's variance clamp uses the mean over the whole CALL's batch (mind.py:159-161) and nnU-Net predicts one
+        # window per call: the batched pass keeps per-window statistics (groups = windows in the batch)
+        with mind_groups(len(group)):
+            out = model(work)
         if isinstance(out, tuple):
             out = out[0]
         out = out.float().contiguous(memory_format=torch.channels_last_3d)        # [n,C,P] stored voxel-major

@@ -13,11 +13,13 @@ _VOLUME_CACHE = {}
 
 def _resident(data, device):
     """Uploads a preprocessed case once and keeps it in HBM (the reference re-uploads it on every call,
-    torch_utils.py:60).  Returns (image [1,1,Dv,Hv,Wv] fp32, min scalar [1], label map [1,1,Dv,Hv,Wv] fp32 or None)."""
-    key = (data.data_ptr(), tuple(data.shape), str(device), data._version)
+    torch_utils.py:60).  Returns (image [1,1,Dv,Hv,Wv] fp32, min scalar [1], label map [1,1,Dv,Hv,Wv] fp32 or None).
+    An entry holds its source tensor, so a hit requires the SAME tensor object at the same version (an address can be
+    reused by a later case of the same shape); tta_main drops the entries of a sample when it is done."""
+    key = (id(data), str(device))
     hit = _VOLUME_CACHE.get(key)
-    if hit is not None:
-        return hit
+    if hit is not None and hit[0] is data and hit[1] == data._version:
+        return hit[2]
     if len(_VOLUME_CACHE) > 16:
         _VOLUME_CACHE.clear()
     img = data[0][None, None].float().contiguous().to(device)
@@ -28,8 +30,13 @@ def _resident(data, device):
         # get_argmaxed_segs (torch_utils.py:79-82) commutes with nearest sampling: apply it once to the volume
         lab = torch.cat([(segs.sum(1, keepdim=True) < 1.0).float(), segs.float()], dim=1).argmax(1, keepdim=True)
         lab = lab.float().contiguous().to(device)
-    _VOLUME_CACHE[key] = (img, mn, lab)
+    _VOLUME_CACHE[key] = (data, data._version, (img, mn, lab))
     return img, mn, lab
+
+
+def release_resident():
+    """Frees the device copies of the cached volumes (called by tta_main after each sample)."""
+    _VOLUME_CACHE.clear()
 
 
 def get_batch(tensor_list, batch_idxs, patch_size, fixed_patch_idx=None, device="cuda"):
@@ -69,11 +76,10 @@ def get_imgs(tta_sample):
 
 
 def soft_dice_loss(smp_a, smp_b):
-    """Reference: torch_utils.py:90-104 (per-class soft Dice of two probability maps, no eps).  Thin wrapper kept for
-    API parity; the TTA loop uses ops.consistency_loss, which fuses mask + softmax + Dice + backward."""
-    raise NotImplementedError(
-        "soft_dice_loss on already-softmaxed inputs is not built as a separate HIP op; use "
-        "dg_tta_amd.ops.consistency_loss(target_a, target_b) which fuses tta.py:263-269")
+    """Reference: torch_utils.py:90-104 — per-class soft Dice [B,C] of two probability maps [B,C,D,H,W] (no eps; all
+    ones when the denominators sum to zero).  Runs on the HIP reduction kernels (csrc/softdice.hip), differentiable.
+    The TTA loop itself uses ops.consistency_loss, which fuses tta.py:263-269 (mask + softmax + this Dice + backward)."""
+    return ops.soft_dice(smp_a, smp_b)
 
 
 def dice_coeff(outputs, labels, max_label):

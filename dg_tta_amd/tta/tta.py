@@ -22,12 +22,13 @@ import torch
 from .. import ops
 from ..gin import gin_aug
 from ..optim import HipAdamW
-from ..sharding import owns
+from ..sharding import done_marker, mark_rank_done, summary_by_parent, unit_owner, wait_for_files
 from ..utils import disable_internal_augmentation, upload_async
 from .augmentation_utils import get_rand_affine
 from .config_log_utils import (get_global_idx, get_parameters_save_path, is_template_modifier, plot_run_results)
 from .model_utils import apply_running_stats, buffer_running_stats, get_model_from_network
-from .torch_utils import (dice_coeff, fix_all, get_batch, get_map_idxs, map_label, release_all, release_norms)
+from .torch_utils import (dice_coeff, fix_all, get_batch, get_map_idxs, map_label, release_all, release_norms,
+                          release_resident)
 
 INTENSITY_AUG_FUNCTION_DICT = {"disabled": lambda img: img, "GIN": gin_aug}
 START_CLASS = 1  # Do not use background for consistency loss (tta.py:103)
@@ -112,7 +113,7 @@ def calc_both_branches(config, model, intensity_aug_func, patch_size, batch_size
     once per epoch): `imgs` is then a callable that samples the next step's patches (get_batch), called in step order so
     that the reference's draw sequence  get_batch_i, branch_a_i, branch_b_i, get_batch_i+1, ...  is kept.  The targets are
     ordered [step][batch item]; ops.consistency_loss on them returns the MEAN of the per-step losses and dice[step]."""
-    from ..mind import clear_noise, push_noise, uses_mind_hook
+    from ..mind import clear_noise, draw_noise_, push_noise, uses_mind_hook
     grad_context = nullcontext if config["have_grad_in"] in ["branch_a", "both"] else torch.no_grad
     after_mapping = modifier_fn_module.ModifierFunctions.modify_tta_output_after_mapping_fn
     with grad_context():
@@ -144,7 +145,7 @@ def calc_both_branches(config, model, intensity_aug_func, patch_size, batch_size
                         noise = torch.empty((2 * steps * nb_, 12) + tuple(imgs_aug.shape[2:]), dtype=torch.float32,
                                             device=imgs_aug.device)
                     slot = k * steps + step
-                    noise[slot * nb_:(slot + 1) * nb_].normal_()
+                    draw_noise_(noise[slot * nb_:(slot + 1) * nb_])
         augs = augs[0] + augs[1]                    # all of branch a (step order), then all of branch b
         inverses = inverses[0] + inverses[1]
         model.apply(buffer_running_stats)
@@ -214,20 +215,87 @@ def _fuse_head_if_possible(model, modifier_fn_module, label_mapping, optimized_l
     return False
 
 
+def tta_epoch(model, optimizer, config, tta_tens_list, patch_size, label_mapping, modifier_fn_module, device,
+              head_is_fused, adapt):
+    """ONE epoch of the unit loop (reference: tta.py:221-338): `patches_to_be_accumulated` steps of {get_batch, both
+    branches, consistency loss, backward of loss/accum when `adapt`}, one AdamW step, then the evaluation patches.
+    Returns (mean step loss, pseudo-Dice) as floats.  bench.py times exactly this function."""
+    B = config["batch_size"]
+    accum = config["patches_to_be_accumulated"]
+    optimized_labels = config["optimized_labels"]
+    intensity_aug_func = INTENSITY_AUG_FUNCTION_DICT[config["intensity_aug_function"]]
+    inv_accum = torch.full((), 1.0 / accum, dtype=torch.float32, device=device)
+    model.train()
+    step_losses = []
+
+    def next_imgs():
+        with torch.no_grad():
+            imgs, _ = get_batch(tta_tens_list, np.random.choice(range(len(tta_tens_list)), B).tolist(), patch_size,
+                                fixed_patch_idx=None, device=device)
+        return imgs[0] if len(imgs) == 1 else torch.cat(imgs, dim=0)
+
+    if batch_branches_enabled():
+        k = batched_steps(accum, B)
+        for _ in range(accum // k):
+            target_a, target_b = calc_both_branches(config, model, intensity_aug_func, patch_size, B, label_mapping,
+                                                    optimized_labels, modifier_fn_module, next_imgs, device,
+                                                    head_is_fused, steps=k)
+            loss, dice = ops.consistency_loss(target_a, target_b, START_CLASS)      # mean of the k step losses
+            if k == 1:
+                step_losses.append(loss.detach())
+            else:
+                step_losses.extend((1.0 - dice.detach().reshape(k, B, -1)[:, :, START_CLASS:].mean((1, 2))).unbind(0))
+            if adapt and loss.requires_grad:
+                torch.autograd.backward(loss, grad_tensors=inv_accum * k)
+    else:
+        for _ in range(accum):
+            imgs = next_imgs()
+            args = (config, model, intensity_aug_func, None, patch_size, B, label_mapping, optimized_labels,
+                    modifier_fn_module, imgs, device, head_is_fused)
+            target_a = calc_branch("branch_a", *args)
+            target_b = calc_branch("branch_b", *args)
+            loss, _ = ops.consistency_loss(target_a, target_b, START_CLASS)
+            step_losses.append(loss.detach())
+            if adapt and loss.requires_grad:
+                # d(loss/accum): the 1/accum factor is handed to the loss kernel as a device scalar
+                torch.autograd.backward(loss, grad_tensors=inv_accum)
+    if adapt:
+        optimizer.step()
+        optimizer.zero_grad()
+    mean_loss = torch.stack(step_losses).mean().item()
+
+    eval_dice = 0.0
+    with torch.inference_mode():
+        model.eval()
+        for _ in range(config["tta_eval_patches"]):
+            imgs, labels = get_batch(tta_tens_list, np.random.choice(range(len(tta_tens_list)), B).tolist(),
+                                     patch_size, fixed_patch_idx="center", device=device)
+            keep = [i for i, l in enumerate(labels) if l is not None]
+            if len(keep) == 0:
+                eval_dice = float("nan")
+                continue
+            f_imgs = torch.cat([imgs[i] for i in keep], dim=0)
+            f_labels = torch.cat([labels[i] for i in keep], dim=0)
+            out = model(f_imgs)
+            if isinstance(out, tuple):
+                out = out[0]
+            if not head_is_fused:
+                out = map_label(out, get_map_idxs(label_mapping, optimized_labels, "pretrain_labels"), "logits")
+            target_argmax, _ = ops.argmax_dice(out)
+            f_labels = map_label(f_labels, get_map_idxs(label_mapping, optimized_labels, "tta_labels"),
+                                 input_format="argmaxed").long()
+            d = dice_coeff(target_argmax, f_labels, len(optimized_labels))
+            eval_dice += 1 / config["tta_eval_patches"] * d.nanmean().item()
+    return mean_loss, eval_dice
+
+
 def tta_unit(model, optimizer, config, tta_tens_list, patch_size, label_mapping, modifier_fn_module, device,
              head_is_fused, debug=False, progress=None):
     """Adapts `model` on one sample for config['epochs'] epochs (reference: tta.py:189-362). Returns (losses, dices)."""
-    B = config["batch_size"]
-    accum = config["patches_to_be_accumulated"]
     num_epochs, start = config["epochs"], config["start_tta_at_epoch"]
-    optimized_labels = config["optimized_labels"]
-    intensity_aug_func = INTENSITY_AUG_FUNCTION_DICT[config["intensity_aug_function"]]
     tta_losses, eval_dices = torch.zeros(num_epochs), torch.zeros(num_epochs)
-    inv_accum = torch.full((), 1.0 / accum, dtype=torch.float32, device=device)
     model.apply(fix_all)
     for epoch in range(num_epochs):
-        model.train()
-        step_losses = []
         if epoch == start:
             model.apply(fix_all)
             mode = config["params_with_grad"]
@@ -241,67 +309,13 @@ def tta_unit(model, optimizer, config, tta_tens_list, patch_size, label_mapping,
                 raise ValueError()
             n_released = sum(p.numel() for p in model.parameters() if p.requires_grad)
             print(f"Released #{n_released / 1e6:.2f} million trainable params")
-        def next_imgs():
-            with torch.no_grad():
-                imgs, _ = get_batch(tta_tens_list, np.random.choice(range(len(tta_tens_list)), B).tolist(), patch_size,
-                                    fixed_patch_idx=None, device=device)
-            return imgs[0] if len(imgs) == 1 else torch.cat(imgs, dim=0)
-
-        if batch_branches_enabled():
-            k = batched_steps(accum, B)
-            for _ in range(accum // k):
-                target_a, target_b = calc_both_branches(config, model, intensity_aug_func, patch_size, B, label_mapping,
-                                                        optimized_labels, modifier_fn_module, next_imgs, device,
-                                                        head_is_fused, steps=k)
-                loss, dice = ops.consistency_loss(target_a, target_b, START_CLASS)      # mean of the k step losses
-                if k == 1:
-                    step_losses.append(loss.detach())
-                else:
-                    step_losses.extend((1.0 - dice.detach().reshape(k, B, -1)[:, :, START_CLASS:].mean((1, 2))).unbind(0))
-                if epoch >= start and loss.requires_grad:
-                    torch.autograd.backward(loss, grad_tensors=inv_accum * k)
-        else:
-            for _ in range(accum):
-                imgs = next_imgs()
-                args = (config, model, intensity_aug_func, None, patch_size, B, label_mapping, optimized_labels,
-                        modifier_fn_module, imgs, device, head_is_fused)
-                target_a = calc_branch("branch_a", *args)
-                target_b = calc_branch("branch_b", *args)
-                loss, _ = ops.consistency_loss(target_a, target_b, START_CLASS)
-                step_losses.append(loss.detach())
-                if epoch >= start and loss.requires_grad:
-                    # d(loss/accum): the 1/accum factor is handed to the loss kernel as a device scalar
-                    torch.autograd.backward(loss, grad_tensors=inv_accum)
-        if epoch >= start:
-            optimizer.step()
-            optimizer.zero_grad()
-        tta_losses[epoch] = torch.stack(step_losses).mean().item()
-
-        with torch.inference_mode():
-            model.eval()
-            for _ in range(config["tta_eval_patches"]):
-                imgs, labels = get_batch(tta_tens_list, np.random.choice(range(len(tta_tens_list)), B).tolist(),
-                                         patch_size, fixed_patch_idx="center", device=device)
-                keep = [i for i, l in enumerate(labels) if l is not None]
-                if len(keep) == 0:
-                    eval_dices[epoch] = float("nan")
-                    continue
-                f_imgs = torch.cat([imgs[i] for i in keep], dim=0)
-                f_labels = torch.cat([labels[i] for i in keep], dim=0)
-                out = model(f_imgs)
-                if isinstance(out, tuple):
-                    out = out[0]
-                if not head_is_fused:
-                    out = map_label(out, get_map_idxs(label_mapping, optimized_labels, "pretrain_labels"), "logits")
-                target_argmax, _ = ops.argmax_dice(out)
-                f_labels = map_label(f_labels, get_map_idxs(label_mapping, optimized_labels, "tta_labels"),
-                                     input_format="argmaxed").long()
-                d = dice_coeff(target_argmax, f_labels, len(optimized_labels))
-                eval_dices[epoch] += 1 / config["tta_eval_patches"] * d.nanmean().item()
-            if debug:
-                break
+        tta_losses[epoch], eval_dices[epoch] = tta_epoch(model, optimizer, config, tta_tens_list, patch_size,
+                                                         label_mapping, modifier_fn_module, device, head_is_fused,
+                                                         adapt=epoch >= start)
         if progress is not None:
             progress(epoch, float(tta_losses[epoch]), float(eval_dices[epoch]))
+        if debug:
+            break       # tta.py:334-335: debug runs stop after the first epoch
     return tta_losses, eval_dices
 
 
@@ -334,14 +348,16 @@ def tta_main(run_name, config, tta_data_dir, save_base_path, label_mapping, modi
     disable_internal_augmentation()
     rank, world = shard
     results = {}
+    n_units_samples = 1 if across else num_samples
     print("\n# Starting TTA")
     for smp_idx in ([0] if across else range(num_samples)):
         _, tta_tens_list, sample_id, _ext, sub_dir_tta = get_sample_specs(config, smp_idx, tta_data, save_path, across)
-        if not owns(smp_idx, rank, world):
-            continue        # another GPU's sample (independent unit: nothing to exchange)
+        mine = [e for e in range(ensemble_count) if unit_owner(smp_idx, e, n_units_samples, ensemble_count, world) == rank]
+        if not mine:
+            continue        # another GPU's units (independent: nothing to exchange)
         print(f"\nSample {sample_id}")
         sub_dir_tta.mkdir(exist_ok=True, parents=True)
-        for ensemble_idx in range(ensemble_count):
+        for ensemble_idx in mine:
             ppath = get_parameters_save_path(sub_dir_tta, sample_id, ensemble_idx)
             if ppath.is_file():
                 print(f"TTA parameters file already exists. Skipping '{ppath}'")
@@ -354,6 +370,7 @@ def tta_main(run_name, config, tta_data_dir, save_base_path, label_mapping, modi
             fused = _fuse_head_if_possible(model, modifier_fn_module, label_mapping, config["optimized_labels"])
             if hasattr(model, "accumulate_grads_in_place"):
                 model.accumulate_grads_in_place = True      # this loop owns the gradients (zero_grad once per epoch)
+                model.exact_zero_bias_grad = True           # see HipPlainConvUNet.exact_zero_bias_grad
             optimizer = HipAdamW(model.parameters(), lr=config["lr"])
 
             def progress(epoch, loss, dice):
@@ -363,12 +380,16 @@ def tta_main(run_name, config, tta_data_dir, save_base_path, label_mapping, modi
                                      modifier_fn_module, device, fused, debug, progress)
             if fused:
                 model.set_selected_classes(None)
-            torch.save([model.state_dict()], ppath)
+            # written under a temporary name and renamed: the owner of the sample polls for the file (filesystem barrier)
+            tmp = ppath.with_name(ppath.name + f".tmp{rank}")
+            torch.save([model.state_dict()], tmp)
+            tmp.replace(ppath)
             results[(sample_id, ensemble_idx)] = (losses, dices)
             if num_epochs > 0:
                 plot_run_results(sub_dir_tta, sample_id, ensemble_idx, losses, dices)
             if debug:
                 break
+        release_resident()      # this sample's volume leaves HBM
     # ---- ensemble sliding-window inference with the TTA'd parameter sets (reference: tta.py:376-416).  Label maps are
     # written as <case>.npy (or <case>.nii.gz when the case carries a NIfTI header in data_properties['nifti_header'])
     # in the preprocessed geometry; the target label channels of the case, mapped to the TTA label set, go to
@@ -380,9 +401,11 @@ def tta_main(run_name, config, tta_data_dir, save_base_path, label_mapping, modi
         print("\n\n# Starting inference")
         for smp_idx in range(num_samples):
             sample, _, sample_id, _ext, sub_dir_tta = get_sample_specs(config, smp_idx, _inference_data, save_path, False)
-            if not owns(smp_idx, rank, world):
-                continue
+            if unit_owner(smp_idx, 0, num_samples, ensemble_count, world) != rank:
+                continue        # the rank that owns member 0 predicts the sample
             paths = [get_parameters_save_path(sub_dir_tta, sample_id, e) for e in range(ensemble_count)]
+            if world > 1:       # members adapted on other GPUs: wait for their files (no collective)
+                wait_for_files(paths, float(config.get("barrier_timeout_s", 24 * 3600)))
             if not all(p.is_file() for p in paths):
                 continue
             params = [torch.load(p, map_location=device)[0] for p in paths]
@@ -395,26 +418,43 @@ def tta_main(run_name, config, tta_data_dir, save_base_path, label_mapping, modi
             out.parent.mkdir(exist_ok=True, parents=True)
             _save_label_map(out, seg.numpy().astype(np.int16), nii)
             results[(sample_id, "prediction")] = out
-            # reference labels of this case (one-hot channels of the preprocessed sample), in the TTA label order
+            # reference labels of this case (one-hot channels of the preprocessed sample = the TTA dataset's label ids),
+            # mapped into the index space of optimized_labels as tta.py:440-447 does (unmapped ids become background)
             if sample["data"].shape[0] > 1:
                 bucket = "Ts" if "outputTs" in out.parent.name else ("Tr" if "outputTr" in out.parent.name else None)
                 if bucket is not None:
                     segs = sample["data"][1:]
                     target = torch.cat([(segs.sum(0, keepdim=True) < 1.0).float(), segs.float()], dim=0).argmax(0)
+                    target = map_label(target[None], get_map_idxs(label_mapping, config["optimized_labels"], "tta_labels"),
+                                       input_format="argmaxed")[0]
                     ref_path = save_path / f"mapped_target_labels{bucket}" / out.name
                     ref_path.parent.mkdir(exist_ok=True, parents=True)
                     _save_label_map(ref_path, target.numpy().astype(np.int16), nii)
-        if rank == 0 or world == 1:
-            from .evaluation import compute_metrics_on_folder_simple
-            for bucket in ["Ts", "Tr"]:
-                refs, preds = save_path / f"mapped_target_labels{bucket}", save_path / f"tta_output{bucket}"
-                if refs.is_dir() and preds.is_dir():
-                    modifier_fn_module.ModifierFunctions.postprocess_results_fn(preds)
-                    summary = compute_metrics_on_folder_simple(refs, preds, list(range(len(config["optimized_labels"]))),
-                                                               output_file=save_path / f"summary_{bucket}.json",
-                                                               device=device)
-                    results[("summary", bucket)] = summary["foreground_mean"]["Dice"]
+        # ---- evaluation over the whole run directory: only once every rank's predictions are on disk
+        mark_rank_done(save_path, rank)
+        if world == 1:
+            results.update(evaluate_run(save_path, config, modifier_fn_module, device))
+        elif rank == 0 and not summary_by_parent():
+            wait_for_files([done_marker(save_path, r) for r in range(world)],
+                           float(config.get("barrier_timeout_s", 24 * 3600)))
+            results.update(evaluate_run(save_path, config, modifier_fn_module, device))
     return results
+
+
+def evaluate_run(save_path, config, modifier_fn_module, device="cuda"):
+    """postprocess_results_fn + summary_{Ts,Tr}.json over a finished run directory (reference: tta.py:447-470).  Runs in
+    the single process, in rank 0 after the filesystem barrier, or in the fan-out parent of `dgtta run_tta --gpus N`
+    after every child has exited."""
+    from .evaluation import compute_metrics_on_folder_simple
+    save_path, out = Path(save_path), {}
+    for bucket in ["Ts", "Tr"]:
+        refs, preds = save_path / f"mapped_target_labels{bucket}", save_path / f"tta_output{bucket}"
+        if refs.is_dir() and preds.is_dir():
+            modifier_fn_module.ModifierFunctions.postprocess_results_fn(preds)
+            summary = compute_metrics_on_folder_simple(refs, preds, list(range(len(config["optimized_labels"]))),
+                                                       output_file=save_path / f"summary_{bucket}.json", device=device)
+            out[("summary", bucket)] = summary["foreground_mean"]["Dice"]
+    return out
 
 
 def _save_label_map(path, arr, nifti_header=None):

@@ -109,6 +109,17 @@ int dgtta_softdice_bwd(const float *la, const float *lb, float *grad_la, float *
                        float grad_scale, const float *grad_scale_dev, int B, int C, int64_t V, int ldc,
                        int start_class, void *stream);
 
+/* Stand-alone soft_dice_loss(smp_a, smp_b) -> dice[B][C] of the reference (dg_tta/tta/torch_utils.py:90-104) on
+ * probability maps: nom = mean_v(2ab), den = mean_v((a+b)^2)/2, dice = nom/den, all ones when den.sum() == 0.
+ * a, b: fp32 [B][C][V] addressed with element strides (stride_b, stride_c, stride_v): NCDHW has stride_v = 1,
+ * channels-last stride_c = 1.  bwd: grad_a / grad_b (same strides) = sum_c grad_dice[b][c] * d dice / d a.
+ * ws: dgtta_softdice_ws_bytes(B, C, V), kept between fwd and bwd. */
+int dgtta_softdice_probs_fwd(const float *a, const float *b, float *dice, void *ws, size_t ws_bytes, int B, int C,
+                             int64_t V, int64_t stride_b, int64_t stride_c, int64_t stride_v, void *stream);
+int dgtta_softdice_probs_bwd(const float *a, const float *b, const float *grad_dice, float *grad_a, float *grad_b,
+                             const void *ws, int B, int C, int64_t V, int64_t stride_b, int64_t stride_c,
+                             int64_t stride_v, void *stream);
+
 /* ---------------------------------------------------------------------------------------------
  * AdamW (decoupled weight decay, bias-corrected, no amsgrad) over a list of tensors.  Replaces
  * torch.optim.AdamW(model.parameters(), lr).step() at dg_tta/tta/tta.py:185,278 (betas 0.9/0.999,

@@ -157,3 +157,61 @@ def adamw_reference_step(p, g, m, v, step, lr, b1=0.9, b2=0.999, eps=1e-8, wd=0.
     denom = (v.sqrt() / (bc2 ** 0.5)) + eps
     p = p - (lr / bc1) * (m / denom)
     return p, m, v
+
+
+# ---------------------------------------------------------------- whole unit (tta.py:189-340)
+def draw_branch(batch, patch_size, gin=True, affine=True, mind=True):
+    """The draws of ONE calc_branch call in the reference's order on the CPU generator: GIN (gin.py:193-195, 65-103),
+    affine (augmentation_utils.py:158), MIND noise (mind.py:150, inside the model's pre-hook)."""
+    return dict(gin_draw=ogin.draw_gin_params(batch) if gin else None,
+                affine_draw=torch.randn(batch, 3, 4) if affine else None,
+                mind_noise=torch.randn(batch, 12, *patch_size) if mind else None)
+
+
+def tta_unit(model, optimizer, data_list, patch_size, map_pre, map_tta, epochs, start, accum, eval_patches=1, batch=1):
+    """Epoch / accumulation loop of tta.py:189-340 for one (sample, ensemble) unit with params_with_grad='all',
+    GIN + affine in both branches and a MIND net.  Every draw comes from the global CPU generators in the reference's
+    order: np.random.choice + rand(3) (get_batch), branch a, branch b, ...; eval: np.random.choice, MIND noise.
+    Returns (tta_losses[epochs], eval_dices[epochs], step_losses)."""
+    import numpy as np
+    n_opt = len(map_pre)
+    tta_losses, eval_dices, all_steps = torch.zeros(epochs), torch.zeros(epochs), []
+    for p in model.parameters():
+        p.requires_grad_(False)
+    for epoch in range(epochs):
+        model.train()
+        if epoch == start:
+            for p in model.parameters():
+                p.requires_grad_(True)
+        step_losses = []
+        for _ in range(accum):
+            idxs = np.random.choice(range(len(data_list)), batch).tolist()
+            imgs = torch.cat([get_batch_item(data_list[i], patch_size, torch.rand(3))[0] for i in idxs], dim=0)
+            da = draw_branch(batch, patch_size)
+            ta = calc_branch(model, imgs, map_pre, **da)
+            db = draw_branch(batch, patch_size)
+            tb = calc_branch(model, imgs, map_pre, **db)
+            loss = consistency_loss(ta, tb)
+            step_losses.append(loss.detach())
+            if epoch >= start:
+                (loss / accum).backward()
+        if epoch >= start:
+            optimizer.step()
+            optimizer.zero_grad()
+        tta_losses[epoch] = torch.stack(step_losses).mean().item()
+        all_steps += step_losses
+        with torch.inference_mode():
+            model.eval()
+            for _ in range(eval_patches):
+                idxs = np.random.choice(range(len(data_list)), batch).tolist()
+                items = [get_batch_item(data_list[i], patch_size, None) for i in idxs]
+                keep = [(im, lb) for im, lb in items if lb is not None]
+                if not keep:
+                    eval_dices[epoch] = float("nan")
+                    continue
+                imgs = torch.cat([im for im, _ in keep], dim=0)
+                labels = torch.cat([lb for _, lb in keep], dim=0)
+                out = map_label(model(omind.mind3d(imgs, torch.randn(imgs.shape[0], 12, *patch_size))), map_pre, "logits")
+                labels = map_label(labels, map_tta, "argmaxed").long()
+                eval_dices[epoch] += 1 / eval_patches * dice_coeff(out.argmax(1), labels, n_opt).nanmean().item()
+    return tta_losses, eval_dices, torch.stack(all_steps)

@@ -1,0 +1,132 @@
+"""GPU parity on the REAL network: nnUNet 3d_fullres (plans.json:279-401: 32/64/128/256/320 features, 12 -> 105 channels)
+running the product's default kernels (conv_impl=0: MFMA implicit GEMM, row-reuse conv, transposed-read weight gradients,
+concat buffers, fused statistics) in fp32 and in bf16 storage, against
+
+* tests/golden/full_{32,64}.npz — one accumulation step (calc_branch a + b, loss, backward) produced by the REFERENCE's
+  calc_branch / soft_dice_loss on torch CPU (tests/golden/make_golden_r2.py), and
+* the CPU oracle run in the test at 128^3 (BASELINE config 2's patch size), forward.
+
+Tolerances: fp32 2e-4 of the tensor's range (different summation order); bf16 storage: loss within 1e-3 (north_star's
+Dice tolerance), logits within 3 % of their range, label maps identical wherever the reference's top-2 margin exceeds the
+measured logit error."""
+import pytest
+import torch
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _nets(w_seed, dtype, conv_impl=0):
+    from dg_tta_amd.unet import HipPlainConvUNet
+    from oracle import unet as ounet
+    om = ounet.perturb_affine(ounet.init_he(ounet.PlainConvUNetOracle(), w_seed), w_seed + 1)
+    hm = HipPlainConvUNet(act_dtype=dtype, conv_impl=conv_impl)          # default cfg = PLANS_3D_FULLRES
+    hm.load_state_dict(om.state_dict())
+    return om, hm.to(DEV)
+
+
+def _hip_branch(model, imgs, d):
+    from dg_tta_amd import ops
+    from dg_tta_amd.mind import MIND3D
+    from oracle import tta as otta
+    alpha, ks, kers, shifts = d["gin_draw"]
+    x = ops.gin_chain(imgs, alpha.to(DEV), ks, [k.to(DEV) for k in kers], [s.to(DEV) for s in shifts])
+    r, rinv = otta.rand_affine_from_draw(d["affine_draw"])
+    x = ops.affine_warp(x, r.to(DEV), padding_mode="border", tta_grid_algebra=True)
+    x = MIND3D()(x, d["mind_noise"].to(DEV), out_dtype=model.act_dtype)
+    return ops.affine_warp(model(x), rinv.to(DEV), padding_mode="zeros", tta_grid_algebra=True)
+
+
+@pytest.mark.parametrize("size", [32, 64])
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_full_topology_step_golden(size, dtype):
+    from dg_tta_amd import ops
+    from oracle import tta as otta
+    g = load_golden(f"full_{size}")
+    adt = torch.float32 if dtype == "fp32" else torch.bfloat16
+    _, hm = _nets(int(g["w_seed"]), adt)
+    sel = torch.arange(int(g["copt"])) * 3
+    hm.set_selected_classes(sel)
+    torch.manual_seed(int(g["img_seed"]))
+    imgs = torch.randn(1, 1, size, size, size)
+    assert abs(imgs.double().sum().item() - float(g["imgs_sum"])) < 1e-9      # same draw as the generator's
+    imgs = imgs.to(DEV)
+    st = int(g["slice_step"])
+    outs = {}
+    for br in ("a", "b"):
+        torch.manual_seed(int(g[f"seed_{br}"]))
+        d = otta.draw_branch(1, [size] * 3)
+        outs[br] = out = _hip_branch(hm, imgs, d)
+        ref = g[f"out_{br}_slice"]
+        rng = float(g[f"out_{br}_absmax"])
+        err = (out.detach().cpu()[:, :, ::st, ::st, ::st] - ref).abs().max().item()
+        tol = 2e-4 if dtype == "fp32" else 3e-2
+        assert err < tol * rng, f"{dtype} {size}^3 branch {br}: logits err {err:.3e} (range {rng:.2f})"
+        csum = out.detach().double().sum((0, 2, 3, 4)).cpu()
+        cabs = g[f"out_{br}_chanabs"]
+        assert ((csum - g[f"out_{br}_chansum"]).abs() < (2e-5 if dtype == "fp32" else 4e-3) * cabs).all()
+        margin = g[f"out_{br}_margin"].float()
+        safe = margin > (1e-3 if dtype == "fp32" else max(4 * err, 1e-2))
+        am = out.detach().argmax(1).cpu().to(torch.uint8)
+        assert torch.equal(am[safe], g[f"out_{br}_argmax"][safe])
+        if dtype == "fp32":
+            assert (am == g[f"out_{br}_argmax"]).float().mean() > 0.9995
+    loss, dice = ops.consistency_loss(outs["a"], outs["b"], 1)
+    ltol = 2e-5 if dtype == "fp32" else 1e-3
+    assert abs(float(loss) - float(g["loss"])) < ltol, f"loss {float(loss):.6f} vs reference {float(g['loss']):.6f}"
+    assert (dice.cpu() - g["dice"]).abs().max() < (5e-5 if dtype == "fp32" else 2e-3)
+    loss.backward()
+    named = dict(hm.named_parameters())
+    worst = {}
+    for key in [k for k in g if k.startswith("g::")]:
+        name = key[3:]
+        ref = g[key]
+        got = named[name].grad.detach().cpu()
+        from make_slices import GRAD_SLICES
+        if name in GRAD_SLICES:
+            got = got[GRAD_SLICES[name]]
+        scale = float(g[f"gmax::{name}"])
+        rel = (got - ref).abs().max().item() / (scale + 1e-30)
+        worst[name] = rel
+        gtol = 5e-4 if dtype == "fp32" else 6e-2
+        assert rel < gtol, f"{dtype} {size}^3 grad {name}: rel err {rel:.3e}"
+    # every parameter's gradient: |sum| checksum within the float tolerance of the reference's abs-sum
+    for name, p in named.items():
+        if f"gabs::{name}" not in g or (name.endswith("conv.bias") and ".convs." in name):
+            continue            # conv bias in front of InstanceNorm: exactly zero in exact arithmetic, noise in autograd
+        gabs = float(g[f"gabs::{name}"])
+        got = p.grad.detach().double()
+        assert abs(got.abs().sum().item() - gabs) < (2e-3 if dtype == "fp32" else 8e-2) * gabs + 1e-12, name
+    print(f"full {size}^3 {dtype}: loss {float(loss):.6f} (ref {float(g['loss']):.6f}), worst grad rel err "
+          f"{max(worst.values()):.2e} ({max(worst, key=worst.get)})")
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_full_topology_forward_128_vs_cpu_oracle(dtype):
+    """BASELINE config 2's patch: one 128^3 forward of the full net (MIND features in, C_opt rows out) against the CPU
+    oracle evaluated in the test (torch CPU conv3d / InstanceNorm3d; ~20 s of host time)."""
+    import os
+    from dg_tta_amd.mind import MIND3D
+    from oracle import mind as omind
+    adt = torch.float32 if dtype == "fp32" else torch.bfloat16
+    om, hm = _nets(7, adt)
+    sel = torch.arange(16) * 3
+    hm.set_selected_classes(sel)
+    torch.manual_seed(3)
+    img = torch.randn(1, 1, 128, 128, 128)
+    noise = torch.randn(1, 12, 128, 128, 128)
+    torch.set_num_threads(min(16, len(os.sched_getaffinity(0))))
+    with torch.no_grad():
+        ref = om(omind.mind3d(img, noise))[:, sel]
+        out = hm(MIND3D()(img.to(DEV), noise.to(DEV), out_dtype=adt)).cpu()
+    rng = ref.abs().max().item()
+    err = (out - ref).abs().max().item()
+    assert err < (2e-4 if dtype == "fp32" else 3e-2) * rng, f"{dtype}: err {err:.3e}, range {rng:.2f}"
+    top2 = ref.topk(2, dim=1).values
+    safe = (top2[:, 0] - top2[:, 1]) > (1e-3 if dtype == "fp32" else max(4 * err, 1e-2))
+    assert torch.equal(out.argmax(1)[safe], ref.argmax(1)[safe])
+    agree = (out.argmax(1) == ref.argmax(1)).float().mean().item()
+    assert agree > (0.9995 if dtype == "fp32" else 0.97)
+    print(f"128^3 {dtype}: max logit err {err:.3e} of range {rng:.2f}; label agreement {agree:.5f}")

@@ -226,6 +226,34 @@ def test_consistency_loss_edge_cases():
     assert abs(float(loss) - float(otta.consistency_loss(a, b))) < 2e-6
 
 
+def test_soft_dice_loss_standalone_golden_and_grad():
+    """The drop-in `soft_dice_loss(a, b) -> [B,C]` (torch_utils.py:90-104) against the reference's own outputs
+    (tests/golden/loss.npz: d_ab, d_aa, and the all-zero guard d_zz), in both memory layouts, with autograd."""
+    from dg_tta_amd.tta.torch_utils import soft_dice_loss
+    from oracle import tta as otta
+    g = load_golden("loss")
+    a, b = g["a"].to(DEV), g["b"].to(DEV)
+    _close(soft_dice_loss(a, b), g["d_ab"], atol=2e-6, what="soft_dice a,b")
+    _close(soft_dice_loss(a, a), g["d_aa"], atol=2e-6, what="soft_dice a,a")
+    z = torch.zeros(1, 3, 4, 4, 4, device=DEV)
+    assert torch.equal(soft_dice_loss(z, z).cpu(), g["d_zz"]) and torch.equal(g["d_zz"], torch.ones(1, 3))
+    cl = a.contiguous(memory_format=torch.channels_last_3d), b.contiguous(memory_format=torch.channels_last_3d)
+    _close(soft_dice_loss(*cl), g["d_ab"], atol=2e-6, what="soft_dice channels-last")
+    # gradient of the loss as tta.py:269 forms it, against torch autograd on the oracle
+    ra, rb = g["a"].clone().requires_grad_(True), g["b"].clone().requires_grad_(True)
+    (1 - otta.soft_dice_loss(ra, rb)[:, 1:].mean()).backward()
+    for layout in (torch.contiguous_format, torch.channels_last_3d):
+        da = g["a"].to(DEV).contiguous(memory_format=layout).requires_grad_(True)
+        db = g["b"].to(DEV).contiguous(memory_format=layout).requires_grad_(True)
+        (1 - soft_dice_loss(da, db)[:, 1:].mean()).backward()
+        _close(da.grad, ra.grad, atol=1e-9, rtol=1e-4, what="d soft_dice / da")
+        _close(db.grad, rb.grad, atol=1e-9, rtol=1e-4, what="d soft_dice / db")
+    # a larger ragged volume, many classes
+    torch.manual_seed(4)
+    x, y = torch.rand(2, 21, 9, 17, 33), torch.rand(2, 21, 9, 17, 33)
+    _close(soft_dice_loss(x.to(DEV), y.to(DEV)), otta.soft_dice_loss(x, y), atol=2e-6, what="soft_dice ragged")
+
+
 def test_argmax_dice_bit_exact():
     from dg_tta_amd import ops
     from dg_tta_amd.tta.torch_utils import dice_coeff

@@ -1,6 +1,7 @@
 """GPU parity of the assembled path: calc_branch and a multi-epoch TTA run against the golden vectors that were
 generated with the reference's own calc_branch / soft_dice_loss / torch AdamW (tests/golden/make_golden.py)."""
 import contextlib
+from pathlib import Path
 from types import SimpleNamespace
 
 import numpy as np
@@ -38,9 +39,10 @@ def hip_branch(model, imgs, draws):
     return ops.affine_warp(y, rinv.to(DEV), padding_mode="zeros", tta_grid_algebra=True)
 
 
-def test_calc_branch_golden():
+@pytest.mark.parametrize("conv_impl", [1, 0])
+def test_calc_branch_golden(conv_impl):
     g = load_golden("calc_branch")
-    model = _model(g)
+    model = _model(g, conv_impl=conv_impl)
     model.set_selected_classes(g["map_idxs"])
     imgs = g["imgs"].to(DEV)
     for br in ("a", "b"):
@@ -71,11 +73,20 @@ def cpu_rng_for_device_draws():
         t = real_randn(*a, **k)
         return t.to(dev) if dev is not None else t
 
+    from dg_tta_amd import mind as hmind
+    from dg_tta_amd.tta import tta as htta
+    real_draw = hmind.draw_noise_
+
+    def draw_noise_(slot):          # the batched path draws a branch's MIND noise in place into its slot of the batch
+        return slot.copy_(real_randn(slot.shape))
+
     torch.rand, torch.randn = rand, randn
+    hmind.draw_noise_ = draw_noise_
     try:
         yield
     finally:
         torch.rand, torch.randn = real_rand, real_randn
+        hmind.draw_noise_ = real_draw
 
 
 def _plan(**over):
@@ -87,23 +98,23 @@ def _plan(**over):
     return cfg
 
 
-def _network_with_hooks(g):
+def _network_with_hooks(g, **kw):
     from dg_tta_amd.gin import gin_hook
     from dg_tta_amd.mind import mind_hook
-    net = _model(g)
+    net = _model(g, **kw)
     net.register_forward_pre_hook(gin_hook)      # nnUNetTrainer_GIN_MIND.py:55-57 order
     net.register_forward_pre_hook(mind_hook)
     return net
 
 
-def _product_model(g):
+def _product_model(g, **kw):
     """network with the trainer's pre-hooks + modifier hooks, exactly as tta_main builds it."""
     from dg_tta_amd.gin import gin_hook
     from dg_tta_amd.mind import mind_hook
     from dg_tta_amd.tta.config_log_utils import ModifierFunctions
     from dg_tta_amd.tta.model_utils import get_model_from_network
     from dg_tta_amd.utils import disable_internal_augmentation
-    net = _network_with_hooks(g)
+    net = _network_with_hooks(g, **kw)
     modmod = SimpleNamespace(ModifierFunctions=ModifierFunctions)
     model = get_model_from_network(net, modmod, None)
     hooks = list(model._forward_pre_hooks.values())
@@ -226,7 +237,8 @@ def test_unfused_head_matches_fused():
     assert torch.equal(map_label(full, g["map_idxs"], "logits"), sel)
 
 
-def test_tta_epochs_golden():
+@pytest.mark.parametrize("conv_impl", [1, 0])
+def test_tta_epochs_golden(conv_impl):
     """3 epochs x 2 accumulation steps (epoch 0 = loss only) with the golden draws: loss trajectory, updated
     parameters and the final label map."""
     from dg_tta_amd import ops
@@ -234,7 +246,7 @@ def test_tta_epochs_golden():
     from dg_tta_amd.optim import HipAdamW
     from dg_tta_amd.tta.torch_utils import fix_all, release_all
     g = load_golden("tta_epoch")
-    model = _model(g)
+    model = _model(g, conv_impl=conv_impl)
     model.set_selected_classes(g["map_idxs"])
     opt = HipAdamW(model.parameters(), lr=float(g["lr"]))
     imgs = g["imgs"].to(DEV)
@@ -350,10 +362,8 @@ def test_tta_main_end_to_end(tmp_path):
     assert sorted(k[0] for k in res1) == ["tta_outputTs/case2"] * 2
     a = torch.load(out / "case2__ensemble_idx_1_tta_parameters.pt", map_location="cpu")[0]
     b = torch.load(tmp_path / "run1" / "tta_outputTs" / "case2__ensemble_idx_1_tta_parameters.pt", map_location="cpu")[0]
-    same = sum(int(torch.equal(a[k], b[k])) for k in a)
-    assert same >= 0.5 * len(a)      # warp backward uses float atomics: identical up to summation order
-    for k in a:
-        assert torch.allclose(a[k], b[k], atol=5e-4), k
+    for k in a:       # every kernel on the path is deterministic (fixed-order reductions, atomic-free warp backward)
+        assert torch.equal(a[k], b[k]), f"sharded run differs from the single-process run in {k}"
 
 
 def test_bf16_path_tracks_fp32_within_dice_tolerance():
@@ -418,3 +428,143 @@ def test_bf16_path_tracks_fp32_within_dice_tolerance():
     # hard Dice of an UNTRAINED net is the worst case (near-tied logits: ~1.2 % of the voxels flip label under bf16
     # rounding); measured mean difference 1.1e-3, per class <= 3.6e-3.  The soft quantities above meet 1e-3.
     assert (d32 - d16).abs().max() < 6e-3 and abs(float(d32.nanmean()) - float(d16.nanmean())) < 2.5e-3
+
+
+UNIT_MAPPING = {"background": (0, 0), "a": (2, 3), "b": (3, 1), "c": (5, 4), "d": (8, 2)}     # TTA ids != positions
+
+
+@pytest.mark.parametrize("mode", ["batched", "sequential"])
+@pytest.mark.parametrize("conv_impl", [0, 1])
+def test_tta_unit_golden(mode, conv_impl, monkeypatch):
+    """The PRODUCT loop `tta_unit` (default: 2 branches x 4 accumulation steps per network pass, in-place gradient
+    accumulation, exact-zero bias gradients as tta_main configures it; and DGTTA_BATCH_BRANCHES=0) driven by the same
+    CPU draw stream as the reference run that produced tests/golden/tta_unit.npz: 5 epochs x 8 steps at the plan's
+    lr = 1e-5 (tta.py:189-340 with the reference's get_batch / calc_branch / soft_dice_loss / dice_coeff / AdamW).
+    Per-epoch losses, pseudo-Dice, adapted parameters, and the final label map bit for bit."""
+    from dg_tta_amd.mind import MIND3D
+    from dg_tta_amd.optim import HipAdamW
+    from dg_tta_amd.tta.tta import _fuse_head_if_possible, tta_unit
+    from dg_tta_amd.tta.torch_utils import get_batch, release_resident
+    monkeypatch.setenv("DGTTA_BATCH_BRANCHES", "1" if mode == "batched" else "0")
+    g = load_golden("tta_unit")
+    model, modmod = _product_model(g, conv_impl=conv_impl)
+    assert _fuse_head_if_possible(model, modmod, UNIT_MAPPING, OPTIMIZED)
+    model.accumulate_grads_in_place = True
+    model.exact_zero_bias_grad = True
+    E, accum = int(g["epochs"]), int(g["accum"])
+    cfg = _plan(epochs=E, patches_to_be_accumulated=accum, lr=float(g["lr"]))
+    opt = HipAdamW(model.parameters(), lr=cfg["lr"])
+    data = g["data"]
+    release_resident()
+    with cpu_rng_for_device_draws():
+        torch.manual_seed(int(g["seed"]))
+        np.random.seed(int(g["seed"]))
+        losses, dices = tta_unit(model, opt, cfg, [data], [16, 16, 16], UNIT_MAPPING, modmod, torch.device(DEV), True)
+    ref_l, ref_d = g["tta_losses"], g["eval_dices"]
+    assert (losses - ref_l).abs().max() < 2e-5, f"epoch losses {losses.tolist()} vs reference {ref_l.tolist()}"
+    # pseudo-Dice = hard Dice of the argmax against the mapped labels (counts): equal unless a near-tied voxel flips
+    assert (dices - ref_d).abs().max() < 2e-4, f"pseudo-Dice {dices.tolist()} vs reference {ref_d.tolist()}"
+    # adapted parameters: 4 AdamW steps of lr 1e-5; Adam's step is ~lr*sign(g) early on, so a parameter whose gradient
+    # is rounding noise may move the other way (2 lr per step).  Everything else follows the reference.
+    post, pre = state_from_golden(g, "p::"), state_from_golden(g, "w::")
+    moved = agree = 0
+    for name, p in model.state_dict().items():
+        if name not in post or (name.endswith("conv.bias") and ".convs." in name):
+            continue
+        d_ref, d = post[name] - pre[name], p.cpu() - pre[name]
+        assert (d - d_ref).abs().max() <= 8.5e-5, name          # never further than 2 lr per step apart
+        moved += d_ref.numel()
+        agree += int(((d - d_ref).abs() <= 0.1 * d_ref.abs() + 2e-7).sum())
+    assert agree / moved > 0.97, f"only {agree / moved:.4f} of the parameter updates agree with the reference"
+    # final label map of the adapted model: bit-exact (the golden draw has a minimal top-2 margin of 4e-4)
+    model.set_selected_classes(get_map(UNIT_MAPPING))
+    with torch.no_grad():
+        imgs, _ = get_batch([data], [0], [16, 16, 16], "center", DEV)
+        logits = model.forward(MIND3D()(imgs[0], g["eval_noise"].to(DEV)))      # .forward: no pre-hooks
+    ref = g["eval_logits"]
+    err = (logits.cpu() - ref).abs().max().item()
+    assert err < 2e-4, f"final logits err {err:.3e} (min top-2 margin of the reference {g['eval_margin'].min():.3e})"
+    assert torch.equal(logits.argmax(1).cpu(), g["eval_argmax"])
+    release_resident()
+
+
+def get_map(mapping):
+    from dg_tta_amd.tta.torch_utils import get_map_idxs
+    return get_map_idxs(mapping, OPTIMIZED, "pretrain_labels")
+
+
+def test_evaluation_targets_use_the_optimized_label_index_space(tmp_path):
+    """tta.py:440-447: mapped_target_labels* hold the TTA dataset's ids mapped to positions in optimized_labels (unmapped
+    ids -> 0), so summary_*.json compares like with like when the TTA ids are not 0..N-1 in list order."""
+    import json
+    from types import SimpleNamespace as NS
+    from dg_tta_amd.tta.config_log_utils import ModifierFunctions
+    from dg_tta_amd.tta.tta import tta_main
+    g = load_golden("calc_branch")
+    net = _network_with_hooks(g, conv_impl=0)
+    modmod = SimpleNamespace(ModifierFunctions=ModifierFunctions)
+    mapping = {"background": (0, 0), "a": (2, 3), "b": (3, 1)}           # TTA label 3 is 'a' (position 1), 1 is 'b'
+    cfg = _plan(epochs=1, ensemble_count=1, patches_to_be_accumulated=2, tta_data_filepaths=[], seed=3,
+                pretrained_weights_filepath="unused", optimized_labels=["background", "a", "b"])
+    case = _synthetic_case(5)                                            # 3 one-hot label channels = TTA ids 1, 2, 3
+    raw = torch.cat([(case[1:].sum(0, keepdim=True) < 1).float(), case[1:]]).argmax(0)
+    bundle = (NS(), [16, 16, 16], net, [{k: v.clone() for k, v in net.state_dict().items()}])
+    data = (iter([{"data": case, "data_properties": {}, "ofile": "tta_outputTs/case5"}]), 1)
+    tta_main("run0", cfg, tmp_path, tmp_path, mapping, modmod, DEV, network_bundle=bundle, tta_data=data)
+    tgt = torch.from_numpy(np.load(tmp_path / "run0" / "mapped_target_labelsTs" / "case5.npy").astype(np.int64))
+    expect = torch.zeros_like(raw)
+    expect[raw == 3] = 1        # 'a'
+    expect[raw == 1] = 2        # 'b'; TTA id 2 is not optimised -> background
+    assert torch.equal(tgt, expect)
+    sj = json.loads((tmp_path / "run0" / "summary_Ts.json").read_text())
+    assert sj["metric_per_case"][0]["metrics"]["1"]["n_ref"] == int((raw == 3).sum())
+    assert sj["metric_per_case"][0]["metrics"]["2"]["n_ref"] == int((raw == 1).sum())
+
+
+def test_two_ranks_one_run_directory(tmp_path):
+    """Multi-GPU correctness without a second GPU: ranks are run one after the other on the same run directory.
+    (a) 2 samples x 2 members on 2 ranks: rank 0 may only write the summary once rank 1's marker exists, and the summary
+    then contains every case; (b) 1 sample x 2 members on 2 ranks: the members are adapted on different ranks, the owner
+    of member 0 waits for the other member's parameter file and predicts with both."""
+    import json
+    from types import SimpleNamespace as NS
+    from dg_tta_amd.tta.config_log_utils import ModifierFunctions
+    from dg_tta_amd.tta.tta import tta_main
+    g = load_golden("calc_branch")
+    net = _network_with_hooks(g, conv_impl=0)
+    modmod = SimpleNamespace(ModifierFunctions=ModifierFunctions)
+    mapping = {"background": (0, 0), "a": (2, 1), "b": (3, 2), "c": (5, 3)}
+    cfg = _plan(epochs=2, ensemble_count=2, patches_to_be_accumulated=2, tta_data_filepaths=[], seed=3,
+                pretrained_weights_filepath="unused", lr=1e-4, optimized_labels=["background", "a", "b", "c"],
+                barrier_timeout_s=1.0)
+    bundle = (NS(), [16, 16, 16], net, [{k: v.clone() for k, v in net.state_dict().items()}])
+
+    def data(seeds):
+        return iter([{"data": _synthetic_case(s), "data_properties": {}, "ofile": f"tta_outputTs/case{s}"}
+                     for s in seeds]), len(seeds)
+
+    # (a) rank 0 alone: the barrier must time out instead of summarising half a run
+    with pytest.raises(TimeoutError):
+        tta_main("runA", cfg, tmp_path, tmp_path, mapping, modmod, DEV, network_bundle=bundle, tta_data=data((1, 2)),
+                 shard=(0, 2))
+    assert not (tmp_path / "runA" / "summary_Ts.json").exists()
+    r1 = tta_main("runA", cfg, tmp_path, tmp_path, mapping, modmod, DEV, network_bundle=bundle, tta_data=data((1, 2)),
+                  shard=(1, 2))
+    assert not any(k[0] == "summary" for k in r1)
+    r0 = tta_main("runA", cfg, tmp_path, tmp_path, mapping, modmod, DEV, network_bundle=bundle, tta_data=data((1, 2)),
+                  shard=(0, 2))
+    assert ("summary", "Ts") in r0
+    sj = json.loads((tmp_path / "runA" / "summary_Ts.json").read_text())
+    assert sorted(Path(c["prediction_file"]).name for c in sj["metric_per_case"]) == ["case1.npy", "case2.npy"]
+    # (b) fewer samples than ranks: members spread over the ranks
+    with pytest.raises(TimeoutError):       # member 1 lives on rank 1: rank 0 cannot predict yet
+        tta_main("runB", cfg, tmp_path, tmp_path, mapping, modmod, DEV, network_bundle=bundle, tta_data=data((4,)),
+                 shard=(0, 2))
+    out = tmp_path / "runB" / "tta_outputTs"
+    assert (out / "case4__ensemble_idx_0_tta_parameters.pt").is_file()
+    assert not (out / "case4__ensemble_idx_1_tta_parameters.pt").exists()
+    tta_main("runB", cfg, tmp_path, tmp_path, mapping, modmod, DEV, network_bundle=bundle, tta_data=data((4,)), shard=(1, 2))
+    assert (out / "case4__ensemble_idx_1_tta_parameters.pt").is_file() and not (tmp_path / "runB" / "tta_outputTs" / "case4.npy").exists()
+    rb = tta_main("runB", cfg, tmp_path, tmp_path, mapping, modmod, DEV, network_bundle=bundle, tta_data=data((4,)),
+                  shard=(0, 2))
+    assert ("tta_outputTs/case4", "prediction") in rb and ("summary", "Ts") in rb

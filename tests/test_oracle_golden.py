@@ -100,3 +100,59 @@ def test_unet_keys_and_size():
     assert "encoder.stages.0.0.convs.0.all_modules.1.weight" in keys
     assert "decoder.encoder.stages.4.0.convs.1.conv.bias" in keys
     assert "decoder.transpconvs.3.weight" in keys and "decoder.seg_layers.0.bias" in keys
+
+
+def test_tta_unit_golden_cpu():
+    """The oracle's restatement of the WHOLE unit loop (tta.py:189-340) reproduces the reference run bit for bit: losses,
+    pseudo-Dice per epoch, post-TTA parameters and the final label map (plan lr 1e-5, 5 epochs x 8 steps)."""
+    import numpy as np
+    g = load_golden("tta_unit")
+    om = ounet.PlainConvUNetOracle(SMALL_CFG)
+    om.load_state_dict(state_from_golden(g, "w::"), strict=False)
+    lm = {"background": (0, 0), "a": (2, 3), "b": (3, 1), "c": (5, 4), "d": (8, 2)}
+    names = ["background", "a", "b", "c", "d"]
+    pre, tta = otta.get_map_idxs(lm, names, "pretrain_labels"), otta.get_map_idxs(lm, names, "tta_labels")
+    opt = torch.optim.AdamW(om.parameters(), lr=float(g["lr"]))
+    torch.manual_seed(int(g["seed"]))
+    np.random.seed(int(g["seed"]))
+    losses, dices, steps = otta.tta_unit(om, opt, [g["data"]], [16, 16, 16], pre, tta, int(g["epochs"]), 1, int(g["accum"]))
+    # bit-identical with the generating thread count (make_golden_r2.py asserts torch.equal); the summation order of
+    # torch's CPU kernels depends on the thread count, hence a float tolerance here
+    assert torch.allclose(steps, g["step_losses"], atol=2e-6) and torch.allclose(losses, g["tta_losses"], atol=2e-6)
+    assert torch.allclose(dices, g["eval_dices"], atol=1e-6)
+    post = state_from_golden(g, "p::")
+    for k, v in om.state_dict().items():
+        if k in post and not (k.endswith("conv.bias") and ".convs." in k):     # zero-gradient biases: Adam on noise
+            assert torch.allclose(v, post[k], atol=2.5e-5), k
+    with torch.no_grad():
+        imgs, _ = otta.get_batch_item(g["data"], [16, 16, 16], None)
+        final = otta.map_label(om(omind.mind3d(imgs, g["eval_noise"])), pre, "logits")
+    assert torch.equal(final.argmax(1), g["eval_argmax"])
+
+
+def test_full_topology_golden_cpu():
+    """Full nnUNet 3d_fullres (32..320 features, 12 -> 105 channels) at 32^3: the oracle reproduces the reference's
+    calc_branch x 2 + loss + backward (strided logit slices, label map, loss, gradient checksums)."""
+    g = load_golden("full_32")
+    torch.set_num_threads(8)
+    om = ounet.perturb_affine(ounet.init_he(ounet.PlainConvUNetOracle(), int(g["w_seed"])), int(g["w_seed"]) + 1)
+    sel = torch.arange(int(g["copt"])) * 3
+    torch.manual_seed(int(g["img_seed"]))
+    imgs = torch.randn(1, 1, 32, 32, 32)
+    assert abs(imgs.double().sum().item() - float(g["imgs_sum"])) < 1e-9
+    outs = {}
+    for br in ("a", "b"):
+        torch.manual_seed(int(g[f"seed_{br}"]))
+        outs[br] = otta.calc_branch(om, imgs, sel, **otta.draw_branch(1, [32, 32, 32]))
+        st = int(g["slice_step"])
+        ref = g[f"out_{br}_slice"]
+        assert (outs[br][:, :, ::st, ::st, ::st] - ref).abs().max() < 2e-5 * ref.abs().max()
+        safe = g[f"out_{br}_margin"].float() > 1e-3
+        assert torch.equal(outs[br].argmax(1)[safe].to(torch.uint8), g[f"out_{br}_argmax"][safe])
+    loss = otta.consistency_loss(outs["a"], outs["b"])
+    assert abs(float(loss) - float(g["loss"])) < 2e-6
+    loss.backward()
+    for name, p in om.named_parameters():
+        if f"g::{name}" in g and name.endswith("norm.weight"):
+            ref = g[f"g::{name}"]
+            assert (p.grad - ref).abs().max() < 2e-4 * ref.abs().max() + 1e-9, name

@@ -50,3 +50,91 @@ def test_single_process_defaults():
     from dg_tta_amd.sharding import max_over_ranks, units_for_rank
     assert units_for_rank(2, 2, 0, 1) == [(0, 0), (0, 1), (1, 0), (1, 1)]
     assert max_over_ranks(0.5) == 0.5
+
+
+def test_pairs_are_sharded_when_samples_are_fewer_than_ranks():
+    """with fewer samples than GPUs the (sample, ensemble) PAIRS are dealt out; the partition stays
+    complete and disjoint, and member 0's owner (who runs the sample's ensemble inference) is well defined."""
+    from dg_tta_amd.sharding import unit_owner, units_for_rank
+    for ns, ens, world in [(1, 3, 8), (2, 3, 4), (3, 3, 8), (8, 3, 8), (5, 1, 2), (1, 1, 2)]:
+        parts = [units_for_rank(ns, ens, r, world) for r in range(world)]
+        flat = [u for p in parts for u in p]
+        assert sorted(flat) == [(s, e) for s in range(ns) for e in range(ens)] and len(set(flat)) == len(flat)
+        if ns >= world:
+            assert all(len({unit_owner(s, e, ns, ens, world) for e in range(ens)}) == 1 for s in range(ns))
+        else:       # pairs spread: no rank idles while another holds two units, as far as the unit count allows
+            sizes = [len(p) for p in parts]
+            assert max(sizes) - min(sizes) <= 1
+    assert units_for_rank(1, 3, 0, 8) == [(0, 0)] and units_for_rank(1, 3, 2, 8) == [(0, 2)]
+
+
+def _barrier_worker(rank, world, port, run_dir, out):
+    """Two ranks on one run directory: each 'adapts' its units (writes the parameter file under a temporary name and
+    renames it), rank 0 waits for rank 1's files and marker before it lists the directory for the summary."""
+    import time
+    from pathlib import Path
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    from dg_tta_amd.sharding import done_marker, mark_rank_done, units_for_rank, wait_for_files
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    run_dir = Path(run_dir)
+    units = [(s, e) for s in range(1) for e in range(2)]
+    for (s, e) in units_for_rank(1, 2, rank, world):
+        if rank == 1:
+            time.sleep(1.0)                         # the other GPU is slower
+        tmp = run_dir / f"case{s}__ensemble_idx_{e}.pt.tmp{rank}"
+        tmp.write_bytes(b"x" * 1000)
+        tmp.replace(run_dir / f"case{s}__ensemble_idx_{e}.pt")
+    if rank == 0:       # owner of member 0: needs every member of the sample
+        wait_for_files([run_dir / f"case{s}__ensemble_idx_{e}.pt" for s, e in units], timeout_s=60)
+        (run_dir / "case0.npy").write_bytes(b"prediction")
+    mark_rank_done(run_dir, rank)
+    if rank == 0:
+        wait_for_files([done_marker(run_dir, r) for r in range(world)], timeout_s=60)
+        out.put(sorted(p.name for p in run_dir.iterdir() if not p.name.startswith(".")))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_filesystem_barrier_two_ranks(tmp_path):
+    import pytest
+    from dg_tta_amd.sharding import wait_for_files
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_barrier_worker, args=(r, 2, port, str(tmp_path), q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    listing = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert listing == ["case0.npy", "case0__ensemble_idx_0.pt", "case0__ensemble_idx_1.pt"]
+    with pytest.raises(TimeoutError, match="never_written"):
+        wait_for_files([tmp_path / "never_written.pt"], timeout_s=0.3, poll_s=0.05)
+
+
+def test_fanout_parent_reports_failed_children(tmp_path):
+    """run.py's parent: a child killed by a signal (negative return code) must not read as success, and the surviving
+    children are stopped instead of waiting in the filesystem barrier."""
+    import subprocess
+    import sys
+    import time
+    from dg_tta_amd.run import _wait_children
+    from dg_tta_amd.sharding import child_devices
+    ok = subprocess.Popen([sys.executable, "-c", "pass"])
+    killed = subprocess.Popen([sys.executable, "-c", "import os, signal; os.kill(os.getpid(), signal.SIGABRT)"])
+    waiting = subprocess.Popen([sys.executable, "-c", "import time; time.sleep(600)"])
+    t0 = time.monotonic()
+    rcs = _wait_children([ok, killed, waiting], poll_s=0.05)
+    assert time.monotonic() - t0 < 60
+    assert rcs[0] == 0 and rcs[1] < 0 and rcs[2] != 0
+    assert max(rcs) == 0          # what the old `max(p.wait())` would have reported
+    old = os.environ.get("HIP_VISIBLE_DEVICES")
+    try:
+        os.environ["HIP_VISIBLE_DEVICES"] = "4,5,6,7"
+        assert child_devices(2) == ["4", "5"]
+        os.environ.pop("HIP_VISIBLE_DEVICES")
+        assert child_devices(3) == ["0", "1", "2"]
+    finally:
+        if old is not None:
+            os.environ["HIP_VISIBLE_DEVICES"] = old

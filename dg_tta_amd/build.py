@@ -7,7 +7,8 @@ from pathlib import Path
 
 CSRC = Path(__file__).resolve().parent / "csrc"
 LIB = Path(__file__).resolve().parent / "libdgtta_hip.so"
-SOURCES = ["lib.hip", "mind3d.hip", "gin.hip", "warp.hip", "softdice.hip", "adamw.hip", "unet_ref.hip", "conv_mfma.hip"]
+SOURCES = ["lib.hip", "mind3d.hip", "gin.hip", "warp.hip", "softdice.hip", "adamw.hip", "unet_ref.hip", "conv_mfma.hip", "conv_rows.hip",
+           "conv_wgrad.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
 
 
@@ -30,7 +31,7 @@ def build(force=False, verbose=True):
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)
 
-    with ThreadPoolExecutor(max_workers=4) as ex:
+    with ThreadPoolExecutor(max_workers=6) as ex:
         list(ex.map(run, jobs))
     if force or jobs or _stale(LIB, objs):
         run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(LIB), *map(str, objs)])

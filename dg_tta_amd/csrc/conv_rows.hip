@@ -1,0 +1,414 @@
+// Row-reuse 3x3x3 convolution kernel (bf16, stride 1) -- see the block comment below.
+#include "conv_common.h"
+#include <stdlib.h>
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Row-reuse kernel (bf16, stride 1, all 27 taps, W tiles of 32): the LDS-lean variant for the large layers.
+//
+// In the kernel above every MFMA fetches a fresh A fragment from LDS (1.5 ds_read_b128 per MFMA incl. B): with 32
+// output channels the LDS pipe saturates before the matrix cores do.  Here a wave owns a PD x PH patch of output rows
+// (one row = 32 voxels along W = one 32x32 accumulator) and walks the (PD+2) x (PH+2) INPUT rows of its patch: an
+// input-row fragment (one per kw shift) is read once and feeds every (kd,kh) tap whose output row lies in the patch
+// (up to 9 MFMAs per read), and the 27 weight fragments of the K-step live in registers.  PD = PH = 2: 48 A reads + 27
+// B reads per 108 MFMAs (0.7 per MFMA instead of 1.5).
+//   Workgroup: WD x WH waves, tile (PD*WD) x (PH*WH) x 32 voxels x 32 output channels; persistent over a contiguous
+//   range of (spatial tile, channel block) jobs, so the first K-chunk of the next tile is in flight during the last
+//   MFMA phase of the current one.
+//   Staging:   global_load_lds_dwordx4 (no staging registers, no ds_write): A chunk (16 channels) double buffered,
+//   B chunk (27 x 1 KiB, contiguous in the packed image) single buffered -- it is copied to registers at phase start.
+//   Padding voxels read a 16-byte zero constant.
+template <int PD, int PH, int WD, int WH>
+struct RowsCfg {
+  static constexpr int NW = WD * WH, NT = NW * 64;
+  static constexpr int TD = PD * WD, TH = PH * WH, TW = 32;
+  static constexpr int ID = TD + 2, IH = TH + 2, ROW = TW + 2;
+  // A chunk in LDS: one 68-entry block (16 B entries) per input row (dz,hy):
+  //   [0,32) channel group 0, columns 0..31 | [32,64) group 1, columns 0..31 | 64,65 group 0, columns 32,33 | 66,67 group 1
+  // = one full 1-KiB DMA piece + one 4-lane piece per row; all per-piece address arithmetic is scalar.
+  static constexpr int NROW = ID * IH, RB = 68;
+  static constexpr size_t A_BYTES = ((size_t)NROW * RB * 16 + 1023) / 1024 * 1024;
+  static constexpr size_t B_BYTES = 27 * 1024;
+  static constexpr size_t RED_BYTES = (size_t)NW * 32 * 2 * sizeof(float);
+  static constexpr size_t LDS_BYTES = 2 * A_BYTES + B_BYTES + RED_BYTES;
+};
+
+template <int PD, int PH, int WD, int WH, int ABL = 0>   // ABL: diagnostic ablation
+__global__ __launch_bounds__(WD *WH * 64) void conv3_rows_kernel(const bf16_t *__restrict__ x, View xv,
+                                                                 const bf16_t *__restrict__ w, Taps taps,
+                                                                 const float *__restrict__ bias, bf16_t *__restrict__ y,
+                                                                 View yv, int Cin, int Cout, int CinP, int tilesW,
+                                                                 int tilesH, int tilesD, int nblkN, int njobs,
+                                                                 double *__restrict__ stats, int ntaps_src) {
+  typedef RowsCfg<PD, PH, WD, WH> Cfg;
+  constexpr int NW = Cfg::NW, IH = Cfg::IH;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char *sAb = smem;                                   // two A buffers
+  unsigned char *sBb = smem + 2 * Cfg::A_BYTES;                // [27][2][32] x 16 B
+  float *red = reinterpret_cast<float *>(smem + 2 * Cfg::A_BYTES + Cfg::B_BYTES);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int wd = wave / WH, wh = wave % WH;
+  const int Di = xv.D, Hi = xv.H, Wi = xv.W, Do = yv.D, Ho = yv.H, Wo = yv.W;
+  const int nk = CinP / 16;
+  const int cin_lim = (Cin + 7) / 8 * 8;
+
+  // contiguous job range of this workgroup; workgroups of one XCD (blockIdx % 8) get neighbouring ranges
+  const int G = gridDim.x;
+  const int lw = (G % 8 == 0) ? (int)(blockIdx.x % 8) * (G / 8) + (int)(blockIdx.x / 8) : (int)blockIdx.x;
+  const int j0 = (int)(((long long)njobs * lw) / G), j1 = (int)(((long long)njobs * (lw + 1)) / G);
+  const int nph = (j1 - j0) * nk;
+  if (nph == 0) return;
+
+  struct Job {
+    int b, n0, od0, oh0, ow0, tile;
+  };
+  auto decode = [&](int j) {
+    Job q;
+    const int td = j % tilesD;
+    j /= tilesD;
+    const int nb = j % nblkN;
+    j /= nblkN;
+    const int th = j % tilesH;
+    j /= tilesH;
+    const int tw = j % tilesW;
+    q.b = j / tilesW;
+    q.n0 = nb * 32;
+    q.od0 = td * Cfg::TD;
+    q.oh0 = th * Cfg::TH;
+    q.ow0 = tw * 32;
+    q.tile = (tw * tilesH + th) * tilesD + td;
+    return q;
+  };
+
+  // source taps of the B pieces this wave copies (read from the kernel arguments before any DMA is in flight)
+  int my_wt[(27 + NW - 1) / NW];
+#pragma unroll
+  for (int i = 0; i < (27 + NW - 1) / NW; ++i) {
+    const int tap = wave + i * NW;
+    my_wt[i] = __builtin_amdgcn_readfirstlane(tap < 27 ? (int)taps.wt[tap] : -1);
+  }
+
+  // DMA of K-chunk kc of job q into A buffer `buf` and the B buffer, one piece per call: this wave's share is NPR input
+  // rows (main + tail piece each) then NPB B pieces.  Issued one at a time between MFMA groups: a burst of all pieces
+  // blocks the issuing wave until the memory pipeline has absorbed them (measured: half of the kernel's cycles).
+  constexpr int NPR = (Cfg::NROW + NW - 1) / NW, NPB = (27 + NW - 1) / NW, NPIECE = 2 * NPR + NPB;
+  // lane roles inside a piece: main = (group lane>>5, column lane&31); tail (lanes 0..3) = (group lane>>1, column 32 + lane&1)
+  const int m_g = lane >> 5, m_wx = lane & 31, t_g = (lane >> 1) & 1, t_wx = 32 + (lane & 1);
+  auto issue_piece = [&](const Job &q, int kc, int buf, int i) {
+    if (i < 2 * NPR) {
+      const int row = wave + (i >> 1) * NW;          // wave-uniform
+      const bool tail = i & 1;
+      if (row < Cfg::NROW && (!tail || lane < 4) && !(ABL == 7 && tail)) {
+        const int dz = row / IH, hy = row % IH;
+        const int gd = q.od0 - 1 + dz, gh = q.oh0 - 1 + hy;
+        const int g = tail ? t_g : m_g, gw = q.ow0 - 1 + (tail ? t_wx : m_wx);
+        const int c = kc * 16 + g * 8;
+        const bool ok = (unsigned)gd < (unsigned)Di && (unsigned)gh < (unsigned)Hi && (unsigned)gw < (unsigned)Wi &&
+                        c < cin_lim;
+        const bf16_t *rowp = x + (long long)q.b * xv.sb + gd * xv.sd + gh * xv.sh;      // scalar part
+        const void *src = ok ? (const void *)(rowp + gw * xv.sw + c) : (const void *)&g_zero16;
+        if (ABL == 1 || ABL == 4) return;
+        dma16_to_lds(src, lds_addr_of(sAb + (size_t)buf * Cfg::A_BYTES + (row * Cfg::RB + (tail ? 64 : 0)) * 16));
+      }
+    } else {
+      const int tap = wave + (i - 2 * NPR) * NW;
+      if (tap < 27) {
+        const int wt = my_wt[i - 2 * NPR];
+        const void *src = wt >= 0 ? (const void *)(w + ((((long long)(q.n0 / 32) * nk + kc) * ntaps_src + wt) * 64 + lane) * 8)
+                                  : (const void *)&g_zero16;
+        if (ABL == 1 || ABL == 5) return;
+        dma16_to_lds(src, lds_addr_of(sBb + tap * 1024));
+      }
+    }
+  };
+
+  f32x16_t acc[PD][PH];
+  // this lane's A read bases (16-byte entries) for the three kw shifts: patch origin row block + entry of column r + kw
+  int abase[3];
+#pragma unroll
+  for (int kw = 0; kw < 3; ++kw) {
+    const int col = r + kw;
+    abase[kw] = ((wd * PD) * IH + wh * PH) * Cfg::RB + (col < 32 ? h * 32 + col : 64 + h * 2 + (col - 32));
+  }
+
+  Job cur = decode(j0);
+  float bv = 0.f;
+  float st1 = 0.f, st2 = 0.f;       // InstanceNorm partial sums of this lane's channel over the current run of jobs
+#pragma unroll
+  for (int i = 0; i < NPIECE; ++i) issue_piece(cur, 0, 0, i);
+  int kc = 0, jn = j0;
+  unsigned long long tseg[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = 0;     // ABL 6: cycle stamps per segment (diagnostic)
+  auto stamp = [&](int k) {
+    if (ABL == 6) {
+      __builtin_amdgcn_sched_barrier(0);
+      const unsigned long long t = __builtin_amdgcn_s_memtime();
+      __builtin_amdgcn_sched_barrier(0);
+      tseg[k] += t - tprev;
+      tprev = t;
+    }
+  };
+  if (ABL == 6) tprev = __builtin_amdgcn_s_memtime();
+  for (int p = 0; p < nph; ++p) {
+    dma_wait_all();
+    stamp(0);                 // waiting for the DMA
+    lds_barrier();            // chunk p has landed; every wave is done with phase p-1
+    uint4 breg[27];
+    {
+      const uint4 *sB = reinterpret_cast<const uint4 *>(sBb);
+#pragma unroll
+      for (int t = 0; t < 27; ++t) breg[t] = sB[t * 64 + lane];
+    }
+    if (kc == 0) {            // bias of this job, fetched while no DMA is in flight (its wait would drain them)
+      const int co = cur.n0 + r;
+      bv = (bias && co < Cout) ? bias[co] : 0.f;
+      asm volatile("" ::"v"(bv));
+    }
+    lds_barrier();            // B buffer is free again
+    stamp(1);                 // barrier + B fragments + barrier
+    // prefetch the next phase (next K-chunk of this job, or chunk 0 of the next job)
+    Job nxt = cur;
+    int kn = kc + 1;
+    if (kn == nk) {
+      kn = 0;
+      if (p + 1 < nph) nxt = decode(jn + 1);
+    }
+    const bool more = p + 1 < nph;
+    stamp(2);
+
+    if (kc == 0) {          // accumulators start at the bias of this lane's output channel (column re of every row)
+#pragma unroll
+      for (int i = 0; i < PD; ++i)
+#pragma unroll
+        for (int j = 0; j < PH; ++j)
+#pragma unroll
+          for (int q = 0; q < 16; ++q) acc[i][j][q] = bv;
+    }
+    {
+      const uint4 *sA = reinterpret_cast<const uint4 *>(sAb + (size_t)(p & 1) * Cfg::A_BYTES);
+#pragma unroll
+      for (int dz = 0; dz < PD + 2; ++dz)
+#pragma unroll
+        for (int hy = 0; hy < PH + 2; ++hy)
+#pragma unroll
+          for (int kw = 0; kw < 3; ++kw) {
+            const uint4 af = sA[abase[kw] + (dz * IH + hy) * Cfg::RB];
+            {   // spread this wave's DMA pieces of the next chunk evenly over the A-read steps
+              constexpr int NSTEP = (PD + 2) * (PH + 2) * 3;
+              const int step = (dz * (PH + 2) + hy) * 3 + kw;
+#pragma unroll
+              for (int i = 0; i < NPIECE; ++i)
+                if (step == (i * NSTEP) / NPIECE + 1 && more) issue_piece(nxt, kn, (p + 1) & 1, i);
+            }
+#pragma unroll
+            for (int kd = 0; kd < 3; ++kd)
+#pragma unroll
+              for (int kh = 0; kh < 3; ++kh) {
+                const int od = dz - kd, oh = hy - kh;
+                if (od >= 0 && od < PD && oh >= 0 && oh < PH) {
+                  if (ABL == 3) acc[od][oh][0] += __uint_as_float(af.x ^ breg[(kd * 3 + kh) * 3 + kw].x);
+                  else mfma_step<bf16_t>(af, breg[(kd * 3 + kh) * 3 + kw], acc[od][oh]);
+                }
+              }
+          }
+    }
+
+    stamp(3);                 // MFMA loop
+    if (kc == nk - 1) {
+      // ---- epilogue of job `cur`: convert, transpose through LDS (this phase's A buffer, one 8-KiB slab per wave) so
+      //      that a lane stores 16 bytes = 8 channels of a voxel; per-channel sum / sum of squares of the unrounded
+      //      values for the following InstanceNorm, kept in registers over the jobs of one (sample, channel block) run.
+      lds_barrier();          // every wave has finished reading this phase's A buffer
+      stamp(5);               // (diagnostic) barrier skew
+      // lane-derived epilogue indices are rebuilt from a laundered lane id: otherwise the compiler hoists them out of
+      // the phase loop, keeps them live across the MFMA phase and spills (a scratch reload's wait drains the DMA)
+      int le = lane;
+      asm volatile("" : "+v"(le));
+      const int re = le & 31, he = le >> 5;
+      const int co = cur.n0 + re;
+      unsigned char *slabb = sAb + (size_t)(p & 1) * Cfg::A_BYTES + wave * (PD * PH * 2048);
+      const bool full = cur.od0 + Cfg::TD <= Do && cur.oh0 + Cfg::TH <= Ho && cur.ow0 + 32 <= Wo && cur.n0 + 32 <= Cout;
+      if (full && ABL != 7) {
+        // Fast path (whole tile inside the volume).  The MFMA leaves a lane with ONE channel (re) and 16 voxels, 4
+        // consecutive ones per q group: the slab is CHANNEL-major [32 ch][32 voxels] bf16 (64-byte rows), written 8 bytes
+        // (4 voxels) at a time - 4 ds_write_b64 + 8 packed converts per accumulator instead of 16 2-byte writes and 16
+        // converts - and read back through ds_read_b64_tr_b16 (hardware transpose: a lane receives 4 channels of one
+        // voxel).  8-byte slot s of row ch sits at s ^ ((ch >> 1) & 7): conflict free for the writes (16-lane groups
+        // over 128 B) and for the transposed reads (32-lane halves over 256 B).
+        const int swz = (re >> 1) & 7;
+        // transposed read: 16-lane group cq = le >> 4 takes channels 8 cq .. 8 cq + 7 (two 4-row blocks) of 16 voxels;
+        // lane 4 q + p of a group supplies the address of block row q, voxels 4 p .. 4 p + 3
+        const int cq = le >> 4, li = le & 15, rq = li >> 2, rp = li & 3;
+        f32x2_t s1v = {0.f, 0.f}, s2v = {0.f, 0.f};       // packed fp32 math: two voxels per instruction
+        auto part1 = [&](int i, int j) {
+          unsigned char *sl = slabb + (i * PH + j) * 2048 + re * 64;
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const f32x2_t a = {acc[i][j][4 * g], acc[i][j][4 * g + 1]}, c = {acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+            s1v += a;
+            s1v += c;
+            s2v = __builtin_elementwise_fma(a, a, s2v);
+            s2v = __builtin_elementwise_fma(c, c, s2v);
+            uint2 pk;
+            pk.x = (unsigned)f32_to_bf16(a[0]) | ((unsigned)f32_to_bf16(a[1]) << 16);
+            pk.y = (unsigned)f32_to_bf16(c[0]) | ((unsigned)f32_to_bf16(c[1]) << 16);
+            *reinterpret_cast<uint2 *>(sl + (((2 * g + he) ^ swz) << 3)) = pk;
+          }
+        };
+        auto part2 = [&](int i, int j) {
+          const int od = cur.od0 + wd * PD + i, oh = cur.oh0 + wh * PH + j;
+          bf16_t *orow = y + (long long)cur.b * yv.sb + od * yv.sd + oh * yv.sh + cur.n0 + cq * 8;
+          const unsigned char *sl = slabb + (i * PH + j) * 2048;
+#pragma unroll
+          for (int vb = 0; vb < 2; ++vb) {
+            const int c0 = 8 * cq + rq, c1 = c0 + 4, sidx = 4 * vb + rp;
+            const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                (lds_s16x4_t *)(sl + c0 * 64 + ((sidx ^ ((c0 >> 1) & 7)) << 3)));
+            const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                (lds_s16x4_t *)(sl + c1 * 64 + ((sidx ^ ((c1 >> 1) & 7)) << 3)));
+            uint4 val;
+            val.x = (unsigned)(unsigned short)lo[0] | ((unsigned)(unsigned short)lo[1] << 16);
+            val.y = (unsigned)(unsigned short)lo[2] | ((unsigned)(unsigned short)lo[3] << 16);
+            val.z = (unsigned)(unsigned short)hi[0] | ((unsigned)(unsigned short)hi[1] << 16);
+            val.w = (unsigned)(unsigned short)hi[2] | ((unsigned)(unsigned short)hi[3] << 16);
+            const int ow = cur.ow0 + 16 * vb + li;
+            if (ABL != 2) *reinterpret_cast<uint4 *>(orow + ow * yv.sw) = val;
+          }
+        };
+        // (a wave reads back only its own slab: LDS operations of one wave complete in order); the read-back and stores
+        // of accumulator k are issued after the conversion of accumulator k+1, which hides the LDS round trip
+#pragma unroll
+        for (int k = 0; k <= PD * PH; ++k) {
+          if (k < PD * PH) part1(k / PH, k % PH);
+          if (k > 0) part2((k - 1) / PH, (k - 1) % PH);
+        }
+        st1 += s1v[0] + s1v[1];
+        st2 += s2v[0] + s2v[1];
+        stamp(7);               // (diagnostic) slab reads + global stores
+      } else {
+        // ragged tile: voxel-major slab [32 voxels][32 ch] with 2-byte writes and per-element bounds
+        bf16_t *slab = reinterpret_cast<bf16_t *>(slabb);
+#pragma unroll
+        for (int i = 0; i < PD; ++i)
+#pragma unroll
+          for (int j = 0; j < PH; ++j) {
+            const int od = cur.od0 + wd * PD + i, oh = cur.oh0 + wh * PH + j;
+            const bool row_ok = od < Do && oh < Ho;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+              const int m = (q & 3) + 8 * (q >> 2) + 4 * he;
+              const float v = acc[i][j][q];
+              slab[(i * PH + j) * 1024 + m * 32 + re] = f32_to_bf16(v);
+              if (row_ok && co < Cout && cur.ow0 + m < Wo) {
+                st1 += v;
+                st2 += v * v;
+              }
+            }
+          }
+        stamp(6);
+#pragma unroll
+        for (int i = 0; i < PD; ++i)
+#pragma unroll
+          for (int j = 0; j < PH; ++j) {
+            const int od = cur.od0 + wd * PD + i, oh = cur.oh0 + wh * PH + j;
+            bf16_t *orow = y + (long long)cur.b * yv.sb + od * yv.sd + oh * yv.sh + cur.n0;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+              const int m = t * 16 + (le >> 2), cq = (le & 3) * 8;
+              const uint4 val = *reinterpret_cast<const uint4 *>(slab + (i * PH + j) * 1024 + m * 32 + cq);
+              const int ow = cur.ow0 + m;
+              if (ABL != 2 && od < Do && oh < Ho && ow < Wo && cur.n0 + cq < Cout)
+                *reinterpret_cast<uint4 *>(orow + ow * yv.sw + cq) = val;
+            }
+          }
+        stamp(7);
+      }
+      if (stats) {
+        // the partial sums of a run of jobs over one (sample, channel block) are flushed once, into the slot of the run's
+        // last tile; the other tiles of the run hold zeros (the finalize kernel adds all tile slots in a fixed order)
+        const bool flush = !(p + 1 < nph) || nxt.b != cur.b || nxt.n0 != cur.n0;
+        const int tiles_per_b = tilesW * tilesH * tilesD;
+        double *pp = stats + 32 + (((int64_t)cur.b * tiles_per_b + cur.tile) * Cout + cur.n0 + tid) * 2;
+        if (flush) {
+          const float a = st1 + __shfl_xor(st1, 32, 64), c2 = st2 + __shfl_xor(st2, 32, 64);
+          if (he == 0) {
+            red[(wave * 32 + re) * 2 + 0] = a;
+            red[(wave * 32 + re) * 2 + 1] = c2;
+          }
+          st1 = st2 = 0.f;
+          lds_barrier();
+          if (tid < 32 && cur.n0 + tid < Cout) {
+            double s = 0.0, ss = 0.0;
+#pragma unroll
+            for (int wv = 0; wv < NW; ++wv) {
+              s += (double)red[(wv * 32 + tid) * 2 + 0];
+              ss += (double)red[(wv * 32 + tid) * 2 + 1];
+            }
+            pp[0] = s;
+            pp[1] = ss;
+          }
+        } else if (tid < 32 && cur.n0 + tid < Cout) {
+          pp[0] = 0.0;
+          pp[1] = 0.0;
+        }
+        if (lw == 0 && tid == 0 && p == nk - 1) reinterpret_cast<long long *>(stats)[0] = tiles_per_b;
+      }
+    }
+    stamp(4);                 // epilogue
+    kc = kn;
+    if (kn == 0) {
+      cur = nxt;
+      ++jn;
+    }
+  }
+  if (ABL == 6 && stats && lane == 0) {
+    for (int k = 0; k < 8; ++k) stats[4096 + ((size_t)blockIdx.x * NW + wave) * 8 + k] = (double)tseg[k];
+  }
+}
+
+template <int PD, int PH, int WD, int WH>
+int launch_conv_rows(const void *x, const View &xv, const void *w, const Taps &taps, const float *bias, void *y,
+                     const View &yv, int B, int Cin, int Cout, int CinP, int CoutP, double *stats, int ntaps_src,
+                     hipStream_t st) {
+  typedef RowsCfg<PD, PH, WD, WH> Cfg;
+  auto kern = conv3_rows_kernel<PD, PH, WD, WH>;
+  static const char *abl = getenv("DGTTA_ROWS_ABL");      // diagnostic only
+  if (abl && abl[0] == '1') kern = conv3_rows_kernel<PD, PH, WD, WH, 1>;
+  if (abl && abl[0] == '2') kern = conv3_rows_kernel<PD, PH, WD, WH, 2>;
+  if (abl && abl[0] == '3') kern = conv3_rows_kernel<PD, PH, WD, WH, 3>;
+  if (abl && abl[0] == '4') kern = conv3_rows_kernel<PD, PH, WD, WH, 4>;
+  if (abl && abl[0] == '5') kern = conv3_rows_kernel<PD, PH, WD, WH, 5>;
+  if (abl && abl[0] == '6') kern = conv3_rows_kernel<PD, PH, WD, WH, 6>;
+  if (abl && abl[0] == '7') kern = conv3_rows_kernel<PD, PH, WD, WH, 7>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)Cfg::LDS_BYTES);
+    DG_REQUIRE(e == hipSuccess, DGTTA_ERR_LAUNCH, "conv3_rows: cannot raise the dynamic LDS limit to %zu", Cfg::LDS_BYTES);
+    attr_set = true;
+  }
+  const int tW = cdiv(yv.W, 32), tH = cdiv(yv.H, Cfg::TH), tD = cdiv(yv.D, Cfg::TD), nblkN = cdiv(CoutP, 32);
+  const long long njobs = (long long)tW * tH * tD * nblkN * B;
+  DG_REQUIRE(njobs < (1ll << 31), DGTTA_ERR_UNSUPPORTED, "conv3_rows: too many tiles");
+  static int ncu = [] {
+    int dev = 0, n = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+    return n > 0 ? n : 256;
+  }();
+  const int wg_per_cu = (int)((160 * 1024) / Cfg::LDS_BYTES) > 0 ? (int)((160 * 1024) / Cfg::LDS_BYTES) : 1;
+  const int grid = (int)(njobs < (long long)ncu * wg_per_cu ? njobs : (long long)ncu * wg_per_cu);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(Cfg::NT), Cfg::LDS_BYTES, st, (const bf16_t *)x, xv, (const bf16_t *)w, taps,
+                     bias, (bf16_t *)y, yv, Cin, Cout, CinP, tW, tH, tD, nblkN, (int)njobs, stats, ntaps_src);
+  DG_CHECK_LAUNCH("conv3_rows_kernel");
+  return DGTTA_OK;
+}
+
+}  // namespace
+
+// entry point used by the dispatcher in conv_mfma.hip
+int conv3_rows_launch(const void *x, const View &xv, const void *w, const Taps &taps, const float *bias, void *y, const View &yv,
+                      int B, int Cin, int Cout, int CinP, int CoutP, double *stats, int ntaps_src, hipStream_t st) {
+  return launch_conv_rows<2, 2, 2, 4>(x, xv, w, taps, bias, y, yv, B, Cin, Cout, CinP, CoutP, stats, ntaps_src, st);
+}

@@ -2,9 +2,10 @@
 // Replaces MIND3D.forward / smooth / filter1D of the reference (dg_tta/mind.py:142-164, :27-43, :5-24).
 //
 // Pass A (mind_ssd_kernel): one workgroup per 8x8x32 output tile.  The image tile (+3 halo, replicate
-//   = clamped coordinates) is staged once in LDS; per channel c the squared edge response
-//   q = (p[v+s1]-p[v+s2] + rw*noise)^2 is formed on the tile +2 halo, then smoothed by the separable
-//   5-tap Gaussian D -> H -> W entirely in LDS; the 12 smoothed values of a voxel stay in registers.
+//   = clamped coordinates) is staged once in LDS; the squared edge responses
+//   q_c = (p[v+s1_c]-p[v+s2_c] + rw*noise_c)^2 are formed on the tile +2 halo from the six face neighbours and
+//   smoothed by the separable 5-tap Gaussian D (register window) -> H -> W (LDS), 4 channels per pass; the 12
+//   smoothed values of a voxel stay in registers.
 //   Writes m_c = ssd_c - min_c (fp32, voxel-major [B][V][12]) to the workspace and a per-workgroup
 //   partial sum of var = mean_c m_c.
 // Pass B (mind_reduce_kernel): fixed-order sum of the partials in double -> global mean of var.
@@ -18,26 +19,58 @@ namespace {
 constexpr int TD = 8, TH = 8, TW = 32;
 constexpr int ID = TD + 6, IH = TH + 6, IW = TW + 6;   // image tile (halo 3)
 constexpr int QD = TD + 4, QH = TH + 4, QW = TW + 4;   // q tile (halo 2)
-constexpr int NT = 512;                                 // 8 waves: twice the occupancy for the 60 barrier phases (212 -> ? us)
-constexpr int VPT = TD * TH * TW / NT;                 // 8 voxels per thread
-constexpr int QN = (QD * QH * QW + NT - 1) / NT;       // q-tile elements per thread
-
-// (d,h,w) offsets inside the 3x3x3 window minus 1, from mshift1/mshift2 (mind.py:112-135).
-__constant__ signed char c_s1[12][3] = {{0, 0, -1}, {0, -1, 0}, {0, -1, 0}, {0, 0, 1}, {0, 0, 1}, {1, 0, 0},
-                                        {1, 0, 0},  {1, 0, 0},  {0, 1, 0},  {0, 1, 0}, {0, 1, 0}, {0, 1, 0}};
-__constant__ signed char c_s2[12][3] = {{-1, 0, 0}, {-1, 0, 0}, {0, 0, -1}, {-1, 0, 0}, {0, -1, 0}, {0, 0, -1},
-                                        {0, -1, 0}, {0, 0, 1},  {-1, 0, 0}, {0, 0, -1}, {0, 0, 1},  {1, 0, 0}};
+constexpr int NT = 512;                                 // 8 waves
+constexpr int VPT = TD * TH * TW / NT;                 // 4 voxels per thread (consecutive along W)
+constexpr int CG = 4, NG = 12 / CG;                    // channels per pass through the LDS filter pipeline
+static_assert(VPT == 4 && TW == 32 && TD * TH * (TW / 4) == NT, "stage-3 thread map: (d, h, w/4)");
 
 __device__ __forceinline__ int clampi(int x, int lo, int hi) { return x < lo ? lo : (x > hi ? hi : x); }
 
 struct Taps { float g[5]; };
 
+// The 12 shift pairs of mshift1/mshift2 (mind.py:112-135) only ever touch the SIX face neighbours of a voxel:
+// e_c = img[v + s1_c] - img[v + s2_c] with (d,h,w) offsets
+//   s1: c0 (0,0,-1) c1,c2 (0,-1,0) c3,c4 (0,0,1) c5..c7 (1,0,0) c8..c11 (0,1,0)
+//   s2: c0,c1,c3,c8 (-1,0,0)  c2,c5,c9 (0,0,-1)  c4,c6 (0,-1,0)  c7,c10 (0,0,1)  c11 (1,0,0)
+// so one fetch of the neighbours (dp = d+1, dm = d-1, hp, hm, wp, wm) serves every channel.
+template <int C>
+__device__ __forceinline__ float edge(float dp, float dm, float hp, float hm, float wp, float wm) {
+  constexpr int S1[12] = {5, 3, 3, 4, 4, 0, 0, 0, 2, 2, 2, 2};      // index into {dp, dm, hp, hm, wp, wm}
+  constexpr int S2[12] = {1, 1, 5, 1, 3, 5, 3, 4, 1, 5, 4, 0};
+  const float n[6] = {dp, dm, hp, hm, wp, wm};
+  return n[S1[C]] - n[S2[C]];
+}
+
+__device__ __forceinline__ float edge_sel(int c, float dp, float dm, float hp, float hm, float wp, float wm) {
+  switch (c) {
+    case 0: return edge<0>(dp, dm, hp, hm, wp, wm);
+    case 1: return edge<1>(dp, dm, hp, hm, wp, wm);
+    case 2: return edge<2>(dp, dm, hp, hm, wp, wm);
+    case 3: return edge<3>(dp, dm, hp, hm, wp, wm);
+    case 4: return edge<4>(dp, dm, hp, hm, wp, wm);
+    case 5: return edge<5>(dp, dm, hp, hm, wp, wm);
+    case 6: return edge<6>(dp, dm, hp, hm, wp, wm);
+    case 7: return edge<7>(dp, dm, hp, hm, wp, wm);
+    case 8: return edge<8>(dp, dm, hp, hm, wp, wm);
+    case 9: return edge<9>(dp, dm, hp, hm, wp, wm);
+    case 10: return edge<10>(dp, dm, hp, hm, wp, wm);
+    default: return edge<11>(dp, dm, hp, hm, wp, wm);
+  }
+}
+
+// Pass A.  One workgroup per 8 x 8 x 32 output tile, channels in NG groups of CG:
+//   stage 1  thread = one (h', w') column of the q tile (halo 2): walks the 12 depths, forms q_c = (e_c + rw n_c)^2 for the
+//            group's channels from the six neighbours (centre column kept in a 3-deep register window) and runs the
+//            D filter on a 5-deep register window per channel -> r1[c][d][h'][w'] in LDS (no q tile in LDS at all);
+//   stage 2  H filter, 4 adjacent w' columns per thread (16-byte LDS accesses): r1 -> r2[c][d][h][w'];
+//   stage 3  W filter: thread = 4 consecutive output voxels of a row, 2 x 16-byte reads per channel -> registers.
+// 2 barriers per group instead of 5 per channel, ~1/3 of the LDS instructions of the first version.
 __global__ __launch_bounds__(NT) void mind_ssd_kernel(const float *__restrict__ img, const float *__restrict__ noise,
                                                       float rw, float *__restrict__ mws, double *__restrict__ partial,
                                                       int D, int H, int W, int tilesD, Taps taps) {
-  __shared__ float simg[ID * IH * IW];
-  __shared__ float sq[QD * QH * QW];      // q, later reused for r2
-  __shared__ float sr1[TD * QH * QW];
+  __shared__ __attribute__((aligned(16))) float simg[ID * IH * IW];
+  __shared__ __attribute__((aligned(16))) float sr1[CG * TD * QH * QW];
+  __shared__ __attribute__((aligned(16))) float sr2[CG * TD * TH * QW];
   __shared__ float sred[16];
 
   const int tid = threadIdx.x;
@@ -46,93 +79,128 @@ __global__ __launch_bounds__(NT) void mind_ssd_kernel(const float *__restrict__ 
   const int64_t V = (int64_t)D * H * W;
   const float *imgb = img + (int64_t)b * V;
 
-  for (int i = tid; i < ID * IH * IW; i += NT) {
-    int iw = i % IW, ih = (i / IW) % IH, id = i / (IW * IH);
-    int gd = clampi(d0 - 3 + id, 0, D - 1), gh = clampi(h0 - 3 + ih, 0, H - 1), gw = clampi(w0 - 3 + iw, 0, W - 1);
-    simg[i] = imgb[((int64_t)gd * H + gh) * W + gw];
+  {   // image tile: all loads of a thread issued back to back (a load-store loop pays the HBM latency once per element)
+    constexpr int NI = (ID * IH * IW + NT - 1) / NT;
+    float pre[NI];
+#pragma unroll
+    for (int k = 0; k < NI; ++k) {
+      const int i = tid + k * NT < ID * IH * IW ? tid + k * NT : 0;
+      const int iw = i % IW, ih = (i / IW) % IH, id = i / (IW * IH);
+      const int gd = clampi(d0 - 3 + id, 0, D - 1), gh = clampi(h0 - 3 + ih, 0, H - 1), gw = clampi(w0 - 3 + iw, 0, W - 1);
+      pre[k] = imgb[((int64_t)gd * H + gh) * W + gw];
+    }
+#pragma unroll
+    for (int k = 0; k < NI; ++k)
+      if (tid + k * NT < ID * IH * IW) simg[tid + k * NT] = pre[k];
   }
+
+  // stage-1 role: column (qh, qw) of the q tile; replicate padding = clamped global coordinates (mind.py:143, :13-14)
+  const bool col_on = tid < QH * QW;
+  const int qw = tid % QW, qh = (tid / QW) % QH;
+  const int gh = clampi(h0 - 2 + qh, 0, H - 1), gw = clampi(w0 - 2 + qw, 0, W - 1);
+  const int ih_c = gh - (h0 - 3), iw_c = gw - (w0 - 3);
+  const int ih_p = clampi(gh + 1, 0, H - 1) - (h0 - 3), ih_m = clampi(gh - 1, 0, H - 1) - (h0 - 3);
+  const int iw_p = clampi(gw + 1, 0, W - 1) - (w0 - 3), iw_m = clampi(gw - 1, 0, W - 1) - (w0 - 3);
+  // stage-3 role: 4 consecutive output voxels
+  const int od = tid / (TH * (TW / 4)), oh = (tid / (TW / 4)) % TH, ow4 = (tid % (TW / 4)) * 4;
 
   float ssd[VPT][12];
-
-  // q-stage bookkeeping that does not depend on the channel: clamped global coordinates (packed 10 bits each) and the
-  // global voxel index of every q-tile element this thread owns.  The noise of channel c+1 is fetched as one batch of
-  // independent loads while channel c is being filtered (the serialized per-element loads were the latency bound).
-  int gidx[QN], pk[QN];
-  float nreg[QN];
+  // noise of the whole column for one channel group (48 values), fetched a full group ahead: the loads of group g+1 are
+  // issued while group g runs (a one-step prefetch left every depth step waiting on HBM latency)
+  float nbuf[QD][CG];
+  const float *nzb = noise + (int64_t)b * 12 * V;
+  int gidx[QD];
 #pragma unroll
-  for (int k = 0; k < QN; ++k) {
-    int i = tid + k * NT;
-    i = i < QD * QH * QW ? i : 0;
-    int qw = i % QW, qh = (i / QW) % QH, qd = i / (QW * QH);
-    int gd = clampi(d0 - 2 + qd, 0, D - 1), gh = clampi(h0 - 2 + qh, 0, H - 1), gw = clampi(w0 - 2 + qw, 0, W - 1);
-    gidx[k] = (gd * H + gh) * W + gw;
-    pk[k] = gd | (gh << 10) | (gw << 20);
-  }
-  {
-    const float *nz = noise + (int64_t)b * 12 * V;
+  for (int qd = 0; qd < QD; ++qd) gidx[qd] = (clampi(d0 - 2 + qd, 0, D - 1) * H + gh) * W + gw;
+  if (col_on) {
 #pragma unroll
-    for (int k = 0; k < QN; ++k) nreg[k] = nz[gidx[k]];
+    for (int qd = 0; qd < QD; ++qd)
+#pragma unroll
+      for (int c = 0; c < CG; ++c) nbuf[qd][c] = nzb[(int64_t)c * V + gidx[qd]];
   }
+  __syncthreads();      // simg ready
 
 #pragma unroll
-  for (int c = 0; c < 12; ++c) {
-    __syncthreads();  // simg ready (c==0) / previous channel's r2 reads done
-    const int a0 = c_s1[c][0], a1 = c_s1[c][1], a2 = c_s1[c][2];
-    const int e0 = c_s2[c][0], e1 = c_s2[c][1], e2 = c_s2[c][2];
+  for (int g = 0; g < NG; ++g) {
+    // ---- stage 1
+    if (col_on) {
+      float win[CG][5];
+      float nv[CG];
 #pragma unroll
-    for (int k = 0; k < QN; ++k) {
-      const int i = tid + k * NT;
-      const int gd = pk[k] & 1023, gh = (pk[k] >> 10) & 1023, gw = pk[k] >> 20;
-      int p1 = ((clampi(gd + a0, 0, D - 1) - (d0 - 3)) * IH + (clampi(gh + a1, 0, H - 1) - (h0 - 3))) * IW +
-               (clampi(gw + a2, 0, W - 1) - (w0 - 3));
-      int p2 = ((clampi(gd + e0, 0, D - 1) - (d0 - 3)) * IH + (clampi(gh + e1, 0, H - 1) - (h0 - 3))) * IW +
-               (clampi(gw + e2, 0, W - 1) - (w0 - 3));
-      float e = (simg[p1] - simg[p2]) + rw * nreg[k];
-      if (i < QD * QH * QW) sq[i] = e * e;
-    }
-    if (c + 1 < 12) {
-      const float *nz = noise + ((int64_t)b * 12 + c + 1) * V;
+      for (int qd = 0; qd < QD; ++qd) {
 #pragma unroll
-      for (int k = 0; k < QN; ++k) nreg[k] = nz[gidx[k]];
+        for (int c = 0; c < CG; ++c) nv[c] = nbuf[qd][c];
+        if (g + 1 < NG) {
+#pragma unroll
+          for (int c = 0; c < CG; ++c) nbuf[qd][c] = nzb[(int64_t)((g + 1) * CG + c) * V + gidx[qd]];
+        }
+        const int gd = clampi(d0 - 2 + qd, 0, D - 1);
+        const int id_c = gd - (d0 - 3), id_p = clampi(gd + 1, 0, D - 1) - (d0 - 3), id_m = clampi(gd - 1, 0, D - 1) - (d0 - 3);
+        const float dp = simg[(id_p * IH + ih_c) * IW + iw_c], dm = simg[(id_m * IH + ih_c) * IW + iw_c];
+        const float hp = simg[(id_c * IH + ih_p) * IW + iw_c], hm = simg[(id_c * IH + ih_m) * IW + iw_c];
+        const float wp = simg[(id_c * IH + ih_c) * IW + iw_p], wm = simg[(id_c * IH + ih_c) * IW + iw_m];
+        float e[CG];
+#pragma unroll
+        for (int c = 0; c < CG; ++c) e[c] = edge_sel(g * CG + c, dp, dm, hp, hm, wp, wm);     // constant after unrolling
+#pragma unroll
+        for (int c = 0; c < CG; ++c) {
+          const float ev = e[c] + rw * nv[c];
+          win[c][qd % 5] = ev * ev;
+        }
+        if (qd >= 4) {            // D filter output d = qd - 4: taps over q[d .. d+4]
+          const int d = qd - 4;
+#pragma unroll
+          for (int c = 0; c < CG; ++c) {
+            float acc = taps.g[0] * win[c][d % 5];
+#pragma unroll
+            for (int t = 1; t < 5; ++t) acc += taps.g[t] * win[c][(d + t) % 5];
+            sr1[((c * TD + d) * QH + qh) * QW + qw] = acc;
+          }
+        }
+      }
     }
     __syncthreads();
-    // D filter: r1[d][h'][w'] = sum_t g[t] q[d+t][h'][w']
-    for (int i = tid; i < TD * QH * QW; i += NT) {
-      const float *q = sq + i;  // (d,h',w') has the same (h',w') strides in sq and sr1
-      float acc = taps.g[0] * q[0];
+    // ---- stage 2: H filter, r2[c][d][h][w'] = sum_t g[t] r1[c][d][h+t][w'], 4 columns per thread
+    for (int i = tid; i < CG * TD * (QW / 4); i += NT) {
+      const int w4 = (i % (QW / 4)) * 4, d = (i / (QW / 4)) % TD, c = i / ((QW / 4) * TD);
+      const float *r = sr1 + ((c * TD + d) * QH) * QW + w4;
+      float4 rowv[QH];
 #pragma unroll
-      for (int t = 1; t < 5; ++t) acc += taps.g[t] * q[t * QH * QW];
-      sr1[i] = acc;
+      for (int k = 0; k < QH; ++k) rowv[k] = *reinterpret_cast<const float4 *>(r + k * QW);
+#pragma unroll
+      for (int h = 0; h < TH; ++h) {
+        float4 acc;
+        acc.x = taps.g[0] * rowv[h].x; acc.y = taps.g[0] * rowv[h].y; acc.z = taps.g[0] * rowv[h].z; acc.w = taps.g[0] * rowv[h].w;
+#pragma unroll
+        for (int t = 1; t < 5; ++t) {
+          acc.x += taps.g[t] * rowv[h + t].x; acc.y += taps.g[t] * rowv[h + t].y;
+          acc.z += taps.g[t] * rowv[h + t].z; acc.w += taps.g[t] * rowv[h + t].w;
+        }
+        *reinterpret_cast<float4 *>(sr2 + ((c * TD + d) * TH + h) * QW + w4) = acc;
+      }
     }
     __syncthreads();
-    // H filter into sq (as r2[d][h][w'], row length QW)
-    for (int i = tid; i < TD * TH * QW; i += NT) {
-      int qw = i % QW, h = (i / QW) % TH, d = i / (QW * TH);
-      const float *r = sr1 + (d * QH + h) * QW + qw;
-      float acc = taps.g[0] * r[0];
+    // ---- stage 3: W filter into registers
 #pragma unroll
-      for (int t = 1; t < 5; ++t) acc += taps.g[t] * r[t * QW];
-      sq[i] = acc;
+    for (int c = 0; c < CG; ++c) {
+      const float *r = sr2 + ((c * TD + od) * TH + oh) * QW + ow4;
+      const float4 a0 = *reinterpret_cast<const float4 *>(r), a1 = *reinterpret_cast<const float4 *>(r + 4);
+      const float v[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+#pragma unroll
+      for (int k = 0; k < VPT; ++k) {
+        float acc = taps.g[0] * v[k];
+#pragma unroll
+        for (int t = 1; t < 5; ++t) acc += taps.g[t] * v[k + t];
+        ssd[k][g * CG + c] = acc;
+      }
     }
-    __syncthreads();
-    // W filter into registers
-#pragma unroll
-    for (int k = 0; k < VPT; ++k) {
-      int idx = tid + k * NT;
-      int w = idx % TW, h = (idx / TW) % TH, d = idx / (TW * TH);
-      const float *r = sq + (d * TH + h) * QW + w;
-      float acc = taps.g[0] * r[0];
-#pragma unroll
-      for (int t = 1; t < 5; ++t) acc += taps.g[t] * r[t];
-      ssd[k][c] = acc;
-    }
+    // (the next group's stage 1 writes sr1 only; sr2 is rewritten after the barrier that follows it)
   }
 
   float vsum = 0.f;
 #pragma unroll
   for (int k = 0; k < VPT; ++k) {
-    int idx = tid + k * NT;
-    int w = w0 + idx % TW, h = h0 + (idx / TW) % TH, d = d0 + idx / (TW * TH);
+    const int w = w0 + ow4 + k, h = h0 + oh, d = d0 + od;
     if (d < D && h < H && w < W) {
       float mn = ssd[k][0];
 #pragma unroll

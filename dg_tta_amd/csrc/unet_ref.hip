@@ -372,6 +372,50 @@ __global__ __launch_bounds__(256) void in_apply_vec_kernel(const T *__restrict__
   const T *yb = y + (int64_t)b * V * ldy;
   const T *gb = MODE == 1 ? gz + (int64_t)b * V * ldgz : nullptr;
   T *ob = out + (int64_t)b * V * ldo;
+  if (256 % G == 0) {
+    // fast path (G = 4, 8, 16, 32: every layer except the 320-channel bottleneck): a thread keeps ONE channel group for the
+    // whole launch, so its per-channel constants sit in registers (no LDS read per element, no 64-bit division per item),
+    // and two rows are in flight per iteration
+    const int c0 = (threadIdx.x % G) * EPV;
+    float kc[EPV][NK];
+#pragma unroll
+    for (int e = 0; e < EPV; ++e)
+#pragma unroll
+      for (int q = 0; q < NK; ++q) kc[e][q] = sc[(c0 + e) * NK + q];
+    const int rpb = 256 / G;                                             // rows per workgroup per step
+    const int64_t rstep = (int64_t)gridDim.x * rpb;
+    auto one = [&](const uint4 &yv, const uint4 &gv, int64_t row) {
+      float f[EPV], g[EPV], o[EPV];
+      unpack16<T>(yv, f);
+      if (MODE == 1) unpack16<T>(gv, g);
+#pragma unroll
+      for (int e = 0; e < EPV; ++e) {
+        if constexpr (MODE == 0) {
+          o[e] = lrelu(f[e] * kc[e][0] + kc[e][1], slope);
+        } else {
+          const float xh = (f[e] - kc[e][0]) * kc[e][1];
+          const float a = xh * kc[e][2] + kc[e][3];
+          const float gg = a > 0.f ? g[e] : g[e] * slope;
+          o[e] = (kc[e][2] * kc[e][1]) * ((gg - kc[e][4]) - xh * kc[e][5]);
+        }
+      }
+      *reinterpret_cast<uint4 *>(ob + row * ldo + c0) = pack16<T>(o);
+    };
+    for (int64_t row = (int64_t)blockIdx.x * rpb + threadIdx.x / G; row < V; row += 2 * rstep) {
+      const int64_t row2 = row + rstep;
+      const bool two = row2 < V;
+      const uint4 y0 = *reinterpret_cast<const uint4 *>(yb + row * ldy + c0);
+      uint4 y1 = y0, g0 = y0, g1 = y0;
+      if (two) y1 = *reinterpret_cast<const uint4 *>(yb + row2 * ldy + c0);
+      if (MODE == 1) {
+        g0 = *reinterpret_cast<const uint4 *>(gb + row * ldgz + c0);
+        if (two) g1 = *reinterpret_cast<const uint4 *>(gb + row2 * ldgz + c0);
+      }
+      one(y0, g0, row);
+      if (two) one(y1, g1, row2);
+    }
+    return;
+  }
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < items; i += (int64_t)gridDim.x * 256) {
     const int64_t row = i / G;
     const int c0 = (int)(i % G) * EPV;

@@ -114,6 +114,34 @@ def cpu_baseline(args):
                       f"x{args.accum + 1 / 6:.2f} (steps per epoch)"}
 
 
+def inference_leg(args, device):
+    """BASELINE config 3's caller-side step: Gaussian sliding-window inference of ONE ensemble member
+    over an `inference_size`^3 volume with 128^3 windows at step 0.5, all 105 classes accumulated in fp32, then argmax.
+    Returns ms per window (network forward + accumulate) and the totals."""
+    from dg_tta_amd.mind import mind_hook
+    from dg_tta_amd.synthetic import he_init_
+    from dg_tta_amd.tta.inference import predict_sliding_window_return_logits
+    from dg_tta_amd.unet import HipPlainConvUNet
+    from dg_tta_amd import ops
+    n = args.inference_size
+    net = he_init_(HipPlainConvUNet(act_dtype=torch.bfloat16 if args.dtype == "bf16" else torch.float32), seed=7)
+    net.register_forward_pre_hook(mind_hook)
+    net = net.to(device)
+    vol = torch.randn(1, n, n, n, generator=torch.Generator().manual_seed(3)).to(device)
+    patch = [args.size] * 3
+    predict_sliding_window_return_logits(net, vol[:, :args.size, :args.size, :args.size], patch)      # warm-up: one window
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    acc, nsum, _ = predict_sliding_window_return_logits(net, vol, patch)
+    seg, _ = ops.argmax_dice(acc.permute(3, 0, 1, 2)[None])
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    nwin = (max(1, -(-(n - args.size) // (args.size // 2))) + 1) ** 3 if n > args.size else 1
+    return {"volume": n, "windows": nwin, "ms_per_window": round(dt / nwin * 1e3, 3), "seconds": round(dt, 3),
+            "accumulator_gib": round(acc.numel() * 4 / 2 ** 30, 2), "classes": int(acc.shape[-1]),
+            "note": "one ensemble member; network forward (4 windows per pass) + Gaussian accumulate + final argmax"}
+
+
 def product_switches():
     """The environment switches of the product path in force for this run (Switches)."""
     from dg_tta_amd.tta.tta import batch_branches_enabled, batched_steps
@@ -167,6 +195,8 @@ def main():
     ap.add_argument("--cpu-warmup", type=int, default=1)
     ap.add_argument("--no-fp32", action="store_true", help="skip the nested reference-precision (fp32) epoch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--inference-size", type=int, default=256,
+                    help="edge of the volume for the sliding-window inference leg (BASELINE config 3: 512); 0 = skip")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0))
@@ -240,6 +270,8 @@ def main():
                "roofline": roof}
         if other is not None:
             out["fp32"] = other
+        if args.inference_size > 0 and world == 1:
+            out["inference"] = inference_leg(args, device)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args)
         print(json.dumps(out), flush=True)

@@ -16,6 +16,7 @@ P, I, I64, F, SZ = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t
 SIGNATURES = {
     "dgtta_version": (I, []),
     "dgtta_last_error": (C.c_char_p, []),
+    "dgtta_reload_env": (I, []),
     "dgtta_mind3d_ws_bytes": (SZ, [I, I, I, I]),
     "dgtta_mind3d_fwd": (I, [P, P, F, P, I, I, I, P, SZ, I, I, I, I, P]),
     "dgtta_gin_ws_bytes": (SZ, [I, I, I, I]),

@@ -10,7 +10,33 @@
 
 #define WAVE 64
 
+#include <atomic>
+
 void dgtta_set_error(const char *fmt, ...);
+
+// Diagnostic / test switches (Switches): a snapshot of the DGTTA_* environment taken ONCE (std::call_once)
+// at first use and again only on dgtta_reload_env(); dispatch code reads the snapshot, never the environment.
+// -1 = variable not set; otherwise the first character ('0', '1', ...) of its value.
+struct DgttaSwitches {
+  int conv_rows, conv_variant, conv_s2, dgrad_s2_allcls, wgrad_tr, wgrad_tr8, wgrad_s2_onepass, convt_wgrad_onepass;
+  int conv_abl, rows_abl, wgrad_abl;
+};
+const DgttaSwitches &dgtta_switches();
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (kernel, device): lock-free and per device (a plain
+// `static bool` was neither).  One static DynLdsOnce per launch site.
+struct DynLdsOnce {
+  std::atomic<unsigned long long> mask{0};
+};
+static inline hipError_t ensure_dyn_lds(DynLdsOnce &o, const void *fn, int bytes) {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  const unsigned long long bit = 1ull << (dev & 63);
+  if (o.mask.load(std::memory_order_acquire) & bit) return hipSuccess;
+  const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e == hipSuccess) o.mask.fetch_or(bit, std::memory_order_release);
+  return e;
+}
 
 #define DG_REQUIRE(cond, code, ...)      \
   do {                                   \

@@ -353,12 +353,9 @@ int launch_conv_allcls(const void *x, const View &xv, const void *w, const ConvC
   typedef ConvCfg<T, MBW, MBH, MBD, 1, 1, 1> Cfg;
   typedef typename Cfg::G G;
   auto kern = conv3_mfma_kernel<T, MBW, MBH, MBD, 1, 1, 1, 0, 8, true>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)Cfg::LDS_BYTES);
-    attr_set = true;
-  }
+  static DynLdsOnce lds_once;
+  DG_REQUIRE(ensure_dyn_lds(lds_once, reinterpret_cast<const void *>(kern), (int)Cfg::LDS_BYTES) == hipSuccess,
+             DGTTA_ERR_LAUNCH, "conv3_mfma: cannot raise the dynamic LDS limit to %zu", (size_t)Cfg::LDS_BYTES);
   const int tW = cdiv(yv.W, G::TW), tH = cdiv(yv.H, G::TH), tD = cdiv(yv.D, G::TD);
   const int64_t tiles = (int64_t)tW * tH * tD * B;
   DG_REQUIRE(tiles < (1ll << 31), DGTTA_ERR_UNSUPPORTED, "conv3_mfma: too many tiles");
@@ -375,25 +372,10 @@ int launch_conv(const void *x, const View &xv, const void *w, const ConvClasses 
                 hipStream_t st) {
   typedef ConvCfg<T, MBW, MBH, MBD, S, NB, KSPC> Cfg;
   typedef typename Cfg::G G;
-  static bool attr_set = false;
   auto kern = conv3_mfma_kernel<T, MBW, MBH, MBD, S, NB, KSPC, 0, NW>;
-  if (MBW == 32 && S == 1 && NW == 8) {
-    static const char *abl = getenv("DGTTA_CONV_ABL");      // diagnostic only
-    if (abl && abl[0] == '1') kern = conv3_mfma_kernel<T, MBW, MBH, MBD, S, NB, KSPC, 1, NW>;
-    if (abl && abl[0] == '2') kern = conv3_mfma_kernel<T, MBW, MBH, MBD, S, NB, KSPC, 2, NW>;
-    if (abl && abl[0] == '3') kern = conv3_mfma_kernel<T, MBW, MBH, MBD, S, NB, KSPC, 3, NW>;
-    if (abl && abl[0] == '4') kern = conv3_mfma_kernel<T, MBW, MBH, MBD, S, NB, KSPC, 4, NW>;
-    if (abl && abl[0] == '5') kern = conv3_mfma_kernel<T, MBW, MBH, MBD, S, NB, KSPC, 5, NW>;
-    if (abl && abl[0] == '6') kern = conv3_mfma_kernel<T, MBW, MBH, MBD, S, NB, KSPC, 6, NW>;
-    if (abl && abl[0] == '7') kern = conv3_mfma_kernel<T, MBW, MBH, MBD, S, NB, KSPC, 7, NW>;
-    if (abl) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)Cfg::LDS_BYTES);
-  }
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)Cfg::LDS_BYTES);
-    attr_set = true;
-  }
+  static DynLdsOnce lds_once;
+  DG_REQUIRE(ensure_dyn_lds(lds_once, reinterpret_cast<const void *>(kern), (int)Cfg::LDS_BYTES) == hipSuccess,
+             DGTTA_ERR_LAUNCH, "conv3_mfma: cannot raise the dynamic LDS limit to %zu", (size_t)Cfg::LDS_BYTES);
   const int tW = cdiv(yv.W, G::TW), tH = cdiv(yv.H, G::TH), tD = cdiv(yv.D, G::TD);
   const int64_t tiles = (int64_t)tW * tH * tD * B;
   DG_REQUIRE(tiles < (1ll << 31), DGTTA_ERR_UNSUPPORTED, "conv3_mfma: too many tiles");
@@ -419,31 +401,25 @@ int dispatch_conv_classes(const void *x, const View &xv, const void *w, const Co
   }
   if (stride == 1 && sizeof(T) == 2 && yv.W >= 32 && cs.n == 1 && cs.acc[0] == 0 && cs.kseg == 0 && cs.xoff[0] == 0 &&
       cs.yoff[0] == 0) {
-    const char *rows = getenv("DGTTA_CONV_ROWS");   // diagnostic / tests: "0" forces the generic kernel, "1" this one
+    const int rows = dgtta_switches().conv_rows;   // DGTTA_CONV_ROWS (tests): '0' forces the generic kernel, '1' this one
     bool all_taps = true;
     for (int t = 0; t < 27; ++t) all_taps = all_taps && cs.taps[0].wt[t] >= 0;
     const bool vec_out = Cout % 8 == 0 && ((uintptr_t)y & 15) == 0 && yv.sw % 8 == 0 && yv.sh % 8 == 0 &&
                          yv.sd % 8 == 0 && yv.sb % 8 == 0;
     // enough (tile, channel block) jobs to fill the chip with one persistent workgroup per CU; below that the generic kernel wins
     const long long njobs = (long long)cdiv(yv.W, 32) * cdiv(yv.H, 8) * cdiv(yv.D, 4) * cdiv(CoutP, 32) * B;
-    if (all_taps && vec_out && (njobs >= 256 || (rows && rows[0] == '1')) && !(rows && rows[0] == '0'))
+    if (all_taps && vec_out && (njobs >= 256 || rows == '1') && rows != '0')
       return conv3_rows_launch(x, xv, w, cs.taps[0], bias, y, yv, B, Cin, Cout, CinP, CoutP, stats, ntaps_src,
                                           st);
   }
   if (stride == 1) {
-    static const char *var = getenv("DGTTA_CONV_VARIANT");      // diagnostic: tile-shape experiments
-    if (yv.W >= 32 && var && var[0] == 'a') return launch_conv<T, 32, 4, 4, 1, 1, 2>(ARGS);   // CK = 2 k-steps
-    if (yv.W >= 32 && var && var[0] == 'b') return launch_conv<T, 32, 4, 4, 1, 2, 1>(ARGS);   // 64 output channels
-    if (yv.W >= 32 && var && var[0] == 'd') return launch_conv<T, 32, 4, 2, 1, 1, 1>(ARGS);   // 256-voxel tile, 3 WG/CU
-    if (yv.W >= 32 && var && var[0] == 'w') return launch_conv<T, 32, 4, 4, 1, 1, 1, 8>(ARGS);   // 8 waves per workgroup
-    if (yv.W >= 32 && var && var[0] == 'e') return launch_conv<T, 32, 2, 4, 1, 1, 1>(ARGS);
-    // 8 waves per workgroup (2 M-blocks each): 16 waves per CU hide the LDS / barrier latency (+27 % over 4 waves)
-    if (yv.W >= 32 && var && var[0] == 'x') return launch_conv<T, 32, 4, 4, 1, 1, 1, 4>(ARGS);
+    // 8 waves per workgroup (2 M-blocks each): 16 waves per CU hide the LDS / barrier latency (+27 % over 4 waves; the
+    // other tile shapes tried in round 1 - 2 k-steps per chunk, 64 output channels, 256-voxel tiles - were slower)
     if (yv.W >= 32) return launch_conv<T, 32, 4, 4, 1, 1, 1, 8>(ARGS);
     // tiny volumes are latency bound (few workgroups, a long serial K loop): when the channel padding allows it, 2
     // k-steps per chunk halve the barrier / load round trips.  (128-voxel tiles for the 16^3 layers measured faster in
     // isolation but slower inside the network: 23.0 vs 20.9 ms per epoch.)
-    const bool k2 = CinP % (4 * Elem<T>::EPV) == 0 && !(var && var[0] == 'k');
+    const bool k2 = CinP % (4 * Elem<T>::EPV) == 0;
     if (yv.W >= 16) return launch_conv<T, 16, 4, 4, 1, 1, 1, 8>(ARGS);
     if (vox <= 4096 && k2) return launch_conv<T, 8, 2, 2, 1, 1, 2>(ARGS);
     if (vox <= 4096) return launch_conv<T, 8, 2, 2, 1, 1, 1>(ARGS);     // tiny volumes: more, smaller workgroups
@@ -451,8 +427,7 @@ int dispatch_conv_classes(const void *x, const View &xv, const void *w, const Co
   }
   if (stride == 2) {
     // 8 waves per workgroup (one M-block each): 231 -> 153 us at 128^3 -> 64^3, 32 -> 64 channels
-    static const char *v2 = getenv("DGTTA_CONV_S2");      // diagnostic: "4" = the former 4-wave tiles
-    if (v2 && v2[0] == '4') {
+    if (dgtta_switches().conv_s2 == '4') {      // DGTTA_CONV_S2=4: the former 4-wave tiles
       if (yv.W >= 16) return launch_conv<T, 16, 2, 4, 2, 1, 1>(ARGS);
       return launch_conv<T, 8, 2, 4, 2, 1, 1>(ARGS);
     }
@@ -593,8 +568,8 @@ static int dgrad_s2(const void *dy, int lddy, const void *w_kmajor, void *dx, in
   }
   {
     // one pass over dy with all 8 classes accumulated per wave (yv: extent of the dy lattice, strides of the parity view)
-    const char *ac = getenv("DGTTA_DGRAD_S2_ALLCLS");      // diagnostic / tests: "0" = the 8-class launch
-    if (!(ac && ac[0] == '0') && CinP % 8 == 0) {
+    const int ac = dgtta_switches().dgrad_s2_allcls;      // DGTTA_DGRAD_S2_ALLCLS (tests): '0' = the 8-class launch
+    if (ac != '0' && CinP % 8 == 0) {
       if (yv.W >= 32) return launch_conv_allcls<T, 32, 4, 2>(dy, xv, w_kmajor, cs, dx, yv, B, Cout, Cin, CoutP, CinP, st);
       if (yv.W >= 16) return launch_conv_allcls<T, 16, 2, 4>(dy, xv, w_kmajor, cs, dx, yv, B, Cout, Cin, CoutP, CinP, st);
       return launch_conv_allcls<T, 8, 2, 4>(dy, xv, w_kmajor, cs, dx, yv, B, Cout, Cin, CoutP, CinP, st);

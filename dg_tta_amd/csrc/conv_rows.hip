@@ -373,22 +373,18 @@ int launch_conv_rows(const void *x, const View &xv, const void *w, const Taps &t
                      const View &yv, int B, int Cin, int Cout, int CinP, int CoutP, double *stats, int ntaps_src,
                      hipStream_t st) {
   typedef RowsCfg<PD, PH, WD, WH> Cfg;
+  // DGTTA_ROWS_ABL (diagnostic builds of the same kernel): 1 no DMA, 3 no MFMA, 6 per-segment cycle stamps, 7 the
+  // voxel-major (ragged-tile) epilogue for every tile
+  const int abl = dgtta_switches().rows_abl;
   auto kern = conv3_rows_kernel<PD, PH, WD, WH>;
-  static const char *abl = getenv("DGTTA_ROWS_ABL");      // diagnostic only
-  if (abl && abl[0] == '1') kern = conv3_rows_kernel<PD, PH, WD, WH, 1>;
-  if (abl && abl[0] == '2') kern = conv3_rows_kernel<PD, PH, WD, WH, 2>;
-  if (abl && abl[0] == '3') kern = conv3_rows_kernel<PD, PH, WD, WH, 3>;
-  if (abl && abl[0] == '4') kern = conv3_rows_kernel<PD, PH, WD, WH, 4>;
-  if (abl && abl[0] == '5') kern = conv3_rows_kernel<PD, PH, WD, WH, 5>;
-  if (abl && abl[0] == '6') kern = conv3_rows_kernel<PD, PH, WD, WH, 6>;
-  if (abl && abl[0] == '7') kern = conv3_rows_kernel<PD, PH, WD, WH, 7>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)Cfg::LDS_BYTES);
-    DG_REQUIRE(e == hipSuccess, DGTTA_ERR_LAUNCH, "conv3_rows: cannot raise the dynamic LDS limit to %zu", Cfg::LDS_BYTES);
-    attr_set = true;
-  }
+  static DynLdsOnce once[5];
+  int slot = 0;
+  if (abl == '1') kern = conv3_rows_kernel<PD, PH, WD, WH, 1>, slot = 1;
+  if (abl == '3') kern = conv3_rows_kernel<PD, PH, WD, WH, 3>, slot = 2;
+  if (abl == '6') kern = conv3_rows_kernel<PD, PH, WD, WH, 6>, slot = 3;
+  if (abl == '7') kern = conv3_rows_kernel<PD, PH, WD, WH, 7>, slot = 4;
+  DG_REQUIRE(ensure_dyn_lds(once[slot], reinterpret_cast<const void *>(kern), (int)Cfg::LDS_BYTES) == hipSuccess,
+             DGTTA_ERR_LAUNCH, "conv3_rows: cannot raise the dynamic LDS limit to %zu", (size_t)Cfg::LDS_BYTES);
   const int tW = cdiv(yv.W, 32), tH = cdiv(yv.H, Cfg::TH), tD = cdiv(yv.D, Cfg::TD), nblkN = cdiv(CoutP, 32);
   const long long njobs = (long long)tW * tH * tD * nblkN * B;
   DG_REQUIRE(njobs < (1ll << 31), DGTTA_ERR_UNSUPPORTED, "conv3_rows: too many tiles");

@@ -973,29 +973,17 @@ static int wgrad_launch_classes(const void *x, const View &xv, const void *dy, c
   const size_t need = (size_t)wc.n * p.units * p.cibs * p.cobs * 27 * 1024 * sizeof(float);
   if (ws_bytes < need || p.units >= (1ll << 31) || p.cibs * p.cobs > 65535) return DGTTA_ERR_UNSUPPORTED;
   if (sizeof(T) == 2) {
-    const char *tr = getenv("DGTTA_WGRAD_TR");        // diagnostic / tests: "0" forces the register-transpose kernel
-    if (!(tr && tr[0] == '0')) {
+    const DgttaSwitches &sw = dgtta_switches();
+    if (sw.wgrad_tr != '0') {        // DGTTA_WGRAD_TR=0 (tests): the register-transpose predecessor
       const bool plain = wc.n == 1 && wc.mask[0] == 0x7ffffffu && wc.xoff[0] == 0 && wc.yoff[0] == 0;
       auto ktr = plain ? conv3_wgrad_tr_kernel<0, false> : conv3_wgrad_tr_kernel<0, true>;
-      static const char *abl = getenv("DGTTA_WGRAD_ABL");      // diagnostic only
-      if (abl && abl[0] == '1' && plain) ktr = conv3_wgrad_tr_kernel<1, false>;
-      if (abl && abl[0] == '3' && plain) ktr = conv3_wgrad_tr_kernel<3, false>;
-      static bool tr_attr[2] = {false, false};
-      if (!tr_attr[plain] || abl) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(ktr), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)WT::LDS_BYTES);
-        DG_REQUIRE(e == hipSuccess, DGTTA_ERR_LAUNCH, "wgrad_tr: cannot raise the dynamic LDS limit");
-        tr_attr[plain] = true;
-      }
-      const char *w8 = getenv("DGTTA_WGRAD_TR8");      // diagnostic / tests: "0" = always the 4-wave kernel
-      if (plain && Cout >= 64 && !abl && !(w8 && w8[0] == '0')) {
-        static bool a8 = false;
-        if (!a8) {
-          hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(conv3_wgrad_tr8_kernel),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)WT8::LDS_BYTES);
-          DG_REQUIRE(e == hipSuccess, DGTTA_ERR_LAUNCH, "wgrad_tr8: cannot raise the dynamic LDS limit");
-          a8 = true;
-        }
+      static DynLdsOnce tr_once[2];
+      DG_REQUIRE(ensure_dyn_lds(tr_once[plain], reinterpret_cast<const void *>(ktr), (int)WT::LDS_BYTES) == hipSuccess,
+                 DGTTA_ERR_LAUNCH, "wgrad_tr: cannot raise the dynamic LDS limit");
+      if (plain && Cout >= 64 && sw.wgrad_tr8 != '0') {      // DGTTA_WGRAD_TR8=0 (tests): always the 4-wave kernel
+        static DynLdsOnce a8;
+        DG_REQUIRE(ensure_dyn_lds(a8, reinterpret_cast<const void *>(conv3_wgrad_tr8_kernel), (int)WT8::LDS_BYTES) ==
+                       hipSuccess, DGTTA_ERR_LAUNCH, "wgrad_tr8: cannot raise the dynamic LDS limit");
         hipLaunchKernelGGL(conv3_wgrad_tr8_kernel, dim3((unsigned)p.units, (unsigned)(p.cibs * ((p.cobs + 1) / 2))), dim3(512),
                            WT8::LDS_BYTES, st, (const bf16_t *)x, xv, (const bf16_t *)dy, yv, (float *)ws, Cin, Cout, p.tW, p.tH,
                            p.nsd, p.DR, p.cobs);
@@ -1010,22 +998,10 @@ static int wgrad_launch_classes(const void *x, const View &xv, const void *dy, c
     }
   }
   {
-  static bool attr_set = false;
   auto kern = conv3_wgrad_mfma_kernel<T, 0>;
-  {
-    static const char *abl = getenv("DGTTA_WGRAD_ABL");      // diagnostic only
-    if (abl && abl[0] == '1') kern = conv3_wgrad_mfma_kernel<T, 1>;
-    if (abl && abl[0] == '2') kern = conv3_wgrad_mfma_kernel<T, 2>;
-    if (abl && abl[0] == '3') kern = conv3_wgrad_mfma_kernel<T, 3>;
-    if (abl && abl[0] == '6') kern = conv3_wgrad_mfma_kernel<T, 6>;
-    if (abl) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)WG<T>::LDS_BYTES);
-  }
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)WG<T>::LDS_BYTES);
-    attr_set = true;
-  }
+  static DynLdsOnce mf_once;
+  DG_REQUIRE(ensure_dyn_lds(mf_once, reinterpret_cast<const void *>(kern), (int)WG<T>::LDS_BYTES) == hipSuccess,
+             DGTTA_ERR_LAUNCH, "wgrad_mfma: cannot raise the dynamic LDS limit");
   hipLaunchKernelGGL(kern, dim3((unsigned)p.units, (unsigned)(p.cibs * p.cobs), (unsigned)wc.n), dim3(256), WG<T>::LDS_BYTES,
                      st, (const T *)x, xv, (const T *)dy, yv, (float *)ws, Cin, Cout, p.tW, p.tH, p.nsd, p.DR, p.cobs, wc);
   DG_CHECK_LAUNCH("conv3_wgrad_mfma_kernel");
@@ -1071,20 +1047,16 @@ static int wgrad_conv(const void *x, int ldx, const void *dy, int lddy, float *d
   const View yv = dense_view(B, Do, Ho, Wo, lddy);
   if (sizeof(T) == 2) {
     // one pass over x (full resolution tile) and dy with all 27 taps: conv3_wgrad_tr_s2_kernel
-    const char *one = getenv("DGTTA_WGRAD_S2_ONEPASS");      // diagnostic / tests: "0" = the 8-class launch
+    const int one = dgtta_switches().wgrad_s2_onepass;      // DGTTA_WGRAD_S2_ONEPASS=0 (tests): the 8-class launch
     const View xfull = dense_view(B, Di, Hi, Wi, ldx);
     WgradPlan p = wgrad_plan_s2(B, Cin, Cout, Do, Ho, Wo);
     const size_t need = (size_t)p.units * p.cibs * p.cobs * 27 * 1024 * sizeof(float);
     const bool ok = Cout % 8 == 0 && ldx % 8 == 0 && lddy % 8 == 0 && !((uintptr_t)x & 15) && !((uintptr_t)dy & 15) &&
                     ldx >= (Cin + 7) / 8 * 8 && ws_bytes >= need && p.units < (1ll << 31) && p.cibs * p.cobs <= 65535;
-    if (ok && !(one && one[0] == '0')) {
-      static bool attr = false;
-      if (!attr) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(conv3_wgrad_tr_s2_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)WT2::LDS_BYTES);
-        DG_REQUIRE(e == hipSuccess, DGTTA_ERR_LAUNCH, "wgrad_tr_s2: cannot raise the dynamic LDS limit");
-        attr = true;
-      }
+    if (ok && one != '0') {
+      static DynLdsOnce once;
+      DG_REQUIRE(ensure_dyn_lds(once, reinterpret_cast<const void *>(conv3_wgrad_tr_s2_kernel), (int)WT2::LDS_BYTES) ==
+                     hipSuccess, DGTTA_ERR_LAUNCH, "wgrad_tr_s2: cannot raise the dynamic LDS limit");
       hipLaunchKernelGGL(conv3_wgrad_tr_s2_kernel, dim3((unsigned)p.units, (unsigned)(p.cibs * p.cobs)), dim3(256),
                          WT2::LDS_BYTES, st, (const bf16_t *)x, xfull, (const bf16_t *)dy, yv, (float *)ws, Cin, Cout, p.tW,
                          p.tH, p.nsd, p.DR, p.cobs);
@@ -1153,20 +1125,16 @@ static int convT_wgrad(const void *x, int ldx, const void *dout, int lddo, float
                        int Cin, int Cout, int Di, int Hi, int Wi, int accumulate, hipStream_t st) {
   const View xv = dense_view(B, Di, Hi, Wi, ldx);
   if (sizeof(T) == 2) {
-    const char *one = getenv("DGTTA_CONVT_WGRAD_ONEPASS");      // diagnostic / tests: "0" = the 8-class launch
+    const int one = dgtta_switches().convt_wgrad_onepass;      // DGTTA_CONVT_WGRAD_ONEPASS=0 (tests): the 8-class launch
     const View yfull = dense_view(B, 2 * Di, 2 * Hi, 2 * Wi, lddo);
     WgradPlan p = wgrad_plan_s2(B, Cin, Cout, Di, Hi, Wi);        // same tile shape (2 rows x 16 voxels) on the input lattice
     const size_t need = (size_t)p.units * p.cibs * p.cobs * 27 * 1024 * sizeof(float);
     const bool ok = Cout % 8 == 0 && ldx % 8 == 0 && lddo % 8 == 0 && !((uintptr_t)x & 15) && !((uintptr_t)dout & 15) &&
                     ldx >= (Cin + 7) / 8 * 8 && ws_bytes >= need && p.units < (1ll << 31) && p.cibs * p.cobs <= 65535;
-    if (ok && !(one && one[0] == '0')) {
-      static bool attr = false;
-      if (!attr) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(convT_wgrad_tr_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)WT3::LDS_BYTES);
-        DG_REQUIRE(e == hipSuccess, DGTTA_ERR_LAUNCH, "convT_wgrad_tr: cannot raise the dynamic LDS limit");
-        attr = true;
-      }
+    if (ok && one != '0') {
+      static DynLdsOnce once;
+      DG_REQUIRE(ensure_dyn_lds(once, reinterpret_cast<const void *>(convT_wgrad_tr_kernel), (int)WT3::LDS_BYTES) ==
+                     hipSuccess, DGTTA_ERR_LAUNCH, "convT_wgrad_tr: cannot raise the dynamic LDS limit");
       hipLaunchKernelGGL(convT_wgrad_tr_kernel, dim3((unsigned)p.units, (unsigned)(p.cibs * p.cobs)), dim3(256),
                          WT3::LDS_BYTES, st, (const bf16_t *)x, xv, (const bf16_t *)dout, yfull, (float *)ws, Cin, Cout, p.tW,
                          p.tH, p.nsd, p.DR, p.cobs);

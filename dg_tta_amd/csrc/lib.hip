@@ -13,3 +13,42 @@ void dgtta_set_error(const char *fmt, ...) {
 
 extern "C" int dgtta_version(void) { return 10000; /* 1.0.0 */ }
 extern "C" const char *dgtta_last_error(void) { return g_err; }
+
+// ---------------------------------------------------------------- environment switches (snapshot, see common.h)
+#include <mutex>
+#include <stdlib.h>
+
+static std::atomic<const DgttaSwitches *> g_switches{nullptr};
+static std::once_flag g_switches_once;
+
+static int env_char(const char *name) {
+  const char *v = getenv(name);
+  return (v && v[0]) ? (int)(unsigned char)v[0] : -1;
+}
+
+static const DgttaSwitches *read_switches() {
+  DgttaSwitches *s = new DgttaSwitches;       // snapshots are immutable and never freed (a handful of bytes per reload)
+  s->conv_rows = env_char("DGTTA_CONV_ROWS");
+  s->conv_variant = env_char("DGTTA_CONV_VARIANT");
+  s->conv_s2 = env_char("DGTTA_CONV_S2");
+  s->dgrad_s2_allcls = env_char("DGTTA_DGRAD_S2_ALLCLS");
+  s->wgrad_tr = env_char("DGTTA_WGRAD_TR");
+  s->wgrad_tr8 = env_char("DGTTA_WGRAD_TR8");
+  s->wgrad_s2_onepass = env_char("DGTTA_WGRAD_S2_ONEPASS");
+  s->convt_wgrad_onepass = env_char("DGTTA_CONVT_WGRAD_ONEPASS");
+  s->conv_abl = env_char("DGTTA_CONV_ABL");
+  s->rows_abl = env_char("DGTTA_ROWS_ABL");
+  s->wgrad_abl = env_char("DGTTA_WGRAD_ABL");
+  return s;
+}
+
+const DgttaSwitches &dgtta_switches() {
+  std::call_once(g_switches_once, [] { g_switches.store(read_switches(), std::memory_order_release); });
+  return *g_switches.load(std::memory_order_acquire);
+}
+
+extern "C" int dgtta_reload_env(void) {
+  (void)dgtta_switches();
+  g_switches.store(read_switches(), std::memory_order_release);
+  return DGTTA_OK;
+}

@@ -335,15 +335,11 @@ bool vec_ok(const void *a, const void *b, const void *c, const void *d, int ldc)
   return ldc % 4 == 0 && (((uintptr_t)a | (uintptr_t)b | (uintptr_t)c | (uintptr_t)d) & 15) == 0;
 }
 
-int allow_big_lds() {
-  static int rc = [] {
-    hipError_t e1 = hipFuncSetAttribute((const void *)softdice_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        (int)LDS_BUDGET);
-    hipError_t e2 = hipFuncSetAttribute((const void *)softdice_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        (int)LDS_BUDGET);
-    return (e1 == hipSuccess && e2 == hipSuccess) ? 0 : -1;
-  }();
-  return rc;
+int allow_big_lds() {      // per device, once (common.h: DynLdsOnce)
+  static DynLdsOnce fwd_once, bwd_once;
+  const hipError_t e1 = ensure_dyn_lds(fwd_once, (const void *)softdice_fwd_kernel, (int)LDS_BUDGET);
+  const hipError_t e2 = ensure_dyn_lds(bwd_once, (const void *)softdice_bwd_kernel, (int)LDS_BUDGET);
+  return (e1 == hipSuccess && e2 == hipSuccess) ? 0 : -1;
 }
 
 }  // namespace

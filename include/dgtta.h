@@ -45,6 +45,9 @@ extern "C" {
 
 int dgtta_version(void);
 const char *dgtta_last_error(void);
+/* The DGTTA_* diagnostic switches are read from the environment once, at first use; this call takes a
+ * fresh snapshot (tests that flip a switch inside one process call it after changing the environment). */
+int dgtta_reload_env(void);
 
 /* ---------------------------------------------------------------------------------------------
  * MIND3D descriptor.  Replaces MIND3D.forward + smooth + filter1D (dg_tta/mind.py:142-164, :27-43,

@@ -40,3 +40,19 @@ SMALL_CFG = dict(features=(8, 16, 24), strides=(1, 2, 2), n_conv_enc=(2, 2, 2), 
 
 def state_from_golden(g, prefix="w::"):
     return {k[len(prefix):]: v for k, v in g.items() if k.startswith(prefix)}
+
+
+def reload_kernel_switches():
+    """The library snapshots the DGTTA_* diagnostic switches once (std::call_once); tests that flip one inside the
+    process take a fresh snapshot after changing the environment."""
+    from dg_tta_amd import _lib
+    _lib.load().dgtta_reload_env()
+
+
+@pytest.fixture(autouse=True)
+def _fresh_kernel_switches():
+    yield
+    try:                                   # after monkeypatch has restored the environment
+        reload_kernel_switches()
+    except Exception:
+        pass

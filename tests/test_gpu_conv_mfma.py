@@ -5,6 +5,8 @@ import pytest
 import torch
 import torch.nn.functional as F
 
+from conftest import reload_kernel_switches
+
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
@@ -101,6 +103,7 @@ def test_conv_rows_kernel_bf16(case, monkeypatch):
 
     def run(rows):
         monkeypatch.setenv("DGTTA_CONV_ROWS", rows)
+        reload_kernel_switches()
         wpack = torch.empty(lib.dgtta_conv3d_packed_bytes(cinp, coutp, 1) // 2, dtype=torch.bfloat16, device=DEV)
         check(lib.dgtta_conv3d_pack_weights(ptr(w), ptr(wpack), cin, cout, cinp, coutp, 1, stream_of()), "pack")
         y = torch.full((B, D, H, W, cout), float("nan"), dtype=torch.bfloat16, device=DEV)
@@ -382,6 +385,7 @@ def test_full_size_128_conv_two_kernels_agree_and_are_linear(monkeypatch):
 
     def conv(x, rows):
         monkeypatch.setenv("DGTTA_CONV_ROWS", rows)
+        reload_kernel_switches()
         y = torch.empty((1, n, n, n, c), dtype=torch.bfloat16, device=DEV)
         st = torch.zeros(nb, dtype=torch.uint8, device=DEV)
         check(lib.dgtta_conv3d_k3_fwd(ptr(x), c, ptr(wpack), None, ptr(y), c, ptr(st), 1, c, c, c, c, n, n, n, 1, 1, 2,
@@ -420,8 +424,10 @@ def test_full_size_128_wgrad_two_kernels_agree(monkeypatch):
     x = torch.randn(1, n, n, n, c, device=DEV, generator=g).bfloat16()
     dy = torch.randn(1, n, n, n, c, device=DEV, generator=g).bfloat16()
     monkeypatch.setenv("DGTTA_WGRAD_TR", "1")
+    reload_kernel_switches()
     dw1, db1 = _call_wgrad(x, dy, c, c, 1, 1, 2)
     monkeypatch.setenv("DGTTA_WGRAD_TR", "0")
+    reload_kernel_switches()
     dw0, db0 = _call_wgrad(x, dy, c, c, 1, 1, 2)
     assert float((dw1 - dw0).abs().max()) < 2e-4 * float(dw0.abs().max()) + 1e-3
     assert torch.equal(db1, db0)
@@ -452,6 +458,7 @@ def test_dgrad_stride2_all_classes(case, dt, monkeypatch):
 
     def run(impl, allcls):
         monkeypatch.setenv("DGTTA_DGRAD_S2_ALLCLS", allcls)
+        reload_kernel_switches()
         dx = dx0.clone()
         check(lib.dgtta_conv3d_k3_dgrad(ptr(dy), cout, ptr(wpack), ptr(dx), cin, B, cin, cout, cinp, coutp, D, H, W, 2, acc,
                                         dt, impl, stream_of()), "dgrad")
@@ -475,8 +482,10 @@ def test_wgrad_stride2_one_pass_bf16(case, monkeypatch):
     dy = torch.randn(B, D // 2, H // 2, W // 2, cout, device=DEV).bfloat16()
     ref, _ = _call_wgrad(x.float(), dy.float(), cin, cout, 2, 0, 1)
     monkeypatch.setenv("DGTTA_WGRAD_S2_ONEPASS", "0")
+    reload_kernel_switches()
     cls8, _ = _call_wgrad(x, dy, cin, cout, 2, 1, 2)
     monkeypatch.setenv("DGTTA_WGRAD_S2_ONEPASS", "1")
+    reload_kernel_switches()
     one, _ = _call_wgrad(x, dy, cin, cout, 2, 1, 2)
     tol = 1e-4 * float(ref.abs().max()) + 1e-4
     assert float((cls8 - ref).abs().max()) < tol

@@ -55,3 +55,51 @@ def test_ensemble_sliding_window_matches_cpu_restatement(tmp_path):
     mapped = run_inference(data, net, [m.state_dict() for m in members], patch, mapping, ["background", "a", "b"])
     assert set(mapped.unique().tolist()) <= {0, 1, 2}
     assert torch.equal(mapped == 1, seg == 2) and torch.equal(mapped == 2, seg == 5)
+
+
+@pytest.mark.gpu
+def test_sliding_window_at_size_properties():
+    """BASELINE config 3's mechanics at size: the FULL 3d_fullres net (105 classes, bf16 MFMA path) over a 256 x 192 x 320
+    volume with 128^3 Gaussian windows (3 x 2 x 4 = 24 windows, batched 4 per pass).  Size-independent properties:
+    (a) the accumulated weight map equals the sum of the window Gaussians (computed on the host from the window origins);
+    (b) acc / nsum inside a region covered by exactly ONE window equals the plain forward of that window;
+    (c) a volume of exactly one window reproduces the plain forward everywhere (weights cancel);
+    (d) the label map is the argmax of the accumulated logits over ALL pretrain classes."""
+    from dg_tta_amd.mind import MIND3D
+    from dg_tta_amd.synthetic import he_init_
+    from dg_tta_amd.tta.inference import (compute_gaussian, compute_steps_for_sliding_window,
+                                          predict_sliding_window_return_logits, run_inference)
+    from dg_tta_amd.unet import HipPlainConvUNet
+    net = he_init_(HipPlainConvUNet(act_dtype=torch.bfloat16), seed=7).to(DEV)
+    net.register_forward_pre_hook(lambda mod, inp: MIND3D(randn_weighting=0.0).forward(*inp, out_dtype=torch.bfloat16))
+    patch = [128, 128, 128]
+    torch.manual_seed(1)
+    vol = torch.randn(1, 256, 192, 320)
+    acc, nsum, crop = predict_sliding_window_return_logits(net, vol, patch)
+    assert tuple(acc.shape) == (256, 192, 320, 105) and all(c == slice(0, s) for c, s in zip(crop, vol.shape[1:]))
+    steps = compute_steps_for_sliding_window(vol.shape[1:], patch)
+    assert steps == [[0, 64, 128], [0, 64], [0, 64, 128, 192]]
+    g = compute_gaussian(tuple(patch))
+    ref_n = torch.zeros(vol.shape[1:])
+    for sx in steps[0]:
+        for sy in steps[1]:
+            for sz in steps[2]:
+                ref_n[sx:sx + 128, sy:sy + 128, sz:sz + 128] += g
+    assert (nsum.cpu() - ref_n).abs().max() < 1e-4 * ref_n.max()                        # (a)
+    # (b) the corner [0:64, 0:64, 0:64] is covered by the first window only
+    with torch.no_grad():
+        first = net(vol[None, :, :128, :128, :128].to(DEV)).float()[0]                  # [105,128,128,128]
+    corner = (acc[:64, :64, :64] / nsum[:64, :64, :64, None]).permute(3, 0, 1, 2)
+    # (batch-1 vs batch-4 passes pick different tilings for the small layers: bf16 rounding of the activations differs)
+    assert (corner - first[:, :64, :64, :64]).abs().max() < 1.5e-2 * first.abs().max()
+    # (d) label map = argmax over all 105 classes of the accumulated logits
+    seg = run_inference(vol, net, [net.state_dict()], patch)
+    am = acc.argmax(-1).cpu()
+    top2 = acc.topk(2, dim=-1).values
+    safe = ((top2[..., 0] - top2[..., 1]) > 1e-3 * nsum).cpu()
+    assert torch.equal(seg[safe], am[safe]) and (seg == am).float().mean() > 0.999
+    del acc, nsum, corner, top2
+    # (c) single-window volume
+    one = vol[:, :128, :128, :128]
+    acc1, nsum1, _ = predict_sliding_window_return_logits(net, one, patch)
+    assert (acc1 / nsum1[..., None] - first.permute(1, 2, 3, 0)).abs().max() < 1e-4 * first.abs().max()

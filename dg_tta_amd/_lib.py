@@ -50,6 +50,8 @@ SIGNATURES = {
     "dgtta_ncdhw_to_ndhwc": (I, [P, P, I, I, I64, I, I, P]),
     "dgtta_ndhwc_to_ncdhw": (I, [P, P, I, I, I64, I, I, P]),
     "dgtta_argmax_dice": (I, [P, I, I, P, P, P, I, I64, P]),
+    "dgtta_resample_axis_ws_bytes": (SZ, [I64, I, I64, I]),
+    "dgtta_resample_axis": (I, [P, P, P, SZ, I64, I, I, I64, I, P]),
     "dgtta_window_accumulate": (I, [P, P, P, P, I, I, I, I, I, I, I, I, I, I, P]),
 }
 

@@ -322,3 +322,36 @@ def argmax_dice_from_labels(pred, labels, num_classes):
     check(lib.dgtta_argmax_dice(None, 0, num_classes, ptr(lb), ptr(pr), ptr(counts), 1, pr.numel(),
                                 stream_of(pr.device)), "dgtta_argmax_dice")
     return pr, counts
+
+
+# ------------------------------------------------------------------------------------------------ resampling
+def resize_volume(x, new_shape, order, axes=None):
+    """skimage.transform.resize(x[c], new_shape, order, mode='edge', anti_aliasing=False, clip=False) for every leading
+    index c, on the GPU: x [..., X, Y, Z] (any float dtype, CUDA) -> double [..., *new_shape].  `axes`: subset of the
+    three trailing axes to resample (others must keep their size).  One separable pass per axis (csrc/resample.hip)."""
+    require_cuda(x)
+    lib = _lib.load()
+    cur = x.double().contiguous()
+    lead = cur.shape[:-3]
+    outer0 = 1
+    for s in lead:
+        outer0 *= int(s)
+    for ax in (range(3) if axes is None else axes):
+        shp = list(cur.shape[-3:])
+        n, m = shp[ax], int(new_shape[ax])
+        if n == m:
+            continue
+        inner = 1
+        for s in shp[ax + 1:]:
+            inner *= s
+        outer = outer0
+        for s in shp[:ax]:
+            outer *= s
+        out_shape = shp[:ax] + [m] + shp[ax + 1:]
+        dst = torch.empty((*lead, *out_shape), dtype=torch.float64, device=cur.device)
+        nbytes = lib.dgtta_resample_axis_ws_bytes(outer, n, inner, int(order))
+        ws = _ws(nbytes, cur.device)
+        check(lib.dgtta_resample_axis(ptr(cur), ptr(dst), ptr(ws), nbytes, outer, n, m, inner, int(order),
+                                      stream_of(cur.device)), "dgtta_resample_axis")
+        cur = dst
+    return cur

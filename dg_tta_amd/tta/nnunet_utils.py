@@ -5,8 +5,8 @@ reference's dg_tta/tta/nnunet_utils.py (load_network :88-113, load_tta_data :63-
   builds a HipPlainConvUNet with the plans' topology and registers the trainer's forward pre-hooks in the reference's
   order (gin_hook, then mind_hook: dg_tta/pretraining/nnUNetTrainer_GIN_MIND.py:55-57).
 * `load_tta_data` yields `{"data": FloatTensor[1+K,D,H,W], "data_properties", "ofile"}` items like
-  preprocess_fromfile.  Cases are read from PRE-PROCESSED arrays (`.npy`, `.npz` with key `data`, or `.pt`);
-  reading NIfTI + nnU-Net resampling/normalisation is the "next" row of SURVEY.md §8f and needs SimpleITK/nnunetv2.
+  preprocess_fromfile.  Raw NIfTI cases are cropped, normalised and resampled as nnU-Net's DefaultPreprocessor does
+  (tta/preprocessing.py); `.npy`, `.npz` (key `data`) and `.pt` files are taken as already preprocessed arrays.
 """
 import json
 import re
@@ -97,7 +97,30 @@ def _read_array(path):
                               f"(SURVEY.md §8f 'next'); provide preprocessed .npy/.npz/.pt arrays [C,D,H,W]")
 
 
-def preprocess_fromfile(image_file, label_file, ofile):
+def _is_nifti(path):
+    n = Path(path).name
+    return n.endswith(".nii") or n.endswith(".nii.gz")
+
+
+def preprocess_fromfile(image_file, label_file, ofile, predictor=None):
+    """dg_tta/tta/nnunet_utils.py:170-204: preprocessed image channel(s) + one one-hot channel per foreground label.
+    NIfTI cases go through the restated DefaultPreprocessor (tta/preprocessing.py: crop, normalise, resample to the
+    plans' spacing; resampling on the GPU); `.npy/.npz/.pt` cases are taken as already preprocessed arrays."""
+    if _is_nifti(image_file):
+        if predictor is None or not hasattr(predictor, "plans"):
+            raise RuntimeError("raw NIfTI cases need the model's plans.json (load_network's predictor) for preprocessing")
+        from .preprocessing import run_case
+        lbl = label_file if (label_file is not None and Path(label_file).is_file()) else None
+        data, seg, props = run_case([image_file], lbl, predictor.plans, predictor.configuration,
+                                    getattr(predictor, "device", "cuda"))
+        img = torch.from_numpy(np.ascontiguousarray(data)).float()
+        out = img
+        if lbl is not None:
+            k = int(max(seg.max(), 0))
+            seg_t = torch.from_numpy(seg[0].astype(np.int64))
+            onehot = torch.stack([(seg_t == i + 1).float() for i in range(k)]) if k > 0 else torch.zeros((0, *seg_t.shape))
+            out = torch.cat([img, onehot], 0)
+        return {"data": out.contiguous().float(), "data_properties": props, "ofile": ofile}
     img = _read_array(image_file).float()
     if img.dim() == 3:
         img = img[None]
@@ -111,7 +134,7 @@ def preprocess_fromfile(image_file, label_file, ofile):
     return {"data": data.contiguous().float(), "data_properties": {"shape": tuple(img.shape[1:])}, "ofile": ofile}
 
 
-def get_data_iterator(tta_data_filepaths, dataset_raw_path, bucket):
+def get_data_iterator(tta_data_filepaths, dataset_raw_path, bucket, predictor=None):
     assert bucket in ("imagesTs", "imagesTr")
     files = [Path(p) for p in tta_data_filepaths if Path(p).parts[-2] == bucket]
     label_folder = Path(dataset_raw_path) / ("labelsTs" if bucket == "imagesTs" else "labelsTr")
@@ -123,14 +146,14 @@ def get_data_iterator(tta_data_filepaths, dataset_raw_path, bucket):
             m = _CASE_RE.match(stem)
             case = m.group(1) if m else stem
             lbl = label_folder / (case + "".join(f.suffixes))
-            yield preprocess_fromfile(f, lbl if lbl.is_file() else None, f"{out_folder}/{case}")
+            yield preprocess_fromfile(f, lbl if lbl.is_file() else None, f"{out_folder}/{case}", predictor)
 
     return gen(), len(files)
 
 
 def load_tta_data(config, dataset_raw_path, predictor=None, tta_across_all_samples=False):
-    ts_it, ts_n = get_data_iterator(config["tta_data_filepaths"], dataset_raw_path, "imagesTs")
-    tr_it, tr_n = get_data_iterator(config["tta_data_filepaths"], dataset_raw_path, "imagesTr")
+    ts_it, ts_n = get_data_iterator(config["tta_data_filepaths"], dataset_raw_path, "imagesTs", predictor)
+    tr_it, tr_n = get_data_iterator(config["tta_data_filepaths"], dataset_raw_path, "imagesTr", predictor)
     if tta_across_all_samples:
         return list(ts_it) + list(tr_it), ts_n + tr_n
     return chain(ts_it, tr_it), ts_n + tr_n

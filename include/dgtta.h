@@ -226,6 +226,15 @@ int dgtta_argmax_dice(const float *logits, int ldc, int C, const int64_t *labels
 int dgtta_window_accumulate(const float *patch, const float *gauss, float *acc, float *nsum, int C, int PD, int PH,
                             int PW, int X, int Y, int Z, int x0, int y0, int z0, void *stream);
 
+/* One-axis spline resampling (order 0 / 1 / 3) with the coordinate rule and boundary handling of
+ * skimage.transform.resize(mode='edge', anti_aliasing=False) = scipy.ndimage.zoom(mode='nearest', grid_mode=True), which is
+ * what nnU-Net's DefaultPreprocessor resamples with (third-party nnunetv2==2.2.1, reached from preprocess_fromfile,
+ * dg_tta/tta/nnunet_utils.py:170-204).  src: double [outer][n][inner], dst: double [outer][m][inner]; applied per axis
+ * by the caller (the nD operation is separable).  ws: dgtta_resample_axis_ws_bytes (order 3 only). */
+size_t dgtta_resample_axis_ws_bytes(int64_t outer, int n, int64_t inner, int order);
+int dgtta_resample_axis(const double *src, double *dst, void *ws, size_t ws_bytes, int64_t outer, int n, int m,
+                        int64_t inner, int order, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -35,7 +35,7 @@ def build_workload(args, device, rank):
     from dg_tta_amd.synthetic import he_init_, synthetic_case, synthetic_label_mapping
     from dg_tta_amd.tta.config_log_utils import ModifierFunctions, TEMPLATE_PLAN
     from dg_tta_amd.unet import HipPlainConvUNet
-    act = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    act = {"fp32": torch.float32, "bf16": torch.bfloat16, "fp16": torch.float16}[args.dtype]
     net = he_init_(HipPlainConvUNet(act_dtype=act, conv_impl=args.impl), seed=7)
     net.exact_zero_bias_grad = True
     net.accumulate_grads_in_place = True
@@ -68,7 +68,7 @@ class EpochRunner:
         self.patch = [args.size] * 3
         self.model = get_model_from_network(net, self.modmod, None)
         self.fused = _fuse_head_if_possible(self.model, self.modmod, self.mapping, self.cfg["optimized_labels"])
-        self.opt = HipAdamW(self.model.parameters(), lr=self.cfg["lr"])
+        self.opt = HipAdamW(self.model.parameters(), lr=self.cfg["lr"], grad_scale=self.model.loss_scale)
         disable_internal_augmentation()
         self.model.apply(fix_all)
         self.model.apply(release_all)            # measured epochs are adaptation epochs (epoch >= start_tta_at_epoch)
@@ -124,7 +124,8 @@ def inference_leg(args, device):
     from dg_tta_amd.unet import HipPlainConvUNet
     from dg_tta_amd import ops
     n = args.inference_size
-    net = he_init_(HipPlainConvUNet(act_dtype=torch.bfloat16 if args.dtype == "bf16" else torch.float32), seed=7)
+    net = he_init_(HipPlainConvUNet(act_dtype={"fp32": torch.float32, "bf16": torch.bfloat16,
+                                               "fp16": torch.float16}[args.dtype]), seed=7)
     net.register_forward_pre_hook(mind_hook)
     net = net.to(device)
     vol = torch.randn(1, n, n, n, generator=torch.Generator().manual_seed(3)).to(device)
@@ -160,12 +161,12 @@ def roofline_of(probe, args, dtype):
     times = [t for t, n in times if n == nb]
     avg_ms = sum(times) / len(times)
     flop = conv_flops(probe["cin"], probe["cout"], probe["vout"]) * nb
-    peak = 2500.0 if dtype == "bf16" else 157.3
+    peak = 157.3 if dtype == "fp32" else 2500.0
     ach = flop / (avg_ms * 1e-3) / 1e12
     traffic, src = None, None       # HBM bytes per launch: rocprofv3 PMC passes committed under profiles/ (not a live counter)
     for cand in ("r02_pmc_summary.json", "r01_pmc_summary.json"):
         pmc = ROOT / "profiles" / cand
-        if pmc.exists() and dtype == "bf16" and args.size == 128:
+        if pmc.exists() and dtype != "fp32" and args.size == 128:
             d = json.loads(pmc.read_text()).get("conv_128cube_32to32", {})
             if "fetch_bytes_corrected_median" in d:     # PMC pass = one sample of this layer; scaled by the batch
                 traffic = (d["fetch_bytes_corrected_median"] + d["write_bytes_median"]) * nb
@@ -173,7 +174,7 @@ def roofline_of(probe, args, dtype):
                 break
     return {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
             "traffic": traffic, "traffic_source": src,
-            "kernel": "conv3_rows_kernel" if dtype == "bf16" else "conv3_mfma_kernel",
+            "kernel": "conv3_mfma_kernel" if dtype == "fp32" else "conv3_rows_kernel",
             "launches": len(times), "avg_ms": round(avg_ms, 4), "flop_per_launch": flop, "samples_per_launch": nb,
             "scope": "forward launches of block dec.3.1 (128^3 32->32, fused statistics) in the training passes "
                      "(samples_per_launch = 2 branches x k accumulation steps); the kernel name also runs the other "
@@ -188,7 +189,7 @@ def main():
     ap.add_argument("--size", type=int, default=128)
     ap.add_argument("--accum", type=int, default=16)
     ap.add_argument("--copt", type=int, default=16)
-    ap.add_argument("--dtype", default="bf16", choices=["fp32", "bf16"],
+    ap.add_argument("--dtype", default="bf16", choices=["fp32", "bf16", "fp16"],
                     help="activation storage; accumulation, statistics, loss, gradients of weights and AdamW are fp32")
     ap.add_argument("--impl", type=int, default=0)
     ap.add_argument("--cpu-size", type=int, default=128)
@@ -240,7 +241,7 @@ def main():
     del runner
     torch.cuda.empty_cache()
     other = None
-    if not args.no_fp32 and main_dtype == "bf16":
+    if not args.no_fp32 and main_dtype != "fp32":
         # the reference never autocasts during TTA: the same epoch with fp32 storage / fp32 MFMA
         fdt, frunner, froof = timed_run("fp32", 1, 1)
         other = {"value": round(world / fdt, 5), "value_per_gpu": round(1.0 / fdt, 5), "unit": "TTA-epochs/s", "steps": 1,

@@ -29,7 +29,7 @@ SIGNATURES = {
     "dgtta_softdice_probs_fwd": (I, [P, P, P, P, SZ, I, I, I64, I64, I64, I64, P]),
     "dgtta_softdice_probs_bwd": (I, [P, P, P, P, P, P, I, I, I64, I64, I64, I64, P]),
     "dgtta_adamw_step": (I, [C.POINTER(P), C.POINTER(P), C.POINTER(P), C.POINTER(P), C.POINTER(I64), I, F, F, F, F, F,
-                             I, P]),
+                             I, F, P]),
     "dgtta_conv3d_packed_bytes": (SZ, [I, I, I]),
     "dgtta_conv3d_pack_weights": (I, [P, P, I, I, I, I, I, P]),
     "dgtta_conv3d_stats_bytes": (SZ, [I, I, I, I, I]),

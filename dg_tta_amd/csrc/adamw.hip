@@ -24,7 +24,7 @@ struct AdamArgs {
 constexpr int CHUNK = 256 * 16;  // elements per workgroup
 
 __global__ __launch_bounds__(256) void adamw_kernel(AdamArgs a, int nt, float lr_wd, float b1, float b2, float eps,
-                                                    float step_size, float sqrt_bc2) {
+                                                    float step_size, float sqrt_bc2, float inv_scale) {
   int t = 0;
   while (t + 1 < nt && (int)blockIdx.x >= a.blk_start[t + 1]) ++t;
   const int64_t base = (int64_t)((int)blockIdx.x - a.blk_start[t]) * CHUNK;
@@ -35,7 +35,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(AdamArgs a, int nt, float lr
   for (int k = 0; k < CHUNK / 256; ++k) {
     const int64_t i = base + k * 256 + threadIdx.x;
     if (i < n) {
-      float gi = g[i], pi = p[i], mi = m[i], vi = v[i];
+      float gi = g[i] * inv_scale, pi = p[i], mi = m[i], vi = v[i];       // inv_scale = 1 / loss scale (exactly 1 if unused)
       pi = pi * (1.0f - lr_wd);
       mi = mi + (gi - mi) * (1.0f - b1);
       vi = vi * b2 + ((1.0f - b2) * gi) * gi;
@@ -52,9 +52,10 @@ __global__ __launch_bounds__(256) void adamw_kernel(AdamArgs a, int nt, float lr
 
 extern "C" int dgtta_adamw_step(float *const *h_p, const float *const *h_g, float *const *h_m, float *const *h_v,
                                 const int64_t *h_n, int ntensors, float lr, float beta1, float beta2, float eps,
-                                float weight_decay, int step, void *stream) {
+                                float weight_decay, int step, float grad_scale, void *stream) {
   DG_REQUIRE(h_p && h_g && h_m && h_v && h_n, DGTTA_ERR_BADARG, "adamw_step: null table");
   DG_REQUIRE(ntensors >= 0 && step >= 1, DGTTA_ERR_BADARG, "adamw_step: bad ntensors/step");
+  DG_REQUIRE(grad_scale > 0.f, DGTTA_ERR_BADARG, "adamw_step: grad_scale must be positive (1 = gradients are unscaled)");
   hipStream_t st = (hipStream_t)stream;
   const double bc1 = 1.0 - pow((double)beta1, (double)step);
   const double bc2 = 1.0 - pow((double)beta2, (double)step);
@@ -81,7 +82,7 @@ extern "C" int dgtta_adamw_step(float *const *h_p, const float *const *h_g, floa
     if (nt == 0) break;
     a.blk_start[nt] = blocks;
     hipLaunchKernelGGL(adamw_kernel, dim3(blocks), dim3(256), 0, st, a, nt, lr * weight_decay, beta1, beta2, eps,
-                       step_size, sqrt_bc2);
+                       step_size, sqrt_bc2, 1.0f / grad_scale);
     DG_CHECK_LAUNCH("adamw_kernel");
   }
   return DGTTA_OK;

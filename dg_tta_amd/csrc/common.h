@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <hip/hip_bf16.h>
+#include <hip/hip_fp16.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdarg.h>
@@ -69,12 +70,47 @@ __device__ __forceinline__ bf16_t f32_to_bf16(float f) {
   return *reinterpret_cast<bf16_t *>(&b);
 }
 
+// fp16 storage (IEEE binary16) is a distinct C++ type so that templates can tell it from bf16; same size and alignment.
+struct f16_t {
+  unsigned short v;
+};
+__device__ __forceinline__ float f16_to_f32(unsigned short h) {
+  return __half2float(__ushort_as_half(h));
+}
+__device__ __forceinline__ unsigned short f32_to_f16(float f) { return __half_as_ushort(__float2half_rn(f)); }
+
+// 16-bit conversions selected by the storage type (bf16_t or f16_t)
+template <typename T>
+__device__ __forceinline__ unsigned short f32_to_16(float f);
+template <>
+__device__ __forceinline__ unsigned short f32_to_16<bf16_t>(float f) { return f32_to_bf16(f); }
+template <>
+__device__ __forceinline__ unsigned short f32_to_16<f16_t>(float f) { return f32_to_f16(f); }
+template <typename T>
+__device__ __forceinline__ unsigned pack2_16(float lo, float hi) {
+  return (unsigned)f32_to_16<T>(lo) | ((unsigned)f32_to_16<T>(hi) << 16);
+}
+template <typename T>
+__device__ __forceinline__ void unpack2_16(unsigned w, float &lo, float &hi);
+template <>
+__device__ __forceinline__ void unpack2_16<bf16_t>(unsigned w, float &lo, float &hi) {
+  lo = __uint_as_float(w << 16);
+  hi = __uint_as_float(w & 0xffff0000u);
+}
+template <>
+__device__ __forceinline__ void unpack2_16<f16_t>(unsigned w, float &lo, float &hi) {
+  lo = f16_to_f32((unsigned short)(w & 0xffffu));
+  hi = f16_to_f32((unsigned short)(w >> 16));
+}
+
 template <typename T>
 __device__ __forceinline__ float ld_f(const T *p);
 template <>
 __device__ __forceinline__ float ld_f<float>(const float *p) { return *p; }
 template <>
 __device__ __forceinline__ float ld_f<bf16_t>(const bf16_t *p) { return bf16_to_f32(*p); }
+template <>
+__device__ __forceinline__ float ld_f<f16_t>(const f16_t *p) { return f16_to_f32(p->v); }
 
 template <typename T>
 __device__ __forceinline__ void st_f(T *p, float v);
@@ -82,6 +118,8 @@ template <>
 __device__ __forceinline__ void st_f<float>(float *p, float v) { *p = v; }
 template <>
 __device__ __forceinline__ void st_f<bf16_t>(bf16_t *p, float v) { *p = f32_to_bf16(v); }
+template <>
+__device__ __forceinline__ void st_f<f16_t>(f16_t *p, float v) { p->v = f32_to_f16(v); }
 
 // ---------------------------------------------------------------- reductions
 __device__ __forceinline__ float wave_sum(float v) {

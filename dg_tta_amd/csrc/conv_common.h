@@ -50,6 +50,10 @@ template <>
 struct Elem<bf16_t> {
   static constexpr int EPV = 8;
 };
+template <>
+struct Elem<f16_t> {
+  static constexpr int EPV = 8;
+};
 
 template <typename T>
 __device__ __forceinline__ void mfma_step(const uint4 &a, const uint4 &b, f32x16_t &acc);
@@ -57,6 +61,11 @@ template <>
 __device__ __forceinline__ void mfma_step<bf16_t>(const uint4 &a, const uint4 &b, f32x16_t &acc) {
   acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), acc, 0,
                                                 0, 0);
+}
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
+template <>
+__device__ __forceinline__ void mfma_step<f16_t>(const uint4 &a, const uint4 &b, f32x16_t &acc) {
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), acc, 0, 0, 0);
 }
 template <>
 __device__ __forceinline__ void mfma_step<float>(const uint4 &a, const uint4 &b, f32x16_t &acc) {

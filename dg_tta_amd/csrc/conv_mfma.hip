@@ -15,9 +15,10 @@
 //   Stride 2:   the halo tile is staged de-interleaved by W parity so that lane reads stay contiguous.
 #include "conv_common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 int conv3_rows_launch(const void *x, const View &xv, const void *w, const Taps &taps, const float *bias, void *y, const View &yv,
-                      int B, int Cin, int Cout, int CinP, int CoutP, double *stats, int ntaps_src, hipStream_t st);
+                      int B, int Cin, int Cout, int CinP, int CoutP, double *stats, int ntaps_src, int is_f16, hipStream_t st);
 
 namespace {
 
@@ -258,22 +259,24 @@ __global__ __launch_bounds__(NW * 64) void conv3_mfma_kernel(const T *__restrict
           const int od = od0 + mbd, oh = oh0 + mbh * G::RPM + m / MBW, ow = ow0 + m % MBW;
           if (n0 + cq < Cout && od < Do && oh < Ho && ow < Wo) {
             T *o = y + cs.yoff[c8] + b * yv.sb + od * yv.sd + oh * yv.sh + ow * yv.sw + n0 + cq;
-            if (sizeof(T) == 2) {
+            if constexpr (sizeof(T) == 2) {
               uint4 *o4 = reinterpret_cast<uint4 *>(o);
               if (accumulate) {
                 const uint4 old = *o4;
                 const unsigned wv[4] = {old.x, old.y, old.z, old.w};
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                  v[2 * e] += __uint_as_float(wv[e] << 16);
-                  v[2 * e + 1] += __uint_as_float(wv[e] & 0xffff0000u);
+                  float lo, hi;
+                  unpack2_16<T>(wv[e], lo, hi);
+                  v[2 * e] += lo;
+                  v[2 * e + 1] += hi;
                 }
               }
               uint4 pk;
-              pk.x = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
-              pk.y = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
-              pk.z = (unsigned)f32_to_bf16(v[4]) | ((unsigned)f32_to_bf16(v[5]) << 16);
-              pk.w = (unsigned)f32_to_bf16(v[6]) | ((unsigned)f32_to_bf16(v[7]) << 16);
+              pk.x = pack2_16<T>(v[0], v[1]);
+              pk.y = pack2_16<T>(v[2], v[3]);
+              pk.z = pack2_16<T>(v[4], v[5]);
+              pk.w = pack2_16<T>(v[6], v[7]);
               *o4 = pk;
             } else {
               float4 *o4 = reinterpret_cast<float4 *>(o);
@@ -410,7 +413,7 @@ int dispatch_conv_classes(const void *x, const View &xv, const void *w, const Co
     const long long njobs = (long long)cdiv(yv.W, 32) * cdiv(yv.H, 8) * cdiv(yv.D, 4) * cdiv(CoutP, 32) * B;
     if (all_taps && vec_out && (njobs >= 256 || rows == '1') && rows != '0')
       return conv3_rows_launch(x, xv, w, cs.taps[0], bias, y, yv, B, Cin, Cout, CinP, CoutP, stats, ntaps_src,
-                                          st);
+                               (int)std::is_same<T, f16_t>::value, st);
   }
   if (stride == 1) {
     // 8 waves per workgroup (2 M-blocks each): 16 waves per CU hide the LDS / barrier latency (+27 % over 4 waves; the
@@ -526,6 +529,10 @@ int conv3_fwd_mfma(const void *x, int ldx, const void *w_kmajor, int mirror, con
     if (!operand_ok<bf16_t>(x, ldx, Cin, CinP)) return DGTTA_ERR_UNSUPPORTED;
     return dispatch_conv<bf16_t>(x, xv, w_kmajor, taps, bias, y, yv, B, Cin, Cout, CinP, CoutP, stride, 0, st, stats);
   }
+  if (dtype == DGTTA_F16) {
+    if (!operand_ok<f16_t>(x, ldx, Cin, CinP)) return DGTTA_ERR_UNSUPPORTED;
+    return dispatch_conv<f16_t>(x, xv, w_kmajor, taps, bias, y, yv, B, Cin, Cout, CinP, CoutP, stride, 0, st, stats);
+  }
   return DGTTA_ERR_UNSUPPORTED;
 }
 
@@ -582,20 +589,21 @@ int conv3_dgrad_s2_mfma(const void *dy, int lddy, const void *w_kmajor, void *dx
                         int CinP, int CoutP, int Di, int Hi, int Wi, int accumulate, int dtype, hipStream_t st) {
   if (dtype == DGTTA_F32) return dgrad_s2<float>(dy, lddy, w_kmajor, dx, lddx, B, Cin, Cout, CinP, CoutP, Di, Hi, Wi, accumulate, st);
   if (dtype == DGTTA_BF16) return dgrad_s2<bf16_t>(dy, lddy, w_kmajor, dx, lddx, B, Cin, Cout, CinP, CoutP, Di, Hi, Wi, accumulate, st);
+  if (dtype == DGTTA_F16) return dgrad_s2<f16_t>(dy, lddy, w_kmajor, dx, lddx, B, Cin, Cout, CinP, CoutP, Di, Hi, Wi, accumulate, st);
   return DGTTA_ERR_UNSUPPORTED;
 }
 
 // ConvTranspose3d(k2,s2) forward / data gradient as 8 single-tap launches (one per output offset o).
 static size_t n32(int c) { return (size_t)(c + 31) / 32 * 32; }
 size_t convT_packed_bytes(int CinP, int CoutP, int dtype) {
-  return (size_t)8 * (CinP * n32(CoutP) + CoutP * n32(CinP)) * (dtype == DGTTA_BF16 ? 2 : 4);
+  return (size_t)8 * (CinP * n32(CoutP) + CoutP * n32(CinP)) * (dtype == DGTTA_F32 ? 4 : 2);
 }
 // image-ordered conv weights (imgF | imgB) appended to the [wf | wb] blob
 size_t conv_image_bytes(int CinP, int CoutP, int dtype) {
-  return (size_t)27 * (CinP * n32(CoutP) + CoutP * n32(CinP)) * (dtype == DGTTA_BF16 ? 2 : 4);
+  return (size_t)27 * (CinP * n32(CoutP) + CoutP * n32(CinP)) * (dtype == DGTTA_F32 ? 4 : 2);
 }
 size_t conv_imgB_offset_bytes(int CinP, int CoutP, int dtype) {
-  return (size_t)27 * CinP * n32(CoutP) * (dtype == DGTTA_BF16 ? 2 : 4);
+  return (size_t)27 * CinP * n32(CoutP) * (dtype == DGTTA_F32 ? 4 : 2);
 }
 int conv_pack_images(const float *w_t, void *img, int Cin, int Cout, int CinP, int CoutP, int dtype, hipStream_t st) {
   const int64_t n = (int64_t)27 * (CinP > CoutP ? CinP : CoutP) * n32(CinP > CoutP ? CinP : CoutP);
@@ -604,9 +612,12 @@ int conv_pack_images(const float *w_t, void *img, int Cin, int Cout, int CinP, i
   if (dtype == DGTTA_F32)
     hipLaunchKernelGGL((conv_pack_image_kernel<float>), dim3(blocks), dim3(256), 0, st, w_t, (float *)img, (float *)imgB, Cin,
                        Cout, CinP, CoutP);
-  else
+  else if (dtype == DGTTA_BF16)
     hipLaunchKernelGGL((conv_pack_image_kernel<bf16_t>), dim3(blocks), dim3(256), 0, st, w_t, (bf16_t *)img, (bf16_t *)imgB,
                        Cin, Cout, CinP, CoutP);
+  else
+    hipLaunchKernelGGL((conv_pack_image_kernel<f16_t>), dim3(blocks), dim3(256), 0, st, w_t, (f16_t *)img, (f16_t *)imgB, Cin,
+                       Cout, CinP, CoutP);
   DG_CHECK_LAUNCH("conv_pack_image_kernel");
   return DGTTA_OK;
 }
@@ -666,12 +677,14 @@ int convT_fwd_mfma(const void *x, int ldx, const float *w_t, const float *bias, 
                    int Cout, int Di, int Hi, int Wi, int dtype, hipStream_t st) {
   if (dtype == DGTTA_F32) return convT_run<float>(0, x, ldx, w_t, bias, out, ldo, ws, B, Cin, Cout, Di, Hi, Wi, st);
   if (dtype == DGTTA_BF16) return convT_run<bf16_t>(0, x, ldx, w_t, bias, out, ldo, ws, B, Cin, Cout, Di, Hi, Wi, st);
+  if (dtype == DGTTA_F16) return convT_run<f16_t>(0, x, ldx, w_t, bias, out, ldo, ws, B, Cin, Cout, Di, Hi, Wi, st);
   return DGTTA_ERR_UNSUPPORTED;
 }
 int convT_dgrad_mfma(const void *dout, int lddo, const float *w_t, void *dx, int lddx, void *ws, int B, int Cin, int Cout,
                      int Di, int Hi, int Wi, int dtype, hipStream_t st) {
   if (dtype == DGTTA_F32) return convT_run<float>(1, dout, lddo, w_t, nullptr, dx, lddx, ws, B, Cin, Cout, Di, Hi, Wi, st);
   if (dtype == DGTTA_BF16) return convT_run<bf16_t>(1, dout, lddo, w_t, nullptr, dx, lddx, ws, B, Cin, Cout, Di, Hi, Wi, st);
+  if (dtype == DGTTA_F16) return convT_run<f16_t>(1, dout, lddo, w_t, nullptr, dx, lddx, ws, B, Cin, Cout, Di, Hi, Wi, st);
   return DGTTA_ERR_UNSUPPORTED;
 }
 

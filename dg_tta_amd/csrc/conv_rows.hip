@@ -1,6 +1,7 @@
 // Row-reuse 3x3x3 convolution kernel (bf16, stride 1) -- see the block comment below.
 #include "conv_common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace {
 
@@ -34,7 +35,7 @@ struct RowsCfg {
   static constexpr size_t LDS_BYTES = 2 * A_BYTES + B_BYTES + RED_BYTES;
 };
 
-template <int PD, int PH, int WD, int WH, int ABL = 0>   // ABL: diagnostic ablation
+template <int PD, int PH, int WD, int WH, int ABL = 0, typename T16 = bf16_t>   // ABL: diagnostic ablation; T16: bf16_t | f16_t
 __global__ __launch_bounds__(WD *WH * 64) void conv3_rows_kernel(const bf16_t *__restrict__ x, View xv,
                                                                  const bf16_t *__restrict__ w, Taps taps,
                                                                  const float *__restrict__ bias, bf16_t *__restrict__ y,
@@ -209,7 +210,7 @@ __global__ __launch_bounds__(WD *WH * 64) void conv3_rows_kernel(const bf16_t *_
                 const int od = dz - kd, oh = hy - kh;
                 if (od >= 0 && od < PD && oh >= 0 && oh < PH) {
                   if (ABL == 3) acc[od][oh][0] += __uint_as_float(af.x ^ breg[(kd * 3 + kh) * 3 + kw].x);
-                  else mfma_step<bf16_t>(af, breg[(kd * 3 + kh) * 3 + kw], acc[od][oh]);
+                  else mfma_step<T16>(af, breg[(kd * 3 + kh) * 3 + kw], acc[od][oh]);
                 }
               }
           }
@@ -252,8 +253,8 @@ __global__ __launch_bounds__(WD *WH * 64) void conv3_rows_kernel(const bf16_t *_
             s2v = __builtin_elementwise_fma(a, a, s2v);
             s2v = __builtin_elementwise_fma(c, c, s2v);
             uint2 pk;
-            pk.x = (unsigned)f32_to_bf16(a[0]) | ((unsigned)f32_to_bf16(a[1]) << 16);
-            pk.y = (unsigned)f32_to_bf16(c[0]) | ((unsigned)f32_to_bf16(c[1]) << 16);
+            pk.x = pack2_16<T16>(a[0], a[1]);
+            pk.y = pack2_16<T16>(c[0], c[1]);
             *reinterpret_cast<uint2 *>(sl + (((2 * g + he) ^ swz) << 3)) = pk;
           }
         };
@@ -300,7 +301,7 @@ __global__ __launch_bounds__(WD *WH * 64) void conv3_rows_kernel(const bf16_t *_
             for (int q = 0; q < 16; ++q) {
               const int m = (q & 3) + 8 * (q >> 2) + 4 * he;
               const float v = acc[i][j][q];
-              slab[(i * PH + j) * 1024 + m * 32 + re] = f32_to_bf16(v);
+              slab[(i * PH + j) * 1024 + m * 32 + re] = f32_to_16<T16>(v);
               if (row_ok && co < Cout && cur.ow0 + m < Wo) {
                 st1 += v;
                 st2 += v * v;
@@ -368,7 +369,7 @@ __global__ __launch_bounds__(WD *WH * 64) void conv3_rows_kernel(const bf16_t *_
   }
 }
 
-template <int PD, int PH, int WD, int WH>
+template <int PD, int PH, int WD, int WH, typename T16>
 int launch_conv_rows(const void *x, const View &xv, const void *w, const Taps &taps, const float *bias, void *y,
                      const View &yv, int B, int Cin, int Cout, int CinP, int CoutP, double *stats, int ntaps_src,
                      hipStream_t st) {
@@ -376,13 +377,15 @@ int launch_conv_rows(const void *x, const View &xv, const void *w, const Taps &t
   // DGTTA_ROWS_ABL (diagnostic builds of the same kernel): 1 no DMA, 3 no MFMA, 6 per-segment cycle stamps, 7 the
   // voxel-major (ragged-tile) epilogue for every tile
   const int abl = dgtta_switches().rows_abl;
-  auto kern = conv3_rows_kernel<PD, PH, WD, WH>;
+  auto kern = conv3_rows_kernel<PD, PH, WD, WH, 0, T16>;
   static DynLdsOnce once[5];
   int slot = 0;
-  if (abl == '1') kern = conv3_rows_kernel<PD, PH, WD, WH, 1>, slot = 1;
-  if (abl == '3') kern = conv3_rows_kernel<PD, PH, WD, WH, 3>, slot = 2;
-  if (abl == '6') kern = conv3_rows_kernel<PD, PH, WD, WH, 6>, slot = 3;
-  if (abl == '7') kern = conv3_rows_kernel<PD, PH, WD, WH, 7>, slot = 4;
+  if (std::is_same<T16, bf16_t>::value) {      // diagnostic builds exist for the bf16 instantiation only
+    if (abl == '1') kern = conv3_rows_kernel<PD, PH, WD, WH, 1, T16>, slot = 1;
+    if (abl == '3') kern = conv3_rows_kernel<PD, PH, WD, WH, 3, T16>, slot = 2;
+    if (abl == '6') kern = conv3_rows_kernel<PD, PH, WD, WH, 6, T16>, slot = 3;
+    if (abl == '7') kern = conv3_rows_kernel<PD, PH, WD, WH, 7, T16>, slot = 4;
+  }
   DG_REQUIRE(ensure_dyn_lds(once[slot], reinterpret_cast<const void *>(kern), (int)Cfg::LDS_BYTES) == hipSuccess,
              DGTTA_ERR_LAUNCH, "conv3_rows: cannot raise the dynamic LDS limit to %zu", (size_t)Cfg::LDS_BYTES);
   const int tW = cdiv(yv.W, 32), tH = cdiv(yv.H, Cfg::TH), tD = cdiv(yv.D, Cfg::TD), nblkN = cdiv(CoutP, 32);
@@ -405,6 +408,8 @@ int launch_conv_rows(const void *x, const View &xv, const void *w, const Taps &t
 
 // entry point used by the dispatcher in conv_mfma.hip
 int conv3_rows_launch(const void *x, const View &xv, const void *w, const Taps &taps, const float *bias, void *y, const View &yv,
-                      int B, int Cin, int Cout, int CinP, int CoutP, double *stats, int ntaps_src, hipStream_t st) {
-  return launch_conv_rows<2, 2, 2, 4>(x, xv, w, taps, bias, y, yv, B, Cin, Cout, CinP, CoutP, stats, ntaps_src, st);
+                      int B, int Cin, int Cout, int CinP, int CoutP, double *stats, int ntaps_src, int is_f16, hipStream_t st) {
+  if (is_f16)
+    return launch_conv_rows<2, 2, 2, 4, f16_t>(x, xv, w, taps, bias, y, yv, B, Cin, Cout, CinP, CoutP, stats, ntaps_src, st);
+  return launch_conv_rows<2, 2, 2, 4, bf16_t>(x, xv, w, taps, bias, y, yv, B, Cin, Cout, CinP, CoutP, stats, ntaps_src, st);
 }

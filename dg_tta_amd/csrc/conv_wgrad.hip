@@ -65,6 +65,9 @@ __device__ __forceinline__ void transpose_unit<bf16_t>(const uint4 *in, uint4 *o
 #undef TR_PAIR
 }
 
+template <>
+__device__ __forceinline__ void transpose_unit<f16_t>(const uint4 *in, uint4 *out) { transpose_unit<bf16_t>(in, out); }
+
 // A operand for tap column kw from the aligned run `c` and the next run's first dwords (e0, e1)
 template <typename T>
 __device__ __forceinline__ uint4 shift_run(const uint4 &c, unsigned e0, unsigned e1, int kw);
@@ -74,6 +77,10 @@ __device__ __forceinline__ uint4 shift_run<bf16_t>(const uint4 &c, unsigned e0, 
   if (kw == 2) return make_uint4(c.y, c.z, c.w, e0);
   return make_uint4((c.x >> 16) | (c.y << 16), (c.y >> 16) | (c.z << 16), (c.z >> 16) | (c.w << 16),
                     (c.w >> 16) | (e0 << 16));
+}
+template <>
+__device__ __forceinline__ uint4 shift_run<f16_t>(const uint4 &c, unsigned e0, unsigned e1, int kw) {
+  return shift_run<bf16_t>(c, e0, e1, kw);          // pure 16-bit lane moves
 }
 template <>
 __device__ __forceinline__ uint4 shift_run<float>(const uint4 &c, unsigned e0, unsigned e1, int kw) {
@@ -88,6 +95,21 @@ template <>
 __device__ __forceinline__ void mfma16<bf16_t>(const uint4 &a, const uint4 &b, f32x4_t &acc) {
   acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), acc, 0,
                                                 0, 0);
+}
+template <>
+__device__ __forceinline__ void mfma16<f16_t>(const uint4 &a, const uint4 &b, f32x4_t &acc) {
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), acc, 0, 0, 0);
+}
+// 32x32x16 step on transposed-read operands (kept as bf16x8 bit patterns; the storage type picks the instruction)
+template <typename T16>
+__device__ __forceinline__ f32x16_t mfma32_tr(const bf16x8_t &a, const bf16x8_t &b, const f32x16_t &acc);
+template <>
+__device__ __forceinline__ f32x16_t mfma32_tr<bf16_t>(const bf16x8_t &a, const bf16x8_t &b, const f32x16_t &acc) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+}
+template <>
+__device__ __forceinline__ f32x16_t mfma32_tr<f16_t>(const bf16x8_t &a, const bf16x8_t &b, const f32x16_t &acc) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), acc, 0, 0, 0);
 }
 template <>
 __device__ __forceinline__ void mfma16<float>(const uint4 &a, const uint4 &b, f32x4_t &acc) {
@@ -310,7 +332,7 @@ __device__ __forceinline__ bf16x8_t tr_operand(const unsigned char *p) {
 
 // CLS: class launch (blockIdx.z selects operand offsets and a tap subset, as in conv3_wgrad_mfma_kernel): the set taps
 // are dealt round-robin to the 4 waves, slots beyond a wave's share are skipped with wave-uniform branches.
-template <int ABL = 0, bool CLS = false>
+template <int ABL = 0, bool CLS = false, typename T16 = bf16_t>
 __global__ __launch_bounds__(256, 2) void conv3_wgrad_tr_kernel(const bf16_t *__restrict__ x, View xv,
                                                                 const bf16_t *__restrict__ dy, View yv,
                                                                 float *__restrict__ slabs, int Cin, int Cout, int tilesW,
@@ -447,7 +469,7 @@ __global__ __launch_bounds__(256, 2) void conv3_wgrad_tr_kernel(const bf16_t *__
         for (int i = 0; i < 7; ++i) {
           if (CLS && i >= ntap_w) continue;
           if (ABL == 3) acc[i][0] += (float)afr[i][0] * (float)bfr[1];
-          else acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[i], bfr, acc[i], 0, 0, 0);
+          else acc[i] = mfma32_tr<T16>(afr[i], bfr, acc[i]);
         }
       }
     }
@@ -480,6 +502,7 @@ struct WT8 {
   static constexpr int NP = WT::NPX + NPY;
 };
 
+template <typename T16 = bf16_t>
 __global__ __launch_bounds__(512, 1) void conv3_wgrad_tr8_kernel(const bf16_t *__restrict__ x, View xv,
                                                                  const bf16_t *__restrict__ dy, View yv,
                                                                  float *__restrict__ slabs, int Cin, int Cout, int tilesW,
@@ -585,7 +608,7 @@ __global__ __launch_bounds__(512, 1) void conv3_wgrad_tr8_kernel(const bf16_t *_
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-          for (int c = 0; c < 2; ++c) acc[i][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[i], bfr[c], acc[i][c], 0, 0, 0);
+          for (int c = 0; c < 2; ++c) acc[i][c] = mfma32_tr<T16>(afr[i], bfr[c], acc[i][c]);
       }
     }
     dma_wait_all();
@@ -626,6 +649,7 @@ struct WT2 {
   static constexpr int NP = 2 * NPX1 + TH;              // pieces per output slice: two x slices + one dy slice
 };
 
+template <typename T16 = bf16_t>
 __global__ __launch_bounds__(256, 2) void conv3_wgrad_tr_s2_kernel(const bf16_t *__restrict__ x, View xv,
                                                                    const bf16_t *__restrict__ dy, View yv,
                                                                    float *__restrict__ slabs, int Cin, int Cout, int tilesW,
@@ -731,7 +755,7 @@ __global__ __launch_bounds__(256, 2) void conv3_wgrad_tr_s2_kernel(const bf16_t 
         afr[i] = __builtin_bit_cast(bf16x8_t, av);
       }
 #pragma unroll
-      for (int i = 0; i < 7; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[i], bfr, acc[i], 0, 0, 0);
+      for (int i = 0; i < 7; ++i) acc[i] = mfma32_tr<T16>(afr[i], bfr, acc[i]);
     }
     dma_wait_all();
     lds_barrier();
@@ -763,6 +787,7 @@ struct WT3 {
   static constexpr int NPY = 2 * 2 * TH * 2;                                     // dout pieces per x slice (16 KiB)
 };
 
+template <typename T16 = bf16_t>
 __global__ __launch_bounds__(256, 2) void convT_wgrad_tr_kernel(const bf16_t *__restrict__ x, View xv,
                                                                 const bf16_t *__restrict__ dout, View yv,
                                                                 float *__restrict__ slabs, int Cin, int Cout, int tilesW,
@@ -842,7 +867,7 @@ __global__ __launch_bounds__(256, 2) void convT_wgrad_tr_kernel(const bf16_t *__
         const s16x4_t blo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t *)pb);
         const s16x4_t bhi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t *)(pb + 4 * 128));
         const s16x8_t bv = {blo[0], blo[1], blo[2], blo[3], bhi[0], bhi[1], bhi[2], bhi[3]};
-        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr, __builtin_bit_cast(bf16x8_t, bv), acc[i], 0, 0, 0);
+        acc[i] = mfma32_tr<T16>(afr, __builtin_bit_cast(bf16x8_t, bv), acc[i]);
       }
     }
     dma_wait_all();
@@ -972,19 +997,20 @@ static int wgrad_launch_classes(const void *x, const View &xv, const void *dy, c
   WgradPlan p = wgrad_plan(B, Cin, Cout, yv.D, yv.H, yv.W, wc.n);
   const size_t need = (size_t)wc.n * p.units * p.cibs * p.cobs * 27 * 1024 * sizeof(float);
   if (ws_bytes < need || p.units >= (1ll << 31) || p.cibs * p.cobs > 65535) return DGTTA_ERR_UNSUPPORTED;
-  if (sizeof(T) == 2) {
+  if constexpr (sizeof(T) == 2) {
+    typedef T T16;
     const DgttaSwitches &sw = dgtta_switches();
     if (sw.wgrad_tr != '0') {        // DGTTA_WGRAD_TR=0 (tests): the register-transpose predecessor
       const bool plain = wc.n == 1 && wc.mask[0] == 0x7ffffffu && wc.xoff[0] == 0 && wc.yoff[0] == 0;
-      auto ktr = plain ? conv3_wgrad_tr_kernel<0, false> : conv3_wgrad_tr_kernel<0, true>;
+      auto ktr = plain ? conv3_wgrad_tr_kernel<0, false, T16> : conv3_wgrad_tr_kernel<0, true, T16>;
       static DynLdsOnce tr_once[2];
       DG_REQUIRE(ensure_dyn_lds(tr_once[plain], reinterpret_cast<const void *>(ktr), (int)WT::LDS_BYTES) == hipSuccess,
                  DGTTA_ERR_LAUNCH, "wgrad_tr: cannot raise the dynamic LDS limit");
       if (plain && Cout >= 64 && sw.wgrad_tr8 != '0') {      // DGTTA_WGRAD_TR8=0 (tests): always the 4-wave kernel
         static DynLdsOnce a8;
-        DG_REQUIRE(ensure_dyn_lds(a8, reinterpret_cast<const void *>(conv3_wgrad_tr8_kernel), (int)WT8::LDS_BYTES) ==
+        DG_REQUIRE(ensure_dyn_lds(a8, reinterpret_cast<const void *>(conv3_wgrad_tr8_kernel<T16>), (int)WT8::LDS_BYTES) ==
                        hipSuccess, DGTTA_ERR_LAUNCH, "wgrad_tr8: cannot raise the dynamic LDS limit");
-        hipLaunchKernelGGL(conv3_wgrad_tr8_kernel, dim3((unsigned)p.units, (unsigned)(p.cibs * ((p.cobs + 1) / 2))), dim3(512),
+        hipLaunchKernelGGL(conv3_wgrad_tr8_kernel<T16>, dim3((unsigned)p.units, (unsigned)(p.cibs * ((p.cobs + 1) / 2))), dim3(512),
                            WT8::LDS_BYTES, st, (const bf16_t *)x, xv, (const bf16_t *)dy, yv, (float *)ws, Cin, Cout, p.tW, p.tH,
                            p.nsd, p.DR, p.cobs);
         DG_CHECK_LAUNCH("conv3_wgrad_tr8_kernel");
@@ -1045,7 +1071,8 @@ static int wgrad_conv(const void *x, int ldx, const void *dy, int lddy, float *d
   // parity 1 <- tap 0 (offset -1) and tap 2 (offset 0).  Each real tap belongs to exactly one of the 8 classes.
   const int Do = (Di - 1) / 2 + 1, Ho = (Hi - 1) / 2 + 1, Wo = (Wi - 1) / 2 + 1;
   const View yv = dense_view(B, Do, Ho, Wo, lddy);
-  if (sizeof(T) == 2) {
+  if constexpr (sizeof(T) == 2) {
+    typedef T T16;
     // one pass over x (full resolution tile) and dy with all 27 taps: conv3_wgrad_tr_s2_kernel
     const int one = dgtta_switches().wgrad_s2_onepass;      // DGTTA_WGRAD_S2_ONEPASS=0 (tests): the 8-class launch
     const View xfull = dense_view(B, Di, Hi, Wi, ldx);
@@ -1055,9 +1082,9 @@ static int wgrad_conv(const void *x, int ldx, const void *dy, int lddy, float *d
                     ldx >= (Cin + 7) / 8 * 8 && ws_bytes >= need && p.units < (1ll << 31) && p.cibs * p.cobs <= 65535;
     if (ok && one != '0') {
       static DynLdsOnce once;
-      DG_REQUIRE(ensure_dyn_lds(once, reinterpret_cast<const void *>(conv3_wgrad_tr_s2_kernel), (int)WT2::LDS_BYTES) ==
+      DG_REQUIRE(ensure_dyn_lds(once, reinterpret_cast<const void *>(conv3_wgrad_tr_s2_kernel<T16>), (int)WT2::LDS_BYTES) ==
                      hipSuccess, DGTTA_ERR_LAUNCH, "wgrad_tr_s2: cannot raise the dynamic LDS limit");
-      hipLaunchKernelGGL(conv3_wgrad_tr_s2_kernel, dim3((unsigned)p.units, (unsigned)(p.cibs * p.cobs)), dim3(256),
+      hipLaunchKernelGGL(conv3_wgrad_tr_s2_kernel<T16>, dim3((unsigned)p.units, (unsigned)(p.cibs * p.cobs)), dim3(256),
                          WT2::LDS_BYTES, st, (const bf16_t *)x, xfull, (const bf16_t *)dy, yv, (float *)ws, Cin, Cout, p.tW,
                          p.tH, p.nsd, p.DR, p.cobs);
       DG_CHECK_LAUNCH("conv3_wgrad_tr_s2_kernel");
@@ -1116,6 +1143,7 @@ int conv3_wgrad_mfma(const void *x, int ldx, const void *dy, int lddy, float *dw
   if (stride == 2 && ((Di | Hi | Wi) & 1)) return DGTTA_ERR_UNSUPPORTED;   // odd extents: leave to the general kernel
   if (dtype == DGTTA_F32) return wgrad_conv<float>(x, ldx, dy, lddy, dw_t, ws, ws_bytes, B, Cin, Cout, Di, Hi, Wi, stride, accumulate, st);
   if (dtype == DGTTA_BF16) return wgrad_conv<bf16_t>(x, ldx, dy, lddy, dw_t, ws, ws_bytes, B, Cin, Cout, Di, Hi, Wi, stride, accumulate, st);
+  if (dtype == DGTTA_F16) return wgrad_conv<f16_t>(x, ldx, dy, lddy, dw_t, ws, ws_bytes, B, Cin, Cout, Di, Hi, Wi, stride, accumulate, st);
   return DGTTA_ERR_UNSUPPORTED;
 }
 
@@ -1124,7 +1152,8 @@ template <typename T>
 static int convT_wgrad(const void *x, int ldx, const void *dout, int lddo, float *dw_t, void *ws, size_t ws_bytes, int B,
                        int Cin, int Cout, int Di, int Hi, int Wi, int accumulate, hipStream_t st) {
   const View xv = dense_view(B, Di, Hi, Wi, ldx);
-  if (sizeof(T) == 2) {
+  if constexpr (sizeof(T) == 2) {
+    typedef T T16;
     const int one = dgtta_switches().convt_wgrad_onepass;      // DGTTA_CONVT_WGRAD_ONEPASS=0 (tests): the 8-class launch
     const View yfull = dense_view(B, 2 * Di, 2 * Hi, 2 * Wi, lddo);
     WgradPlan p = wgrad_plan_s2(B, Cin, Cout, Di, Hi, Wi);        // same tile shape (2 rows x 16 voxels) on the input lattice
@@ -1133,9 +1162,9 @@ static int convT_wgrad(const void *x, int ldx, const void *dout, int lddo, float
                     ldx >= (Cin + 7) / 8 * 8 && ws_bytes >= need && p.units < (1ll << 31) && p.cibs * p.cobs <= 65535;
     if (ok && one != '0') {
       static DynLdsOnce once;
-      DG_REQUIRE(ensure_dyn_lds(once, reinterpret_cast<const void *>(convT_wgrad_tr_kernel), (int)WT3::LDS_BYTES) ==
+      DG_REQUIRE(ensure_dyn_lds(once, reinterpret_cast<const void *>(convT_wgrad_tr_kernel<T16>), (int)WT3::LDS_BYTES) ==
                      hipSuccess, DGTTA_ERR_LAUNCH, "convT_wgrad_tr: cannot raise the dynamic LDS limit");
-      hipLaunchKernelGGL(convT_wgrad_tr_kernel, dim3((unsigned)p.units, (unsigned)(p.cibs * p.cobs)), dim3(256),
+      hipLaunchKernelGGL(convT_wgrad_tr_kernel<T16>, dim3((unsigned)p.units, (unsigned)(p.cibs * p.cobs)), dim3(256),
                          WT3::LDS_BYTES, st, (const bf16_t *)x, xv, (const bf16_t *)dout, yfull, (float *)ws, Cin, Cout, p.tW,
                          p.tH, p.nsd, p.DR, p.cobs);
       DG_CHECK_LAUNCH("convT_wgrad_tr_kernel");
@@ -1175,17 +1204,19 @@ int convT_wgrad_mfma(const void *x, int ldx, const void *dout, int lddo, float *
                      int Cin, int Cout, int Di, int Hi, int Wi, int accumulate, int dtype, hipStream_t st) {
   if (dtype == DGTTA_F32) return convT_wgrad<float>(x, ldx, dout, lddo, dw_t, ws, ws_bytes, B, Cin, Cout, Di, Hi, Wi, accumulate, st);
   if (dtype == DGTTA_BF16) return convT_wgrad<bf16_t>(x, ldx, dout, lddo, dw_t, ws, ws_bytes, B, Cin, Cout, Di, Hi, Wi, accumulate, st);
+  if (dtype == DGTTA_F16) return convT_wgrad<f16_t>(x, ldx, dout, lddo, dw_t, ws, ws_bytes, B, Cin, Cout, Di, Hi, Wi, accumulate, st);
   return DGTTA_ERR_UNSUPPORTED;
 }
 
 // 1x1x1 head weight gradient dw[k][ci] = sum_rows dout[row][k] * x[row][ci] as a single-tap run of the wgrad kernel:
 // the [rows] axis is folded into a D x 4 x 32 lattice (no neighbour access with one tap, so any folding is valid).
 namespace {
-__global__ void f32_to_bf16_rows_kernel(const float *__restrict__ src, int lds_, bf16_t *__restrict__ dst, int C,
-                                        int64_t rows) {
+template <typename T16>
+__global__ void f32_to_16_rows_kernel(const float *__restrict__ src, int lds_, unsigned short *__restrict__ dst, int C,
+                                      int64_t rows) {
   const int64_t n = rows * C;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
-    dst[i] = f32_to_bf16(src[(i / C) * lds_ + i % C]);
+    dst[i] = f32_to_16<T16>(src[(i / C) * lds_ + i % C]);
 }
 }  // namespace
 
@@ -1209,14 +1240,20 @@ int head_wgrad_mfma(const void *x, int ldx, const float *dout, int lddo, float *
     return wgrad_launch<float>(x, xv, dout, yv, dw_sel, ws, ws_bytes, 1, Cin, nsel, 1u << 13, real, Cin, 1, 0, accumulate,
                                st);
   }
-  if (dtype == DGTTA_BF16) {
+  if (dtype == DGTTA_BF16 || dtype == DGTTA_F16) {
     const size_t cbytes = align_up((size_t)rows * nsel * 2, 256);
-    bf16_t *d16 = (bf16_t *)ws;
-    hipLaunchKernelGGL(f32_to_bf16_rows_kernel, dim3(2048), dim3(256), 0, st, dout, lddo, d16, nsel, rows);
-    DG_CHECK_LAUNCH("f32_to_bf16_rows_kernel");
+    unsigned short *d16 = (unsigned short *)ws;
+    if (dtype == DGTTA_BF16)
+      hipLaunchKernelGGL(f32_to_16_rows_kernel<bf16_t>, dim3(2048), dim3(256), 0, st, dout, lddo, d16, nsel, rows);
+    else
+      hipLaunchKernelGGL(f32_to_16_rows_kernel<f16_t>, dim3(2048), dim3(256), 0, st, dout, lddo, d16, nsel, rows);
+    DG_CHECK_LAUNCH("f32_to_16_rows_kernel");
     const View yv = dense_view(1, D, 4, 32, nsel);
-    return wgrad_launch<bf16_t>(x, xv, d16, yv, dw_sel, (char *)ws + cbytes, ws_bytes - cbytes, 1, Cin, nsel, 1u << 13, real,
-                                Cin, 1, 0, accumulate, st);
+    if (dtype == DGTTA_BF16)
+      return wgrad_launch<bf16_t>(x, xv, d16, yv, dw_sel, (char *)ws + cbytes, ws_bytes - cbytes, 1, Cin, nsel, 1u << 13, real,
+                                  Cin, 1, 0, accumulate, st);
+    return wgrad_launch<f16_t>(x, xv, d16, yv, dw_sel, (char *)ws + cbytes, ws_bytes - cbytes, 1, Cin, nsel, 1u << 13, real,
+                               Cin, 1, 0, accumulate, st);
   }
   return DGTTA_ERR_UNSUPPORTED;
 }

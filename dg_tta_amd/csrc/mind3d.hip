@@ -289,7 +289,8 @@ extern "C" int dgtta_mind3d_fwd(const float *img, const float *noise, float rw, 
   DG_REQUIRE(ws_bytes >= dgtta_mind3d_ws_bytes(B, D, H, W), DGTTA_ERR_WORKSPACE, "mind3d_fwd: workspace too small");
   DG_REQUIRE(out_ndhwc ? (out_ldc >= 12) : (out_dtype == DGTTA_F32), DGTTA_ERR_BADARG,
              "mind3d_fwd: NCDHW output must be fp32; NDHWC needs ldc >= 12");
-  DG_REQUIRE(out_dtype == DGTTA_F32 || out_dtype == DGTTA_BF16, DGTTA_ERR_BADARG, "mind3d_fwd: bad dtype");
+  DG_REQUIRE(out_dtype == DGTTA_F32 || out_dtype == DGTTA_BF16 || out_dtype == DGTTA_F16, DGTTA_ERR_BADARG,
+             "mind3d_fwd: bad dtype");
   hipStream_t st = (hipStream_t)stream;
   int td, th, tw;
   tile_counts(D, H, W, td, th, tw);
@@ -315,8 +316,11 @@ extern "C" int dgtta_mind3d_fwd(const float *img, const float *noise, float rw, 
   } else if (out_dtype == DGTTA_F32) {
     hipLaunchKernelGGL((mind_finish_kernel<float, true>), dim3(blocks), dim3(256), 0, st, mws, gmean, (float *)out,
                        out_ldc, V, total);
-  } else {
+  } else if (out_dtype == DGTTA_BF16) {
     hipLaunchKernelGGL((mind_finish_kernel<bf16_t, true>), dim3(blocks), dim3(256), 0, st, mws, gmean, (bf16_t *)out,
+                       out_ldc, V, total);
+  } else {
+    hipLaunchKernelGGL((mind_finish_kernel<f16_t, true>), dim3(blocks), dim3(256), 0, st, mws, gmean, (f16_t *)out,
                        out_ldc, V, total);
   }
   DG_CHECK_LAUNCH("mind_finish_kernel");

@@ -220,6 +220,12 @@ __device__ __forceinline__ void unpack16<bf16_t>(const uint4 &v, float *f) {
     f[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
   }
 }
+template <>
+__device__ __forceinline__ void unpack16<f16_t>(const uint4 &v, float *f) {
+  const unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) unpack2_16<f16_t>(w[i], f[2 * i], f[2 * i + 1]);
+}
 
 template <typename T, int MODE>
 __global__ __launch_bounds__(256) void chan_reduce_vec_kernel(const T *__restrict__ y, int ldy, const T *__restrict__ gz,
@@ -336,6 +342,11 @@ __device__ __forceinline__ uint4 pack16<bf16_t>(const float *f) {
 #pragma unroll
   for (int i = 0; i < 4; ++i) w[i] = (unsigned)f32_to_bf16(f[2 * i]) | ((unsigned)f32_to_bf16(f[2 * i + 1]) << 16);
   return make_uint4(w[0], w[1], w[2], w[3]);
+}
+template <>
+__device__ __forceinline__ uint4 pack16<f16_t>(const float *f) {
+  return make_uint4(pack2_16<f16_t>(f[0], f[1]), pack2_16<f16_t>(f[2], f[3]), pack2_16<f16_t>(f[4], f[5]),
+                    pack2_16<f16_t>(f[6], f[7]));
 }
 
 // 16-byte vectorised InstanceNorm+LeakyReLU apply kernels (forward MODE 0, backward MODE 1): grid (blocks, B); the
@@ -871,6 +882,9 @@ int wgrad_splits(int64_t nvox) {
     } else if ((dtype) == DGTTA_BF16) {                                                \
       typedef bf16_t T;                                                                \
       CALL;                                                                            \
+    } else if ((dtype) == DGTTA_F16) {                                                 \
+      typedef f16_t T;                                                                 \
+      CALL;                                                                            \
     } else {                                                                           \
       dgtta_set_error("bad dtype %d", (int)(dtype));                                   \
       return DGTTA_ERR_BADARG;                                                         \
@@ -895,7 +909,7 @@ int conv3_wgrad_mfma(const void *x, int ldx, const void *dy, int lddy, float *dw
                      int B, int Cin, int Cout, int Di, int Hi, int Wi, int stride, int accumulate, int dtype,
                      hipStream_t st);
 
-static size_t esize(int dtype) { return dtype == DGTTA_BF16 ? 2 : 4; }
+static size_t esize(int dtype) { return dtype == DGTTA_F32 ? 4 : 2; }
 static const void *wb_of(const void *wpack, int CinP, int CoutP, int dtype) {
   return (const char *)wpack + (size_t)27 * CinP * CoutP * esize(dtype);
 }
@@ -926,7 +940,7 @@ extern "C" int dgtta_conv3d_pack_weights(const float *w_t, void *wpack, int Cin,
   DISPATCH_T(dtype, hipLaunchKernelGGL((pack_weights_kernel<T>), dim3(gs_blocks(n)), dim3(256), 0, (hipStream_t)stream,
                                        w_t, (T *)wf, (T *)wb, Cin, Cout, CinP, CoutP));
   DG_CHECK_LAUNCH("pack_weights_kernel");
-  if (CinP % (dtype == DGTTA_BF16 ? 16 : 8) == 0 && CoutP % (dtype == DGTTA_BF16 ? 16 : 8) == 0)
+  if (CinP % (dtype == DGTTA_F32 ? 8 : 16) == 0 && CoutP % (dtype == DGTTA_F32 ? 8 : 16) == 0)
     return conv_pack_images(w_t, const_cast<void *>(img_of(wpack, CinP, CoutP, dtype)), Cin, Cout, CinP, CoutP, dtype,
                             (hipStream_t)stream);
   return DGTTA_OK;
@@ -1097,7 +1111,7 @@ extern "C" int dgtta_instnorm_lrelu_fwd(const void *y, int ldy, const void *stat
   }
   DG_CHECK_LAUNCH("in_stats_finalize_kernel");
   const int64_t total = (int64_t)B * V * C;
-  const int esz = dtype == DGTTA_BF16 ? 2 : 4, epv = 16 / esz;
+  const int esz = dtype == DGTTA_F32 ? 4 : 2, epv = 16 / esz;
   if (C % epv == 0 && ldy % epv == 0 && ldz % epv == 0 && !((uintptr_t)y & 15) && !((uintptr_t)z & 15) && C <= 2048) {
     const int64_t items = V * (C / epv);
     const int blocks = (int)(cdiv64(items, 256 * 4) < 4096 ? (cdiv64(items, 256 * 4) > 0 ? cdiv64(items, 256 * 4) : 1) : 4096);
@@ -1132,7 +1146,7 @@ extern "C" int dgtta_instnorm_lrelu_bwd(const void *gz, int ldgz, const void *y,
                      accumulate);
   DG_CHECK_LAUNCH("in_bwd_finalize_kernel");
   const int64_t total = (int64_t)B * V * C;
-  const int esz = dtype == DGTTA_BF16 ? 2 : 4, epv = 16 / esz;
+  const int esz = dtype == DGTTA_F32 ? 4 : 2, epv = 16 / esz;
   if (C % epv == 0 && ldy % epv == 0 && ldgz % epv == 0 && lddy % epv == 0 && !((uintptr_t)y & 15) && !((uintptr_t)gz & 15) &&
       !((uintptr_t)dy & 15) && C <= 2048) {
     const int64_t items = V * (C / epv);
@@ -1151,7 +1165,7 @@ extern "C" int dgtta_instnorm_lrelu_bwd(const void *gz, int ldgz, const void *y,
 }
 
 static size_t convT_pack_region(int Cin, int Cout, int dtype) {
-  const int g = (dtype == DGTTA_BF16) ? 16 : 8;
+  const int g = (dtype == DGTTA_F32) ? 8 : 16;
   return align_up(convT_packed_bytes((Cin + g - 1) / g * g, (Cout + g - 1) / g * g, dtype), 256);
 }
 

@@ -11,7 +11,15 @@ import torch
 from . import _lib
 from ._lib import check, ptr, require_cuda, stream_of
 
-F32, BF16 = 0, 1
+F32, BF16, F16 = 0, 1, 2
+
+
+def dtype_code(torch_dtype):
+    """DGTTA_F32 / DGTTA_BF16 / DGTTA_F16 of a torch storage dtype."""
+    try:
+        return {torch.float32: F32, torch.bfloat16: BF16, torch.float16: F16}[torch_dtype]
+    except KeyError:
+        raise ValueError(f"unsupported activation dtype {torch_dtype}") from None
 PAD_ZEROS, PAD_BORDER = 0, 1
 LINEAR, NEAREST = 0, 1
 
@@ -58,7 +66,7 @@ def mind3d(img, noise, randn_weighting=0.05, out_format="ncdhw", out_ldc=12, out
     for g in range(groups):
         sl = slice(g * bg, (g + 1) * bg)
         check(lib.dgtta_mind3d_fwd(ptr(img[sl]), ptr(noise[sl]), float(randn_weighting), ptr(out[sl]), int(ndhwc),
-                                   int(out_ldc), BF16 if out_dtype == torch.bfloat16 else F32, ptr(ws), nbytes, bg, d, h, w,
+                                   int(out_ldc), dtype_code(out_dtype), ptr(ws), nbytes, bg, d, h, w,
                                    stream_of(img.device)), "dgtta_mind3d_fwd")
     return out
 
@@ -274,7 +282,8 @@ def soft_dice(smp_a, smp_b):
 
 
 # ------------------------------------------------------------------------------------------------ AdamW
-def adamw_step(params, grads, exp_avgs, exp_avg_sqs, step, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01):
+def adamw_step(params, grads, exp_avgs, exp_avg_sqs, step, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01,
+               grad_scale=1.0):
     lib = _lib.load()
     n = len(params)
     if n == 0:
@@ -287,7 +296,8 @@ def adamw_step(params, grads, exp_avgs, exp_avg_sqs, step, lr, betas=(0.9, 0.999
     hv = P(*[v.data_ptr() for v in exp_avg_sqs])
     hn = (C.c_int64 * n)(*[p.numel() for p in params])
     check(lib.dgtta_adamw_step(hp, hg, hm, hv, hn, n, float(lr), float(betas[0]), float(betas[1]), float(eps),
-                               float(weight_decay), int(step), stream_of(params[0].device)), "dgtta_adamw_step")
+                               float(weight_decay), int(step), float(grad_scale), stream_of(params[0].device)),
+          "dgtta_adamw_step")
 
 
 # ------------------------------------------------------------------------------------------------ eval helpers

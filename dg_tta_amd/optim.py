@@ -7,7 +7,10 @@ from . import ops
 
 
 class HipAdamW(torch.optim.Optimizer):
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, grad_scale=1.0):
+        """grad_scale: static loss scale carried by the gradients (fp16 storage path, HipPlainConvUNet.loss_scale); the
+        kernel divides it out on load, so state and parameters are those of the unscaled problem."""
+        self.grad_scale = float(grad_scale)
         if lr < 0.0 or eps < 0.0 or not (0.0 <= betas[0] < 1.0) or not (0.0 <= betas[1] < 1.0) or weight_decay < 0.0:
             raise ValueError("invalid AdamW hyper-parameter")
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
@@ -37,7 +40,7 @@ class HipAdamW(torch.optim.Optimizer):
             for step, ps in by_step.items():
                 ops.adamw_step([p.data for p in ps], [p.grad for p in ps], [self.state[p]["exp_avg"] for p in ps],
                                [self.state[p]["exp_avg_sq"] for p in ps], step, group["lr"], group["betas"],
-                               group["eps"], group["weight_decay"])
+                               group["eps"], group["weight_decay"], self.grad_scale)
                 # the kernel wrote through raw pointers: tell autograd / weight caches that the tensors changed
                 torch.autograd.graph.increment_version(ps)
         return loss

@@ -95,7 +95,9 @@ class DGTTAProgram:
         _add_common(parser)
         parser.add_argument("--device", help="Device to be used", default="cuda")
         parser.add_argument("--gpus", type=int, default=1, help="one TTA process per GPU, samples sharded round-robin")
-        parser.add_argument("--dtype", choices=["fp32", "bf16"], default="fp32")
+        parser.add_argument("--dtype", choices=["fp32", "bf16", "fp16"], default="fp32",
+                            help="activation storage: fp32 = the reference's precision; bf16 / fp16 = MFMA-rate 16-bit "
+                                 "storage with fp32 accumulation (fp16 with a static loss scale)")
         parser.add_argument("--run_name", default=None, help=argparse.SUPPRESS)
         args = parser.parse_args(self.argv[2:])
         ds, trainer, cfg, fold = check_dataset_pretrain_config(args.pretrained_dataset_id, args.pretrainer,
@@ -145,7 +147,8 @@ class DGTTAProgram:
         (results_dir / run_name).parent.mkdir(exist_ok=True, parents=True)
         tta_main(run_name=run_name, config=config, tta_data_dir=tta_data_dir, save_base_path=results_dir,
                  label_mapping=label_mapping, modifier_fn_module=modifier_fn_module, device=torch.device(args.device),
-                 shard=(rank, world), act_dtype=torch.bfloat16 if args.dtype == "bf16" else torch.float32)
+                 shard=(rank, world),
+                 act_dtype={"fp32": torch.float32, "bf16": torch.bfloat16, "fp16": torch.float16}[args.dtype])
 
 
 def main():

@@ -224,7 +224,8 @@ def tta_epoch(model, optimizer, config, tta_tens_list, patch_size, label_mapping
     accum = config["patches_to_be_accumulated"]
     optimized_labels = config["optimized_labels"]
     intensity_aug_func = INTENSITY_AUG_FUNCTION_DICT[config["intensity_aug_function"]]
-    inv_accum = torch.full((), 1.0 / accum, dtype=torch.float32, device=device)
+    # d(loss/accum), times the model's static loss scale (fp16 storage only; HipAdamW divides it out again)
+    inv_accum = torch.full((), float(getattr(model, "loss_scale", 1.0)) / accum, dtype=torch.float32, device=device)
     model.train()
     step_losses = []
 
@@ -371,7 +372,7 @@ def tta_main(run_name, config, tta_data_dir, save_base_path, label_mapping, modi
             if hasattr(model, "accumulate_grads_in_place"):
                 model.accumulate_grads_in_place = True      # this loop owns the gradients (zero_grad once per epoch)
                 model.exact_zero_bias_grad = True           # see HipPlainConvUNet.exact_zero_bias_grad
-            optimizer = HipAdamW(model.parameters(), lr=config["lr"])
+            optimizer = HipAdamW(model.parameters(), lr=config["lr"], grad_scale=getattr(model, "loss_scale", 1.0))
 
             def progress(epoch, loss, dice):
                 print(f"  epoch {epoch}: loss={loss:.3f}, Pseudo-Dice={dice * 100:.1f}%", flush=True)

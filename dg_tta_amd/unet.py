@@ -17,7 +17,7 @@ from torch import nn
 
 from . import _lib
 from ._lib import check, ptr, stream_of
-from .ops import F32, BF16, _ws, is_cl3d
+from .ops import F32, BF16, F16, _ws, dtype_code, is_cl3d
 
 PLANS_3D_FULLRES = dict(features=(32, 64, 128, 256, 320), strides=(1, 2, 2, 2, 2),
                         n_conv_enc=(2, 2, 2, 2, 2), n_conv_dec=(2, 2, 2, 2),
@@ -114,7 +114,8 @@ class _Block:
 class HipPlainConvUNet(nn.Module):
     """PlainConvUNet whose forward/backward run on hand-written gfx950 kernels.
 
-    act_dtype: torch.float32 (parity mode) or torch.bfloat16 (bf16 storage + MFMA, fp32 accumulation).
+    act_dtype: torch.float32 (parity mode), torch.bfloat16 or torch.float16 (16-bit storage + MFMA, fp32 accumulation;
+    fp16 carries 3 more mantissa bits than bf16 and needs `loss_scale` for its gradients: BASELINE config 5).
     conv_impl: 0 auto (MFMA where covered, else general VALU kernel), 1 force VALU, 2 force MFMA.
     """
 
@@ -134,6 +135,9 @@ class HipPlainConvUNet(nn.Module):
         # tensors to autograd - saves a zero-fill + add per parameter and backward pass.  Tensor hooks on parameters
         # are then not invoked; torch.autograd.grad() w.r.t. parameters is not supported in this mode.
         self.accumulate_grads_in_place = False
+        # static loss scale of the fp16 storage path: the TTA loop multiplies the loss gradient by it (tta.tta_epoch) and
+        # HipAdamW divides it out; 1 for fp32 / bf16 (their exponent range needs none)
+        self.loss_scale = 16384.0 if act_dtype == torch.float16 else 1.0
         self._packed = {}        # id(weight) -> (version, wf, wb)
         self.selected_classes = None   # optional LongTensor: evaluate only these head rows (== map_label 'logits')
 
@@ -165,18 +169,19 @@ class HipPlainConvUNet(nn.Module):
         return _UNetFn.apply(self, x, sel, need_grad, *params)
 
     # -- packed weights (re-packed only when the parameter changed)
-    def packed(self, conv, dtype_code, cinp, coutp):
+    def packed(self, conv, dt, cinp, coutp):
+        """Packed weight blob of `conv` in storage format dt (F32 | BF16 | F16), re-packed only when the parameter changed."""
         w = conv.weight
-        key = (id(w), dtype_code, cinp, coutp)
+        key = (id(w), dt, cinp, coutp)
         ent = self._packed.get(key)
         if ent is not None and ent[0] == w._version and ent[1].device == w.device:
             return ent[1]
         lib = _lib.load()
-        tdt = torch.float32 if dtype_code == F32 else torch.bfloat16
-        nbytes = lib.dgtta_conv3d_packed_bytes(cinp, coutp, dtype_code)
+        tdt = {F32: torch.float32, BF16: torch.bfloat16, F16: torch.float16}[dt]
+        nbytes = lib.dgtta_conv3d_packed_bytes(cinp, coutp, dt)
         wpack = torch.empty(nbytes // tdt.itemsize, dtype=tdt, device=w.device)
         check(lib.dgtta_conv3d_pack_weights(ptr(w.detach()), ptr(wpack), conv.in_channels, conv.out_channels,
-                                            cinp, coutp, dtype_code, stream_of(w.device)), "dgtta_conv3d_pack_weights")
+                                            cinp, coutp, dt, stream_of(w.device)), "dgtta_conv3d_pack_weights")
         self._packed[key] = (w._version, wpack)
         return wpack
 
@@ -206,7 +211,7 @@ class _UNetFn(torch.autograd.Function):
         st = stream_of(dev)
         cfg = net.cfg
         adt = net.act_dtype
-        dt = F32 if adt == torch.float32 else BF16
+        dt = dtype_code(adt)
         impl = net.conv_impl
         B, cin0, D, H, W = x.shape
         assert cin0 == cfg["in_channels"], f"expected {cfg['in_channels']} input channels, got {cin0}"
@@ -217,7 +222,7 @@ class _UNetFn(torch.autograd.Function):
         assert D % tot_stride == 0 and H % tot_stride == 0 and W % tot_stride == 0, \
             f"patch {D}x{H}x{W} must be divisible by {tot_stride}"
         enc, dec = net.conv_blocks()
-        CP = 16 if dt == BF16 else 8      # channel padding granule of packed weights / first-layer input
+        CP = 8 if dt == F32 else 16      # channel padding granule of packed weights / first-layer input
 
         # ---- input -> NDHWC, padded to CP channels
         cin0p = _pad(cin0, CP)

@@ -17,7 +17,9 @@
  *        NCDHW  [B][C][D][H][W]          (PyTorch contiguous; the reference's layout)
  *        NDHWC  [B][D][H][W][ldc]        (channels-last; `ldc` >= C elements per voxel, so a
  *                                          tensor may be a channel slice of a wider buffer)
- *  - dtype: 0 = fp32, 1 = bf16 (storage; accumulation is always fp32).
+ *  - dtype: 0 = fp32, 1 = bf16, 2 = fp16 (storage of activations and packed weights; accumulation, statistics,
+ *    weight gradients and the optimizer state are always fp32).  fp16 gradients need the caller's static loss scale
+ *    (dgtta_adamw_step divides it out).
  */
 #ifndef DGTTA_H
 #define DGTTA_H
@@ -37,6 +39,7 @@ extern "C" {
 
 #define DGTTA_F32 0
 #define DGTTA_BF16 1
+#define DGTTA_F16 2
 
 #define DGTTA_PAD_ZEROS 0
 #define DGTTA_PAD_BORDER 1
@@ -128,11 +131,12 @@ int dgtta_softdice_probs_bwd(const float *a, const float *b, const float *grad_d
  * torch.optim.AdamW(model.parameters(), lr).step() at dg_tta/tta/tta.py:185,278 (betas 0.9/0.999,
  * eps 1e-8, weight_decay 0.01 = PyTorch defaults).  h_* are HOST arrays of ntensors device
  * pointers / element counts; tensors whose h_g[i] is NULL are skipped (grad None in PyTorch).
- * step is the 1-based step count of those tensors.
+ * step is the 1-based step count of those tensors.  grad_scale: the static loss scale the gradients carry (fp16
+ * storage path: the caller multiplied the loss gradient by it); every gradient is divided by it on load. 1 = none.
  * ------------------------------------------------------------------------------------------- */
 int dgtta_adamw_step(float *const *h_p, const float *const *h_g, float *const *h_m, float *const *h_v,
                      const int64_t *h_n, int ntensors, float lr, float beta1, float beta2, float eps,
-                     float weight_decay, int step, void *stream);
+                     float weight_decay, int step, float grad_scale, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * nnUNet PlainConvUNet building blocks (third-party dynamic-network-architectures==0.2, built at

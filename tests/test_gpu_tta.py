@@ -366,8 +366,9 @@ def test_tta_main_end_to_end(tmp_path):
         assert torch.equal(a[k], b[k]), f"sharded run differs from the single-process run in {k}"
 
 
-def test_bf16_path_tracks_fp32_within_dice_tolerance():
-    """bf16 storage / fp32 accumulation vs the fp32 HIP path on an MFMA-shaped net (32^3): logits, consistency loss,
+@pytest.mark.parametrize("low", ["bf16", "fp16"])
+def test_16bit_path_tracks_fp32_within_dice_tolerance(low):
+    """bf16 / fp16 storage (fp32 accumulation; fp16 with its static loss scale through HipAdamW) vs the fp32 HIP path on an MFMA-shaped net (32^3): logits, consistency loss,
     label maps, and the loss after adaptation epochs.  north_star tolerance: Dice within 1e-3."""
     from dg_tta_amd import ops
     from dg_tta_amd.mind import MIND3D
@@ -380,7 +381,7 @@ def test_bf16_path_tracks_fp32_within_dice_tolerance():
                num_classes=20)
     sel = torch.tensor([0, 3, 5, 7, 11, 13, 17, 19])
     nets = {}
-    for name, dt in (("fp32", torch.float32), ("bf16", torch.bfloat16)):
+    for name, dt in (("fp32", torch.float32), ("bf16", torch.bfloat16 if low == "bf16" else torch.float16)):
         m = he_init_(HipPlainConvUNet(cfg, act_dtype=dt), seed=5).to(DEV)
         m.set_selected_classes(sel)
         nets[name] = m
@@ -401,8 +402,8 @@ def test_bf16_path_tracks_fp32_within_dice_tolerance():
         return ops.affine_warp(model(x), rinv.to(DEV), padding_mode="zeros", tta_grid_algebra=True)
 
     hist = {k: [] for k in nets}
-    opts = {k: HipAdamW(m.parameters(), lr=1e-5) for k, m in nets.items()}
-    inv = torch.full((), 0.5, device=DEV)
+    opts = {k: HipAdamW(m.parameters(), lr=1e-5, grad_scale=m.loss_scale) for k, m in nets.items()}
+    inv = {k: torch.full((), 0.5 * m.loss_scale, device=DEV) for k, m in nets.items()}
     for epoch in range(3):
         for name, m in nets.items():
             for acc in range(2):
@@ -410,7 +411,7 @@ def test_bf16_path_tracks_fp32_within_dice_tolerance():
                 ta, tb = branch(m, da), branch(m, db)
                 loss, dice = ops.consistency_loss(ta, tb, 1)
                 hist[name].append((float(loss), dice.cpu()))
-                torch.autograd.backward(loss, grad_tensors=inv)
+                torch.autograd.backward(loss, grad_tensors=inv[name])
             opts[name].step()
             opts[name].zero_grad()
     for (l32, d32), (l16, d16) in zip(hist["fp32"], hist["bf16"]):
@@ -420,14 +421,17 @@ def test_bf16_path_tracks_fp32_within_dice_tolerance():
     with torch.no_grad():
         noise = torch.randn(1, 12, 32, 32, 32, device=DEV)
         l32 = nets["fp32"](MIND3D()(imgs, noise))
-        l16 = nets["bf16"](MIND3D()(imgs, noise, out_dtype=torch.bfloat16))
+        l16 = nets["bf16"](MIND3D()(imgs, noise, out_dtype=nets["bf16"].act_dtype))
     a32, a16 = l32.argmax(1), l16.argmax(1)
-    assert (a32 == a16).float().mean() > 0.97      # random-weight logits are near-tied; measured 0.988
+    assert (a32 == a16).float().mean() > (0.97 if low == "bf16" else 0.995)      # near-tied random-weight logits; bf16 measured 0.988
     gt = a32.roll(1, dims=-1)
     d32, d16 = dice_coeff(a32, gt, 8), dice_coeff(a16, gt, 8)
     # hard Dice of an UNTRAINED net is the worst case (near-tied logits: ~1.2 % of the voxels flip label under bf16
     # rounding); measured mean difference 1.1e-3, per class <= 3.6e-3.  The soft quantities above meet 1e-3.
-    assert (d32 - d16).abs().max() < 6e-3 and abs(float(d32.nanmean()) - float(d16.nanmean())) < 2.5e-3
+    if low == "bf16":
+        assert (d32 - d16).abs().max() < 6e-3 and abs(float(d32.nanmean()) - float(d16.nanmean())) < 2.5e-3
+    else:       # fp16 storage meets north_star's 1e-3 on the hard Dice as well
+        assert (d32 - d16).abs().max() < 1e-3 and abs(float(d32.nanmean()) - float(d16.nanmean())) < 1e-3
 
 
 UNIT_MAPPING = {"background": (0, 0), "a": (2, 3), "b": (3, 1), "c": (5, 4), "d": (8, 2)}     # TTA ids != positions

@@ -861,10 +861,15 @@ int gs_blocks(int64_t total, int cap = 16384) {
   return (int)(b < cap ? (b > 0 ? b : 1) : cap);
 }
 
-// per-channel reductions: >= 32 rows per block, at most 2048 blocks (small volumes used to run on 1-4 workgroups)
-int reduce_blocks(int64_t V) {
+// per-channel reductions: >= 32 rows per block (small volumes used to run on 1-4 workgroups) and about 4096 workgroups
+// per launch over the whole batch: 16 per CU keep an HBM stream saturated, while the finalize kernels that read the
+// B x nblk partial rows stay short (with 2048 blocks per SAMPLE at batch 8 they took 30-84 us each, ~5 ms per epoch)
+int reduce_blocks(int64_t V, int B) {
   int64_t b = cdiv64(V, 32);
-  return (int)(b < 2048 ? (b > 0 ? b : 1) : 2048);
+  int64_t cap = 4096 / (B > 0 ? B : 1);
+  if (cap < 128) cap = 128;
+  if (cap > 2048) cap = 2048;
+  return (int)(b < cap ? (b > 0 ? b : 1) : cap);
 }
 
 int wgrad_splits(int64_t nvox) {
@@ -951,7 +956,7 @@ static int out_dim(int i, int s) { return (i + 2 - 3) / s + 1; }
 // statistics buffer: [256-byte header: int64 nblk][partial sums: B x nblk x Cout x 2 doubles]
 extern "C" size_t dgtta_conv3d_stats_bytes(int B, int Cout, int Do, int Ho, int Wo) {
   int64_t nb = conv3_mfma_max_tiles(Do, Ho, Wo);
-  const int64_t rb = reduce_blocks((int64_t)Do * Ho * Wo);
+  const int64_t rb = reduce_blocks((int64_t)Do * Ho * Wo, B);
   if (rb > nb) nb = rb;
   return 256 + (size_t)B * nb * Cout * 2 * sizeof(double);
 }
@@ -982,7 +987,7 @@ extern "C" int dgtta_conv3d_k3_fwd(const void *x, int ldx, const void *wpack, co
   DG_CHECK_LAUNCH("conv3_fwd_ref_kernel");
   if (stats) {   // general kernel: statistics by a separate reduction pass, same buffer layout
     const int64_t V = (int64_t)Do * Ho * Wo;
-    const int nblk = reduce_blocks(V);
+    const int nblk = reduce_blocks(V, B);
     hipLaunchKernelGGL(set_header_kernel, dim3(1), dim3(1), 0, st, (long long *)stats, (long long)nblk);
     DISPATCH_T(dtype, hipLaunchKernelGGL((chan_reduce_kernel<T, 0>), dim3(nblk, B), dim3(256), 0, st, (const T *)y, ldy,
                                          (const T *)nullptr, 0, nullptr, nullptr, nullptr, 0.f, (double *)stats + 32,
@@ -1029,7 +1034,7 @@ size_t conv3_wgrad_mfma_ws_bytes(int B, int Cin, int Cout, int D, int H, int W);
 
 // workspace layout: [bias partials][main: split partials of the VALU kernel | slabs of the MFMA kernel]
 static size_t wgrad_bias_bytes(int B, int Cout, int Do, int Ho, int Wo) {
-  return align_up((size_t)B * reduce_blocks((int64_t)Do * Ho * Wo) * Cout * 2 * sizeof(double), 256);
+  return align_up((size_t)B * reduce_blocks((int64_t)Do * Ho * Wo, B) * Cout * 2 * sizeof(double), 256);
 }
 
 extern "C" size_t dgtta_conv3d_wgrad_ws_bytes(int B, int Cin, int Cout, int Do, int Ho, int Wo) {
@@ -1041,7 +1046,7 @@ extern "C" size_t dgtta_conv3d_wgrad_ws_bytes(int B, int Cin, int Cout, int Do, 
 
 static int bias_grad(const void *dy, int lddy, float *db, void *ws, int B, int C, int64_t V, int accumulate, int dtype,
                      hipStream_t st) {
-  const int nblk = reduce_blocks(V);
+  const int nblk = reduce_blocks(V, B);
   double *partial = (double *)ws;
   DISPATCH_T(dtype, (launch_chan_reduce<T, 2>(dy, lddy, nullptr, 0, nullptr, nullptr, nullptr, 0.f, partial, nblk, B, C, V, st)));
   DG_CHECK_LAUNCH("chan_reduce_kernel<2>");
@@ -1087,7 +1092,7 @@ extern "C" int dgtta_conv3d_k3_wgrad(const void *x, int ldx, const void *dy, int
 }
 
 extern "C" size_t dgtta_instnorm_ws_bytes(int B, int C, int64_t V) {
-  return align_up((size_t)B * reduce_blocks(V) * C * 2 * sizeof(double), 256) +
+  return align_up((size_t)B * reduce_blocks(V, B) * C * 2 * sizeof(double), 256) +
          align_up((size_t)B * C * 2 * sizeof(float), 256);
 }
 
@@ -1098,7 +1103,7 @@ extern "C" int dgtta_instnorm_lrelu_fwd(const void *y, int ldy, const void *stat
   DG_REQUIRE(B > 0 && C > 0 && V > 0 && ldy >= C && ldz >= C, DGTTA_ERR_BADARG, "instnorm_lrelu_fwd: bad dims");
   DG_REQUIRE(ws_bytes >= dgtta_instnorm_ws_bytes(B, C, V), DGTTA_ERR_WORKSPACE, "instnorm_lrelu_fwd: workspace too small");
   hipStream_t st = (hipStream_t)stream;
-  const int nblk = reduce_blocks(V);
+  const int nblk = reduce_blocks(V, B);
   if (stats) {   // partial sums came with the conv epilogue (header + partials)
     hipLaunchKernelGGL(in_stats_finalize_kernel, dim3(B * C), dim3(256), 0, st, (const double *)stats + 32,
                        (const long long *)stats, 0, B, C, V, eps, mean_rstd);
@@ -1137,7 +1142,7 @@ extern "C" int dgtta_instnorm_lrelu_bwd(const void *gz, int ldgz, const void *y,
              "instnorm_lrelu_bwd: bad dims");
   DG_REQUIRE(ws_bytes >= dgtta_instnorm_ws_bytes(B, C, V), DGTTA_ERR_WORKSPACE, "instnorm_lrelu_bwd: workspace too small");
   hipStream_t st = (hipStream_t)stream;
-  const int nblk = reduce_blocks(V);
+  const int nblk = reduce_blocks(V, B);
   double *partial = (double *)ws;
   float *c12 = (float *)((char *)ws + align_up((size_t)B * nblk * C * 2 * sizeof(double), 256));
   DISPATCH_T(dtype, (launch_chan_reduce<T, 1>(y, ldy, gz, ldgz, mean_rstd, gamma, beta, slope, partial, nblk, B, C, V, st)));
@@ -1192,7 +1197,7 @@ extern "C" int dgtta_convT3d_k2s2_fwd(const void *x, int ldx, const float *w_t, 
 
 // workspace layout: [bias partials][packed weights][main: split partials (VALU) | slabs (MFMA)]
 static size_t convT_bias_region(int B, int Cout, int Di, int Hi, int Wi) {
-  return align_up((size_t)B * reduce_blocks((int64_t)Di * Hi * Wi * 8) * Cout * 2 * sizeof(double), 256);
+  return align_up((size_t)B * reduce_blocks((int64_t)Di * Hi * Wi * 8, B) * Cout * 2 * sizeof(double), 256);
 }
 
 extern "C" size_t dgtta_convT3d_bwd_ws_bytes(int B, int Cin, int Cout, int Di, int Hi, int Wi) {
@@ -1301,7 +1306,7 @@ int head_wgrad_mfma(const void *x, int ldx, const float *dout, int lddo, float *
 
 // workspace layout: [bias partials][main: split partials (VALU) | bf16 copy + slabs (MFMA)]
 static size_t head_bias_region(int B, int nsel, int64_t V) {
-  return align_up((size_t)B * reduce_blocks(V) * nsel * 2 * sizeof(double), 256);
+  return align_up((size_t)B * reduce_blocks(V, B) * nsel * 2 * sizeof(double), 256);
 }
 
 extern "C" size_t dgtta_seghead_bwd_ws_bytes(int B, int Cin, int nsel, int64_t V) {

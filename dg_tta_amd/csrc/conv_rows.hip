@@ -49,7 +49,10 @@ __global__ __launch_bounds__(WD *WH * 64) void conv3_rows_kernel(const bf16_t *_
   unsigned char *sBb = smem + 2 * Cfg::A_BYTES;                // [27][2][32] x 16 B
   float *red = reinterpret_cast<float *>(smem + 2 * Cfg::A_BYTES + Cfg::B_BYTES);
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // the wave id is made explicitly scalar: derived from threadIdx it is a 'divergent' VGPR value to the compiler, and
+  // every per-row address of a DMA piece (64-bit multiplies and adds) was computed per lane - ~25 VALU per piece, 20
+  // pieces per wave and phase, on a VALU shared with the partner wave: the MFMA loop was VALU-bound on address math
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 31, h = lane >> 5;
   const int wd = wave / WH, wh = wave % WH;
   const int Di = xv.D, Hi = xv.H, Wi = xv.W, Do = yv.D, Ho = yv.H, Wo = yv.W;
@@ -151,7 +154,11 @@ __global__ __launch_bounds__(WD *WH * 64) void conv3_rows_kernel(const bf16_t *_
       tprev = t;
     }
   };
-  if (ABL == 6) tprev = __builtin_amdgcn_s_memtime();
+  unsigned long long t_begin = 0, rt_begin = 0;      // ABL 6: in-kernel clock = d(s_memtime) / d(s_memrealtime) x 100 MHz
+  if (ABL == 6) {
+    tprev = t_begin = __builtin_amdgcn_s_memtime();
+    rt_begin = __builtin_amdgcn_s_memrealtime();
+  }
   for (int p = 0; p < nph; ++p) {
     dma_wait_all();
     stamp(0);                 // waiting for the DMA
@@ -366,6 +373,10 @@ __global__ __launch_bounds__(WD *WH * 64) void conv3_rows_kernel(const bf16_t *_
   }
   if (ABL == 6 && stats && lane == 0) {
     for (int k = 0; k < 8; ++k) stats[4096 + ((size_t)blockIdx.x * NW + wave) * 8 + k] = (double)tseg[k];
+    stats[4096 + (size_t)gridDim.x * NW * 8 + ((size_t)blockIdx.x * NW + wave) * 2 + 0] =
+        (double)(__builtin_amdgcn_s_memtime() - t_begin);
+    stats[4096 + (size_t)gridDim.x * NW * 8 + ((size_t)blockIdx.x * NW + wave) * 2 + 1] =
+        (double)(__builtin_amdgcn_s_memrealtime() - rt_begin);
   }
 }
 

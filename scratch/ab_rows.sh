@@ -1,8 +1,7 @@
 #!/bin/bash
-# A/B of the row-reuse kernel inside ONE box: default build vs DGTTA_ROWS_ABL=<n> variants, interleaved, 3 rounds
+# timing of the row-reuse kernel on three layer shapes, 3 rounds (run-to-run spread inside one box)
 for round in 1 2 3; do
-  for a in 0 $@; do
-    if [ $a = 0 ]; then unset DGTTA_ROWS_ABL; else export DGTTA_ROWS_ABL=$a; fi
-    echo -n "round $round ABL=$a: "; KB_STATS=1 python scratch/kbench.py conv bf16 32 32 128 50 2>&1 | tail -1
+  for shape in "32 32 128" "64 64 64" "64 32 128"; do
+    echo -n "round $round: "; KB_STATS=1 python scratch/kbench.py conv bf16 $shape 30 2>&1 | tail -1
   done
 done

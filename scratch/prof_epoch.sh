@@ -3,7 +3,7 @@
 tag=$1; shift
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d $R/gpurun_out/$tag -o $tag --output-format csv -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-fp32 "$@" > $R/gpurun_out/$tag.log 2>&1 || exit 1
+rocprofv3 --kernel-trace --stats -d $R/gpurun_out/$tag -o $tag --output-format csv -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-fp32 --inference-size 0 "$@" > $R/gpurun_out/$tag.log 2>&1 || exit 1
 cd $R
 python - "$tag" <<'PY'
 import csv, sys

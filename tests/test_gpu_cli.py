@@ -1,0 +1,64 @@
+"""BASELINE config 1 on the GPU: the whole `dgtta prepare_tta` + `dgtta run_tta` command line on ONE synthetic 64^3 "MRI"
+case stored as NIfTI (raw-case preprocessing included), full nnUNet 3d_fullres topology (seeded He-init stand-in for the
+TS104_GIN_MIND checkpoint, which cannot be downloaded), 1 TTA epoch with backward, ensemble inference and summary."""
+import json
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def test_prepare_and_run_tta_cli_full_net_64(tmp_path, monkeypatch):
+    from dg_tta_amd.run import DGTTAProgram
+    from dg_tta_amd.synthetic import he_init_, synthetic_case
+    from dg_tta_amd.tta.nifti_io import read_nifti, write_nifti
+    from dg_tta_amd.unet import HipPlainConvUNet
+    raw = tmp_path / "raw" / "Dataset803_Target"
+    (raw / "imagesTs").mkdir(parents=True)
+    (raw / "labelsTs").mkdir()
+    case = synthetic_case(size=64, k=3, seed=5)                      # [1+3, 64,64,64]: image + 3 ellipsoid labels
+    img = (case[0] * 300.0).numpy()                                  # CT-like range for the plans' CTNormalization
+    lab = torch.cat([(case[1:].sum(0, keepdim=True) < 1).float(), case[1:]]).argmax(0).numpy().astype(np.int16)
+    write_nifti(raw / "imagesTs" / "mr01_0000.nii.gz", img.astype(np.float32), spacing=(1.5, 1.5, 1.5))
+    write_nifti(raw / "labelsTs" / "mr01.nii.gz", lab, spacing=(1.5, 1.5, 1.5))
+    json.dump({"labels": {"background": 0, "liver": 1, "spleen": 2, "my_organ": 3}}, open(raw / "dataset.json", "w"))
+    root = tmp_path / "dgroot"
+    root.mkdir()
+    for k, v in {"nnUNet_raw": str(tmp_path / "raw"), "nnUNet_results": str(tmp_path / "res"),
+                 "nnUNet_preprocessed": str(tmp_path / "pre"), "DG_TTA_ROOT": str(root)}.items():
+        monkeypatch.setenv(k, v)
+    DGTTAProgram(["dgtta", "prepare_tta", "TS104_GIN_MIND", "803"])
+    plan_dir = root / "plans" / "Pretrained_TS104_GIN_MIND_at_Dataset803_Target" / "nnUNetTrainer_GIN_MIND__3d_fullres" / "fold_0"
+    plan = json.load(open(plan_dir / "tta_plan.json"))
+    assert [Path(p).name for p in plan["tta_data_filepaths"]] == ["mr01_0000.nii.gz"]
+    # the model folder: patch 64^3 (config 1), seeded stand-in checkpoint with the real key layout
+    weights = Path(plan["pretrained_weights_filepath"])
+    mplans = json.load(open(weights.parents[1] / "plans.json"))
+    mplans["configurations"]["3d_fullres"]["patch_size"] = [64, 64, 64]
+    json.dump(mplans, open(weights.parents[1] / "plans.json", "w"))
+    net = he_init_(HipPlainConvUNet(), seed=7)
+    torch.save({"network_weights": net.state_dict(), "trainer_name": "nnUNetTrainer_GIN_MIND"}, weights)
+    # 1 epoch that adapts (start_tta_at_epoch = 0), 4 accumulation steps, one ensemble member
+    plan.update(epochs=1, start_tta_at_epoch=0, patches_to_be_accumulated=4, ensemble_count=1)
+    json.dump(plan, open(plan_dir / "tta_plan.json", "w"), indent=4)
+    DGTTAProgram(["dgtta", "run_tta", "TS104_GIN_MIND", "803", "--device", "cuda:0", "--dtype", "bf16"])
+    runs = sorted((root / "results" / "Pretrained_TS104_GIN_MIND_at_Dataset803_Target" /
+                   "nnUNetTrainer_GIN_MIND__3d_fullres" / "fold_0").iterdir())
+    assert len(runs) == 1
+    run = runs[0]
+    out = run / "tta_outputTs"
+    assert (run / "tta_plan.json").is_file() and (out / "mr01__ensemble_idx_0_tta_parameters.pt").is_file()
+    state = torch.load(out / "mr01__ensemble_idx_0_tta_parameters.pt", map_location="cpu")[0]
+    assert set(state) == set(net.state_dict())
+    moved = sum(int(not torch.equal(state[k], v)) for k, v in net.state_dict().items())
+    assert moved > 30                                              # the adaptation step changed the parameters
+    seg, hdr = read_nifti(out / "mr01.nii.gz")                     # prediction written with the case's geometry
+    assert seg.shape == (64, 64, 64) and hdr["pixdim"] == pytest.approx((1.5, 1.5, 1.5))
+    assert set(np.unique(seg).tolist()) <= {0, 1, 2}               # ids of the optimized labels (background, liver, spleen)
+    tgt, _ = read_nifti(run / "mapped_target_labelsTs" / "mr01.nii.gz")
+    assert (tgt == 1).sum() == (lab == 1).sum() and (tgt == 2).sum() == (lab == 2).sum() and (tgt == 3).sum() == 0
+    sj = json.loads((run / "summary_Ts.json").read_text())
+    assert len(sj["metric_per_case"]) == 1 and set(sj["mean"]) == {"0", "1", "2"}

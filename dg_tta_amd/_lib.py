@@ -18,7 +18,7 @@ SIGNATURES = {
     "dgtta_last_error": (C.c_char_p, []),
     "dgtta_reload_env": (I, []),
     "dgtta_mind3d_ws_bytes": (SZ, [I, I, I, I]),
-    "dgtta_mind3d_fwd": (I, [P, P, F, P, I, I, I, P, SZ, I, I, I, I, P]),
+    "dgtta_mind3d_fwd": (I, [P, P, F, I, C.POINTER(F), I, P, I, I, I, P, SZ, I, I, I, I, P]),
     "dgtta_gin_ws_bytes": (SZ, [I, I, I, I]),
     "dgtta_gin_chain_fwd": (I, [P, P, C.POINTER(I), C.POINTER(P), C.POINTER(P), P, P, SZ, I, I, I, I, P]),
     "dgtta_affine_warp3d_fwd": (I, [P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, I, I, P, P]),

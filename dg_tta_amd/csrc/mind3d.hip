@@ -17,22 +17,19 @@
 namespace {
 
 constexpr int TD = 8, TH = 8, TW = 32;
-constexpr int ID = TD + 6, IH = TH + 6, IW = TW + 6;   // image tile (halo 3)
-constexpr int QD = TD + 4, QH = TH + 4, QW = TW + 4;   // q tile (halo 2)
 constexpr int NT = 512;                                 // 8 waves
 constexpr int VPT = TD * TH * TW / NT;                 // 4 voxels per thread (consecutive along W)
-constexpr int CG = 4, NG = 12 / CG;                    // channels per pass through the LDS filter pipeline
 static_assert(VPT == 4 && TW == 32 && TD * TH * (TW / 4) == NT, "stage-3 thread map: (d, h, w/4)");
 
 __device__ __forceinline__ int clampi(int x, int lo, int hi) { return x < lo ? lo : (x > hi ? hi : x); }
 
-struct Taps { float g[5]; };
+struct Taps { float g[7]; };      // 2 R + 1 Gaussian taps (R <= 3, i.e. sigma <= 2)
 
-// The 12 shift pairs of mshift1/mshift2 (mind.py:112-135) only ever touch the SIX face neighbours of a voxel:
-// e_c = img[v + s1_c] - img[v + s2_c] with (d,h,w) offsets
+// The 12 shift pairs of mshift1/mshift2 (mind.py:112-135) only ever touch the SIX face neighbours of a voxel (at distance
+// delta): e_c = img[v + delta s1_c] - img[v + delta s2_c] with (d,h,w) offsets
 //   s1: c0 (0,0,-1) c1,c2 (0,-1,0) c3,c4 (0,0,1) c5..c7 (1,0,0) c8..c11 (0,1,0)
 //   s2: c0,c1,c3,c8 (-1,0,0)  c2,c5,c9 (0,0,-1)  c4,c6 (0,-1,0)  c7,c10 (0,0,1)  c11 (1,0,0)
-// so one fetch of the neighbours (dp = d+1, dm = d-1, hp, hm, wp, wm) serves every channel.
+// so one fetch of the neighbours (dp = d+delta, dm = d-delta, hp, hm, wp, wm) serves every channel.
 template <int C>
 __device__ __forceinline__ float edge(float dp, float dm, float hp, float hm, float wp, float wm) {
   constexpr int S1[12] = {5, 3, 3, 4, 4, 0, 0, 0, 2, 2, 2, 2};      // index into {dp, dm, hp, hm, wp, wm}
@@ -58,20 +55,38 @@ __device__ __forceinline__ float edge_sel(int c, float dp, float dm, float hp, f
   }
 }
 
+// Geometry for neighbour distance DELTA (mind.py:137: ReplicationPad3d(delta), dilation delta) and filter radius R
+// (mind.py:30-31: N = 2 ceil(1.5 sigma) + 1 taps), CG channels per pass through the LDS filter pipeline.
+template <int DELTA, int R, int CG>
+struct MG {
+  static constexpr int HL = R + DELTA;                                          // image halo
+  static constexpr int ID = TD + 2 * HL, IH = TH + 2 * HL, IW = TW + 2 * HL;    // image tile
+  static constexpr int QD = TD + 2 * R, QH = TH + 2 * R, QW = TW + 2 * R;       // q tile (halo R)
+  static constexpr int QWP = (QW + 3) / 4 * 4;                                  // row pitch of the filter buffers
+  static constexpr int NTAP = 2 * R + 1, NG = 12 / CG;
+  static constexpr int NV3 = (4 + 2 * R + 3) / 4;                               // 16-byte reads per row in stage 3
+  static constexpr size_t LDS_BYTES = (size_t)(ID * IH * IW + CG * TD * QH * QWP + CG * TD * TH * QWP + 8 + 16) * 4;
+};
+
 // Pass A.  One workgroup per 8 x 8 x 32 output tile, channels in NG groups of CG:
-//   stage 1  thread = one (h', w') column of the q tile (halo 2): walks the 12 depths, forms q_c = (e_c + rw n_c)^2 for the
-//            group's channels from the six neighbours (centre column kept in a 3-deep register window) and runs the
-//            D filter on a 5-deep register window per channel -> r1[c][d][h'][w'] in LDS (no q tile in LDS at all);
+//   stage 1  thread = one (h', w') column of the q tile (halo R): walks the depths, forms q_c = (e_c + rw n_c)^2 for the
+//            group's channels from the six neighbours and runs the D filter on a (2R+1)-deep register window per channel
+//            -> r1[c][d][h'][w'] in LDS (no q tile in LDS at all);
 //   stage 2  H filter, 4 adjacent w' columns per thread (16-byte LDS accesses): r1 -> r2[c][d][h][w'];
-//   stage 3  W filter: thread = 4 consecutive output voxels of a row, 2 x 16-byte reads per channel -> registers.
+//   stage 3  W filter: thread = 4 consecutive output voxels of a row, 16-byte reads per channel -> registers.
 // 2 barriers per group instead of 5 per channel, ~1/3 of the LDS instructions of the first version.
+template <int DELTA, int R, int CG>
 __global__ __launch_bounds__(NT) void mind_ssd_kernel(const float *__restrict__ img, const float *__restrict__ noise,
                                                       float rw, float *__restrict__ mws, double *__restrict__ partial,
                                                       int D, int H, int W, int tilesD, Taps taps) {
-  __shared__ __attribute__((aligned(16))) float simg[ID * IH * IW];
-  __shared__ __attribute__((aligned(16))) float sr1[CG * TD * QH * QW];
-  __shared__ __attribute__((aligned(16))) float sr2[CG * TD * TH * QW];
-  __shared__ float sred[16];
+  typedef MG<DELTA, R, CG> G;
+  constexpr int ID = G::ID, IH = G::IH, IW = G::IW, QD = G::QD, QH = G::QH, QW = G::QW, QWP = G::QWP, NTAP = G::NTAP,
+                NG = G::NG, HL = G::HL;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float *simg = smem;                                   // [ID][IH][IW]
+  float *sr1 = simg + (ID * IH * IW + 3) / 4 * 4;       // [CG][TD][QH][QWP]
+  float *sr2 = sr1 + CG * TD * QH * QWP;                // [CG][TD][TH][QWP] (+ pad: stage 3 reads past the last row)
+  float *sred = sr2 + CG * TD * TH * QWP + 8;
 
   const int tid = threadIdx.x;
   const int b = blockIdx.z / tilesD;
@@ -86,7 +101,7 @@ __global__ __launch_bounds__(NT) void mind_ssd_kernel(const float *__restrict__ 
     for (int k = 0; k < NI; ++k) {
       const int i = tid + k * NT < ID * IH * IW ? tid + k * NT : 0;
       const int iw = i % IW, ih = (i / IW) % IH, id = i / (IW * IH);
-      const int gd = clampi(d0 - 3 + id, 0, D - 1), gh = clampi(h0 - 3 + ih, 0, H - 1), gw = clampi(w0 - 3 + iw, 0, W - 1);
+      const int gd = clampi(d0 - HL + id, 0, D - 1), gh = clampi(h0 - HL + ih, 0, H - 1), gw = clampi(w0 - HL + iw, 0, W - 1);
       pre[k] = imgb[((int64_t)gd * H + gh) * W + gw];
     }
 #pragma unroll
@@ -97,21 +112,21 @@ __global__ __launch_bounds__(NT) void mind_ssd_kernel(const float *__restrict__ 
   // stage-1 role: column (qh, qw) of the q tile; replicate padding = clamped global coordinates (mind.py:143, :13-14)
   const bool col_on = tid < QH * QW;
   const int qw = tid % QW, qh = (tid / QW) % QH;
-  const int gh = clampi(h0 - 2 + qh, 0, H - 1), gw = clampi(w0 - 2 + qw, 0, W - 1);
-  const int ih_c = gh - (h0 - 3), iw_c = gw - (w0 - 3);
-  const int ih_p = clampi(gh + 1, 0, H - 1) - (h0 - 3), ih_m = clampi(gh - 1, 0, H - 1) - (h0 - 3);
-  const int iw_p = clampi(gw + 1, 0, W - 1) - (w0 - 3), iw_m = clampi(gw - 1, 0, W - 1) - (w0 - 3);
+  const int gh = clampi(h0 - R + qh, 0, H - 1), gw = clampi(w0 - R + qw, 0, W - 1);
+  const int ih_c = gh - (h0 - HL), iw_c = gw - (w0 - HL);
+  const int ih_p = clampi(gh + DELTA, 0, H - 1) - (h0 - HL), ih_m = clampi(gh - DELTA, 0, H - 1) - (h0 - HL);
+  const int iw_p = clampi(gw + DELTA, 0, W - 1) - (w0 - HL), iw_m = clampi(gw - DELTA, 0, W - 1) - (w0 - HL);
   // stage-3 role: 4 consecutive output voxels
   const int od = tid / (TH * (TW / 4)), oh = (tid / (TW / 4)) % TH, ow4 = (tid % (TW / 4)) * 4;
 
   float ssd[VPT][12];
-  // noise of the whole column for one channel group (48 values), fetched a full group ahead: the loads of group g+1 are
-  // issued while group g runs (a one-step prefetch left every depth step waiting on HBM latency)
+  // noise of the whole column for one channel group, fetched a full group ahead: the loads of group g+1 are issued while
+  // group g runs
   float nbuf[QD][CG];
   const float *nzb = noise + (int64_t)b * 12 * V;
   int gidx[QD];
 #pragma unroll
-  for (int qd = 0; qd < QD; ++qd) gidx[qd] = (clampi(d0 - 2 + qd, 0, D - 1) * H + gh) * W + gw;
+  for (int qd = 0; qd < QD; ++qd) gidx[qd] = (clampi(d0 - R + qd, 0, D - 1) * H + gh) * W + gw;
   if (col_on) {
 #pragma unroll
     for (int qd = 0; qd < QD; ++qd)
@@ -124,7 +139,7 @@ __global__ __launch_bounds__(NT) void mind_ssd_kernel(const float *__restrict__ 
   for (int g = 0; g < NG; ++g) {
     // ---- stage 1
     if (col_on) {
-      float win[CG][5];
+      float win[CG][NTAP];
       float nv[CG];
 #pragma unroll
       for (int qd = 0; qd < QD; ++qd) {
@@ -134,8 +149,9 @@ __global__ __launch_bounds__(NT) void mind_ssd_kernel(const float *__restrict__ 
 #pragma unroll
           for (int c = 0; c < CG; ++c) nbuf[qd][c] = nzb[(int64_t)((g + 1) * CG + c) * V + gidx[qd]];
         }
-        const int gd = clampi(d0 - 2 + qd, 0, D - 1);
-        const int id_c = gd - (d0 - 3), id_p = clampi(gd + 1, 0, D - 1) - (d0 - 3), id_m = clampi(gd - 1, 0, D - 1) - (d0 - 3);
+        const int gd = clampi(d0 - R + qd, 0, D - 1);
+        const int id_c = gd - (d0 - HL), id_p = clampi(gd + DELTA, 0, D - 1) - (d0 - HL),
+                  id_m = clampi(gd - DELTA, 0, D - 1) - (d0 - HL);
         const float dp = simg[(id_p * IH + ih_c) * IW + iw_c], dm = simg[(id_m * IH + ih_c) * IW + iw_c];
         const float hp = simg[(id_c * IH + ih_p) * IW + iw_c], hm = simg[(id_c * IH + ih_m) * IW + iw_c];
         const float wp = simg[(id_c * IH + ih_c) * IW + iw_p], wm = simg[(id_c * IH + ih_c) * IW + iw_m];
@@ -145,52 +161,94 @@ __global__ __launch_bounds__(NT) void mind_ssd_kernel(const float *__restrict__ 
 #pragma unroll
         for (int c = 0; c < CG; ++c) {
           const float ev = e[c] + rw * nv[c];
-          win[c][qd % 5] = ev * ev;
+          win[c][qd % NTAP] = ev * ev;
         }
-        if (qd >= 4) {            // D filter output d = qd - 4: taps over q[d .. d+4]
-          const int d = qd - 4;
+        if (qd >= NTAP - 1) {     // D filter output d = qd - 2R: taps over q[d .. d+2R]
+          const int d = qd - (NTAP - 1);
 #pragma unroll
           for (int c = 0; c < CG; ++c) {
-            float acc = taps.g[0] * win[c][d % 5];
+            float acc = taps.g[0] * win[c][d % NTAP];
 #pragma unroll
-            for (int t = 1; t < 5; ++t) acc += taps.g[t] * win[c][(d + t) % 5];
-            sr1[((c * TD + d) * QH + qh) * QW + qw] = acc;
+            for (int t = 1; t < NTAP; ++t) acc += taps.g[t] * win[c][(d + t) % NTAP];
+            sr1[((c * TD + d) * QH + qh) * QWP + qw] = acc;
+          }
+        }
+      }
+    }
+    if constexpr (QH * QW > NT) {
+      // R = 3: the q tile has 14 x 38 = 532 columns for 512 threads; the last ones are walked by the first threads in
+      // a second, unpipelined pass (noise loaded where it is used)
+      const int col = tid + NT;
+      if (col < QH * QW) {
+        const int qw2 = col % QW, qh2 = col / QW;
+        const int gh2 = clampi(h0 - R + qh2, 0, H - 1), gw2 = clampi(w0 - R + qw2, 0, W - 1);
+        const int jh_c = gh2 - (h0 - HL), jw_c = gw2 - (w0 - HL);
+        const int jh_p = clampi(gh2 + DELTA, 0, H - 1) - (h0 - HL), jh_m = clampi(gh2 - DELTA, 0, H - 1) - (h0 - HL);
+        const int jw_p = clampi(gw2 + DELTA, 0, W - 1) - (w0 - HL), jw_m = clampi(gw2 - DELTA, 0, W - 1) - (w0 - HL);
+        float win[CG][NTAP];
+#pragma unroll
+        for (int qd = 0; qd < QD; ++qd) {
+          const int gd = clampi(d0 - R + qd, 0, D - 1);
+          const int64_t gi = ((int64_t)gd * H + gh2) * W + gw2;
+          const int id_c = gd - (d0 - HL), id_p = clampi(gd + DELTA, 0, D - 1) - (d0 - HL),
+                    id_m = clampi(gd - DELTA, 0, D - 1) - (d0 - HL);
+          const float dp = simg[(id_p * IH + jh_c) * IW + jw_c], dm = simg[(id_m * IH + jh_c) * IW + jw_c];
+          const float hp = simg[(id_c * IH + jh_p) * IW + jw_c], hm = simg[(id_c * IH + jh_m) * IW + jw_c];
+          const float wp = simg[(id_c * IH + jh_c) * IW + jw_p], wm = simg[(id_c * IH + jh_c) * IW + jw_m];
+#pragma unroll
+          for (int c = 0; c < CG; ++c) {
+            const float ev = edge_sel(g * CG + c, dp, dm, hp, hm, wp, wm) + rw * nzb[(int64_t)(g * CG + c) * V + gi];
+            win[c][qd % NTAP] = ev * ev;
+          }
+          if (qd >= NTAP - 1) {
+            const int d = qd - (NTAP - 1);
+#pragma unroll
+            for (int c = 0; c < CG; ++c) {
+              float acc = taps.g[0] * win[c][d % NTAP];
+#pragma unroll
+              for (int t = 1; t < NTAP; ++t) acc += taps.g[t] * win[c][(d + t) % NTAP];
+              sr1[((c * TD + d) * QH + qh2) * QWP + qw2] = acc;
+            }
           }
         }
       }
     }
     __syncthreads();
     // ---- stage 2: H filter, r2[c][d][h][w'] = sum_t g[t] r1[c][d][h+t][w'], 4 columns per thread
-    for (int i = tid; i < CG * TD * (QW / 4); i += NT) {
-      const int w4 = (i % (QW / 4)) * 4, d = (i / (QW / 4)) % TD, c = i / ((QW / 4) * TD);
-      const float *r = sr1 + ((c * TD + d) * QH) * QW + w4;
+    for (int i = tid; i < CG * TD * (QWP / 4); i += NT) {
+      const int w4 = (i % (QWP / 4)) * 4, d = (i / (QWP / 4)) % TD, c = i / ((QWP / 4) * TD);
+      const float *r = sr1 + ((c * TD + d) * QH) * QWP + w4;
       float4 rowv[QH];
 #pragma unroll
-      for (int k = 0; k < QH; ++k) rowv[k] = *reinterpret_cast<const float4 *>(r + k * QW);
+      for (int k = 0; k < QH; ++k) rowv[k] = *reinterpret_cast<const float4 *>(r + k * QWP);
 #pragma unroll
       for (int h = 0; h < TH; ++h) {
         float4 acc;
         acc.x = taps.g[0] * rowv[h].x; acc.y = taps.g[0] * rowv[h].y; acc.z = taps.g[0] * rowv[h].z; acc.w = taps.g[0] * rowv[h].w;
 #pragma unroll
-        for (int t = 1; t < 5; ++t) {
+        for (int t = 1; t < NTAP; ++t) {
           acc.x += taps.g[t] * rowv[h + t].x; acc.y += taps.g[t] * rowv[h + t].y;
           acc.z += taps.g[t] * rowv[h + t].z; acc.w += taps.g[t] * rowv[h + t].w;
         }
-        *reinterpret_cast<float4 *>(sr2 + ((c * TD + d) * TH + h) * QW + w4) = acc;
+        *reinterpret_cast<float4 *>(sr2 + ((c * TD + d) * TH + h) * QWP + w4) = acc;
       }
     }
     __syncthreads();
     // ---- stage 3: W filter into registers
 #pragma unroll
     for (int c = 0; c < CG; ++c) {
-      const float *r = sr2 + ((c * TD + od) * TH + oh) * QW + ow4;
-      const float4 a0 = *reinterpret_cast<const float4 *>(r), a1 = *reinterpret_cast<const float4 *>(r + 4);
-      const float v[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+      const float *r = sr2 + ((c * TD + od) * TH + oh) * QWP + ow4;
+      float v[4 * G::NV3];
+#pragma unroll
+      for (int q = 0; q < G::NV3; ++q) {
+        const float4 a = *reinterpret_cast<const float4 *>(r + 4 * q);
+        v[4 * q] = a.x; v[4 * q + 1] = a.y; v[4 * q + 2] = a.z; v[4 * q + 3] = a.w;
+      }
 #pragma unroll
       for (int k = 0; k < VPT; ++k) {
         float acc = taps.g[0] * v[k];
 #pragma unroll
-        for (int t = 1; t < 5; ++t) acc += taps.g[t] * v[k + t];
+        for (int t = 1; t < NTAP; ++t) acc += taps.g[t] * v[k + t];
         ssd[k][g * CG + c] = acc;
       }
     }
@@ -221,6 +279,20 @@ __global__ __launch_bounds__(NT) void mind_ssd_kernel(const float *__restrict__ 
   }
   float tot = block_sum(vsum, sred);
   if (tid == 0) partial[(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = (double)tot;
+}
+
+template <int DELTA, int R, int CG>
+int launch_mind_ssd(const float *img, const float *noise, float rw, float *mws, double *partial, int D, int H, int W, int td,
+                    dim3 grid, const Taps &taps, hipStream_t st) {
+  typedef MG<DELTA, R, CG> G;
+  static_assert(G::LDS_BYTES <= 163840, "MIND tile does not fit the LDS");
+  static DynLdsOnce once;
+  DG_REQUIRE(ensure_dyn_lds(once, (const void *)mind_ssd_kernel<DELTA, R, CG>, (int)G::LDS_BYTES) == hipSuccess,
+             DGTTA_ERR_LAUNCH, "mind3d: cannot raise the dynamic LDS limit to %zu", (size_t)G::LDS_BYTES);
+  hipLaunchKernelGGL((mind_ssd_kernel<DELTA, R, CG>), grid, dim3(NT), G::LDS_BYTES, st, img, noise, rw, mws, partial, D, H, W,
+                     td, taps);
+  DG_CHECK_LAUNCH("mind_ssd_kernel");
+  return DGTTA_OK;
 }
 
 __global__ void mind_reduce_kernel(const double *__restrict__ partial, int n, double inv_count, float *gmean) {
@@ -280,10 +352,14 @@ extern "C" size_t dgtta_mind3d_ws_bytes(int B, int D, int H, int W) {
   return m + p + 256;
 }
 
-extern "C" int dgtta_mind3d_fwd(const float *img, const float *noise, float rw, void *out, int out_ndhwc, int out_ldc,
-                                int out_dtype, void *ws, size_t ws_bytes, int B, int D, int H, int W, void *stream) {
+extern "C" int dgtta_mind3d_fwd(const float *img, const float *noise, float rw, int delta, const float *h_taps, int ntaps,
+                                void *out, int out_ndhwc, int out_ldc, int out_dtype, void *ws, size_t ws_bytes, int B,
+                                int D, int H, int W, void *stream) {
   DG_REQUIRE(img && noise && out && ws, DGTTA_ERR_BADARG, "mind3d_fwd: null pointer");
   DG_REQUIRE(B > 0 && D > 0 && H > 0 && W > 0, DGTTA_ERR_BADARG, "mind3d_fwd: bad dims %d %d %d %d", B, D, H, W);
+  DG_REQUIRE(h_taps && (ntaps == 3 || ntaps == 5 || ntaps == 7), DGTTA_ERR_UNSUPPORTED,
+             "mind3d_fwd: %d filter taps (sigma up to 2, i.e. 3 / 5 / 7 taps, are built)", ntaps);
+  DG_REQUIRE(delta == 1 || delta == 2, DGTTA_ERR_UNSUPPORTED, "mind3d_fwd: delta %d (1 and 2 are built)", delta);
   DG_REQUIRE(D <= 1024 && H <= 1024 && W <= 1024 && (int64_t)D * H * W < (1ll << 31), DGTTA_ERR_UNSUPPORTED,
              "mind3d_fwd: each dim must be <= 1024 (got %d %d %d)", D, H, W);
   DG_REQUIRE(ws_bytes >= dgtta_mind3d_ws_bytes(B, D, H, W), DGTTA_ERR_WORKSPACE, "mind3d_fwd: workspace too small");
@@ -301,11 +377,17 @@ extern "C" int dgtta_mind3d_fwd(const float *img, const float *noise, float rw, 
   const int nblk = B * td * th * tw;
   float *gmean = (float *)((char *)partial + align_up((size_t)nblk * sizeof(double), 256));
 
-  // taps as mind.py:30-37 evaluates them in fp32 for sigma=1: exp(-x^2/2)/sum, x=-2..2 (bit patterns of torch's result)
-  Taps taps = {{0x1.be5f1p-5f, 0x1.f41fd8p-3f, 0x1.9c4868p-2f, 0x1.f41fd8p-3f, 0x1.be5f1p-5f}};
+  // taps as mind.py:30-37 evaluates them (fp32, computed by the caller with the reference's expression)
+  Taps taps;
+  for (int t = 0; t < 7; ++t) taps.g[t] = t < ntaps ? h_taps[t] : 0.f;
   dim3 grid(tw, th, td * B);
-  hipLaunchKernelGGL(mind_ssd_kernel, grid, dim3(NT), 0, st, img, noise, rw, mws, partial, D, H, W, td, taps);
-  DG_CHECK_LAUNCH("mind_ssd_kernel");
+  const int R = ntaps / 2;
+  int rc = DGTTA_ERR_UNSUPPORTED;
+#define MIND_CASE(DL, RR, CGG) \
+  if (delta == DL && R == RR) rc = launch_mind_ssd<DL, RR, CGG>(img, noise, rw, mws, partial, D, H, W, td, grid, taps, st);
+  MIND_CASE(1, 1, 4) MIND_CASE(1, 2, 4) MIND_CASE(1, 3, 4) MIND_CASE(2, 1, 4) MIND_CASE(2, 2, 4) MIND_CASE(2, 3, 2)
+#undef MIND_CASE
+  if (rc != DGTTA_OK) return rc;
   hipLaunchKernelGGL(mind_reduce_kernel, dim3(1), dim3(256), 0, st, partial, nblk, 1.0 / ((double)B * V), gmean);
   DG_CHECK_LAUNCH("mind_reduce_kernel");
   const int64_t total = (int64_t)B * V;

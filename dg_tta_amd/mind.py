@@ -9,8 +9,9 @@ from . import ops
 class MIND3D(torch.nn.Module):
     def __init__(self, delta=1, sigma=1, randn_weighting=0.05) -> None:
         super().__init__()
-        if delta != 1 or sigma != 1:
-            raise NotImplementedError("the HIP MIND3D kernel is built for delta=1, sigma=1 (all the reference ever uses)")
+        if delta not in (1, 2) or not (0 < sigma <= 2):
+            raise NotImplementedError("the HIP MIND3D kernels are built for delta in {1, 2} and 0 < sigma <= 2 "
+                                      "(the reference itself only ever uses delta=1, sigma=1)")
         self.delta, self.sigma, self.randn_weighting = delta, sigma, randn_weighting
         self.out_channels = 12
 
@@ -20,7 +21,8 @@ class MIND3D(torch.nn.Module):
         b, _, d, h, w = img.shape
         if noise is None:
             noise = torch.randn((b, 12, d, h, w), dtype=torch.float32, device=img.device)
-        buf = ops.mind3d(img, noise, self.randn_weighting, out_format="ndhwc", out_ldc=16, out_dtype=out_dtype, groups=groups)
+        buf = ops.mind3d(img, noise, self.randn_weighting, out_format="ndhwc", out_ldc=16, out_dtype=out_dtype, groups=groups,
+                         delta=self.delta, sigma=self.sigma)
         return buf[..., :12].permute(0, 4, 1, 2, 3)
 
 

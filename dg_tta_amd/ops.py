@@ -42,7 +42,16 @@ def empty_cl3d(b, c, d, h, w, dtype, device):
 
 
 # ------------------------------------------------------------------------------------------------ MIND
-def mind3d(img, noise, randn_weighting=0.05, out_format="ncdhw", out_ldc=12, out_dtype=torch.float32, groups=1):
+def gauss_taps(sigma):
+    """The smoothing kernel exactly as the reference evaluates it (mind.py:30-37, fp32 on the CPU)."""
+    s = torch.tensor([float(sigma)])
+    n = int(torch.ceil(s * 3.0 / 2.0).long().item()) * 2 + 1
+    w = torch.exp(-torch.pow(torch.linspace(-(n // 2), n // 2, n), 2) / (2 * torch.pow(s, 2)))
+    return (w / w.sum()).tolist()
+
+
+def mind3d(img, noise, randn_weighting=0.05, out_format="ncdhw", out_ldc=12, out_dtype=torch.float32, groups=1, delta=1,
+           sigma=1.0):
     """MIND3D descriptor of img [B,1,D,H,W] with the randn draw `noise` [B,12,D,H,W] (reference: dg_tta/mind.py:142-164).
 
     out_format 'ncdhw' -> contiguous [B,12,D,H,W] fp32; 'ndhwc' -> raw [B,D,H,W,out_ldc] buffer (fp32 or bf16).
@@ -63,9 +72,12 @@ def mind3d(img, noise, randn_weighting=0.05, out_format="ncdhw", out_ldc=12, out
     bg = b // groups
     nbytes = lib.dgtta_mind3d_ws_bytes(bg, d, h, w)
     ws = _ws(nbytes, img.device)
+    taps = gauss_taps(sigma)
+    h_taps = (C.c_float * len(taps))(*taps)
     for g in range(groups):
         sl = slice(g * bg, (g + 1) * bg)
-        check(lib.dgtta_mind3d_fwd(ptr(img[sl]), ptr(noise[sl]), float(randn_weighting), ptr(out[sl]), int(ndhwc),
+        check(lib.dgtta_mind3d_fwd(ptr(img[sl]), ptr(noise[sl]), float(randn_weighting), int(delta), h_taps, len(taps),
+                                   ptr(out[sl]), int(ndhwc),
                                    int(out_ldc), dtype_code(out_dtype), ptr(ws), nbytes, bg, d, h, w,
                                    stream_of(img.device)), "dgtta_mind3d_fwd")
     return out

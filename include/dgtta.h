@@ -57,14 +57,15 @@ int dgtta_reload_env(void);
  * :5-24) and mind_hook (:167-168).  img [B,1,D,H,W] fp32; noise [B,12,D,H,W] fp32 = the
  * torch.randn_like draw of mind.py:150 (caller supplies it so RNG semantics stay the caller's).
  * out: 12 channels, either NCDHW fp32 (out_ndhwc=0) or NDHWC with row length out_ldc (>=12;
- * channels 12..out_ldc-1 are written as zero) in out_dtype.  delta is fixed to 1, sigma to 1
- * (the only values the reference ever uses: mind.py:98).
+ * channels 12..out_ldc-1 are written as zero) in out_dtype.  delta (mind.py:98,137: neighbour distance,
+ * 1 or 2) and the Gaussian taps of `sigma` (h_taps: HOST array of 3 / 5 / 7 floats evaluated as mind.py:30-37
+ * does, i.e. sigma <= 2; the reference itself only ever uses delta = 1, sigma = 1).
  * ws: dgtta_mind3d_ws_bytes(B,D,H,W) bytes.
  * ------------------------------------------------------------------------------------------- */
 size_t dgtta_mind3d_ws_bytes(int B, int D, int H, int W);
-int dgtta_mind3d_fwd(const float *img, const float *noise, float randn_weighting, void *out, int out_ndhwc,
-                     int out_ldc, int out_dtype, void *ws, size_t ws_bytes, int B, int D, int H, int W,
-                     void *stream);
+int dgtta_mind3d_fwd(const float *img, const float *noise, float randn_weighting, int delta, const float *h_taps,
+                     int ntaps, void *out, int out_ndhwc, int out_ldc, int out_dtype, void *ws, size_t ws_bytes, int B,
+                     int D, int H, int W, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * GIN random-convolution chain.  Replaces GINGroupConv.forward / GradlessGCReplayNonlinBlock.forward

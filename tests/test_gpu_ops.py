@@ -62,6 +62,24 @@ def test_mind_module_draws_device_noise():
     assert torch.equal(mind_hook(None, (x,)), a)
 
 
+@pytest.mark.parametrize("delta,sigma", [(1, 1.0), (2, 1.0), (1, 0.6), (1, 2.0), (2, 1.7)])
+def test_mind_delta_sigma_variants(delta, sigma):
+    """MIND3D(delta, sigma) other than the reference's default (mind.py:98-140): neighbour distance 1 / 2 (replicate
+    padding by delta, dilated shifts), Gaussian of 3 / 5 / 7 taps, on a ragged multi-tile volume against the oracle."""
+    from dg_tta_amd.mind import MIND3D
+    from oracle import mind as omind
+    torch.manual_seed(int(10 * sigma) + delta)
+    img = torch.randn(2, 1, 19, 23, 41) * 1.5
+    noise = torch.randn(2, 12, 19, 23, 41)
+    ref = omind.mind3d(img, noise, delta=delta, sigma=sigma)
+    out = MIND3D(delta=delta, sigma=sigma)(img.to(DEV), noise.to(DEV))
+    _close(out, ref, atol=3e-5, what=f"mind3d delta={delta} sigma={sigma}")
+    with pytest.raises(NotImplementedError):
+        MIND3D(delta=3)
+    with pytest.raises(NotImplementedError):
+        MIND3D(sigma=2.5)
+
+
 # ------------------------------------------------------------------------------------------------ GIN
 @pytest.mark.parametrize("i", range(7))
 def test_gin_golden(i):

@@ -37,7 +37,7 @@ def test_library_exports_every_declared_symbol():
     loaded = _lib.load()
     assert loaded.dgtta_version() >= 10000
     # host-side argument validation works without a device
-    assert loaded.dgtta_mind3d_fwd(None, None, 0.05, None, 0, 12, 0, None, 0, 1, 8, 8, 8, None) == -1
+    assert loaded.dgtta_mind3d_fwd(None, None, 0.05, 1, None, 5, None, 0, 12, 0, None, 0, 1, 8, 8, 8, None) == -1
     assert b"null pointer" in loaded.dgtta_last_error()
     assert loaded.dgtta_mind3d_ws_bytes(1, 16, 16, 16) >= 16 ** 3 * 12 * 4
 

@@ -4,7 +4,7 @@ R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
 for what in conv wgrad; do
   for ctr in FETCH_SIZE WRITE_SIZE; do
-    KB_STATS=1 rocprofv3 --pmc $ctr --kernel-trace -d $R/gpurun_out/pmc_${what}_${ctr} -o pmc --output-format csv -- python $R/scratch/kbench.py $what bf16 32 32 128 12 > $R/gpurun_out/pmc_${what}_${ctr}.log 2>&1 || exit 1
+    KB_STATS=1 rocprofv3 --pmc $ctr --kernel-trace -d $R/gpurun_out/pmc_${what}_${ctr} -o pmc --output-format csv -- python3 $R/scratch/kbench.py $what bf16 32 32 128 12 > $R/gpurun_out/pmc_${what}_${ctr}.log 2>&1 || exit 1
   done
 done
 cd $R

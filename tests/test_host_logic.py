@@ -35,7 +35,7 @@ def test_library_exports_every_declared_symbol():
     for name, n in protos.items():
         assert len(_lib.SIGNATURES[name][1]) == n, f"{name}: header has {n} args, ctypes table {len(_lib.SIGNATURES[name][1])}"
     loaded = _lib.load()
-    assert loaded.dgtta_version() >= 10000
+    assert loaded.dgtta_version() >= 20000
     # host-side argument validation works without a device
     assert loaded.dgtta_mind3d_fwd(None, None, 0.05, 1, None, 5, None, 0, 12, 0, None, 0, 1, 8, 8, 8, None) == -1
     assert b"null pointer" in loaded.dgtta_last_error()

@@ -434,6 +434,9 @@ int dispatch_conv_classes(const void *x, const View &xv, const void *w, const Co
       if (yv.W >= 16) return launch_conv<T, 16, 2, 4, 2, 1, 1>(ARGS);
       return launch_conv<T, 8, 2, 4, 2, 1, 1>(ARGS);
     }
+    // two output-channel blocks per workgroup when there are that many: the input tile is staged once for 64 channels
+    // (157 -> 112 us at 128^3 -> 64^3, 32 -> 64; DGTTA_CONV_S2=1: one block per workgroup, the round-1 shape)
+    if (dgtta_switches().conv_s2 != '1' && yv.W >= 32 && CoutP % 64 == 0) return launch_conv<T, 32, 4, 2, 2, 2, 1, 8>(ARGS);
     if (yv.W >= 32) return launch_conv<T, 32, 4, 2, 2, 1, 1, 8>(ARGS);
     if (yv.W >= 16) return launch_conv<T, 16, 2, 4, 2, 1, 1, 8>(ARGS);
     return launch_conv<T, 8, 2, 4, 2, 1, 1, 8>(ARGS);
@@ -673,8 +676,15 @@ static int convT_run(int mode /*0 fwd, 1 dgrad*/, const void *in, int ldin, cons
   return dispatch_conv_classes<T>(in, xv, wb, cs, nullptr, out, yv, B, Cout, Cin, 8 * CoutP, CinP, 0, st, nullptr, 1);
 }
 
+// convt_gemm.hip: register-operand kernels of the two large decoder stages
+bool convT_gemm_eligible(int mode, const void *in, int ldin, const void *out, int ldout, int Cin, int Cout, int Wi, int dtype);
+int convT_gemm_run(int mode, const void *in, int ldin, const float *w_t, const float *bias, void *out, int ldout, void *ws, int B,
+                   int Cin, int Cout, int Di, int Hi, int Wi, int dtype, hipStream_t st);
+
 int convT_fwd_mfma(const void *x, int ldx, const float *w_t, const float *bias, void *out, int ldo, void *ws, int B, int Cin,
                    int Cout, int Di, int Hi, int Wi, int dtype, hipStream_t st) {
+  if (ldx >= Cin && ldo >= Cout && convT_gemm_eligible(0, x, ldx, out, ldo, Cin, Cout, Wi, dtype))
+    return convT_gemm_run(0, x, ldx, w_t, bias, out, ldo, ws, B, Cin, Cout, Di, Hi, Wi, dtype, st);
   if (dtype == DGTTA_F32) return convT_run<float>(0, x, ldx, w_t, bias, out, ldo, ws, B, Cin, Cout, Di, Hi, Wi, st);
   if (dtype == DGTTA_BF16) return convT_run<bf16_t>(0, x, ldx, w_t, bias, out, ldo, ws, B, Cin, Cout, Di, Hi, Wi, st);
   if (dtype == DGTTA_F16) return convT_run<f16_t>(0, x, ldx, w_t, bias, out, ldo, ws, B, Cin, Cout, Di, Hi, Wi, st);
@@ -682,6 +692,8 @@ int convT_fwd_mfma(const void *x, int ldx, const float *w_t, const float *bias, 
 }
 int convT_dgrad_mfma(const void *dout, int lddo, const float *w_t, void *dx, int lddx, void *ws, int B, int Cin, int Cout,
                      int Di, int Hi, int Wi, int dtype, hipStream_t st) {
+  if (lddo >= Cout && lddx >= Cin && convT_gemm_eligible(1, dout, lddo, dx, lddx, Cin, Cout, Wi, dtype))
+    return convT_gemm_run(1, dout, lddo, w_t, nullptr, dx, lddx, ws, B, Cin, Cout, Di, Hi, Wi, dtype, st);
   if (dtype == DGTTA_F32) return convT_run<float>(1, dout, lddo, w_t, nullptr, dx, lddx, ws, B, Cin, Cout, Di, Hi, Wi, st);
   if (dtype == DGTTA_BF16) return convT_run<bf16_t>(1, dout, lddo, w_t, nullptr, dx, lddx, ws, B, Cin, Cout, Di, Hi, Wi, st);
   if (dtype == DGTTA_F16) return convT_run<f16_t>(1, dout, lddo, w_t, nullptr, dx, lddx, ws, B, Cin, Cout, Di, Hi, Wi, st);

@@ -43,6 +43,7 @@ def _call_dgrad(dy, wpack, cin, cinp, coutp, dims, stride, dt, impl):
 CASES = [  # (B, cin, cout, D, H, W, stride)
     (1, 16, 32, 8, 8, 32, 1), (1, 32, 32, 9, 7, 45, 1), (2, 8, 64, 6, 10, 16, 1), (1, 24, 40, 8, 8, 8, 1),
     (1, 64, 32, 5, 9, 20, 1), (1, 32, 64, 8, 8, 32, 2), (1, 16, 24, 10, 12, 14, 2), (1, 320, 320, 4, 4, 4, 1),
+    (1, 32, 64, 6, 10, 72, 2), (2, 64, 128, 4, 6, 64, 2),     # stride 2 with >= 32 output columns: 2 channel blocks per workgroup
 ]
 
 
@@ -494,3 +495,52 @@ def test_wgrad_stride2_one_pass_bf16(case, monkeypatch):
     dw = ref.clone()
     _call_wgrad(x, dy, cin, cout, 2, 1, 2, accumulate=1, dw=dw, db=torch.zeros(cout, device=DEV))
     assert float((dw - 2 * ref).abs().max()) < 2 * tol
+
+
+@pytest.mark.parametrize("case", [(1, 64, 32, 4, 6, 40), (2, 128, 64, 3, 4, 32), (1, 64, 32, 2, 3, 96)])
+@pytest.mark.parametrize("dt", [1, 2])
+def test_convT_register_operand_kernel(case, dt, monkeypatch):
+    """ConvTranspose k2 s2 of the two large decoder stages: the register-operand GEMM kernel (csrc/convt_gemm.hip) against
+    its predecessor (DGTTA_CONVT_GEMM=0) and torch, with the decoder's operand strides: the output / its gradient are the
+    first Cout channels of a concat buffer of 2 * Cout, ragged last 32-voxel block, batch 2."""
+    from dg_tta_amd import _lib
+    from dg_tta_amd._lib import check, ptr, stream_of
+    lib = _lib.load()
+    B, cin, cout, D, H, W = case
+    tdt = torch.bfloat16 if dt == 1 else torch.float16
+    torch.manual_seed(sum(case) + dt)
+    x = torch.randn(B, D, H, W, cin, device=DEV).to(tdt)
+    w = (torch.randn(cin, cout, 2, 2, 2, device=DEV) / cin ** 0.5).to(tdt).float()
+    bias = torch.randn(cout, device=DEV)
+    dcat = torch.randn(B, 2 * D, 2 * H, 2 * W, 2 * cout, device=DEV).to(tdt)          # gradient of the concat buffer
+
+    def run(gemm):
+        monkeypatch.setenv("DGTTA_CONVT_GEMM", gemm)
+        reload_kernel_switches()
+        cat = torch.full((B, 2 * D, 2 * H, 2 * W, 2 * cout), 7.0, dtype=tdt, device=DEV)
+        nb = lib.dgtta_convT3d_fwd_ws_bytes(cin, cout, dt)
+        ws = torch.empty(nb, dtype=torch.uint8, device=DEV)
+        check(lib.dgtta_convT3d_k2s2_fwd(ptr(x), cin, ptr(w), ptr(bias), ptr(cat), 2 * cout, ptr(ws), nb, B, cin, cout, D, H, W,
+                                         dt, 2, stream_of()), "convT fwd")
+        dx = torch.empty_like(x)
+        dw, db = torch.empty_like(w), torch.empty_like(bias)
+        nb = lib.dgtta_convT3d_bwd_ws_bytes(B, cin, cout, D, H, W)
+        ws2 = torch.empty(nb, dtype=torch.uint8, device=DEV)
+        check(lib.dgtta_convT3d_k2s2_bwd(ptr(x), cin, ptr(dcat), 2 * cout, ptr(w), ptr(dx), cin, ptr(dw), ptr(db), ptr(ws2), nb,
+                                         B, cin, cout, D, H, W, 0, dt, 2, stream_of()), "convT bwd")
+        torch.cuda.synchronize()
+        return cat.float(), dx.float(), dw
+
+    cat_new, dx_new, dw_new = run("1")
+    cat_old, dx_old, dw_old = run("0")
+    assert torch.equal(cat_new[..., cout:], torch.full_like(cat_new[..., cout:], 7.0))      # the skip half is not touched
+    ref = F.conv_transpose3d(x.float().permute(0, 4, 1, 2, 3).cpu(), w.cpu(), bias.cpu(), stride=2).permute(0, 2, 3, 4, 1)
+    eps = 2.0 ** -8 if dt == 1 else 2.0 ** -11
+    assert float((cat_new[..., :cout].cpu() - ref).abs().max()) < eps * float(ref.abs().max()) + 1e-4
+    assert float((cat_new - cat_old).abs().max()) < 2 * eps * float(ref.abs().max()) + 1e-4
+    xr = x.float().permute(0, 4, 1, 2, 3).cpu().double().requires_grad_(True)
+    F.conv_transpose3d(xr, w.cpu().double(), None, stride=2).backward(dcat[..., :cout].float().permute(0, 4, 1, 2, 3).cpu().double())
+    gref = xr.grad.permute(0, 2, 3, 4, 1).float()
+    assert float((dx_new.cpu() - gref).abs().max()) < eps * float(gref.abs().max()) + 1e-4
+    assert float((dx_new - dx_old).abs().max()) < 2 * eps * float(gref.abs().max()) + 1e-4
+    assert torch.equal(dw_new, dw_old)              # the weight gradient does not go through the new kernel

@@ -282,7 +282,15 @@ __global__ __launch_bounds__(WD *WH * 64) void conv3_rows_kernel(const bf16_t *_
             val.z = (unsigned)(unsigned short)hi[0] | ((unsigned)(unsigned short)hi[1] << 16);
             val.w = (unsigned)(unsigned short)hi[2] | ((unsigned)(unsigned short)hi[3] << 16);
             const int ow = cur.ow0 + 16 * vb + li;
-            if (ABL != 2) *reinterpret_cast<uint4 *>(orow + ow * yv.sw) = val;
+            // NON-TEMPORAL store: the output streams through L2 instead of displacing the input lines, whose second
+            // 16-channel half is fetched one phase later.  PMC, 128^3 32->32, one sample: FETCH 353 -> 197 MB (134 MB
+            // of input; the rest is the D-halo of consecutive jobs), WRITE unchanged (DGTTA_ROWS_ABL=8: plain stores)
+            if (ABL == 8) *reinterpret_cast<uint4 *>(orow + ow * yv.sw) = val;
+            else if (ABL != 2) {
+              typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+              const u32x4_t nv = {val.x, val.y, val.z, val.w};
+              __builtin_nontemporal_store(nv, reinterpret_cast<u32x4_t *>(orow + ow * yv.sw));
+            }
           }
         };
         // (a wave reads back only its own slab: LDS operations of one wave complete in order); the read-back and stores
@@ -386,16 +394,17 @@ int launch_conv_rows(const void *x, const View &xv, const void *w, const Taps &t
                      hipStream_t st) {
   typedef RowsCfg<PD, PH, WD, WH> Cfg;
   // DGTTA_ROWS_ABL (diagnostic builds of the same kernel): 1 no DMA, 3 no MFMA, 6 per-segment cycle stamps, 7 the
-  // voxel-major (ragged-tile) epilogue for every tile
+  // voxel-major (ragged-tile) epilogue for every tile, 8 plain (temporal) output stores
   const int abl = dgtta_switches().rows_abl;
   auto kern = conv3_rows_kernel<PD, PH, WD, WH, 0, T16>;
-  static DynLdsOnce once[5];
+  static DynLdsOnce once[6];
   int slot = 0;
   if (std::is_same<T16, bf16_t>::value) {      // diagnostic builds exist for the bf16 instantiation only
     if (abl == '1') kern = conv3_rows_kernel<PD, PH, WD, WH, 1, T16>, slot = 1;
     if (abl == '3') kern = conv3_rows_kernel<PD, PH, WD, WH, 3, T16>, slot = 2;
     if (abl == '6') kern = conv3_rows_kernel<PD, PH, WD, WH, 6, T16>, slot = 3;
     if (abl == '7') kern = conv3_rows_kernel<PD, PH, WD, WH, 7, T16>, slot = 4;
+    if (abl == '8') kern = conv3_rows_kernel<PD, PH, WD, WH, 8, T16>, slot = 5;
   }
   DG_REQUIRE(ensure_dyn_lds(once[slot], reinterpret_cast<const void *>(kern), (int)Cfg::LDS_BYTES) == hipSuccess,
              DGTTA_ERR_LAUNCH, "conv3_rows: cannot raise the dynamic LDS limit to %zu", (size_t)Cfg::LDS_BYTES);

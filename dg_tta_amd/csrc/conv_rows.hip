@@ -41,7 +41,7 @@ __global__ __launch_bounds__(WD *WH * 64) void conv3_rows_kernel(const bf16_t *_
                                                                  const float *__restrict__ bias, bf16_t *__restrict__ y,
                                                                  View yv, int Cin, int Cout, int CinP, int tilesW,
                                                                  int tilesH, int tilesD, int nblkN, int njobs,
-                                                                 double *__restrict__ stats, int ntaps_src) {
+                                                                 double *__restrict__ stats, int ntaps_src, int order) {
   typedef RowsCfg<PD, PH, WD, WH> Cfg;
   constexpr int NW = Cfg::NW, IH = Cfg::IH;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -59,24 +59,60 @@ __global__ __launch_bounds__(WD *WH * 64) void conv3_rows_kernel(const bf16_t *_
   const int nk = CinP / 16;
   const int cin_lim = (Cin + 7) / 8 * 8;
 
-  // contiguous job range of this workgroup; workgroups of one XCD (blockIdx % 8) get neighbouring ranges
+  // Job order.  The workgroups of one XCD (blockIdx % 8; one per CU) share an L2, and a job's input tile overlaps its
+  // neighbours' by the halo.  A workgroup that walks a contiguous range meets each neighbour one job later, by which time
+  // the XCD has streamed ~8 MB through its 4 MB L2: the shared D-halo planes came from HBM again (PMC: 1.47x the input).
+  // So the XCD's share of the jobs is dealt out ROUND ROBIN: at any time its workgroups hold ~32 consecutive jobs, and
+  // the job index is decoded so that 32 consecutive jobs form a compact block of tiles (all channel blocks of a tile
+  // first - they read the same input -, then 4-8 tiles along D, then 2-4 along H): the halos are shared while hot.
   const int G = gridDim.x;
-  const int lw = (G % 8 == 0) ? (int)(blockIdx.x % 8) * (G / 8) + (int)(blockIdx.x / 8) : (int)blockIdx.x;
-  const int j0 = (int)(((long long)njobs * lw) / G), j1 = (int)(((long long)njobs * (lw + 1)) / G);
-  const int nph = (j1 - j0) * nk;
+  int jbeg, jstep, jend;
+  if (order == 0) {           // DGTTA_ROWS_ORDER=0: the round-2a order (a contiguous range per workgroup, D fastest)
+    const int lw = (G % 8 == 0) ? (int)(blockIdx.x % 8) * (G / 8) + (int)(blockIdx.x / 8) : (int)blockIdx.x;
+    jbeg = (int)(((long long)njobs * lw) / G), jend = (int)(((long long)njobs * (lw + 1)) / G), jstep = 1;
+  } else if (G % 8 == 0) {
+    const int xcd = (int)(blockIdx.x % 8), nl = G / 8;
+    jbeg = (int)(((long long)njobs * xcd) / 8) + (int)(blockIdx.x / 8);
+    jend = (int)(((long long)njobs * (xcd + 1)) / 8);
+    jstep = nl;
+  } else {
+    jbeg = (int)blockIdx.x, jend = njobs, jstep = G;
+  }
+  const int nmine = jbeg < jend ? (jend - jbeg + jstep - 1) / jstep : 0;
+  const int nph = nmine * nk;
   if (nph == 0) return;
-
+  // block shape (NBL x TDL x THL jobs, ~32): powers of two that divide the tile counts
+  const int NBL = (order != 0 && (nblkN == 2 || nblkN == 4)) ? nblkN : 1;
+  int TDL = NBL == 1 ? 8 : 4, THL = NBL == 4 ? 2 : 4;
+  while (tilesD % TDL) TDL >>= 1;
+  while (tilesH % THL) THL >>= 1;
+  if (order == 0) TDL = tilesD, THL = 1;      // (td, nb, th, tw, b)
+  const int nbH = nblkN / NBL, tdH = tilesD / TDL, thH = tilesH / THL;
   struct Job {
     int b, n0, od0, oh0, ow0, tile;
   };
   auto decode = [&](int j) {
     Job q;
-    const int td = j % tilesD;
-    j /= tilesD;
-    const int nb = j % nblkN;
-    j /= nblkN;
-    const int th = j % tilesH;
-    j /= tilesH;
+    const int nb_lo = j % NBL;
+    j /= NBL;
+    const int td_lo = j % TDL;
+    j /= TDL;
+    const int th_lo = j % THL;
+    j /= THL;
+    const int td = (j % tdH) * TDL + td_lo;
+    j /= tdH;
+    int th, nb;
+    if (order == 0) {
+      nb = j % nblkN;
+      j /= nblkN;
+      th = j % tilesH;
+      j /= tilesH;
+    } else {
+      th = (j % thH) * THL + th_lo;
+      j /= thH;
+      nb = (j % nbH) * NBL + nb_lo;
+      j /= nbH;
+    }
     const int tw = j % tilesW;
     q.b = j / tilesW;
     q.n0 = nb * 32;
@@ -138,12 +174,12 @@ __global__ __launch_bounds__(WD *WH * 64) void conv3_rows_kernel(const bf16_t *_
     abase[kw] = ((wd * PD) * IH + wh * PH) * Cfg::RB + (col < 32 ? h * 32 + col : 64 + h * 2 + (col - 32));
   }
 
-  Job cur = decode(j0);
+  Job cur = decode(jbeg);
   float bv = 0.f;
   float st1 = 0.f, st2 = 0.f;       // InstanceNorm partial sums of this lane's channel over the current run of jobs
 #pragma unroll
   for (int i = 0; i < NPIECE; ++i) issue_piece(cur, 0, 0, i);
-  int kc = 0, jn = j0;
+  int kc = 0, jn = jbeg;
   unsigned long long tseg[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = 0;     // ABL 6: cycle stamps per segment (diagnostic)
   auto stamp = [&](int k) {
     if (ABL == 6) {
@@ -181,7 +217,7 @@ __global__ __launch_bounds__(WD *WH * 64) void conv3_rows_kernel(const bf16_t *_
     int kn = kc + 1;
     if (kn == nk) {
       kn = 0;
-      if (p + 1 < nph) nxt = decode(jn + 1);
+      if (p + 1 < nph) nxt = decode(jn + jstep);
     }
     const bool more = p + 1 < nph;
     stamp(2);
@@ -369,14 +405,14 @@ __global__ __launch_bounds__(WD *WH * 64) void conv3_rows_kernel(const bf16_t *_
           pp[0] = 0.0;
           pp[1] = 0.0;
         }
-        if (lw == 0 && tid == 0 && p == nk - 1) reinterpret_cast<long long *>(stats)[0] = tiles_per_b;
+        if (blockIdx.x == 0 && tid == 0 && p == nk - 1) reinterpret_cast<long long *>(stats)[0] = tiles_per_b;
       }
     }
     stamp(4);                 // epilogue
     kc = kn;
     if (kn == 0) {
       cur = nxt;
-      ++jn;
+      jn += jstep;
     }
   }
   if (ABL == 6 && stats && lane == 0) {
@@ -419,7 +455,8 @@ int launch_conv_rows(const void *x, const View &xv, const void *w, const Taps &t
   const int wg_per_cu = (int)((160 * 1024) / Cfg::LDS_BYTES) > 0 ? (int)((160 * 1024) / Cfg::LDS_BYTES) : 1;
   const int grid = (int)(njobs < (long long)ncu * wg_per_cu ? njobs : (long long)ncu * wg_per_cu);
   hipLaunchKernelGGL(kern, dim3(grid), dim3(Cfg::NT), Cfg::LDS_BYTES, st, (const bf16_t *)x, xv, (const bf16_t *)w, taps,
-                     bias, (bf16_t *)y, yv, Cin, Cout, CinP, tW, tH, tD, nblkN, (int)njobs, stats, ntaps_src);
+                     bias, (bf16_t *)y, yv, Cin, Cout, CinP, tW, tH, tD, nblkN, (int)njobs, stats, ntaps_src,
+                     dgtta_switches().rows_order == '0' ? 0 : 1);
   DG_CHECK_LAUNCH("conv3_rows_kernel");
   return DGTTA_OK;
 }

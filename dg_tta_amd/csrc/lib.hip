@@ -32,6 +32,7 @@ static const DgttaSwitches *read_switches() {
   s->conv_variant = env_char("DGTTA_CONV_VARIANT");
   s->conv_s2 = env_char("DGTTA_CONV_S2");
   s->convt_gemm = env_char("DGTTA_CONVT_GEMM");
+  s->rows_order = env_char("DGTTA_ROWS_ORDER");
   s->dgrad_s2_allcls = env_char("DGTTA_DGRAD_S2_ALLCLS");
   s->wgrad_tr = env_char("DGTTA_WGRAD_TR");
   s->wgrad_tr8 = env_char("DGTTA_WGRAD_TR8");

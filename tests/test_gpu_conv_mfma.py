@@ -84,6 +84,7 @@ def test_conv_mfma_bf16(case):
 
 ROWS_CASES = [  # (B, cin, cout, D, H, W): ragged tiles, several channel blocks / K-chunks, batch 2, concat-style strides
     (1, 32, 32, 9, 13, 45), (2, 16, 64, 5, 17, 32), (1, 64, 96, 8, 8, 70), (1, 8, 32, 4, 8, 33),
+    (2, 32, 64, 32, 32, 64), (1, 16, 128, 16, 64, 32), (1, 32, 32, 36, 40, 32),      # > 256 jobs: persistent loops, block decode
 ]
 
 
@@ -102,8 +103,9 @@ def test_conv_rows_kernel_bf16(case, monkeypatch):
     cinp, coutp = (cin + 15) // 16 * 16, (cout + 15) // 16 * 16
     y_ref, _ = _call_fwd(xb.float(), w, bias, 1, 0, 1, (cin + 7) // 8 * 8, (cout + 7) // 8 * 8)
 
-    def run(rows):
+    def run(rows, order="1"):
         monkeypatch.setenv("DGTTA_CONV_ROWS", rows)
+        monkeypatch.setenv("DGTTA_ROWS_ORDER", order)
         reload_kernel_switches()
         wpack = torch.empty(lib.dgtta_conv3d_packed_bytes(cinp, coutp, 1) // 2, dtype=torch.bfloat16, device=DEV)
         check(lib.dgtta_conv3d_pack_weights(ptr(w), ptr(wpack), cin, cout, cinp, coutp, 1, stream_of()), "pack")
@@ -136,6 +138,11 @@ def test_conv_rows_kernel_bf16(case, monkeypatch):
     assert (m1 - ref_mean).abs().max() < 1e-4 and (m1 - m0).abs().max() < 1e-5
     assert ((r1 - ref_rstd) / ref_rstd).abs().max() < 1e-4 and ((r1 - r0) / r0).abs().max() < 1e-5
     assert (dx1.float() - dx0.float()).abs().max() < dx0.float().abs().max() / 128 + 1e-3
+    # job order of the persistent workgroups (round robin in compact blocks vs the contiguous ranges of round 2a): the
+    # same tiles are computed, so outputs are identical; only the grouping of the statistics' partial sums differs
+    y2, m2, r2, dx2 = run("1", order="0")
+    assert torch.equal(y2, y1) and torch.equal(dx2, dx1)
+    assert (m2 - m1).abs().max() < 1e-5 and ((r2 - r1) / r1).abs().max() < 1e-5
 
 
 def test_conv_mfma_timing_report(capsys):

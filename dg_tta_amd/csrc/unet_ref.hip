@@ -357,8 +357,10 @@ __global__ __launch_bounds__(256) void in_apply_vec_kernel(const T *__restrict__
                                                            int ldgz, const float *__restrict__ mean_rstd,
                                                            const float *__restrict__ gamma,
                                                            const float *__restrict__ beta, const float *__restrict__ c12,
-                                                           T *__restrict__ out, int ldo, int C, int64_t V, float slope) {
+                                                           T *__restrict__ out, int ldo, int C, int64_t V, float slope,
+                                                           int nt) {
   constexpr int EPV = 16 / sizeof(T);
+  typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
   extern __shared__ float sc[];     // fwd: [C][2] (alpha, beta'); bwd: [C][6] (mu, rs, ga, be, c1, c2)
   const int b = blockIdx.y;
   constexpr int NK = MODE == 0 ? 2 : 6;
@@ -410,17 +412,30 @@ __global__ __launch_bounds__(256) void in_apply_vec_kernel(const T *__restrict__
           o[e] = (kc[e][2] * kc[e][1]) * ((gg - kc[e][4]) - xh * kc[e][5]);
         }
       }
-      *reinterpret_cast<uint4 *>(ob + row * ldo + c0) = pack16<T>(o);
+      const uint4 pk = pack16<T>(o);
+      if (nt) {
+        const u32x4_t nv = {pk.x, pk.y, pk.z, pk.w};
+        __builtin_nontemporal_store(nv, reinterpret_cast<u32x4_t *>(ob + row * ldo + c0));
+      } else {
+        *reinterpret_cast<uint4 *>(ob + row * ldo + c0) = pk;
+      }
+    };
+    auto ld = [&](const T *p) {
+      if (nt) {
+        const u32x4_t v = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t *>(p));
+        return make_uint4(v[0], v[1], v[2], v[3]);
+      }
+      return *reinterpret_cast<const uint4 *>(p);
     };
     for (int64_t row = (int64_t)blockIdx.x * rpb + threadIdx.x / G; row < V; row += 2 * rstep) {
       const int64_t row2 = row + rstep;
       const bool two = row2 < V;
-      const uint4 y0 = *reinterpret_cast<const uint4 *>(yb + row * ldy + c0);
+      const uint4 y0 = ld(yb + row * ldy + c0);
       uint4 y1 = y0, g0 = y0, g1 = y0;
-      if (two) y1 = *reinterpret_cast<const uint4 *>(yb + row2 * ldy + c0);
+      if (two) y1 = ld(yb + row2 * ldy + c0);
       if (MODE == 1) {
-        g0 = *reinterpret_cast<const uint4 *>(gb + row * ldgz + c0);
-        if (two) g1 = *reinterpret_cast<const uint4 *>(gb + row2 * ldgz + c0);
+        g0 = ld(gb + row * ldgz + c0);
+        if (two) g1 = ld(gb + row2 * ldgz + c0);
       }
       one(y0, g0, row);
       if (two) one(y1, g1, row2);
@@ -1122,7 +1137,7 @@ extern "C" int dgtta_instnorm_lrelu_fwd(const void *y, int ldy, const void *stat
     const int blocks = (int)(cdiv64(items, 256 * 4) < 4096 ? (cdiv64(items, 256 * 4) > 0 ? cdiv64(items, 256 * 4) : 1) : 4096);
     DISPATCH_T(dtype, hipLaunchKernelGGL((in_apply_vec_kernel<T, 0>), dim3(blocks, B), dim3(256), (size_t)C * 2 * 4, st,
                                          (const T *)y, ldy, (const T *)nullptr, 0, mean_rstd, gamma, beta, nullptr, (T *)z,
-                                         ldz, C, V, slope));
+                                         ldz, C, V, slope, dgtta_switches().in_nt - '0'));
     DG_CHECK_LAUNCH("in_apply_vec_kernel<0>");
     return DGTTA_OK;
   }
@@ -1158,7 +1173,7 @@ extern "C" int dgtta_instnorm_lrelu_bwd(const void *gz, int ldgz, const void *y,
     const int blocks = (int)(cdiv64(items, 256 * 4) < 4096 ? (cdiv64(items, 256 * 4) > 0 ? cdiv64(items, 256 * 4) : 1) : 4096);
     DISPATCH_T(dtype, hipLaunchKernelGGL((in_apply_vec_kernel<T, 1>), dim3(blocks, B), dim3(256), (size_t)C * 6 * 4, st,
                                          (const T *)y, ldy, (const T *)gz, ldgz, mean_rstd, gamma, beta, c12, (T *)dy, lddy,
-                                         C, V, slope));
+                                         C, V, slope, dgtta_switches().in_nt - '0'));
     DG_CHECK_LAUNCH("in_apply_vec_kernel<1>");
     return DGTTA_OK;
   }

@@ -518,12 +518,21 @@ int64_t conv3_mfma_max_tiles(int Do, int Ho, int Wo) {
   return best;
 }
 
+int conv3_s2_regs(const void *x, const View &xv, const void *wimg, const float *bias, void *y, const View &yv, int B, int Cin,
+                  int Cout, int CinP, int CoutP, double *stats, int64_t cap_slots, int dtype, hipStream_t st);      // conv_s2.hip
+
 int conv3_fwd_mfma(const void *x, int ldx, const void *w_kmajor, int mirror, const float *bias, void *y, int ldy, int B,
                    int Cin, int Cout, int CinP, int CoutP, int Di, int Hi, int Wi, int stride, int dtype,
                    hipStream_t st, double *stats) {
   const int Do = (Di - 1) / stride + 1, Ho = (Hi - 1) / stride + 1, Wo = (Wi - 1) / stride + 1;
   const View xv = dense_view(B, Di, Hi, Wi, ldx), yv = dense_view(B, Do, Ho, Wo, ldy);
   const Taps taps = identity_taps(mirror);
+  if (stride == 2 && !mirror && dtype != DGTTA_F32 && dgtta_switches().conv_s2 != '1' && dgtta_switches().conv_s2 != '4') {
+    // the two large encoder transitions: register-operand kernel (conv_s2.hip)
+    const int rc = conv3_s2_regs(x, xv, w_kmajor, bias, y, yv, B, Cin, Cout, CinP, CoutP, stats,
+                                 conv3_mfma_max_tiles(Do, Ho, Wo), dtype, st);
+    if (rc != DGTTA_ERR_UNSUPPORTED) return rc;
+  }
   if (dtype == DGTTA_F32) {
     if (!operand_ok<float>(x, ldx, Cin, CinP)) return DGTTA_ERR_UNSUPPORTED;
     return dispatch_conv<float>(x, xv, w_kmajor, taps, bias, y, yv, B, Cin, Cout, CinP, CoutP, stride, 0, st, stats);

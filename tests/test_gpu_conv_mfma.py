@@ -551,3 +551,53 @@ def test_convT_register_operand_kernel(case, dt, monkeypatch):
     assert float((dx_new.cpu() - gref).abs().max()) < eps * float(gref.abs().max()) + 1e-4
     assert float((dx_new - dx_old).abs().max()) < 2 * eps * float(gref.abs().max()) + 1e-4
     assert torch.equal(dw_new, dw_old)              # the weight gradient does not go through the new kernel
+
+
+@pytest.mark.parametrize("case", [(1, 32, 64, 6, 10, 72), (2, 64, 128, 4, 6, 64), (1, 32, 128, 9, 7, 66), (8, 64, 32, 2, 2, 64)])
+@pytest.mark.parametrize("dt", [1, 2])
+def test_conv_stride2_register_operand_kernel(case, dt, monkeypatch):
+    """Stride-2 forward of the large encoder transitions: the register-operand kernel (csrc/conv_s2.hip) against its
+    predecessor (DGTTA_CONV_S2=1) and torch on the same 16-bit operands, with the fused InstanceNorm statistics; odd
+    extents (zero padding on the high side too), ragged last 32-voxel block, batch 2 and 8, several channel groups."""
+    from dg_tta_amd import _lib
+    from dg_tta_amd._lib import check, ptr, stream_of
+    lib = _lib.load()
+    B, cin, cout, D, H, W = case
+    tdt = torch.bfloat16 if dt == 1 else torch.float16
+    torch.manual_seed(sum(case) + dt)
+    xb = torch.randn(B, D, H, W, cin, device=DEV).to(tdt)
+    w = (torch.randn(cout, cin, 3, 3, 3, device=DEV) / (27 * cin) ** 0.5).to(tdt).float()
+    bias = torch.randn(cout, device=DEV)
+    Do, Ho, Wo = [(n - 1) // 2 + 1 for n in (D, H, W)]
+
+    def run(s2):
+        monkeypatch.setenv("DGTTA_CONV_S2", s2)
+        reload_kernel_switches()
+        wpack = torch.empty(lib.dgtta_conv3d_packed_bytes(cin, cout, dt) // 2, dtype=tdt, device=DEV)
+        check(lib.dgtta_conv3d_pack_weights(ptr(w), ptr(wpack), cin, cout, cin, cout, dt, stream_of()), "pack")
+        y = torch.full((B, Do, Ho, Wo, cout), float("nan"), dtype=tdt, device=DEV)
+        st = torch.zeros(lib.dgtta_conv3d_stats_bytes(B, cout, Do, Ho, Wo), dtype=torch.uint8, device=DEV)
+        check(lib.dgtta_conv3d_k3_fwd(ptr(xb), cin, ptr(wpack), ptr(bias), ptr(y), cout, ptr(st), B, cin, cout, cin, cout,
+                                      D, H, W, 2, dt, 2, stream_of()), "fwd")
+        mr = torch.empty(B, cout, 2, device=DEV)
+        z = torch.empty_like(y)
+        gamma, beta = torch.ones(cout, device=DEV), torch.zeros(cout, device=DEV)
+        nws = lib.dgtta_instnorm_ws_bytes(B, cout, Do * Ho * Wo)
+        ws = torch.empty(nws, dtype=torch.uint8, device=DEV)
+        check(lib.dgtta_instnorm_lrelu_fwd(ptr(y), cout, ptr(st), ptr(gamma), ptr(beta), ptr(mr), ptr(z), cout, ptr(ws), nws,
+                                           B, cout, Do * Ho * Wo, 1e-5, 0.01, dt, stream_of()), "instnorm")
+        torch.cuda.synchronize()
+        return y.float(), mr[..., 0].reshape(-1).clone(), mr[..., 1].reshape(-1).clone()
+
+    y1, m1, r1 = run("0")
+    y0, m0, r0 = run("1")
+    ref = F.conv3d(xb.float().permute(0, 4, 1, 2, 3).cpu(), w.cpu(), bias.cpu(), stride=2, padding=1).permute(0, 2, 3, 4, 1)
+    eps = 2.0 ** -8 if dt == 1 else 2.0 ** -11
+    scale = float(ref.abs().max())
+    assert torch.isfinite(y1).all()
+    assert float((y1.cpu() - ref).abs().max()) < eps * scale + 1e-4
+    assert float((y1 - y0).abs().max()) < 2 * eps * scale + 1e-4
+    ref_mean = ref.reshape(B, -1, cout).mean(1).reshape(-1)
+    ref_rstd = (ref.reshape(B, -1, cout).var(1, unbiased=False) + 1e-5).rsqrt().reshape(-1)
+    assert float((m1.cpu() - ref_mean).abs().max()) < 1e-4 and float((m1 - m0).abs().max()) < 1e-5
+    assert float(((r1.cpu() - ref_rstd) / ref_rstd).abs().max()) < 1e-4 and float(((r1 - r0) / r0).abs().max()) < 1e-5

@@ -128,13 +128,13 @@ def _theta(b, seed, strength=0.05):
 
 
 @pytest.mark.parametrize("pad", ["border", "zeros"])
-@pytest.mark.parametrize("cl", [False, True])
-def test_warp_forward(pad, cl):
+@pytest.mark.parametrize("cl,ch", [(False, 4), (True, 4), (True, 16), (True, 6)])
+def test_warp_forward(pad, cl, ch):
     from dg_tta_amd import ops
     from oracle import tta as otta
     r, _ = _theta(2, 1, 0.08)
     torch.manual_seed(2)
-    x = torch.randn(2, 4, 12, 14, 18)
+    x = torch.randn(2, ch, 12, 14, 18)
     ref = otta.warp(x, r, pad)
     xd = x.to(DEV)
     if cl:

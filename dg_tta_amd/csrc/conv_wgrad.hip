@@ -336,7 +336,8 @@ template <int ABL = 0, bool CLS = false, typename T16 = bf16_t>
 __global__ __launch_bounds__(256, 2) void conv3_wgrad_tr_kernel(const bf16_t *__restrict__ x, View xv,
                                                                 const bf16_t *__restrict__ dy, View yv,
                                                                 float *__restrict__ slabs, int Cin, int Cout, int tilesW,
-                                                                int tilesH, int nsd, int DR, int cobs, WgradClasses wc) {
+                                                                int tilesH, int nsd, int DR, int cobs, WgradClasses wc, int upw,
+                                                                int units) {
   const int cls = CLS ? blockIdx.z : 0;
   if (CLS) {
     x += wc.xoff[cls];
@@ -349,14 +350,23 @@ __global__ __launch_bounds__(256, 2) void conv3_wgrad_tr_kernel(const bf16_t *__
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
-  int t = blockIdx.x;
+  int tap_id[7], tap_kd[7], tap_off[7];
+  int ntap_w = 7;
+  // a workgroup sweeps `upw` consecutive units (columns of the volume) into the same accumulators: one slab per
+  // workgroup, i.e. upw times fewer partial slabs to write and to reduce
+  f32x16_t acc[7];
+#pragma unroll
+  for (int i = 0; i < 7; ++i)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[i][q] = 0.f;
+  const int cib = blockIdx.y / cobs, cob = blockIdx.y % cobs;
+  auto sweep = [&](int t) __attribute__((always_inline)) {
   const int tw = t % tilesW;
   t /= tilesW;
   const int th = t % tilesH;
   t /= tilesH;
   const int ds = t % nsd;
   const int b = t / nsd;
-  const int cib = blockIdx.y / cobs, cob = blockIdx.y % cobs;
   const int h0 = th * WT::TH, w0 = tw * 32;
   const int d_begin = ds * DR, d_end = (d_begin + DR < D) ? d_begin + DR : D;
   const bf16_t *xb = x + b * xv.sb + cib * 32;
@@ -400,8 +410,6 @@ __global__ __launch_bounds__(256, 2) void conv3_wgrad_tr_kernel(const bf16_t *__
 
   // this wave's taps: tap = wave + 4 i (i < 7) -- with classes, the (wave + 4 i)-th set bit of the class mask;
   // wave-uniform offsets of the x operand
-  int tap_id[7], tap_kd[7], tap_off[7];
-  int ntap_w = 7;
   if (CLS) {
     const unsigned mask = wc.mask[cls];
     ntap_w = 0;
@@ -428,12 +436,6 @@ __global__ __launch_bounds__(256, 2) void conv3_wgrad_tr_kernel(const bf16_t *__
     tap_kd[i] = tc / 9;
     tap_off[i] = ((tc / 3) % 3) * WT::X_ROW_B + (tc % 3) * 64;
   }
-
-  f32x16_t acc[7];
-#pragma unroll
-  for (int i = 0; i < 7; ++i)
-#pragma unroll
-    for (int q = 0; q < 16; ++q) acc[i][q] = 0.f;
 
   // prologue: x slices d_begin-1, d_begin, d_begin+1 and dy slice d_begin
   issue_slice(d_begin - 1, (d_begin - 1) & 3, true, d_begin, d_begin & 1, true);
@@ -476,6 +478,16 @@ __global__ __launch_bounds__(256, 2) void conv3_wgrad_tr_kernel(const bf16_t *__
     dma_wait_all();
     lds_barrier();
   }
+  };
+  if (CLS) {                 // class launches: one unit per workgroup, the body specialised as before
+    sweep((int)blockIdx.x);
+  } else {
+    for (int uu = 0; uu < upw; ++uu) {
+      const int t = blockIdx.x * upw + uu;
+      if (t >= units) break;
+      sweep(t);
+    }
+  }
 
   // partial slab [27][32 ci][32 co]; C/D map of the 32x32 MFMA: col = lane&31 (co), row = (q&3) + 8(q>>2) + 4(lane>>5) (ci)
   float *slab = slabs + (((int64_t)cls * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * (27 * 1024);
@@ -506,22 +518,33 @@ template <typename T16 = bf16_t>
 __global__ __launch_bounds__(512, 1) void conv3_wgrad_tr8_kernel(const bf16_t *__restrict__ x, View xv,
                                                                  const bf16_t *__restrict__ dy, View yv,
                                                                  float *__restrict__ slabs, int Cin, int Cout, int tilesW,
-                                                                 int tilesH, int nsd, int DR, int cobs) {
+                                                                 int tilesH, int nsd, int DR, int cobs, int upw, int units) {
   const int D = yv.D, H = yv.H, W = yv.W;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char *sX = smem;
   unsigned char *sY = smem + 4 * WT::X_SLICE_B;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  int t = blockIdx.x;
+  // a workgroup sweeps `upw` consecutive units (columns of the volume) into the same accumulators: one slab per
+  // workgroup, i.e. upw times fewer partial slabs to write and to reduce
+  f32x16_t acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[i][c][q] = 0.f;
+  const int cobs2 = (cobs + 1) / 2;
+  const int cib = blockIdx.y / cobs2, cob2 = blockIdx.y % cobs2;          // channel-block pair (2 cob2, 2 cob2 + 1)
+  for (int uu = 0; uu < upw; ++uu) {
+  int t = blockIdx.x * upw + uu;
+  if (t >= units) break;
   const int tw = t % tilesW;
   t /= tilesW;
   const int th = t % tilesH;
   t /= tilesH;
   const int ds = t % nsd;
   const int b = t / nsd;
-  const int cobs2 = (cobs + 1) / 2;
-  const int cib = blockIdx.y / cobs2, cob2 = blockIdx.y % cobs2;          // channel-block pair (2 cob2, 2 cob2 + 1)
   const int h0 = th * WT::TH, w0 = tw * 32;
   const int d_begin = ds * DR, d_end = (d_begin + DR < D) ? d_begin + DR : D;
   const bf16_t *xb = x + b * xv.sb + cib * 32;
@@ -561,14 +584,6 @@ __global__ __launch_bounds__(512, 1) void conv3_wgrad_tr8_kernel(const bf16_t *_
     tap_kd[i] = tc / 9;
     tap_off[i] = ((tc / 3) % 3) * WT::X_ROW_B + (tc % 3) * 64;
   }
-  f32x16_t acc[4][2];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int c = 0; c < 2; ++c)
-#pragma unroll
-      for (int q = 0; q < 16; ++q) acc[i][c][q] = 0.f;
-
   // prologue: x slices d_begin-1, d_begin, d_begin+1 and dy slice d_begin
 #pragma unroll
   for (int i = 0; i < NPW; ++i) issue_piece(i, d_begin - 1, (d_begin - 1) & 3, d_begin, d_begin & 1, true);
@@ -614,6 +629,7 @@ __global__ __launch_bounds__(512, 1) void conv3_wgrad_tr8_kernel(const bf16_t *_
     dma_wait_all();
     lds_barrier();
   }
+  }   // units
   const int co = lane & 31, hh = lane >> 5;
 #pragma unroll
   for (int c = 0; c < 2; ++c) {
@@ -982,6 +998,18 @@ size_t conv3_wgrad_mfma_ws_bytes(int B, int Cin, int Cout, int D, int H, int W) 
   return (a > c ? a : c) * 27 * 1024 * sizeof(float);
 }
 
+// units a workgroup sweeps into one slab: as many as keep >= `slots` workgroups in the launch (at most 4; DGTTA_WGRAD_UPW=1:
+// one unit per workgroup, the round-2a partition; =2..4: forced, for the tests)
+static int units_per_workgroup(int64_t units, int64_t gy, int slots) {
+  const int sw = dgtta_switches().wgrad_upw;
+  if (sw == '1') return 1;
+  if (sw >= '2' && sw <= '4') return (int)(units < sw - '0' ? units : sw - '0');      // forced (tests)
+  int64_t u = units * gy / slots;
+  if (u > 4) u = 4;
+  if (u > units) u = units;
+  return u < 1 ? 1 : (int)u;
+}
+
 template <typename T>
 static int wgrad_launch_classes(const void *x, const View &xv, const void *dy, const View &yv, float *dw, void *ws,
                                 size_t ws_bytes, int B, int Cin, int Cout, const WgradClasses &wc, const RealTaps &reals,
@@ -997,6 +1025,8 @@ static int wgrad_launch_classes(const void *x, const View &xv, const void *dy, c
   WgradPlan p = wgrad_plan(B, Cin, Cout, yv.D, yv.H, yv.W, wc.n);
   const size_t need = (size_t)wc.n * p.units * p.cibs * p.cobs * 27 * 1024 * sizeof(float);
   if (ws_bytes < need || p.units >= (1ll << 31) || p.cibs * p.cobs > 65535) return DGTTA_ERR_UNSUPPORTED;
+  int upw = 1;
+  int64_t nslab = p.units;            // partial slabs per (channel-block pair, class)
   if constexpr (sizeof(T) == 2) {
     typedef T T16;
     const DgttaSwitches &sw = dgtta_switches();
@@ -1010,15 +1040,22 @@ static int wgrad_launch_classes(const void *x, const View &xv, const void *dy, c
         static DynLdsOnce a8;
         DG_REQUIRE(ensure_dyn_lds(a8, reinterpret_cast<const void *>(conv3_wgrad_tr8_kernel<T16>), (int)WT8::LDS_BYTES) ==
                        hipSuccess, DGTTA_ERR_LAUNCH, "wgrad_tr8: cannot raise the dynamic LDS limit");
-        hipLaunchKernelGGL(conv3_wgrad_tr8_kernel<T16>, dim3((unsigned)p.units, (unsigned)(p.cibs * ((p.cobs + 1) / 2))), dim3(512),
+        const int64_t gy = (int64_t)p.cibs * ((p.cobs + 1) / 2);
+        upw = units_per_workgroup(p.units, gy, 256);          // one 8-wave workgroup per CU
+        nslab = cdiv64(p.units, upw);
+        hipLaunchKernelGGL(conv3_wgrad_tr8_kernel<T16>, dim3((unsigned)nslab, (unsigned)gy), dim3(512),
                            WT8::LDS_BYTES, st, (const bf16_t *)x, xv, (const bf16_t *)dy, yv, (float *)ws, Cin, Cout, p.tW, p.tH,
-                           p.nsd, p.DR, p.cobs);
+                           p.nsd, p.DR, p.cobs, upw, (int)p.units);
         DG_CHECK_LAUNCH("conv3_wgrad_tr8_kernel");
         goto reduce;
       }
-      hipLaunchKernelGGL(ktr, dim3((unsigned)p.units, (unsigned)(p.cibs * p.cobs), (unsigned)wc.n), dim3(256), WT::LDS_BYTES,
+      // two 4-wave workgroups per CU; class launches keep one unit per workgroup (their classes carry 1..8 taps: many
+      // small workgroups balance that, 4 units each measured 1.5x slower)
+      upw = plain ? units_per_workgroup(p.units, (int64_t)p.cibs * p.cobs, 512) : 1;
+      nslab = cdiv64(p.units, upw);
+      hipLaunchKernelGGL(ktr, dim3((unsigned)nslab, (unsigned)(p.cibs * p.cobs), (unsigned)wc.n), dim3(256), WT::LDS_BYTES,
                          st, (const bf16_t *)x, xv, (const bf16_t *)dy, yv, (float *)ws, Cin, Cout, p.tW, p.tH, p.nsd,
-                         p.DR, p.cobs, wc);
+                         p.DR, p.cobs, wc, upw, (int)p.units);
       DG_CHECK_LAUNCH("conv3_wgrad_tr_kernel");
       goto reduce;
     }
@@ -1035,12 +1072,12 @@ static int wgrad_launch_classes(const void *x, const View &xv, const void *dy, c
 reduce:
   const int64_t rrows = (int64_t)27 * Cin * ((Cout + 31) / 32);
   const int npairs = p.cibs * p.cobs;
-  if (p.units >= 64)
+  if (nslab >= 64)
     hipLaunchKernelGGL(wgrad_reduce_kernel<8>, dim3((unsigned)rrows, (unsigned)wc.n), dim3(256), 0, st, (const float *)ws, dw,
-                       Cin, Cout, p.cobs, npairs, (int)p.units, accumulate, reals, s_co, s_ci, s_tap);
+                       Cin, Cout, p.cobs, npairs, (int)nslab, accumulate, reals, s_co, s_ci, s_tap);
   else
     hipLaunchKernelGGL(wgrad_reduce_kernel<1>, dim3((unsigned)cdiv64(rrows, 8), (unsigned)wc.n), dim3(256), 0, st,
-                       (const float *)ws, dw, Cin, Cout, p.cobs, npairs, (int)p.units, accumulate, reals, s_co, s_ci, s_tap);
+                       (const float *)ws, dw, Cin, Cout, p.cobs, npairs, (int)nslab, accumulate, reals, s_co, s_ci, s_tap);
   DG_CHECK_LAUNCH("wgrad_reduce_kernel");
   return DGTTA_OK;
 }

@@ -601,3 +601,29 @@ def test_conv_stride2_register_operand_kernel(case, dt, monkeypatch):
     ref_rstd = (ref.reshape(B, -1, cout).var(1, unbiased=False) + 1e-5).rsqrt().reshape(-1)
     assert float((m1.cpu() - ref_mean).abs().max()) < 1e-4 and float((m1 - m0).abs().max()) < 1e-5
     assert float(((r1.cpu() - ref_rstd) / ref_rstd).abs().max()) < 1e-4 and float(((r1 - r0) / r0).abs().max()) < 1e-5
+
+
+@pytest.mark.parametrize("case", [(2, 32, 32, 8, 12, 40), (1, 32, 64, 6, 8, 64), (2, 64, 96, 5, 9, 33)])
+@pytest.mark.parametrize("upw", ["2", "3"])
+def test_wgrad_units_per_workgroup(case, upw, monkeypatch):
+    """Weight-gradient kernels sweeping several units (columns of the volume) into one partial slab: forced here at
+    small sizes (the product picks it when there are >= 2 units per workgroup slot) against one unit per workgroup and
+    torch; 3 does not divide the unit counts, so the last workgroup of a row runs short."""
+    B, cin, cout, D, H, W = case
+    torch.manual_seed(sum(case))
+    x = torch.randn(B, D, H, W, cin, device=DEV).bfloat16()
+    dy = torch.randn(B, D, H, W, cout, device=DEV).bfloat16()
+
+    def run(u):
+        monkeypatch.setenv("DGTTA_WGRAD_UPW", u)
+        reload_kernel_switches()
+        dw, db = _call_wgrad(x, dy, cin, cout, 1, 1, 2)
+        torch.cuda.synchronize()
+        return dw
+
+    one, many = run("1"), run(upw)
+    ref = torch.nn.grad.conv3d_weight(x.float().permute(0, 4, 1, 2, 3).cpu().double(), (cout, cin, 3, 3, 3),
+                                      dy.float().permute(0, 4, 1, 2, 3).cpu().double(), stride=1, padding=1).float()
+    scale = float(ref.abs().max())
+    assert float((many.cpu() - ref).abs().max()) < 2e-4 * scale + 1e-3
+    assert float((many - one).abs().max()) < 1e-4 * scale + 1e-3       # same products, another fp32 summation order

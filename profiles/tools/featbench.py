@@ -1,6 +1,6 @@
 """Micro-bench of the feature / loss kernels at 128^3 (per-sample microseconds): GIN chain, MIND, warps, loss."""
 import os, sys, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from dg_tta_amd import ops
 from dg_tta_amd.gin import draw_gin_params
 from dg_tta_amd.mind import MIND3D

@@ -1,6 +1,6 @@
 """Micro-bench of single kernels through the C ABI (for rocprofv3 --pmc runs). usage: kbench.py [conv|wgrad] [bf16|fp32] cin cout n iters"""
 import os, sys, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from dg_tta_amd import _lib
 from dg_tta_amd._lib import check, ptr, stream_of
 lib = _lib.load()

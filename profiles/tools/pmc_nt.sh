@@ -4,9 +4,9 @@ R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
 for abl in 0 8; do
   export DGTTA_ROWS_ABL=$abl
-  python3 $R/scratch/kbench.py conv bf16 32 32 128 20 > $R/gpurun_out/nt_time_$abl.log 2>&1
+  python3 $R/profiles/tools/kbench.py conv bf16 32 32 128 20 > $R/gpurun_out/nt_time_$abl.log 2>&1
   for ctr in FETCH_SIZE WRITE_SIZE; do
-    KB_STATS=1 rocprofv3 --pmc $ctr --kernel-trace -d $R/gpurun_out/nt_${abl}_${ctr} -o pmc --output-format csv -- python3 $R/scratch/kbench.py conv bf16 32 32 128 12 > $R/gpurun_out/nt_${abl}_${ctr}.log 2>&1 || exit 1
+    KB_STATS=1 rocprofv3 --pmc $ctr --kernel-trace -d $R/gpurun_out/nt_${abl}_${ctr} -o pmc --output-format csv -- python3 $R/profiles/tools/kbench.py conv bf16 32 32 128 12 > $R/gpurun_out/nt_${abl}_${ctr}.log 2>&1 || exit 1
   done
 done
 cd $R

@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage (inside gpurun): bash scratch/prof_epoch.sh <tag> [bench args]; writes gpurun_out/<tag>_stats.txt
+# usage (inside gpurun): bash profiles/tools/prof_epoch.sh <tag> [bench args]; writes gpurun_out/<tag>_stats.txt
 tag=$1; shift
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp

@@ -86,7 +86,7 @@ def test_full_topology_step_golden(size, dtype):
     # within rounding distance of zero takes the other slope (1 vs 0.01), and with ~10^7 activations per pass a handful do
     # in ANY fp32 evaluation.  The REFERENCE's own fp32 gradients therefore deviate from a float64 evaluation of the same
     # graph by up to 2-4 % of a tensor's range in the layers with few voxels (`gcond::<name>`, measured by
-    # make_golden_r2.py; scratch/dbg_block.py shows torch-CPU and the HIP kernels each hitting such flips on 2-stage nets
+    # make_golden_r2.py; profiles/tools/dbg_block.py shows torch-CPU and the HIP kernels each hitting such flips on 2-stage nets
     # while agreeing to 3e-6 otherwise).  fp32 kernels are checked against the float64 values (`g64::`) with the
     # reference's own deviation as the yardstick (the MFMA K-loop accumulates 8640 terms in sequence: ~4x torch's forward
     # rounding, hence more flips), plus direction (cosine) and sign agreement, which is what Adam consumes.

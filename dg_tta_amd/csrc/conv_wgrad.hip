@@ -19,6 +19,15 @@ namespace {
 // =====================================================================================================================
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 
+// Workgroups are dispatched round robin over the 8 XCDs (each with its own L2), units are columns of the volume whose x
+// tiles overlap their H neighbours' by the halo rows: give every XCD a CONTIGUOUS range of units, so that the halo is
+// fetched from HBM by one L2 instead of two (DGTTA_WGRAD_XCD=0: units in dispatch order)
+__device__ __forceinline__ int xcd_unit(int xcd_map) {
+  const int i = blockIdx.x, n = gridDim.x;
+  if (!xcd_map || (n & 7)) return i;
+  return (i & 7) * (n >> 3) + (i >> 3);
+}
+
 template <typename T>
 struct WG {
   static constexpr int EPV = Elem<T>::EPV;
@@ -337,7 +346,7 @@ __global__ __launch_bounds__(256, 2) void conv3_wgrad_tr_kernel(const bf16_t *__
                                                                 const bf16_t *__restrict__ dy, View yv,
                                                                 float *__restrict__ slabs, int Cin, int Cout, int tilesW,
                                                                 int tilesH, int nsd, int DR, int cobs, WgradClasses wc, int upw,
-                                                                int units) {
+                                                                int units, int xcd_map) {
   const int cls = CLS ? blockIdx.z : 0;
   if (CLS) {
     x += wc.xoff[cls];
@@ -483,7 +492,7 @@ __global__ __launch_bounds__(256, 2) void conv3_wgrad_tr_kernel(const bf16_t *__
     sweep((int)blockIdx.x);
   } else {
     for (int uu = 0; uu < upw; ++uu) {
-      const int t = blockIdx.x * upw + uu;
+      const int t = xcd_unit(xcd_map) * upw + uu;
       if (t >= units) break;
       sweep(t);
     }
@@ -518,7 +527,7 @@ template <typename T16 = bf16_t>
 __global__ __launch_bounds__(512, 1) void conv3_wgrad_tr8_kernel(const bf16_t *__restrict__ x, View xv,
                                                                  const bf16_t *__restrict__ dy, View yv,
                                                                  float *__restrict__ slabs, int Cin, int Cout, int tilesW,
-                                                                 int tilesH, int nsd, int DR, int cobs, int upw, int units) {
+                                                                 int tilesH, int nsd, int DR, int cobs, int upw, int units, int xcd_map) {
   const int D = yv.D, H = yv.H, W = yv.W;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char *sX = smem;
@@ -537,7 +546,7 @@ __global__ __launch_bounds__(512, 1) void conv3_wgrad_tr8_kernel(const bf16_t *_
   const int cobs2 = (cobs + 1) / 2;
   const int cib = blockIdx.y / cobs2, cob2 = blockIdx.y % cobs2;          // channel-block pair (2 cob2, 2 cob2 + 1)
   for (int uu = 0; uu < upw; ++uu) {
-  int t = blockIdx.x * upw + uu;
+  int t = xcd_unit(xcd_map) * upw + uu;
   if (t >= units) break;
   const int tw = t % tilesW;
   t /= tilesW;
@@ -677,7 +686,7 @@ __global__ __launch_bounds__(256, 2) void conv3_wgrad_tr_s2_kernel(const bf16_t 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
-  int t = blockIdx.x;
+  int t = xcd_unit(1);
   const int tw = t % tilesW;
   t /= tilesW;
   const int th = t % tilesH;
@@ -814,7 +823,7 @@ __global__ __launch_bounds__(256, 2) void convT_wgrad_tr_kernel(const bf16_t *__
   unsigned char *sY = smem + 2 * WT3::X_SLICE_B;           // 2 slots of a slice pair
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  int t = blockIdx.x;
+  int t = xcd_unit(1);
   const int tw = t % tilesW;
   t /= tilesW;
   const int th = t % tilesH;
@@ -1045,7 +1054,7 @@ static int wgrad_launch_classes(const void *x, const View &xv, const void *dy, c
         nslab = cdiv64(p.units, upw);
         hipLaunchKernelGGL(conv3_wgrad_tr8_kernel<T16>, dim3((unsigned)nslab, (unsigned)gy), dim3(512),
                            WT8::LDS_BYTES, st, (const bf16_t *)x, xv, (const bf16_t *)dy, yv, (float *)ws, Cin, Cout, p.tW, p.tH,
-                           p.nsd, p.DR, p.cobs, upw, (int)p.units);
+                           p.nsd, p.DR, p.cobs, upw, (int)p.units, dgtta_switches().wgrad_xcd != '0');
         DG_CHECK_LAUNCH("conv3_wgrad_tr8_kernel");
         goto reduce;
       }
@@ -1055,7 +1064,7 @@ static int wgrad_launch_classes(const void *x, const View &xv, const void *dy, c
       nslab = cdiv64(p.units, upw);
       hipLaunchKernelGGL(ktr, dim3((unsigned)nslab, (unsigned)(p.cibs * p.cobs), (unsigned)wc.n), dim3(256), WT::LDS_BYTES,
                          st, (const bf16_t *)x, xv, (const bf16_t *)dy, yv, (float *)ws, Cin, Cout, p.tW, p.tH, p.nsd,
-                         p.DR, p.cobs, wc, upw, (int)p.units);
+                         p.DR, p.cobs, wc, upw, (int)p.units, dgtta_switches().wgrad_xcd != '0');
       DG_CHECK_LAUNCH("conv3_wgrad_tr_kernel");
       goto reduce;
     }

@@ -34,6 +34,7 @@ static const DgttaSwitches *read_switches() {
   s->convt_gemm = env_char("DGTTA_CONVT_GEMM");
   s->rows_order = env_char("DGTTA_ROWS_ORDER");
   s->wgrad_upw = env_char("DGTTA_WGRAD_UPW");
+  s->wgrad_xcd = env_char("DGTTA_WGRAD_XCD");
   s->in_nt = env_char("DGTTA_IN_NT");
   s->in_nt = s->in_nt == '0' ? '0' : '1';       // default on: streaming loads / stores in the InstanceNorm apply passes
   s->dgrad_s2_allcls = env_char("DGTTA_DGRAD_S2_ALLCLS");

@@ -29,7 +29,17 @@ __global__ __launch_bounds__(512) void conv_s2_regs_kernel(const T *__restrict__
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   uint4 *sW = reinterpret_cast<uint4 *>(smem);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
-  const int grp = (int)(blockIdx.x % NG), n0 = grp * NBW * 32;
+  // workgroup -> (channel group, position in the group's job list).  Dispatch is round robin over the 8 XCDs: the NG
+  // workgroups that read the same rows and the neighbours in the job list (adjacent output rows share input rows) are
+  // put on the SAME XCD, whose L2 then serves the 3.4x re-reads of an input line
+  const int ngw = (int)(gridDim.x / NG);            // workgroups per channel group
+  int grp = (int)(blockIdx.x % NG), gpos = (int)(blockIdx.x / NG);
+  if ((gridDim.x & 7) == 0 && (ngw & 7) == 0) {
+    const int xcd = (int)(blockIdx.x & 7), j = (int)(blockIdx.x >> 3);
+    grp = j % NG;
+    gpos = xcd * (ngw >> 3) + j / NG;
+  }
+  const int n0 = grp * NBW * 32;
   // weight fragments of this channel group: image order [N/32][KC][27][64 lanes][8] -> LDS [tap][c][nb][64 lanes]
   for (int i = tid; i < NF * 64; i += 512) {
     const int l = i & 63;
@@ -49,8 +59,8 @@ __global__ __launch_bounds__(512) void conv_s2_regs_kernel(const T *__restrict__
   if (stats && blockIdx.x == 0 && tid == 0) reinterpret_cast<long long *>(stats)[0] = nslots;
 
   const long long njobs = (long long)B * nslots;
-  const long long wstride = (long long)(gridDim.x / NG) * 8;
-  for (long long job = (long long)(blockIdx.x / NG) * 8 + wave; job < njobs; job += wstride) {
+  const long long wstride = (long long)ngw * 8;
+  for (long long job = (long long)gpos * 8 + wave; job < njobs; job += wstride) {
     const int b = (int)(job / nslots), chunk = (int)(job % nslots);
     float st1[NBW], st2[NBW];
 #pragma unroll

@@ -89,8 +89,15 @@ __global__ __launch_bounds__(NT) void mind_ssd_kernel(const float *__restrict__ 
   float *sred = sr2 + CG * TD * TH * QWP + 8;
 
   const int tid = threadIdx.x;
-  const int b = blockIdx.z / tilesD;
-  const int d0 = (blockIdx.z % tilesD) * TD, h0 = blockIdx.y * TH, w0 = blockIdx.x * TW;
+  // Workgroups are dispatched round robin over the 8 XCDs; tiles that are neighbours in H or W (their q tiles overlap by
+  // the +2 halo of the 48-byte noise rows, 2.5x the tile) would sit on different XCDs and each L2 would fetch the overlap
+  // from HBM.  Give every XCD a contiguous run of tiles (W fastest, then H, then D) instead.
+  int tlin = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+  const int ntile = gridDim.x * gridDim.y * gridDim.z;
+  if ((ntile & 7) == 0) tlin = (tlin & 7) * (ntile >> 3) + (tlin >> 3);
+  const int bx = tlin % gridDim.x, by = (tlin / gridDim.x) % gridDim.y, bz = tlin / (gridDim.x * gridDim.y);
+  const int b = bz / tilesD;
+  const int d0 = (bz % tilesD) * TD, h0 = by * TH, w0 = bx * TW;
   const int64_t V = (int64_t)D * H * W;
   const float *imgb = img + (int64_t)b * V;
 
@@ -278,7 +285,7 @@ __global__ __launch_bounds__(NT) void mind_ssd_kernel(const float *__restrict__ 
     }
   }
   float tot = block_sum(vsum, sred);
-  if (tid == 0) partial[(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = (double)tot;
+  if (tid == 0) partial[tlin] = (double)tot;
 }
 
 template <int DELTA, int R, int CG>

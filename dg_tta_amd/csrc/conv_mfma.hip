@@ -51,7 +51,11 @@ __global__ __launch_bounds__(NW * 64) void conv3_mfma_kernel(const T *__restrict
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
 
-  int t = blockIdx.x;
+  // tile index: a contiguous run of tiles per XCD (workgroups are dispatched round robin over the 8 XCDs; neighbouring
+  // tiles share their input halo, which one L2 should fetch once)
+  int tlin = blockIdx.x;
+  if ((gridDim.x & 7) == 0) tlin = (tlin & 7) * (int)(gridDim.x >> 3) + (tlin >> 3);
+  int t = tlin;
   const int tw = t % tilesW;
   t /= tilesW;
   const int th = t % tilesH;
@@ -341,7 +345,7 @@ __global__ __launch_bounds__(NW * 64) void conv3_mfma_kernel(const T *__restrict
         s += (double)red[(wv * NC + tid) * 2 + 0];
         ss += (double)red[(wv * NC + tid) * 2 + 1];
       }
-      double *p = stats + 32 + (((int64_t)b * tiles_per_b + (blockIdx.x % tiles_per_b)) * Cout + n0 + tid) * 2;
+      double *p = stats + 32 + (((int64_t)b * tiles_per_b + (tlin % tiles_per_b)) * Cout + n0 + tid) * 2;
       p[0] = s;
       p[1] = ss;
     }

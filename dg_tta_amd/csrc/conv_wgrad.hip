@@ -1272,8 +1272,9 @@ size_t head_wgrad_mfma_ws_bytes(int Cin, int nsel, int64_t rows) {
   return conv3_wgrad_mfma_ws_bytes(1, Cin, nsel, D, 4, 32) + align_up((size_t)rows * nsel * 2, 256);
 }
 
+// have_d16: the 16-bit copy of dout already sits at the start of ws (written by the head's data-gradient kernel)
 int head_wgrad_mfma(const void *x, int ldx, const float *dout, int lddo, float *dw_sel, void *ws, size_t ws_bytes, int Cin,
-                    int nsel, int64_t rows, int accumulate, int dtype, hipStream_t st) {
+                    int nsel, int64_t rows, int accumulate, int dtype, hipStream_t st, bool have_d16) {
   if (rows % 128 || rows / 128 >= (1ll << 30)) return DGTTA_ERR_UNSUPPORTED;
   const int D = (int)(rows / 128);
   if (ws_bytes < head_wgrad_mfma_ws_bytes(Cin, nsel, rows)) return DGTTA_ERR_UNSUPPORTED;
@@ -1289,11 +1290,13 @@ int head_wgrad_mfma(const void *x, int ldx, const float *dout, int lddo, float *
   if (dtype == DGTTA_BF16 || dtype == DGTTA_F16) {
     const size_t cbytes = align_up((size_t)rows * nsel * 2, 256);
     unsigned short *d16 = (unsigned short *)ws;
-    if (dtype == DGTTA_BF16)
-      hipLaunchKernelGGL(f32_to_16_rows_kernel<bf16_t>, dim3(2048), dim3(256), 0, st, dout, lddo, d16, nsel, rows);
-    else
-      hipLaunchKernelGGL(f32_to_16_rows_kernel<f16_t>, dim3(2048), dim3(256), 0, st, dout, lddo, d16, nsel, rows);
-    DG_CHECK_LAUNCH("f32_to_16_rows_kernel");
+    if (!have_d16) {
+      if (dtype == DGTTA_BF16)
+        hipLaunchKernelGGL(f32_to_16_rows_kernel<bf16_t>, dim3(2048), dim3(256), 0, st, dout, lddo, d16, nsel, rows);
+      else
+        hipLaunchKernelGGL(f32_to_16_rows_kernel<f16_t>, dim3(2048), dim3(256), 0, st, dout, lddo, d16, nsel, rows);
+      DG_CHECK_LAUNCH("f32_to_16_rows_kernel");
+    }
     const View yv = dense_view(1, D, 4, 32, nsel);
     if (dtype == DGTTA_BF16)
       return wgrad_launch<bf16_t>(x, xv, d16, yv, dw_sel, (char *)ws + cbytes, ws_bytes - cbytes, 1, Cin, nsel, 1u << 13, real,

@@ -770,7 +770,9 @@ __global__ __launch_bounds__(256) void head_fwd_lds_kernel(const T *__restrict__
 template <typename T>
 __global__ __launch_bounds__(256) void head_dgrad_lds_kernel(const float *__restrict__ dout, const float *__restrict__ w,
                                                              const int *__restrict__ sel, int nsel, T *__restrict__ dx,
-                                                             int64_t rows) {
+                                                             int64_t rows, unsigned short *__restrict__ d16) {
+  // d16 != NULL: also leave the 16-bit copy of dout [rows][nsel] that the MFMA weight gradient of the head reads (saves
+  // its own conversion pass over the fp32 gradient)
   constexpr int CIN = 32, EPV = 16 / sizeof(T), XU = CIN / EPV, XP = XU + 1;
   __shared__ float sw[16 * CIN];
   __shared__ float sg[256 * 17];
@@ -780,8 +782,23 @@ __global__ __launch_bounds__(256) void head_dgrad_lds_kernel(const float *__rest
     const int nr = rows - r0 < 256 ? (int)(rows - r0) : 256;
     __syncthreads();
     const float *gg = dout + r0 * nsel;
-    for (int i = threadIdx.x; i < nr * nsel; i += 256) sg[(i / nsel) * 17 + i % nsel] = gg[i];
+    for (int i = threadIdx.x; i < nr * nsel; i += 256) {
+      const float v = gg[i];
+      sg[(i / nsel) * 17 + i % nsel] = v;
+      if constexpr (sizeof(T) == 2) {
+        if (d16 && nsel != 16) d16[r0 * nsel + i] = f32_to_16<T>(v);
+      }
+    }
     __syncthreads();
+    if constexpr (sizeof(T) == 2) {
+      if (d16 && nsel == 16 && (int)threadIdx.x < nr) {      // one 32-byte row per thread: two 16-byte stores
+        uint4 *o = reinterpret_cast<uint4 *>(d16 + (r0 + threadIdx.x) * 16);
+        const float *g = sg + threadIdx.x * 17;
+        o[0] = make_uint4(pack2_16<T>(g[0], g[1]), pack2_16<T>(g[2], g[3]), pack2_16<T>(g[4], g[5]), pack2_16<T>(g[6], g[7]));
+        o[1] = make_uint4(pack2_16<T>(g[8], g[9]), pack2_16<T>(g[10], g[11]), pack2_16<T>(g[12], g[13]),
+                          pack2_16<T>(g[14], g[15]));
+      }
+    }
     if ((int)threadIdx.x < nr) {
       float acc[CIN];
 #pragma unroll
@@ -1317,7 +1334,7 @@ static int head_splits(int64_t rows) {
 
 size_t head_wgrad_mfma_ws_bytes(int Cin, int nsel, int64_t rows);
 int head_wgrad_mfma(const void *x, int ldx, const float *dout, int lddo, float *dw_sel, void *ws, size_t ws_bytes, int Cin,
-                    int nsel, int64_t rows, int accumulate, int dtype, hipStream_t st);
+                    int nsel, int64_t rows, int accumulate, int dtype, hipStream_t st, bool have_d16);
 
 // workspace layout: [bias partials][main: split partials (VALU) | bf16 copy + slabs (MFMA)]
 static size_t head_bias_region(int B, int nsel, int64_t V) {
@@ -1341,13 +1358,18 @@ extern "C" int dgtta_seghead_bwd(const void *x, int ldx, const float *dout, int 
   void *ws_bias = ws;
   void *ws_main = (char *)ws + head_bias_region(B, nsel, V);
   const size_t main_bytes = ws_bytes - head_bias_region(B, nsel, V);
+  unsigned short *d16 = nullptr;      // 16-bit copy of dout written by the data-gradient kernel for the weight gradient
   if (dx) {
     DG_REQUIRE(lddx >= Cin, DGTTA_ERR_BADARG, "seghead_bwd: lddx < Cin");
     if (Cin == 32 && nsel <= 32) {
       const int blocks = (int)(cdiv64(rows, 256) < 8192 ? cdiv64(rows, 256) : 8192);
       if (lddx == 32 && lddo == nsel && nsel <= 16 && ((uintptr_t)dx & 15) == 0) {
+        if (dw_sel && dtype != DGTTA_F32 && head_wgrad_mfma_ws_bytes(Cin, nsel, rows) > 0 &&
+            main_bytes >= head_wgrad_mfma_ws_bytes(Cin, nsel, rows)) {
+          d16 = (unsigned short *)ws_main;       // the first region of head_wgrad_mfma's workspace
+        }
         DISPATCH_T(dtype, hipLaunchKernelGGL((head_dgrad_lds_kernel<T>), dim3(blocks), dim3(256), 0, st, dout, w, sel, nsel,
-                                             (T *)dx, rows));
+                                             (T *)dx, rows, d16));
         DG_CHECK_LAUNCH("head_dgrad_lds_kernel");
       } else {
         DISPATCH_T(dtype, hipLaunchKernelGGL((head_dgrad_fast_kernel<T, 32>), dim3(blocks), dim3(256), 0, st, dout, lddo, w,
@@ -1362,7 +1384,8 @@ extern "C" int dgtta_seghead_bwd(const void *x, int ldx, const float *dout, int 
     }
   }
   if (dw_sel) {
-    int rc = head_wgrad_mfma(x, ldx, dout, lddo, dw_sel, ws_main, main_bytes, Cin, nsel, rows, accumulate, dtype, st);
+    int rc = head_wgrad_mfma(x, ldx, dout, lddo, dw_sel, ws_main, main_bytes, Cin, nsel, rows, accumulate, dtype, st,
+                             d16 != nullptr);
     if (rc == DGTTA_ERR_UNSUPPORTED) {
       const int ns = head_splits(rows);
       float *part = (float *)ws_main;

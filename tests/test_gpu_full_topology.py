@@ -161,3 +161,40 @@ def test_full_topology_forward_128_vs_cpu_oracle(dtype):
     agree = (out.argmax(1) == ref.argmax(1)).float().mean().item()
     assert agree > {"fp32": 0.9995, "bf16": 0.97, "fp16": 0.995}[dtype]
     print(f"128^3 {dtype}: max logit err {err:.3e} of range {rng:.2f}; label agreement {agree:.5f}")
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+def test_noncubic_batch_16bit_kernels_vs_reference_kernels(dtype):
+    """A non-cubic patch (64 x 96 x 160: different tile counts per axis, ragged 32-voxel blocks at the coarse levels) with
+    batch 2 through the full 3d_fullres topology: the product's 16-bit kernels (row-reuse conv with the XCD job order,
+    register-operand stride-2 and transposed-conv kernels, transposed-read weight gradients sweeping several units) against
+    the general VALU kernels in fp32 (conv_impl=1) on the same weights and inputs - logits and every parameter gradient."""
+    adt = torch.bfloat16 if dtype == "bf16" else torch.float16
+    _, ref = _nets(11, torch.float32, conv_impl=1)
+    _, hm = _nets(11, adt)
+    sel = torch.arange(16) * 5
+    for m in (ref, hm):
+        m.set_selected_classes(sel)
+    torch.manual_seed(3)
+    x = torch.randn(2, 12, 64, 96, 160, device=DEV)
+    gout = torch.randn(2, 16, 64, 96, 160, device=DEV) * 1e-3
+    outs, grads = [], []
+    for m in (ref, hm):
+        xin = x.to(m.act_dtype) if m.act_dtype != torch.float32 else x
+        out = m(xin)
+        scale = float(getattr(m, "loss_scale", 1.0))
+        (out.float() * gout * scale).sum().backward()
+        outs.append(out.float())
+        grads.append({n: p.grad.float() / scale for n, p in m.named_parameters() if p.grad is not None})
+    rng = float(outs[0].abs().max())
+    tol = 0.03 if dtype == "bf16" else 0.005
+    assert float((outs[1] - outs[0]).abs().max()) < tol * rng
+    assert set(grads[0]) == set(grads[1])
+    cosines = {}
+    for n, gr in grads[0].items():
+        # a conv bias in front of InstanceNorm has an identically-zero gradient in exact arithmetic (rounding noise in both)
+        if gr.numel() < 2 or (n.endswith("conv.bias") and "seg_layers" not in n and "transpconvs" not in n):
+            continue
+        cosines[n] = float(torch.nn.functional.cosine_similarity(gr.flatten().double(), grads[1][n].flatten().double(), dim=0))
+    bad = {n: round(c, 4) for n, c in cosines.items() if c < (0.85 if dtype == "bf16" else 0.97)}
+    assert not bad, bad

@@ -25,6 +25,23 @@ PLANS_3D_FULLRES = dict(features=(32, 64, 128, 256, 320), strides=(1, 2, 2, 2, 2
 EPS, SLOPE = 1e-5, 1e-2
 
 
+_SIDE_STREAMS = {}
+
+
+def _side_stream(dev):
+    d = torch.device(dev)
+    key = d.index if d.index is not None else torch.cuda.current_device()
+    s_ = _SIDE_STREAMS.get(key)
+    if s_ is None:
+        s_ = _SIDE_STREAMS[key] = torch.cuda.Stream(device=d)
+    return s_
+
+
+def _wgrad_on_side_stream():
+    import os
+    return os.environ.get("DGTTA_WGRAD_STREAM", "1") != "0"
+
+
 def _pad(c, m):
     return (c + m - 1) // m * m
 
@@ -373,13 +390,21 @@ class _UNetFn(torch.autograd.Function):
 
         ws_cache = {}
 
-        def ws_for(nbytes):
+        def ws_for(nbytes, key="ws"):
             nb = int(nbytes)
-            t = ws_cache.get("ws")
+            t = ws_cache.get(key)
             if t is None or t.numel() < nb:
                 t = _ws(nb, dev)
-                ws_cache["ws"] = t
+                ws_cache[key] = t
             return t
+
+        # The weight gradients of the conv blocks are leaves of the backward chain (IN-bwd(L) -> dgrad(L) -> IN-bwd(L-1) ...
+        # only passes dy on): they run on a SIDE STREAM, so that the MFMA-bound weight-gradient kernels overlap the
+        # HBM-bound InstanceNorm passes of the main chain instead of queueing between them (DGTTA_WGRAD_STREAM=0: one stream)
+        main_stream = torch.cuda.current_stream(dev)
+        side = _side_stream(dev) if _wgrad_on_side_stream() else None
+        if side is not None:
+            side.wait_stream(main_stream)
 
         V = D * H * W
         g = gout.contiguous(memory_format=torch.channels_last_3d).float()      # [B,nsel,D,H,W] stored NDHWC
@@ -432,13 +457,22 @@ class _UNetFn(torch.autograd.Function):
             # -- weight / bias gradient
             if want(conv.weight) or want(conv.bias):
                 nb = lib.dgtta_conv3d_wgrad_ws_bytes(B, cin, cout, do, ho, wo)
-                w_ = ws_for(nb)
                 dw = gbuf(conv.weight) if want(conv.weight) else torch.empty_like(conv.weight)
                 db = gbuf(conv.bias) if want(conv.bias) else None
                 if net.exact_zero_bias_grad:
                     db = None       # gradient buffer stays exactly zero (see HipPlainConvUNet.exact_zero_bias_grad)
+                if side is None:
+                    w_, st_w = ws_for(nb), st
+                else:
+                    ev = torch.cuda.Event()
+                    ev.record(main_stream)          # dy (and the gradient buffers) are complete on the main stream
+                    side.wait_event(ev)
+                    dy.record_stream(side)          # the allocator must not hand dy's block out again before the side stream is done
+                    with torch.cuda.stream(side):
+                        w_ = ws_for(nb, "ws_side")
+                    st_w = side.cuda_stream
                 check(lib.dgtta_conv3d_k3_wgrad(rec["u"], rec["ldu"], ptr(dy), cout, ptr(dw), ptr(db), ptr(w_), nb, B,
-                                                cin, cout, di, hi, wi, s, ACC, dt, impl, st), "dgtta_conv3d_k3_wgrad")
+                                                cin, cout, di, hi, wi, s, ACC, dt, impl, st_w), "dgtta_conv3d_k3_wgrad")
             # -- data gradient towards the block input
             where = rec["where"]
             if idx == 0:
@@ -487,6 +521,8 @@ class _UNetFn(torch.autograd.Function):
                 keep_alive = [gin]
             idx -= 1
         del keep_alive, first_rec
+        if side is not None:
+            main_stream.wait_stream(side)         # gradients complete before anything downstream (optimizer, next pass)
         out = [None, None, None, None]
         for p in params:
             out.append(grads.get(id(p)) if p.requires_grad else None)

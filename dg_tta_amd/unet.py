@@ -496,9 +496,24 @@ class _UNetFn(torch.autograd.Function):
                 need_w = want(upm.weight) or want(upm.bias)
                 dwu = (gbuf(upm.weight) if want(upm.weight) else torch.empty_like(upm.weight)) if need_w else None
                 dbu = gbuf(upm.bias) if want(upm.bias) else None
-                check(lib.dgtta_convT3d_k2s2_bwd(up["x"], up["ldx"], ptr(gc), 2 * cskip, ptr(upm.weight), ptr(glow),
-                                                 up["cin"], ptr(dwu), ptr(dbu), ptr(w_), nb, B, up["cin"], up["cout"],
-                                                 ld0, lh0, lw0, ACC, dt, impl, st), "dgtta_convT3d_k2s2_bwd")
+                if side is None or not need_w:
+                    check(lib.dgtta_convT3d_k2s2_bwd(up["x"], up["ldx"], ptr(gc), 2 * cskip, ptr(upm.weight), ptr(glow),
+                                                     up["cin"], ptr(dwu), ptr(dbu), ptr(w_), nb, B, up["cin"], up["cout"],
+                                                     ld0, lh0, lw0, ACC, dt, impl, st), "dgtta_convT3d_k2s2_bwd")
+                else:
+                    # data gradient on the main chain, weight / bias gradient (a leaf) on the side stream
+                    ev = torch.cuda.Event()
+                    ev.record(main_stream)          # gc is complete
+                    check(lib.dgtta_convT3d_k2s2_bwd(up["x"], up["ldx"], ptr(gc), 2 * cskip, ptr(upm.weight), ptr(glow),
+                                                     up["cin"], None, None, ptr(w_), nb, B, up["cin"], up["cout"],
+                                                     ld0, lh0, lw0, ACC, dt, impl, st), "dgtta_convT3d_k2s2_bwd")
+                    side.wait_event(ev)
+                    gc.record_stream(side)
+                    with torch.cuda.stream(side):
+                        w2 = ws_for(nb, "ws_side")
+                    check(lib.dgtta_convT3d_k2s2_bwd(up["x"], up["ldx"], ptr(gc), 2 * cskip, ptr(upm.weight), None,
+                                                     up["cin"], ptr(dwu), ptr(dbu), ptr(w2), nb, B, up["cin"], up["cout"],
+                                                     ld0, lh0, lw0, ACC, dt, impl, side.cuda_stream), "dgtta_convT3d_k2s2_bwd")
                 gz_ptr, gz_ld = glow.data_ptr(), up["cin"]
                 keep_alive = [glow, gc]
             elif kind == "enc" and bidx == 0:

@@ -42,8 +42,18 @@ def push_noise(noise, groups=1):
     _PENDING_NOISE.append((noise, groups))
 
 
+_PENDING_FEATURES = []
+
+
+def push_features(feat):
+    """Descriptor computed ahead of the network pass (tta.prepare_both_branches, on a side stream): the next mind_hook call
+    on an input of the same batch / spatial shape returns it instead of computing MIND again."""
+    _PENDING_FEATURES.append(feat)
+
+
 def clear_noise():
     _PENDING_NOISE.clear()
+    _PENDING_FEATURES.clear()
 
 
 def uses_mind_hook(model):
@@ -67,6 +77,10 @@ class mind_groups:
 
 
 def mind_hook(module, input):
+    if _PENDING_FEATURES:
+        cand = _PENDING_FEATURES[0]
+        if cand.shape[0] == input[0].shape[0] and tuple(cand.shape[2:]) == tuple(input[0].shape[2:]):
+            return _PENDING_FEATURES.pop(0)
     noise, groups = None, 1
     if _PENDING_NOISE:
         cand = _PENDING_NOISE[0][0]

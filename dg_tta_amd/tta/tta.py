@@ -113,10 +113,18 @@ def calc_both_branches(config, model, intensity_aug_func, patch_size, batch_size
     once per epoch): `imgs` is then a callable that samples the next step's patches (get_batch), called in step order so
     that the reference's draw sequence  get_batch_i, branch_a_i, branch_b_i, get_batch_i+1, ...  is kept.  The targets are
     ordered [step][batch item]; ops.consistency_loss on them returns the MEAN of the per-step losses and dice[step]."""
-    from ..mind import clear_noise, draw_noise_, push_noise, uses_mind_hook
-    grad_context = nullcontext if config["have_grad_in"] in ["branch_a", "both"] else torch.no_grad
-    after_mapping = modifier_fn_module.ModifierFunctions.modify_tta_output_after_mapping_fn
-    with grad_context():
+    prepared = prepare_both_branches(config, model, intensity_aug_func, batch_size, imgs, device, steps=steps)
+    return run_both_branches(prepared, config, model, label_mapping, optimized_labels, modifier_fn_module, head_is_fused,
+                             steps=steps)
+
+
+def prepare_both_branches(config, model, intensity_aug_func, batch_size, imgs, device, steps=1, precompute_mind=False):
+    """The input side of calc_both_branches: patch sampling, intensity / spatial augmentation and the MIND noise draws of
+    `steps` accumulation steps x 2 branches, in the reference's draw order.  Holds no reference to the weights, so
+    tta_epoch runs it for pass k+1 on a side stream while pass k is still in its backward.  precompute_mind: also
+    evaluate the MIND descriptor here (it is handed to the model's mind_hook by run_both_branches)."""
+    from ..mind import MIND3D, draw_noise_, uses_mind_hook
+    with torch.no_grad():
         augs, inverses = [[], []], [[], []]
         want_noise = uses_mind_hook(model)
         noise = None
@@ -146,19 +154,36 @@ def calc_both_branches(config, model, intensity_aug_func, patch_size, batch_size
                                             device=imgs_aug.device)
                     slot = k * steps + step
                     draw_noise_(noise[slot * nb_:(slot + 1) * nb_])
-        augs = augs[0] + augs[1]                    # all of branch a (step order), then all of branch b
-        inverses = inverses[0] + inverses[1]
+        x = torch.cat(augs[0] + augs[1], dim=0)     # all of branch a (step order), then all of branch b
+        feat = None
+        if want_noise and precompute_mind:
+            feat = MIND3D().forward(x, noise=noise, out_dtype=getattr(model, "act_dtype", torch.float32), groups=2 * steps)
+            noise = None
+    return {"x": x, "inverses": inverses[0] + inverses[1], "noise": noise, "feat": feat, "per": augs[0][0].shape[0],
+            "want_noise": want_noise}
+
+
+def run_both_branches(prepared, config, model, label_mapping, optimized_labels, modifier_fn_module, head_is_fused=False,
+                      steps=1):
+    """The network side of calc_both_branches on inputs from prepare_both_branches.  Returns (target_a, target_b)."""
+    from ..mind import clear_noise, push_features, push_noise
+    grad_context = nullcontext if config["have_grad_in"] in ["branch_a", "both"] else torch.no_grad
+    after_mapping = modifier_fn_module.ModifierFunctions.modify_tta_output_after_mapping_fn
+    inverses, noise, want_noise = prepared["inverses"], prepared["noise"], prepared["want_noise"]
+    with grad_context():
         model.apply(buffer_running_stats)
         model.apply(apply_running_stats)
-        if want_noise:
+        if prepared["feat"] is not None:
+            push_features(prepared["feat"])
+        elif want_noise:
             push_noise(noise, groups=2 * steps)
         try:
-            both = model(torch.cat(augs, dim=0))
+            both = model(prepared["x"])
         finally:
             clear_noise()
         if isinstance(both, tuple):
             both = both[0]
-        per = augs[0].shape[0]
+        per = prepared["per"]
         nb = steps * per
         template_after = is_template_modifier(after_mapping, "modify_tta_output_after_mapping_fn")
         if head_is_fused and template_after and all(r is not None for r in inverses):
@@ -185,6 +210,23 @@ def calc_both_branches(config, model, intensity_aug_func, patch_size, batch_size
                    torch.cat(pieces[steps:], dim=0) if steps > 1 else pieces[1]]
         targets[0]._dgtta_guard_items = targets[1]._dgtta_guard_items = per
     return targets[0], targets[1]
+
+
+_PREP_STREAMS = {}
+
+
+def _prep_stream(device):
+    d = torch.device(device)
+    key = d.index if d.index is not None else torch.cuda.current_device()
+    st = _PREP_STREAMS.get(key)
+    if st is None:
+        st = _PREP_STREAMS[key] = torch.cuda.Stream(device=d)
+    return st
+
+
+def _pipeline_prep():
+    import os
+    return os.environ.get("DGTTA_PIPELINE_PREP", "1") != "0"
 
 
 def batch_branches_enabled():
@@ -237,10 +279,36 @@ def tta_epoch(model, optimizer, config, tta_tens_list, patch_size, label_mapping
 
     if batch_branches_enabled():
         k = batched_steps(accum, B)
-        for _ in range(accum // k):
-            target_a, target_b = calc_both_branches(config, model, intensity_aug_func, patch_size, B, label_mapping,
-                                                    optimized_labels, modifier_fn_module, next_imgs, device,
-                                                    head_is_fused, steps=k)
+        n_pass = accum // k
+        # The inputs of pass i+1 (patch sampling, GIN, affine warp, noise draws, MIND) do not depend on the weights or on
+        # pass i: they are produced on a side stream while pass i is in its network passes (DGTTA_PIPELINE_PREP=0: in
+        # line).  Draw order on both generators is unchanged - the draws happen when the work is enqueued.
+        prep_stream = _prep_stream(device) if (_pipeline_prep() and torch.device(device).type == "cuda") else None
+        main_stream = torch.cuda.current_stream(device) if prep_stream is not None else None
+
+        def prepare(on_side):
+            if not on_side:
+                return prepare_both_branches(config, model, intensity_aug_func, B, next_imgs, device, steps=k,
+                                             precompute_mind=prep_stream is not None)
+            with torch.cuda.stream(prep_stream):
+                pr = prepare_both_branches(config, model, intensity_aug_func, B, next_imgs, device, steps=k,
+                                           precompute_mind=True)
+            for t in [pr["x"], pr["noise"], pr["feat"]] + list(pr["inverses"]):
+                if torch.is_tensor(t):
+                    t.record_stream(main_stream)       # consumed on the main stream: no reuse of the block before that
+            return pr
+
+        if prep_stream is not None:
+            # once per epoch, before this epoch enqueues anything: the side stream sees the resident volumes (uploaded on
+            # the main stream).  NOT per pass - that would order the next pass's inputs behind the current backward
+            prep_stream.wait_stream(main_stream)
+        prepared = prepare(False)
+        for i_pass in range(n_pass):
+            if prep_stream is not None:
+                main_stream.wait_stream(prep_stream)
+            target_a, target_b = run_both_branches(prepared, config, model, label_mapping, optimized_labels,
+                                                   modifier_fn_module, head_is_fused, steps=k)
+            prepared = None
             loss, dice = ops.consistency_loss(target_a, target_b, START_CLASS)      # mean of the k step losses
             if k == 1:
                 step_losses.append(loss.detach())
@@ -248,6 +316,8 @@ def tta_epoch(model, optimizer, config, tta_tens_list, patch_size, label_mapping
                 step_losses.extend((1.0 - dice.detach().reshape(k, B, -1)[:, :, START_CLASS:].mean((1, 2))).unbind(0))
             if adapt and loss.requires_grad:
                 torch.autograd.backward(loss, grad_tensors=inv_accum * k)
+            if i_pass + 1 < n_pass:
+                prepared = prepare(prep_stream is not None)
     else:
         for _ in range(accum):
             imgs = next_imgs()

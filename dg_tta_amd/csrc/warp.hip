@@ -262,10 +262,15 @@ __global__ __launch_bounds__(256) void warp_bwd_gather_kernel(const float *__res
   const int b = blockIdx.z / tilesZ;
   const int x = (blockIdx.x % tilesX) * 16 + (threadIdx.x & 15), y = blockIdx.y * 4 + ((threadIdx.x >> 4) & 3),
             z = (blockIdx.z % tilesZ) * 4 + (threadIdx.x >> 6);
+  // the inverse map is the same for the whole workgroup (one batch item): one thread evaluates it (~150 instructions,
+  // 4 calls of the sample-position arithmetic), the others read the 22 numbers from LDS
+  __shared__ InvMap s_im;
+  const float *th = theta + b * 12;
+  if (threadIdx.x == 0) s_im = inverse_map(th, Ds, Hs, Ws, Dd, Hd, Wd, algebra);
+  __syncthreads();
   if (x < Ws && y < Hs && z < Ds) {
     const int64_t u = ((int64_t)z * Hs + y) * Ws + x;
-    const float *th = theta + b * 12;
-    const InvMap im = inverse_map(th, Ds, Hs, Ws, Dd, Hd, Wd, algebra);
+    const InvMap im = s_im;
     if (!im.ok) return;   // the scatter kernels (launched next) take over (uniform per batch item)
     const float rel[3] = {(float)x - im.s0[0], (float)y - im.s0[1], (float)z - im.s0[2]};
     int lo[3], hi[3];

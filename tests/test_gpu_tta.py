@@ -575,3 +575,37 @@ def test_two_ranks_one_run_directory(tmp_path):
     rb = tta_main("runB", cfg, tmp_path, tmp_path, mapping, modmod, DEV, network_bundle=bundle, tta_data=data((4,)),
                   shard=(0, 2))
     assert ("tta_outputTs/case4", "prediction") in rb and ("summary", "Ts") in rb
+
+
+def test_side_streams_do_not_change_a_bit(monkeypatch):
+    """The weight-gradient side stream (unet backward) and the input pipeline of tta_epoch (next pass prepared on a third
+    stream, MIND precomputed) against the one-stream schedule: same seeds -> identical losses, pseudo-Dice and adapted
+    parameters, bit for bit (draws happen at enqueue time in the same order; accumulation orders are fixed per stream)."""
+    from dg_tta_amd.optim import HipAdamW
+    from dg_tta_amd.tta.tta import _fuse_head_if_possible, tta_unit
+    from dg_tta_amd.tta.torch_utils import release_resident
+    g = load_golden("tta_unit")
+
+    def run(streams):
+        monkeypatch.setenv("DGTTA_WGRAD_STREAM", streams)
+        monkeypatch.setenv("DGTTA_PIPELINE_PREP", streams)
+        model, modmod = _product_model(g, conv_impl=0, act_dtype=torch.bfloat16)
+        assert _fuse_head_if_possible(model, modmod, UNIT_MAPPING, OPTIMIZED)
+        model.accumulate_grads_in_place = True
+        model.exact_zero_bias_grad = True
+        cfg = _plan(epochs=4, patches_to_be_accumulated=8, lr=1e-4)
+        opt = HipAdamW(model.parameters(), lr=cfg["lr"])
+        release_resident()
+        torch.manual_seed(77)
+        torch.cuda.manual_seed(77)
+        np.random.seed(77)
+        losses, dices = tta_unit(model, opt, cfg, [g["data"]], [16, 16, 16], UNIT_MAPPING, modmod, torch.device(DEV), True)
+        torch.cuda.synchronize()
+        release_resident()
+        return losses, dices, {k: v.clone() for k, v in model.state_dict().items()}
+
+    l1, d1, p1 = run("1")
+    l0, d0, p0 = run("0")
+    assert torch.equal(l1, l0) and torch.equal(d1, d0)
+    assert all(torch.equal(p1[k], p0[k]) for k in p1)
+    assert float((l1[1:] - l1[:-1]).abs().max()) > 0          # the runs did adapt

@@ -224,6 +224,20 @@ def _prep_stream(device):
     return st
 
 
+def _can_precompute_mind(model, modifier_fn_module):
+    """MIND may be evaluated ahead of the network call only if nothing in front of mind_hook changes the input: the user's
+    input modifier is the untouched template and the trainers' internal GIN augmentation is off (tta_main disables it)."""
+    from ..gin import gin_hook
+    from ..mind import mind_hook
+    from ..utils import get_internal_augmentation_enabled
+    hooks = list(model._forward_pre_hooks.values())
+    if not hooks or hooks[-1] is not mind_hook or get_internal_augmentation_enabled():
+        return False
+    others = [h for h in hooks if h is not mind_hook and h is not gin_hook]
+    mf = modifier_fn_module.ModifierFunctions
+    return len(others) <= 1 and is_template_modifier(mf.modify_tta_input_fn, "modify_tta_input_fn")
+
+
 def _pipeline_prep():
     import os
     return os.environ.get("DGTTA_PIPELINE_PREP", "1") != "0"
@@ -284,15 +298,16 @@ def tta_epoch(model, optimizer, config, tta_tens_list, patch_size, label_mapping
         # pass i: they are produced on a side stream while pass i is in its network passes (DGTTA_PIPELINE_PREP=0: in
         # line).  Draw order on both generators is unchanged - the draws happen when the work is enqueued.
         prep_stream = _prep_stream(device) if (_pipeline_prep() and torch.device(device).type == "cuda") else None
+        mind_ahead = prep_stream is not None and _can_precompute_mind(model, modifier_fn_module)
         main_stream = torch.cuda.current_stream(device) if prep_stream is not None else None
 
         def prepare(on_side):
             if not on_side:
                 return prepare_both_branches(config, model, intensity_aug_func, B, next_imgs, device, steps=k,
-                                             precompute_mind=prep_stream is not None)
+                                             precompute_mind=mind_ahead)
             with torch.cuda.stream(prep_stream):
                 pr = prepare_both_branches(config, model, intensity_aug_func, B, next_imgs, device, steps=k,
-                                           precompute_mind=True)
+                                           precompute_mind=mind_ahead)
             for t in [pr["x"], pr["noise"], pr["feat"]] + list(pr["inverses"]):
                 if torch.is_tensor(t):
                     t.record_stream(main_stream)       # consumed on the main stream: no reuse of the block before that

@@ -609,3 +609,35 @@ def test_side_streams_do_not_change_a_bit(monkeypatch):
     assert torch.equal(l1, l0) and torch.equal(d1, d0)
     assert all(torch.equal(p1[k], p0[k]) for k in p1)
     assert float((l1[1:] - l1[:-1]).abs().max()) > 0          # the runs did adapt
+
+
+def test_mind_is_not_precomputed_behind_a_user_input_modifier():
+    """tta_epoch evaluates MIND ahead of the network call only when nothing in front of mind_hook can change the input: a
+    user-defined modify_tta_input_fn (or the trainers' internal GIN augmentation) switches the shortcut off."""
+    from dg_tta_amd.tta.config_log_utils import ModifierFunctions
+    from dg_tta_amd.tta.model_utils import get_model_from_network
+    from dg_tta_amd.tta.tta import _can_precompute_mind
+    from dg_tta_amd import utils
+    g = load_golden("tta_unit")
+    model, modmod = _product_model(g)
+    assert _can_precompute_mind(model, modmod)
+
+    class Custom(ModifierFunctions):
+        @staticmethod
+        def modify_tta_input_fn(image: torch.Tensor):
+            return image * 2.0
+
+    custom = SimpleNamespace(ModifierFunctions=Custom)
+    model2 = get_model_from_network(_network_with_hooks(g), custom, None)
+    assert not _can_precompute_mind(model2, custom)
+    import os
+    old = os.environ.get("DG_TTA_INTERNAL_AUGMENTATION")
+    try:
+        os.environ["DG_TTA_INTERNAL_AUGMENTATION"] = "true"
+        assert not _can_precompute_mind(model, modmod)
+    finally:
+        if old is None:
+            os.environ.pop("DG_TTA_INTERNAL_AUGMENTATION", None)
+        else:
+            os.environ["DG_TTA_INTERNAL_AUGMENTATION"] = old
+    utils.disable_internal_augmentation()

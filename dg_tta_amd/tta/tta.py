@@ -348,7 +348,7 @@ def tta_epoch(model, optimizer, config, tta_tens_list, patch_size, label_mapping
     if adapt:
         optimizer.step()
         optimizer.zero_grad()
-    mean_loss = torch.stack(step_losses).mean().item()
+    mean_loss_t = torch.stack(step_losses).mean()      # read back after the evaluation pass: one pipeline drain per epoch
 
     eval_dice = 0.0
     with torch.inference_mode():
@@ -372,7 +372,7 @@ def tta_epoch(model, optimizer, config, tta_tens_list, patch_size, label_mapping
                                  input_format="argmaxed").long()
             d = dice_coeff(target_argmax, f_labels, len(optimized_labels))
             eval_dice += 1 / config["tta_eval_patches"] * d.nanmean().item()
-    return mean_loss, eval_dice
+    return mean_loss_t.item(), eval_dice
 
 
 def tta_unit(model, optimizer, config, tta_tens_list, patch_size, label_mapping, modifier_fn_module, device,

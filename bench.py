@@ -1,15 +1,22 @@
 #!/usr/bin/env python3
-"""Benchmark of the DG-TTA hot path on MI355X: TTA epochs per second on a 128^3 patch (BASELINE.json metric).
+"""Benchmark of the DG-TTA hot path on MI355X: TTA epochs per second on a 128^3 patch (BASELINE.json metric) and the
+Dice delta of the 16-bit storage path against the reference's precision (fp32).
 
 One "step" = one TTA epoch of the reference's inner loop (dg_tta/tta/tta.py:190-338): 16 accumulation steps x
 {get_batch, 2 augmented branches (GIN -> affine warp -> MIND -> nnUNet 3d_fullres fwd -> inverse warp), masked
 soft-Dice loss, backward through both branches}, one AdamW step, one centre-patch eval forward.
+
 N > 1: one independent TTA instance per GPU (different sample per rank, no data-path collective); torch.distributed is
-used only for the barrier and the max-over-ranks time.  Prints ONE JSON line on rank 0.
+used only for the barrier, the max-over-ranks time and the gather of the per-rank rates.  `bench.py --gpus N` without
+RANK / WORLD_SIZE in the environment LAUNCHES the N ranks itself (fresh child processes, started before this process
+touches the GPU); under `torch.distributed.run` (RANK / WORLD_SIZE set) it is one of the ranks.  Prints ONE JSON line
+on rank 0.
 """
 import argparse
+import hashlib
 import json
 import os
+import subprocess
 import sys
 import time
 from pathlib import Path
@@ -18,24 +25,92 @@ from types import SimpleNamespace
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
-import numpy as np  # noqa: E402
-import torch  # noqa: E402
-
 # algorithmic work of one PlainConvUNet forward at 128^3
 FWD_GFLOP_128 = 998.84
+DTYPES = ("fp32", "bf16", "fp16")
+DICE_TOLERANCE = 1e-3            # north_star: "Dice within 1e-3 of the reference"
 
 
 def conv_flops(cin, cout, vout):
     return 2.0 * 27 * cin * cout * vout
 
 
-def build_workload(args, device, rank):
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--size", type=int, default=128)
+    ap.add_argument("--accum", type=int, default=16)
+    ap.add_argument("--copt", type=int, default=16)
+    ap.add_argument("--dtype", default="fp16", choices=list(DTYPES),
+                    help="activation storage; accumulation, statistics, loss, gradients of weights and AdamW are fp32")
+    ap.add_argument("--impl", type=int, default=0)
+    ap.add_argument("--cpu-size", type=int, default=128)
+    ap.add_argument("--cpu-warmup", type=int, default=1)
+    ap.add_argument("--ab-epochs", type=int, default=4,
+                    help="epochs of the same-seed fp32 vs 16-bit comparison (dice_delta; the fp32 leg's timing: the first "
+                         "epoch is its warm-up); 0 = skip")
+    ap.add_argument("--no-fp32", action="store_true", help="skip the reference-precision (fp32) leg and dice_delta")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--inference-size", type=int, default=512,
+                    help="edge of the volume for the sliding-window inference leg (BASELINE config 3: 512); 0 = skip")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="rendezvous for the barrier / max-time only (nccl = RCCL)")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="rehearsal on a one-GPU box: every rank uses cuda:0 (implies --dist-backend gloo)")
+    ap.add_argument("--stub-runner", type=float, default=None, metavar="SECONDS",
+                    help="test hook: an epoch is a sleep of this length, no GPU is touched (implies gloo)")
+    return ap.parse_args(argv)
+
+
+# ------------------------------------------------------------------------------------------------ N-rank launcher
+def _free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(args, argv):
+    """Starts `args.gpus` ranks of this script (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* as torch.distributed.run sets
+    them) and waits for them.  Runs BEFORE anything in this process touches the GPU; the children are fresh processes
+    (never an exec of a process that has initialised HIP).  Rank 0's stdout carries the JSON line."""
+    port = os.environ.get("MASTER_PORT") or str(_free_port())
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=port, DGTTA_BENCH_CHILD="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, str(Path(__file__).resolve())] + list(argv), env=env))
+    rcs = [None] * len(procs)
+    while any(rc is None for rc in rcs):
+        for i, p in enumerate(procs):
+            if rcs[i] is None:
+                rcs[i] = p.poll()
+        if any(rc not in (None, 0) for rc in rcs):           # a failed rank would leave the others in the barrier
+            for p in procs:
+                if p.poll() is None:
+                    p.terminate()
+            rcs = [p.wait() for p in procs]
+            break
+        time.sleep(0.2)
+    bad = [(i, rc) for i, rc in enumerate(rcs) if rc != 0]
+    if bad:
+        print(f"bench.py: rank return codes {rcs}", file=sys.stderr)
+        return 1
+    return 0
+
+
+# ------------------------------------------------------------------------------------------------ workload
+def build_workload(args, device, rank, dtype):
+    import torch
     from dg_tta_amd.gin import gin_hook
     from dg_tta_amd.mind import mind_hook
     from dg_tta_amd.synthetic import he_init_, synthetic_case, synthetic_label_mapping
     from dg_tta_amd.tta.config_log_utils import ModifierFunctions, TEMPLATE_PLAN
     from dg_tta_amd.unet import HipPlainConvUNet
-    act = {"fp32": torch.float32, "bf16": torch.bfloat16, "fp16": torch.float16}[args.dtype]
+    act = {"fp32": torch.float32, "bf16": torch.bfloat16, "fp16": torch.float16}[dtype]
     net = he_init_(HipPlainConvUNet(act_dtype=act, conv_impl=args.impl), seed=7)
     net.exact_zero_bias_grad = True
     net.accumulate_grads_in_place = True
@@ -56,14 +131,14 @@ def build_workload(args, device, rank):
 class EpochRunner:
     """Runs TTA epochs back to back on one sample (the body of tta_unit, one epoch per call)."""
 
-    def __init__(self, args, device, rank):
+    def __init__(self, args, device, rank, dtype):
         from dg_tta_amd.optim import HipAdamW
         from dg_tta_amd.tta.model_utils import get_model_from_network
         from dg_tta_amd.tta.tta import _fuse_head_if_possible
         from dg_tta_amd.tta.torch_utils import fix_all, release_all
         from dg_tta_amd.utils import disable_internal_augmentation
         self.args, self.device = args, device
-        net, self.cfg, self.mapping, self.modmod, data = build_workload(args, device, rank)
+        net, self.cfg, self.mapping, self.modmod, data = build_workload(args, device, rank, dtype)
         self.data = [data]
         self.patch = [args.size] * 3
         self.model = get_model_from_network(net, self.modmod, None)
@@ -72,15 +147,46 @@ class EpochRunner:
         disable_internal_augmentation()
         self.model.apply(fix_all)
         self.model.apply(release_all)            # measured epochs are adaptation epochs (epoch >= start_tta_at_epoch)
-        self.losses = []
+        self.losses, self.dices = [], []
 
     def epoch(self):
         """One adaptation epoch through the PRODUCT's own epoch function (dg_tta_amd.tta.tta.tta_epoch, the body of
         tta_unit): nothing of the loop is restated here."""
         from dg_tta_amd.tta.tta import tta_epoch
-        loss, self.dice = tta_epoch(self.model, self.opt, self.cfg, self.data, self.patch, self.mapping, self.modmod,
-                                    self.device, self.fused, adapt=True)
+        loss, dice = tta_epoch(self.model, self.opt, self.cfg, self.data, self.patch, self.mapping, self.modmod,
+                               self.device, self.fused, adapt=True)
         self.losses.append(loss)
+        self.dices.append(dice)
+        self.dice = dice
+
+    def final_labels(self):
+        """Label map of the adapted model on the sample's centre patch (the evaluation patch of tta.py:283-338) and the
+        per-class hard Dice against the sample's own label channels."""
+        import torch
+        from dg_tta_amd import ops
+        from dg_tta_amd.tta.torch_utils import dice_coeff, get_batch, get_map_idxs, map_label
+        with torch.inference_mode():
+            self.model.eval()
+            imgs, labels = get_batch(self.data, [0], self.patch, fixed_patch_idx="center", device=self.device)
+            out = self.model(imgs[0])
+            am, _ = ops.argmax_dice(out)
+            gt = map_label(labels[0], get_map_idxs(self.mapping, self.cfg["optimized_labels"], "tta_labels"), "argmaxed").long()
+            per_class = dice_coeff(am, gt, len(self.cfg["optimized_labels"]))
+            self.model.train()
+        return am, per_class
+
+
+class StubRunner:
+    """Test hook (--stub-runner): same interface, an epoch is a sleep; exercises launcher, rendezvous and the line."""
+
+    def __init__(self, args, device, rank, dtype):
+        self.seconds = args.stub_runner * (1.0 + 0.1 * rank)
+        self.losses, self.dices, self.dice, self.model = [], [], 0.0, None
+
+    def epoch(self):
+        time.sleep(self.seconds)
+        self.losses.append(0.0)
+        self.dices.append(0.0)
 
 
 def cpu_baseline(args):
@@ -88,6 +194,7 @@ def cpu_baseline(args):
     BASELINE.md §4 prescribes: ONE warm-up + ONE measured accumulation step (2 branches fwd + loss + bwd) on a
     `cpu_size`^3 patch (default: the full 128^3), scaled by the voxel count if smaller and by (accum + eval forward)
     to one epoch."""
+    import torch
     from oracle import tta as otta, unet as ounet
     n = args.cpu_size
     cores = min(len(os.sched_getaffinity(0)), 16)     # a one-GPU box's CPU share is 16 cores (oversubscribing 256 hurts)
@@ -114,10 +221,11 @@ def cpu_baseline(args):
                       f"x{args.accum + 1 / 6:.2f} (steps per epoch)"}
 
 
-def inference_leg(args, device):
+def inference_leg(args, device, dtype):
     """BASELINE config 3's caller-side step: Gaussian sliding-window inference of ONE ensemble member
     over an `inference_size`^3 volume with 128^3 windows at step 0.5, all 105 classes accumulated in fp32, then argmax.
     Returns ms per window (network forward + accumulate) and the totals."""
+    import torch
     from dg_tta_amd.mind import mind_hook
     from dg_tta_amd.synthetic import he_init_
     from dg_tta_amd.tta.inference import predict_sliding_window_return_logits
@@ -125,7 +233,7 @@ def inference_leg(args, device):
     from dg_tta_amd import ops
     n = args.inference_size
     net = he_init_(HipPlainConvUNet(act_dtype={"fp32": torch.float32, "bf16": torch.bfloat16,
-                                               "fp16": torch.float16}[args.dtype]), seed=7)
+                                               "fp16": torch.float16}[dtype]), seed=7)
     net.register_forward_pre_hook(mind_hook)
     net = net.to(device)
     vol = torch.randn(1, n, n, n, generator=torch.Generator().manual_seed(3)).to(device)
@@ -139,7 +247,7 @@ def inference_leg(args, device):
     dt = time.perf_counter() - t0
     nwin = (max(1, -(-(n - args.size) // (args.size // 2))) + 1) ** 3 if n > args.size else 1
     return {"volume": n, "windows": nwin, "ms_per_window": round(dt / nwin * 1e3, 3), "seconds": round(dt, 3),
-            "accumulator_gib": round(acc.numel() * 4 / 2 ** 30, 2), "classes": int(acc.shape[-1]),
+            "accumulator_gib": round(acc.numel() * 4 / 2 ** 30, 2), "classes": int(acc.shape[-1]), "dtype": dtype,
             "note": "one ensemble member; network forward (4 windows per pass) + Gaussian accumulate + final argmax"}
 
 
@@ -148,12 +256,39 @@ def product_switches():
     from dg_tta_amd.tta.tta import batch_branches_enabled, batched_steps
     return {"DGTTA_BATCH_BRANCHES": int(batch_branches_enabled()), "steps_per_pass": batched_steps(16, 1),
             "exact_zero_bias_grad": True, "accumulate_grads_in_place": True,
-            "env": {k: v for k, v in os.environ.items() if k.startswith("DGTTA_")}}
+            "env": {k: v for k, v in os.environ.items() if k.startswith("DGTTA_") and k != "DGTTA_BENCH_CHILD"}}
+
+
+def kernel_source_sha():
+    """sha256 (16 hex) of the dominant kernel's source: a PMC summary taken from another version of it is stale."""
+    return hashlib.sha256((ROOT / "dg_tta_amd" / "csrc" / "conv_rows.hip").read_bytes()).hexdigest()[:16]
+
+
+def pmc_traffic(args, dtype, nb):
+    """HBM bytes per launch of the dominant kernel from the rocprofv3 PMC passes committed under profiles/ (a counter
+    cannot be read from inside this process).  The summary carries the hash of the kernel source it was measured on; a
+    mismatch (or no summary) reports null with the reason instead of a stale number."""
+    if dtype == "fp32" or args.size != 128:
+        return None, "no PMC pass for this dtype / size"
+    cands = sorted((ROOT / "profiles").glob("r*_pmc_summary.json"), reverse=True)
+    for pmc in cands:
+        d = json.loads(pmc.read_text())
+        ent = d.get("conv_128cube_32to32", {})
+        if "fetch_bytes_corrected_median" not in ent:
+            continue
+        sha = d.get("kernel_source_sha16")
+        if sha != kernel_source_sha():
+            return None, (f"stale: profiles/{pmc.name} was measured on conv_rows.hip {sha or 'of an unrecorded version'}, "
+                          f"the tree holds {kernel_source_sha()}")
+        traffic = (ent["fetch_bytes_corrected_median"] + ent["write_bytes_median"]) * nb
+        return traffic, (f"profiles/{pmc.name} (rocprofv3 --pmc passes of one sample of this layer x samples_per_launch; "
+                         f"same kernel source {sha})")
+    return None, "no PMC summary under profiles/"
 
 
 def roofline_of(probe, args, dtype):
     """Roofline of the dominant kernel from the events recorded around its launches inside the timed region."""
-    if not probe["events"]:
+    if not probe or not probe["events"]:
         return None
     # launches of the probed block: training passes carry 2 branches x k accumulation steps, the eval pass 1 sample
     times = [(s.elapsed_time(e), nb_) for s, e, nb_ in probe["events"]]
@@ -163,15 +298,7 @@ def roofline_of(probe, args, dtype):
     flop = conv_flops(probe["cin"], probe["cout"], probe["vout"]) * nb
     peak = 157.3 if dtype == "fp32" else 2500.0
     ach = flop / (avg_ms * 1e-3) / 1e12
-    traffic, src = None, None       # HBM bytes per launch: rocprofv3 PMC passes committed under profiles/ (not a live counter)
-    for cand in ("r02_pmc_summary.json", "r01_pmc_summary.json"):
-        pmc = ROOT / "profiles" / cand
-        if pmc.exists() and dtype != "fp32" and args.size == 128:
-            d = json.loads(pmc.read_text()).get("conv_128cube_32to32", {})
-            if "fetch_bytes_corrected_median" in d:     # PMC pass = one sample of this layer; scaled by the batch
-                traffic = (d["fetch_bytes_corrected_median"] + d["write_bytes_median"]) * nb
-                src = f"profiles/{cand} (rocprofv3 --pmc passes of one sample of this layer x samples_per_launch)"
-                break
+    traffic, src = pmc_traffic(args, dtype, nb)
     return {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
             "traffic": traffic, "traffic_source": src,
             "kernel": "conv3_mfma_kernel" if dtype == "fp32" else "conv3_rows_kernel",
@@ -181,103 +308,176 @@ def roofline_of(probe, args, dtype):
                      "large layers, so rocprofv3's per-name average is a mix of shapes"}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--size", type=int, default=128)
-    ap.add_argument("--accum", type=int, default=16)
-    ap.add_argument("--copt", type=int, default=16)
-    ap.add_argument("--dtype", default="bf16", choices=["fp32", "bf16", "fp16"],
-                    help="activation storage; accumulation, statistics, loss, gradients of weights and AdamW are fp32")
-    ap.add_argument("--impl", type=int, default=0)
-    ap.add_argument("--cpu-size", type=int, default=128)
-    ap.add_argument("--cpu-warmup", type=int, default=1)
-    ap.add_argument("--no-fp32", action="store_true", help="skip the nested reference-precision (fp32) epoch")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--inference-size", type=int, default=256,
-                    help="edge of the volume for the sliding-window inference leg (BASELINE config 3: 512); 0 = skip")
-    args = ap.parse_args()
-
+# ------------------------------------------------------------------------------------------------ one rank
+def run_rank(args):
+    import numpy as np
+    import torch
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
-    local = int(os.environ.get("LOCAL_RANK", 0))
+    local = 0 if args.share_gpu else int(os.environ.get("LOCAL_RANK", 0))
+    stub = args.stub_runner is not None
+    backend = "gloo" if (stub or args.share_gpu) else args.dist_backend
+    dist = None
     if world > 1:
         import torch.distributed as dist
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
-    device = torch.device(f"cuda:{local}")
-
-    from dg_tta_amd.sharding import max_over_ranks
-    from dg_tta_amd.unet import set_probe
+        if stub:
+            dist.init_process_group("gloo")
+        elif backend == "gloo":
+            torch.cuda.set_device(local)
+            dist.init_process_group("gloo")
+        else:
+            torch.cuda.set_device(local)
+            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
+    device = torch.device("cpu") if stub else torch.device(f"cuda:{local}")
+    coll_device = device if (dist is not None and backend == "nccl") else torch.device("cpu")
 
     def barrier():
+        if not stub:
+            torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        if not stub:
+            torch.cuda.synchronize()
 
-    def timed_run(dtype, steps, warmup):
-        """W untimed + K timed epochs of the product path in `dtype`; returns (seconds max over ranks, runner, roofline)."""
-        args.dtype = dtype
-        torch.manual_seed(1234 + rank)
-        np.random.seed(1234 + rank)
-        runner = EpochRunner(args, device, rank)
+    def over_ranks(seconds):
+        """(max over ranks, list of every rank's seconds)."""
+        if world == 1:
+            return float(seconds), [float(seconds)]
+        t = torch.tensor([float(seconds)], dtype=torch.float64, device=coll_device)
+        allt = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(allt, t)
+        vals = [float(x.item()) for x in allt]
+        return max(vals), vals
+
+    Runner = StubRunner if stub else EpochRunner
+
+    def set_probe_(runner, where):
+        if stub:
+            return None
+        from dg_tta_amd.unet import set_probe
+        return set_probe(runner.model, where)
+
+    def timed_run(dtype, steps, warmup, seed):
+        """W untimed + K timed epochs of the product path in `dtype`; returns (seconds max over ranks, per-rank seconds,
+        runner, roofline)."""
+        torch.manual_seed(seed + rank)
+        np.random.seed(seed + rank)
+        runner = Runner(args, device, rank, dtype)
         for _ in range(warmup):
             runner.epoch()
-        probe = set_probe(("dec", 3, 1))          # the 128^3 32->32 conv block (largest single-shape FLOP share)
+        probe = set_probe_(runner, ("dec", 3, 1))     # the 128^3 32->32 conv block (largest single-shape FLOP share)
         barrier()
         t0 = time.perf_counter()
         for _ in range(steps):
             runner.epoch()
         barrier()
-        dt = max_over_ranks(time.perf_counter() - t0, device)
-        set_probe(None)
-        return dt, runner, roofline_of(probe, args, dtype)
+        dt, per_rank = over_ranks(time.perf_counter() - t0)
+        set_probe_(runner, None)
+        return dt, per_rank, runner, roofline_of(probe, args, dtype)
 
     main_dtype = args.dtype
-    dt, runner, roof = timed_run(main_dtype, args.steps, args.warmup)
+    dt, per_rank, runner, roof = timed_run(main_dtype, args.steps, args.warmup, 1234)
     losses, dice = list(runner.losses), runner.dice
     del runner
-    torch.cuda.empty_cache()
-    other = None
-    if not args.no_fp32 and main_dtype != "fp32":
-        # the reference never autocasts during TTA (SURVEY.md §8a N1): the same epoch with fp32 storage / fp32 MFMA
-        fdt, frunner, froof = timed_run("fp32", 1, 1)
-        other = {"value": round(world / fdt, 5), "value_per_gpu": round(1.0 / fdt, 5), "unit": "TTA-epochs/s", "steps": 1,
-                 "warmup": 1, "ms_per_step": round(fdt * 1e3, 2), "loss_last_epoch": frunner.losses[-1],
-                 "pseudo_dice": frunner.dice, "roofline": froof}
-        del frunner
+    if not stub:
         torch.cuda.empty_cache()
-    args.dtype = main_dtype
+
+    # ---- reference precision (fp32) + Dice delta: same seeds, same draws, same number of epochs, every storage type
+    fp32_leg, dice_delta = None, None
+    if world == 1 and not stub and not args.no_fp32 and args.ab_epochs > 0:
+        legs = {}
+        for dtp in ("fp32", "fp16", "bf16"):
+            torch.manual_seed(4321)
+            np.random.seed(4321)
+            r = EpochRunner(args, device, 0, dtp)
+            probe = set_probe_(r, ("dec", 3, 1)) if dtp == "fp32" else None
+            ep_s = []
+            for _ in range(args.ab_epochs):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                r.epoch()
+                torch.cuda.synchronize()
+                ep_s.append(time.perf_counter() - t0)
+            labels, per_class = r.final_labels()
+            legs[dtp] = dict(losses=list(r.losses), dices=list(r.dices), labels=labels, per_class=per_class, ep_s=ep_s,
+                             roof=roofline_of(probe, args, dtp) if probe is not None else None,
+                             skipped=int(r.opt.skipped_steps), scale=float(r.opt.grad_scale))
+            set_probe_(r, None)
+            del r
+            torch.cuda.empty_cache()
+        ref = legs["fp32"]
+        timed = ref["ep_s"][1:] if len(ref["ep_s"]) > 1 else ref["ep_s"]
+        fdt = sum(timed) / len(timed)
+        fp32_leg = {"value": round(1.0 / fdt, 5), "value_per_gpu": round(1.0 / fdt, 5), "unit": "TTA-epochs/s",
+                    "steps": len(timed), "warmup": len(ref["ep_s"]) - len(timed), "ms_per_step": round(fdt * 1e3, 2),
+                    "ms_per_step_each": [round(t * 1e3, 1) for t in timed], "loss_last_epoch": ref["losses"][-1],
+                    "pseudo_dice": ref["dices"][-1], "roofline": ref["roof"]}
+        dice_delta = {"reference": f"fp32 storage / fp32 MFMA kernels of this engine, same seeds and draws, "
+                                   f"{args.ab_epochs} adaptation epochs (AdamW steps) from the same weights",
+                      "tolerance": DICE_TOLERANCE}
+        for dtp in ("fp16", "bf16"):
+            leg = legs[dtp]
+            dl = [abs(a - b) for a, b in zip(leg["losses"], ref["losses"])]
+            dd = [abs(a - b) for a, b in zip(leg["dices"], ref["dices"])]
+            pc = (leg["per_class"] - ref["per_class"]).abs()
+            pc = pc[~torch.isnan(pc)]
+            agree = float((leg["labels"] == ref["labels"]).float().mean())
+            ent = {"loss": max(dl), "loss_per_epoch": [round(x, 6) for x in dl],
+                   "pseudo_dice": max(dd), "pseudo_dice_per_epoch": [round(x, 6) for x in dd],
+                   "hard_dice_per_class_max": float(pc.max()) if pc.numel() else None,
+                   "hard_dice_mean": abs(float(leg["per_class"].nanmean()) - float(ref["per_class"].nanmean())),
+                   "label_agreement": round(agree, 6), "ms_per_step": round(sum(leg["ep_s"][1:]) / max(1, len(leg["ep_s"]) - 1) * 1e3, 2),
+                   "skipped_optimizer_steps": leg["skipped"], "loss_scale": leg["scale"]}
+            ent["within_tolerance"] = bool(ent["loss"] <= DICE_TOLERANCE and ent["pseudo_dice"] <= DICE_TOLERANCE
+                                           and ent["hard_dice_mean"] <= DICE_TOLERANCE)
+            dice_delta[dtp] = ent
+        main = dice_delta.get(main_dtype)
+        if main is not None:            # the headline dtype's numbers at the top level of the object
+            dice_delta.update(loss=main["loss"], pseudo_dice=main["pseudo_dice"], label_agreement=main["label_agreement"],
+                              dtype=main_dtype, within_tolerance=main["within_tolerance"])
+        del legs
 
     if rank == 0:
         ms = dt / args.steps * 1e3
         value = world * args.steps / dt
-        out = {"metric": "TTA-epochs/sec per GPU on 128^3 patch", "value": round(value, 5), "unit": "TTA-epochs/s",
-               "value_per_gpu": round(args.steps / dt, 5),
+        out = {"metric": "TTA-epochs/sec per GPU on 128^3 patch; Dice delta vs reference", "value": round(value, 5),
+               "unit": "TTA-epochs/s", "value_per_gpu": round(args.steps / dt, 5),
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 2),
-               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": main_dtype,
                "data": "synthetic",
                "config": {"workload": f"tta_epoch: {args.size}^3 patch from a {args.size + 32}^3 volume, "
                                       f"{args.accum} accumulation steps, GIN+affine in both branches, MIND 12ch, "
                                       f"nnUNet 3d_fullres 105 classes, C_opt={args.copt}, AdamW, 1 eval patch",
                           "patch": args.size, "accum": args.accum, "c_opt": args.copt,
-                          "parallelism": f"{world} independent TTA instance(s), sample-sharded",
+                          "parallelism": f"{world} independent TTA instance(s), sample-sharded, no data-path collective",
                           "value_is": "whole-job aggregate over all GPUs (value_per_gpu = one instance)",
-                          "product_switches": product_switches()},
+                          "launcher": ("bench.py --gpus N (own child processes)" if os.environ.get("DGTTA_BENCH_CHILD")
+                                       else ("torch.distributed.run" if world > 1 else "single process")),
+                          "product_switches": None if stub else product_switches()},
+               "per_rank_epochs_per_s": [round(args.steps / t, 5) for t in per_rank],
                "loss_last_epoch": losses[-1], "pseudo_dice": dice,
                "epoch_tflop": round(96.89 * (args.size / 128) ** 3 * (args.accum * 6 + 1) / 97.0, 2),
                "roofline": roof}
-        if other is not None:
-            out["fp32"] = other
-        if args.inference_size > 0 and world == 1:
-            out["inference"] = inference_leg(args, device)
-        if not args.no_cpu_baseline and world == 1:
+        if dice_delta is not None:
+            out["dice_delta"] = dice_delta
+        if fp32_leg is not None:
+            out["fp32"] = fp32_leg
+        if args.inference_size > 0 and world == 1 and not stub:
+            out["inference"] = inference_leg(args, device, main_dtype)
+        if not args.no_cpu_baseline and world == 1 and not stub:
             out["cpu_baseline"] = cpu_baseline(args)
         print(json.dumps(out), flush=True)
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    args = parse_args(argv)
+    if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(args, argv))
+    run_rank(args)
 
 
 if __name__ == "__main__":

@@ -29,7 +29,8 @@ SIGNATURES = {
     "dgtta_softdice_probs_fwd": (I, [P, P, P, P, SZ, I, I, I64, I64, I64, I64, P]),
     "dgtta_softdice_probs_bwd": (I, [P, P, P, P, P, P, I, I, I64, I64, I64, I64, P]),
     "dgtta_adamw_step": (I, [C.POINTER(P), C.POINTER(P), C.POINTER(P), C.POINTER(P), C.POINTER(I64), I, F, F, F, F, F,
-                             I, F, P]),
+                             I, F, P, P]),
+    "dgtta_grads_nonfinite": (I, [C.POINTER(P), C.POINTER(I64), I, P, P]),
     "dgtta_conv3d_packed_bytes": (SZ, [I, I, I]),
     "dgtta_conv3d_pack_weights": (I, [P, P, I, I, I, I, I, P]),
     "dgtta_conv3d_stats_bytes": (SZ, [I, I, I, I, I]),
@@ -53,6 +54,8 @@ SIGNATURES = {
     "dgtta_resample_axis_ws_bytes": (SZ, [I64, I, I64, I]),
     "dgtta_resample_axis": (I, [P, P, P, SZ, I64, I, I, I64, I, P]),
     "dgtta_window_accumulate": (I, [P, P, P, P, I, I, I, I, I, I, I, I, I, I, P]),
+    "dgtta_logits_chunk_f64": (I, [P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, P]),
+    "dgtta_argmax_merge_f64": (I, [P, I64, I, I, P, P, I, P]),
 }
 
 _lib = None

@@ -11,7 +11,7 @@ void dgtta_set_error(const char *fmt, ...) {
   va_end(ap);
 }
 
-extern "C" int dgtta_version(void) { return 20000; /* 2.0.0: round-2 signatures of mind3d_fwd / adamw_step */ }
+extern "C" int dgtta_version(void) { return 30000; /* 3.0.0: adamw_step(skip_if_nonzero), grads_nonfinite, export kernels */ }
 extern "C" const char *dgtta_last_error(void) { return g_err; }
 
 // ---------------------------------------------------------------- environment switches (snapshot, see common.h)

@@ -98,7 +98,64 @@ __global__ void resample_axis_kernel(const double *__restrict__ src, double *__r
   }
 }
 
+// ---- export of a prediction in the case's original geometry (nnU-Net's
+// convert_predicted_logits_to_segmentation_with_correct_shape, reached from dg_tta/tta/nnunet_utils.py:208-230): the
+// accumulated window logits are normalised, resampled class group by class group (the passes above) and reduced to a label
+// map by a running argmax, so that the 105-class volume never exists twice.
+__global__ void logits_chunk_kernel(const float *__restrict__ acc, const float *__restrict__ nsum, double *__restrict__ dst,
+                                    int C, int Y, int Z, int x0, int y0, int z0, int ys, int zs, int c0, int cg,
+                                    int64_t total) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int j = (int)(i % cg);
+  const int64_t v = i / cg;
+  const int z = (int)(v % zs), y = (int)((v / zs) % ys);
+  const int64_t x = v / ((int64_t)zs * ys);
+  const int64_t sv = ((x + x0) * Y + (y + y0)) * Z + (z + z0);
+  dst[i] = (double)(acc[sv * C + c0 + j] / nsum[sv]);
+}
+
+__global__ void argmax_merge_kernel(const double *__restrict__ vals, int64_t V, int cg, int c0, double *__restrict__ best_val,
+                                    int *__restrict__ best_idx, int first) {
+  const int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= V) return;
+  double bv = first ? vals[v * cg] : best_val[v];
+  int bi = first ? c0 : best_idx[v];
+  for (int j = first ? 1 : 0; j < cg; ++j) {
+    const double x = vals[v * cg + j];
+    if (x > bv) {            // strict: the first maximum wins, as argmax does
+      bv = x;
+      bi = c0 + j;
+    }
+  }
+  best_val[v] = bv;
+  best_idx[v] = bi;
+}
+
 }  // namespace
+
+extern "C" int dgtta_logits_chunk_f64(const float *acc, const float *nsum, double *dst, int C, int X, int Y, int Z, int x0,
+                                      int y0, int z0, int xs, int ys, int zs, int c0, int cg, void *stream) {
+  DG_REQUIRE(acc && nsum && dst, DGTTA_ERR_BADARG, "logits_chunk: null pointer");
+  DG_REQUIRE(C > 0 && cg > 0 && c0 >= 0 && c0 + cg <= C, DGTTA_ERR_BADARG, "logits_chunk: class range outside [0,%d)", C);
+  DG_REQUIRE(x0 >= 0 && y0 >= 0 && z0 >= 0 && xs > 0 && ys > 0 && zs > 0 && x0 + xs <= X && y0 + ys <= Y && z0 + zs <= Z,
+             DGTTA_ERR_BADARG, "logits_chunk: crop outside the volume");
+  const int64_t total = (int64_t)xs * ys * zs * cg;
+  hipLaunchKernelGGL(logits_chunk_kernel, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, (hipStream_t)stream, acc, nsum,
+                     dst, C, Y, Z, x0, y0, z0, ys, zs, c0, cg, total);
+  DG_CHECK_LAUNCH("logits_chunk_kernel");
+  return DGTTA_OK;
+}
+
+extern "C" int dgtta_argmax_merge_f64(const double *vals, int64_t V, int cg, int c0, double *best_val, int *best_idx,
+                                      int first, void *stream) {
+  DG_REQUIRE(vals && best_val && best_idx, DGTTA_ERR_BADARG, "argmax_merge: null pointer");
+  DG_REQUIRE(V > 0 && cg > 0 && c0 >= 0, DGTTA_ERR_BADARG, "argmax_merge: bad dims");
+  hipLaunchKernelGGL(argmax_merge_kernel, dim3((unsigned)cdiv64(V, 256)), dim3(256), 0, (hipStream_t)stream, vals, V, cg, c0,
+                     best_val, best_idx, first);
+  DG_CHECK_LAUNCH("argmax_merge_kernel");
+  return DGTTA_OK;
+}
 
 extern "C" size_t dgtta_resample_axis_ws_bytes(int64_t outer, int n, int64_t inner, int order) {
   return order == 3 ? (size_t)outer * (size_t)inner * (size_t)(n + 2 * NPAD) * sizeof(double) : 256;

@@ -6,19 +6,20 @@ re-normalisation run in the fused HIP kernels of csrc/gin.hip."""
 import torch
 
 from . import ops
-from .utils import get_internal_augmentation_enabled, upload_async
+from .utils import cpu_generator, device_generator, get_internal_augmentation_enabled, upload_async
 
 N_LAYER, INTERM_CHANNELS, SCALE_POOL = 4, 2, (1, 3)
 
 
 def draw_gin_params(nb, device):
-    alpha = torch.rand(nb, device=device)
+    alpha = torch.rand(nb, device=device, generator=device_generator())
+    g = cpu_generator()
     chans = [1] + [INTERM_CHANNELS] * (N_LAYER - 1) + [1]
     ks, kers, shifts = [], [], []
     for cin, cout in zip(chans[:-1], chans[1:]):
-        k = SCALE_POOL[int(torch.randint(high=len(SCALE_POOL), size=(1,))[0])]
-        kers.append(torch.randn([cout * nb, cin, k, k, k]))
-        shifts.append(torch.randn([cout * nb, 1, 1, 1]) * 1.0)
+        k = SCALE_POOL[int(torch.randint(high=len(SCALE_POOL), size=(1,), generator=g)[0])]
+        kers.append(torch.randn([cout * nb, cin, k, k, k], generator=g))
+        shifts.append(torch.randn([cout * nb, 1, 1, 1], generator=g) * 1.0)
         ks.append(k)
     up = upload_async(kers + shifts, device)          # one non-blocking copy for the whole chain
     return alpha, ks, up[:len(kers)], up[len(kers):]

@@ -4,6 +4,8 @@ kernels of csrc/mind3d.hip.  The Gaussian noise of mind.py:150 is drawn with tor
 import torch
 
 from . import ops
+from ._state import state_of
+from .utils import device_generator
 
 
 class MIND3D(torch.nn.Module):
@@ -20,7 +22,7 @@ class MIND3D(torch.nn.Module):
         ([B,D,H,W,16], channels 12..15 zero), i.e. exactly what HipPlainConvUNet's first conv reads."""
         b, _, d, h, w = img.shape
         if noise is None:
-            noise = torch.randn((b, 12, d, h, w), dtype=torch.float32, device=img.device)
+            noise = torch.randn((b, 12, d, h, w), dtype=torch.float32, device=img.device, generator=device_generator())
         buf = ops.mind3d(img, noise, self.randn_weighting, out_format="ndhwc", out_ldc=16, out_dtype=out_dtype, groups=groups,
                          delta=self.delta, sigma=self.sigma)
         return buf[..., :12].permute(0, 4, 1, 2, 3)
@@ -28,64 +30,66 @@ class MIND3D(torch.nn.Module):
 
 # Noise tensors drawn ahead of time by the batched two-branch path (tta.calc_both_branches): the reference draws a
 # branch's MIND noise inside that branch's forward pass, i.e. BEFORE the other branch's GIN draws; pre-drawing keeps
-# that order on the device generator when both branches run as one batch.
-_PENDING_NOISE = []
-
-
+# that order on the device generator when both branches run as one batch.  The hand-over is per MODEL (_state.py): two
+# TTA instances in one process never take each other's noise or descriptor.
 def draw_noise_(slot):
     """mind.py:150's torch.randn draw for one branch, written in place into its slot of the batched noise tensor (device
     generator, as the reference).  A function of its own so that parity tests can route it through the CPU generator."""
-    return slot.normal_()
+    return slot.normal_(generator=device_generator())
 
 
-def push_noise(noise, groups=1):
-    _PENDING_NOISE.append((noise, groups))
+def hook_owner(model):
+    """The module mind_hook is registered on (the model itself in every supported configuration)."""
+    for m in model.modules():
+        if any(h is mind_hook for h in m._forward_pre_hooks.values()):
+            return m
+    return model
 
 
-_PENDING_FEATURES = []
+def push_noise(model, noise, groups=1):
+    state_of(hook_owner(model)).noise.append((noise, groups))
 
 
-def push_features(feat):
+def push_features(model, feat):
     """Descriptor computed ahead of the network pass (tta.prepare_both_branches, on a side stream): the next mind_hook call
-    on an input of the same batch / spatial shape returns it instead of computing MIND again."""
-    _PENDING_FEATURES.append(feat)
+    of THIS model on an input of the same batch / spatial shape returns it instead of computing MIND again."""
+    state_of(hook_owner(model)).features.append(feat)
 
 
-def clear_noise():
-    _PENDING_NOISE.clear()
-    _PENDING_FEATURES.clear()
+def clear_noise(model):
+    st = state_of(hook_owner(model))
+    st.noise.clear()
+    st.features.clear()
 
 
 def uses_mind_hook(model):
     return any(h is mind_hook for m in model.modules() for h in m._forward_pre_hooks.values())
 
 
-_FORCED_GROUPS = [None]
-
-
 class mind_groups:
-    """Context: mind_hook treats the batch as `groups` independent calls (one variance-clamp mean per group)."""
+    """Context: `model`'s mind_hook treats the batch as `groups` independent calls (one variance-clamp mean per group)."""
 
-    def __init__(self, groups):
-        self.groups = groups
+    def __init__(self, model, groups):
+        self.state, self.groups = state_of(hook_owner(model)), groups
 
     def __enter__(self):
-        self.prev, _FORCED_GROUPS[0] = _FORCED_GROUPS[0], self.groups
+        self.prev, self.state.forced_groups = self.state.forced_groups, self.groups
 
     def __exit__(self, *exc):
-        _FORCED_GROUPS[0] = self.prev
+        self.state.forced_groups = self.prev
 
 
 def mind_hook(module, input):
-    if _PENDING_FEATURES:
-        cand = _PENDING_FEATURES[0]
+    st = state_of(module)
+    if st.features:
+        cand = st.features[0]
         if cand.shape[0] == input[0].shape[0] and tuple(cand.shape[2:]) == tuple(input[0].shape[2:]):
-            return _PENDING_FEATURES.pop(0)
+            return st.features.pop(0)
     noise, groups = None, 1
-    if _PENDING_NOISE:
-        cand = _PENDING_NOISE[0][0]
+    if st.noise:
+        cand = st.noise[0][0]
         if cand.shape[0] == input[0].shape[0] and tuple(cand.shape[2:]) == tuple(input[0].shape[2:]):
-            noise, groups = _PENDING_NOISE.pop(0)
-    if _FORCED_GROUPS[0] is not None and noise is None and input[0].shape[0] % _FORCED_GROUPS[0] == 0:
-        groups = _FORCED_GROUPS[0]
+            noise, groups = st.noise.pop(0)
+    if st.forced_groups is not None and noise is None and input[0].shape[0] % st.forced_groups == 0:
+        groups = st.forced_groups
     return MIND3D().forward(*input, noise=noise, out_dtype=getattr(module, "act_dtype", torch.float32), groups=groups)

@@ -295,7 +295,8 @@ def soft_dice(smp_a, smp_b):
 
 # ------------------------------------------------------------------------------------------------ AdamW
 def adamw_step(params, grads, exp_avgs, exp_avg_sqs, step, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01,
-               grad_scale=1.0):
+               grad_scale=1.0, skip_flag=None):
+    """One multi-tensor AdamW step; skipped on the device when skip_flag (int32 device scalar) is non-zero."""
     lib = _lib.load()
     n = len(params)
     if n == 0:
@@ -308,8 +309,21 @@ def adamw_step(params, grads, exp_avgs, exp_avg_sqs, step, lr, betas=(0.9, 0.999
     hv = P(*[v.data_ptr() for v in exp_avg_sqs])
     hn = (C.c_int64 * n)(*[p.numel() for p in params])
     check(lib.dgtta_adamw_step(hp, hg, hm, hv, hn, n, float(lr), float(betas[0]), float(betas[1]), float(eps),
-                               float(weight_decay), int(step), float(grad_scale), stream_of(params[0].device)),
-          "dgtta_adamw_step")
+                               float(weight_decay), int(step), float(grad_scale), ptr(skip_flag),
+                               stream_of(params[0].device)), "dgtta_adamw_step")
+
+
+def grads_nonfinite(grads, flag):
+    """Sets flag (int32 device scalar, zeroed by the caller) when any element of `grads` is inf / NaN."""
+    lib = _lib.load()
+    grads = [g for g in grads if g is not None]
+    if not grads:
+        return
+    require_cuda(*grads)
+    n = len(grads)
+    hg = (C.c_void_p * n)(*[g.data_ptr() for g in grads])
+    hn = (C.c_int64 * n)(*[g.numel() for g in grads])
+    check(lib.dgtta_grads_nonfinite(hg, hn, n, ptr(flag), stream_of(grads[0].device)), "dgtta_grads_nonfinite")
 
 
 # ------------------------------------------------------------------------------------------------ eval helpers

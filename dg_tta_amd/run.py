@@ -19,6 +19,8 @@ from .tta.torch_utils import generate_label_mapping
 from .tta.config_log_utils import (check_dataset_pretrain_config, get_tta_folders, load_current_modifier_functions,
                                    prepare_tta as _prepare_tta)
 
+DEFAULT_DTYPE = "fp16"      # activation storage of `run_tta` and bench.py (tests/test_gpu_at_size.py holds it to 1e-3 of fp32)
+
 _ADJ = ("brisk", "calm", "eager", "fuzzy", "keen", "lucid", "mellow", "nimble", "quiet", "rapid", "solid", "vivid")
 _NOUN = ("atlas", "beacon", "cortex", "delta", "ember", "fjord", "gamma", "harbor", "isthmus", "kernel", "lattice", "voxel")
 
@@ -95,16 +97,22 @@ class DGTTAProgram:
         _add_common(parser)
         parser.add_argument("--device", help="Device to be used", default="cuda")
         parser.add_argument("--gpus", type=int, default=1, help="one TTA process per GPU, samples sharded round-robin")
-        parser.add_argument("--dtype", choices=["fp32", "bf16", "fp16"], default="fp32",
-                            help="activation storage: fp32 = the reference's precision; bf16 / fp16 = MFMA-rate 16-bit "
-                                 "storage with fp32 accumulation (fp16 with a static loss scale)")
-        parser.add_argument("--run_name", default=None, help=argparse.SUPPRESS)
+        parser.add_argument("--dtype", choices=["fp32", "bf16", "fp16"], default=DEFAULT_DTYPE,
+                            help="activation storage: fp32 = the reference's precision; fp16 / bf16 = MFMA-rate 16-bit "
+                                 "storage with fp32 accumulation (fp16 with a guarded loss scale; it holds the reference's "
+                                 "Dice to 1e-3 at 5x the fp32 rate and is the default, bf16 does not)")
+        parser.add_argument("--run_name", default=None,
+                            help="name of the run directory (default: timestamp + random name).  Required, and the same on "
+                                 "every rank, when RANK / WORLD_SIZE are set by an external launcher")
         args = parser.parse_args(self.argv[2:])
         ds, trainer, cfg, fold = check_dataset_pretrain_config(args.pretrained_dataset_id, args.pretrainer,
                                                                args.pretrainer_config, args.pretrainer_fold)
         tta_data_dir, plan_dir, results_dir, pre_name, tta_name = get_tta_folders(ds, int(args.tta_dataset_id), trainer,
                                                                                   cfg, fold)
         run_name = args.run_name
+        if run_name is None and int(os.environ.get("WORLD_SIZE", 1)) > 1:
+            # every rank would invent its own timestamp + random name and then wait for the others in a directory of its own
+            raise SystemExit("run_tta: WORLD_SIZE > 1 needs --run_name (the same on every rank); `--gpus N` sets it itself")
         if run_name is None:
             now_str = datetime.now().strftime("%Y%m%d__%H_%M_%S")
             results_dir.mkdir(exist_ok=True, parents=True)
@@ -117,10 +125,11 @@ class DGTTAProgram:
             # fan out: one independent process per GPU, pinned with HIP_VISIBLE_DEVICES, same run directory
             (results_dir / run_name).mkdir(exist_ok=True, parents=True)
             from .sharding import child_devices
-            procs = []
+            import uuid
+            procs, launch = [], uuid.uuid4().hex
             for r, dev_id in enumerate(child_devices(args.gpus)):
                 env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(args.gpus), HIP_VISIBLE_DEVICES=dev_id,
-                           DGTTA_SUMMARY_BY_PARENT="1")
+                           DGTTA_SUMMARY_BY_PARENT="1", DGTTA_LAUNCH_ID=launch)
                 env.pop("CUDA_VISIBLE_DEVICES", None)
                 cmd = [sys.executable, "-m", "dg_tta_amd.run"] + self.argv[1:] + ["--run_name", run_name]
                 procs.append(subprocess.Popen(cmd, env=env))

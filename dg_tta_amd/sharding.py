@@ -29,17 +29,23 @@ def units_for_rank(num_samples, ensemble_count, rank, world):
             if unit_owner(s, e, num_samples, ensemble_count, world) == rank]
 
 
-def wait_for_files(paths, timeout_s=24 * 3600.0, poll_s=0.5):
+def wait_for_files(paths, timeout_s=6 * 3600.0, poll_s=0.5, abort_if=()):
     """Filesystem barrier (the mechanism the reference's resume logic already relies on, tta.py:164-170): blocks until
-    every path exists; raises TimeoutError naming the missing files.  Writers rename complete files into place."""
+    every path exists; raises TimeoutError naming the missing files, or RuntimeError as soon as one of the `abort_if`
+    paths (the peers' failure markers) appears.  Writers rename complete files into place."""
     import time
     from pathlib import Path
     paths = [Path(p) for p in paths]
+    abort_if = [Path(p) for p in abort_if]
     t0 = time.monotonic()
     while True:
         missing = [p for p in paths if not p.is_file()]
         if not missing:
             return
+        dead = [p for p in abort_if if p.is_file()]
+        if dead:
+            raise RuntimeError(f"filesystem barrier: a peer rank failed ({[p.name for p in dead]}); still missing "
+                               f"{[str(p) for p in missing]}")
         if time.monotonic() - t0 > timeout_s:
             raise TimeoutError(f"filesystem barrier: still missing after {timeout_s:.0f} s: {[str(p) for p in missing]}")
         time.sleep(poll_s)
@@ -50,8 +56,39 @@ def done_marker(save_path, rank):
     return Path(save_path) / f".rank_{rank}.done"
 
 
+def failed_marker(save_path, rank):
+    from pathlib import Path
+    return Path(save_path) / f".rank_{rank}.failed"
+
+
+def launch_id():
+    """Identifies ONE launch of a multi-rank run: set by `dgtta run_tta --gpus N` for its children (DGTTA_LAUNCH_ID) and by
+    torch.distributed.run (TORCHELASTIC_RUN_ID); empty otherwise.  Written into the done markers, so that a resumed run in
+    the same directory does not pass the barrier on a previous launch's markers."""
+    return os.environ.get("DGTTA_LAUNCH_ID") or os.environ.get("TORCHELASTIC_RUN_ID") or ""
+
+
 def mark_rank_done(save_path, rank):
-    done_marker(save_path, rank).write_text("done\n")
+    m = done_marker(save_path, rank)
+    tmp = m.with_name(m.name + ".tmp")
+    tmp.write_text(f"done {launch_id()}\n")
+    tmp.replace(m)
+
+
+def wait_for_done_markers(save_path, world, timeout_s, poll_s=0.5):
+    """Barrier of the summary: every rank's marker exists AND belongs to this launch."""
+    import time
+    want = f"done {launch_id()}\n"
+    t0 = time.monotonic()
+    while True:
+        wait_for_files([done_marker(save_path, r) for r in range(world)], max(timeout_s - (time.monotonic() - t0), 0.0),
+                       poll_s, abort_if=[failed_marker(save_path, r) for r in range(world)])
+        stale = [r for r in range(world) if done_marker(save_path, r).read_text() != want]
+        if not stale:
+            return
+        if time.monotonic() - t0 > timeout_s:
+            raise TimeoutError(f"filesystem barrier: ranks {stale} only left markers of an earlier launch in {save_path}")
+        time.sleep(poll_s)
 
 
 def summary_by_parent():

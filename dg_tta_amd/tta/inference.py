@@ -8,7 +8,7 @@ The window logic is a restatement of nnunetv2==2.2.1 (`compute_gaussian`, `compu
 `predict_sliding_window_return_logits`) from its published behaviour: that package is not vendored with the reference, so
 this stage is "parity unpinned" (checked against the CPU restatement in oracle/inference.py only).  Accumulators are
 fp32 and live in HBM for the whole volume (105 classes x 512^3 = 56 GB fits the 288 GB of an MI355X), where nnU-Net
-uses fp16; resampling back to the original spacing / NIfTI export stay with nnU-Net.
+uses fp16.  `export_segmentation` takes the logits back to the case's original geometry.
 """
 import numpy as np
 import torch
@@ -96,7 +96,7 @@ def predict_sliding_window_return_logits(model, data, patch_size, acc=None, tile
                             for sx, sy, sz in group]).contiguous()
         # MIND's variance clamp uses the mean over the whole CALL's batch (mind.py:159-161) and nnU-Net predicts one
         # window per call: the batched pass keeps per-window statistics (groups = windows in the batch)
-        with mind_groups(len(group)):
+        with mind_groups(model, len(group)):
             out = model(work)
         if isinstance(out, tuple):
             out = out[0]
@@ -112,11 +112,11 @@ def predict_sliding_window_return_logits(model, data, patch_size, acc=None, tile
 
 
 @torch.no_grad()
-def run_inference(data, model, parameter_sets, patch_size, label_mapping=None, optimized_labels=None):
-    """Ensemble prediction of one preprocessed case: data [C,X,Y,Z] (image channel(s) only).
-    parameter_sets: list of state dicts (the `*_tta_parameters.pt` contents).  Returns the label map [X,Y,Z] (int64, CPU),
-    mapped to the target ids when label_mapping/optimized_labels are given (tta.py:407-411)."""
-    from .torch_utils import get_map_idxs
+def predict_ensemble_logits(data, model, parameter_sets, patch_size):
+    """Window-accumulated logits of the whole ensemble for one preprocessed case: data [C,X,Y,Z] (image channel(s) only),
+    parameter_sets: list of state dicts (the `*_tta_parameters.pt` contents).  Returns (acc [X,Y,Z,ncls] fp32 on the GPU =
+    sum over members and windows of gauss * logits, nsum [X,Y,Z], crop): the ensemble-mean logits nnU-Net's predictor hands
+    on are acc / nsum / len(parameter_sets) inside `crop`."""
     if hasattr(model, "set_selected_classes"):
         model.set_selected_classes(None)          # argmax runs over ALL pretrain classes, as in the reference
     acc, nsum, crop = None, None, None
@@ -124,9 +124,94 @@ def run_inference(data, model, parameter_sets, patch_size, label_mapping=None, o
     for params in parameter_sets:
         model.load_state_dict(params)
         acc, nsum, crop = predict_sliding_window_return_logits(model, data, patch_size, acc)
-    # sum over members of (acc_m / nsum) has the argmax of sum_m acc_m (nsum > 0 is shared): no division pass needed
-    seg, _ = ops.argmax_dice(acc.permute(3, 0, 1, 2)[None])
-    seg = seg[0][tuple(crop)].cpu()
+    return acc, nsum, crop
+
+
+@torch.no_grad()
+def run_inference(data, model, parameter_sets, patch_size, label_mapping=None, optimized_labels=None):
+    """Ensemble prediction of one preprocessed case in the PREPROCESSED geometry.  Returns the label map [X,Y,Z] (int64,
+    CPU), mapped to the target ids when label_mapping/optimized_labels are given (tta.py:407-411)."""
+    from .torch_utils import get_map_idxs
+    acc, nsum, crop = predict_ensemble_logits(data, model, parameter_sets, patch_size)
+    seg = torch.as_tensor(export_segmentation(acc, nsum, crop, None, None, None).astype(np.int64))
     if label_mapping is not None:
         seg = map_label(seg[None], get_map_idxs(label_mapping, optimized_labels, "pretrain_labels"), "argmaxed")[0]
     return seg
+
+
+EXPORT_CLASS_GROUP = 8
+
+
+def _resolved_configuration(plans, configuration):
+    conf = plans["configurations"][configuration]
+    while "inherits_from" in conf:
+        parent = dict(plans["configurations"][conf["inherits_from"]])
+        parent.update({k: v for k, v in conf.items() if k != "inherits_from"})
+        conf = parent
+    return conf
+
+
+@torch.no_grad()
+def export_segmentation(acc, nsum, crop, properties, plans, configuration):
+    """Label map (pretrain class ids, numpy) of accumulated ensemble logits.
+
+    properties None: argmax in the preprocessed geometry (sum over members of acc_m / nsum has the argmax of sum_m acc_m,
+    nsum > 0 being shared: no division pass).  Otherwise nnU-Net's
+    convert_predicted_logits_to_segmentation_with_correct_shape [3P nnunetv2==2.2.1, reached from
+    dg_tta/tta/nnunet_utils.py:208-230]: the normalised logits are resampled to
+    properties['shape_after_cropping_and_before_resampling'] with the plans' probability resampler (linear; nearest along
+    a strongly anisotropic axis), argmax'd (softmax is monotone), pasted into a zero volume of 'shape_before_cropping' at
+    'bbox_used_for_cropping' and transposed back with the plans' transpose_backward.  The resampling runs on the GPU class
+    group by class group with a running argmax, so the full-resolution 105-class volume never exists."""
+    from .preprocessing import separate_z
+    lib = _lib.load()
+    dev = acc.device
+    X, Y, Z, C = acc.shape
+    st = stream_of(dev)
+    cs = [(sl.start or 0, (sl.stop if sl.stop is not None else dim) - (sl.start or 0)) for sl, dim in zip(crop, (X, Y, Z))]
+    (x0, xs), (y0, ys), (z0, zs) = cs
+    cur_shape = [xs, ys, zs]
+    if properties is None:
+        seg, _ = ops.argmax_dice(acc.permute(3, 0, 1, 2)[None])
+        return seg[0][tuple(crop)].cpu().numpy()
+    tgt_shape = [int(v) for v in properties["shape_after_cropping_and_before_resampling"]]
+    if tgt_shape == cur_shape:
+        seg, _ = ops.argmax_dice(acc.permute(3, 0, 1, 2)[None])
+        seg = seg[0][tuple(crop)].cpu().numpy()
+    else:
+        conf = _resolved_configuration(plans, configuration)
+        cur_spacing = list(conf["spacing"])
+        if len(cur_spacing) < 3:
+            cur_spacing = [properties["spacing"][0]] + cur_spacing
+        kw = conf.get("resampling_fn_probabilities_kwargs", {"order": 1, "order_z": 0})
+        order, order_z = int(kw.get("order", 1)), int(kw.get("order_z", 0))
+        if order not in (0, 1) or order_z != 0:
+            raise NotImplementedError("probability resampling is built for order 0 / 1 and order_z 0 (nnU-Net's defaults)")
+        do_sep, axis = separate_z(cur_spacing, properties["spacing"])
+        vout = tgt_shape[0] * tgt_shape[1] * tgt_shape[2]
+        best_val = torch.empty(vout, dtype=torch.float64, device=dev)
+        best_idx = torch.empty(vout, dtype=torch.int32, device=dev)
+        for c0 in range(0, C, EXPORT_CLASS_GROUP):
+            cg = min(EXPORT_CLASS_GROUP, C - c0)
+            cur = torch.empty((xs, ys, zs, cg), dtype=torch.float64, device=dev)
+            check(lib.dgtta_logits_chunk_f64(ptr(acc), ptr(nsum), ptr(cur), C, X, Y, Z, x0, y0, z0, xs, ys, zs, c0, cg, st),
+                  "dgtta_logits_chunk_f64")
+            for ax in range(3):          # channels-last: the class group rides in `inner` of every pass
+                n, m = cur.shape[ax], tgt_shape[ax]
+                if n == m:
+                    continue
+                shp = list(cur.shape[:3])
+                outer = int(np.prod(shp[:ax], dtype=np.int64))
+                inner = int(np.prod(shp[ax + 1:], dtype=np.int64)) * cg
+                dst = torch.empty((*shp[:ax], m, *shp[ax + 1:], cg), dtype=torch.float64, device=dev)
+                o = 0 if (do_sep and ax == axis) else order      # nearest slices along the low-resolution axis
+                check(lib.dgtta_resample_axis(ptr(cur), ptr(dst), None, 0, outer, n, m, inner, o, st), "dgtta_resample_axis")
+                cur = dst
+            check(lib.dgtta_argmax_merge_f64(ptr(cur), vout, cg, c0, ptr(best_val), ptr(best_idx), int(c0 == 0), st),
+                  "dgtta_argmax_merge_f64")
+        seg = best_idx.reshape(tgt_shape).cpu().numpy()
+    full = np.zeros(tuple(int(v) for v in properties["shape_before_cropping"]),
+                    dtype=np.uint8 if C - 1 < 255 else np.uint16)
+    sl = tuple(slice(int(a), int(b)) for a, b in properties["bbox_used_for_cropping"])
+    full[sl] = seg
+    return np.ascontiguousarray(full.transpose(plans["transpose_backward"]))

@@ -134,26 +134,36 @@ def preprocess_fromfile(image_file, label_file, ofile, predictor=None):
     return {"data": data.contiguous().float(), "data_properties": {"shape": tuple(img.shape[1:])}, "ofile": ofile}
 
 
-def get_data_iterator(tta_data_filepaths, dataset_raw_path, bucket, predictor=None):
+def get_data_iterator(tta_data_filepaths, dataset_raw_path, bucket, predictor=None, wanted=None, first_index=0,
+                      total=None):
+    """Lazy iterator over the bucket's cases.  wanted(global_index, total) -> bool: cases it rejects are NOT read or
+    preprocessed; a stub {"ofile", "skipped": True} takes their place so that the consumer's indexing is unchanged
+    (multi-GPU runs: every rank walks the same file list and loads only the cases it works on)."""
     assert bucket in ("imagesTs", "imagesTr")
     files = [Path(p) for p in tta_data_filepaths if Path(p).parts[-2] == bucket]
     label_folder = Path(dataset_raw_path) / ("labelsTs" if bucket == "imagesTs" else "labelsTr")
     out_folder = "tta_outputTs" if bucket == "imagesTs" else "tta_outputTr"
 
     def gen():
-        for f in files:
+        for k, f in enumerate(files):
             stem = f.name[: -len("".join(f.suffixes))] if f.suffixes else f.name
             m = _CASE_RE.match(stem)
             case = m.group(1) if m else stem
+            if wanted is not None and not wanted(first_index + k, total if total is not None else len(files)):
+                yield {"ofile": f"{out_folder}/{case}", "skipped": True}
+                continue
             lbl = label_folder / (case + "".join(f.suffixes))
             yield preprocess_fromfile(f, lbl if lbl.is_file() else None, f"{out_folder}/{case}", predictor)
 
     return gen(), len(files)
 
 
-def load_tta_data(config, dataset_raw_path, predictor=None, tta_across_all_samples=False):
-    ts_it, ts_n = get_data_iterator(config["tta_data_filepaths"], dataset_raw_path, "imagesTs", predictor)
-    tr_it, tr_n = get_data_iterator(config["tta_data_filepaths"], dataset_raw_path, "imagesTr", predictor)
+def load_tta_data(config, dataset_raw_path, predictor=None, tta_across_all_samples=False, wanted=None):
+    paths = config["tta_data_filepaths"]
+    n_ts = sum(1 for p in paths if Path(p).parts[-2] == "imagesTs")
+    n_tr = sum(1 for p in paths if Path(p).parts[-2] == "imagesTr")
+    ts_it, ts_n = get_data_iterator(paths, dataset_raw_path, "imagesTs", predictor, wanted, 0, n_ts + n_tr)
+    tr_it, tr_n = get_data_iterator(paths, dataset_raw_path, "imagesTr", predictor, wanted, n_ts, n_ts + n_tr)
     if tta_across_all_samples:
         return list(ts_it) + list(tr_it), ts_n + tr_n
     return chain(ts_it, tr_it), ts_n + tr_n

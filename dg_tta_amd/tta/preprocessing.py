@@ -21,11 +21,12 @@ def _resize(vol, new_shape, order, device, clip=True, axes=None):
     vol: numpy [..., X, Y, Z]; returns a float64 numpy array."""
     t = torch.from_numpy(np.ascontiguousarray(vol, dtype=np.float64)).to(device)
     out = ops.resize_volume(t, new_shape, order, axes=axes)
-    if clip and order != 0:
+    if clip and order > 1:          # (linear interpolation cannot leave the input range)
+        # skimage clips to the range of the array it was called on: the whole channel volume, or - on nnU-Net's
+        # separate-z path, where resize runs per 2-D slice - each slice's own range
         lead = t.dim() - 3
-        red = tuple(range(lead, t.dim()))
-        lo = t.amin(dim=red, keepdim=True) if lead else t.min()
-        hi = t.amax(dim=red, keepdim=True) if lead else t.max()
+        red = tuple(range(lead, t.dim())) if axes is None else tuple(lead + a for a in axes)
+        lo, hi = t.amin(dim=red, keepdim=True), t.amax(dim=red, keepdim=True)
         out = torch.maximum(torch.minimum(out, hi), lo)
     return out.cpu().numpy()
 

@@ -6,7 +6,7 @@ from collections import OrderedDict
 import torch
 
 from .. import ops
-from ..utils import upload_async
+from ..utils import cpu_generator, upload_async
 
 _VOLUME_CACHE = {}
 
@@ -20,8 +20,6 @@ def _resident(data, device):
     hit = _VOLUME_CACHE.get(key)
     if hit is not None and hit[0] is data and hit[1] == data._version:
         return hit[2]
-    if len(_VOLUME_CACHE) > 16:
-        _VOLUME_CACHE.clear()
     img = data[0][None, None].float().contiguous().to(device)
     mn = data[0].min().reshape(1).float().to(device)                  # torch_utils.py:58
     lab = None
@@ -34,9 +32,16 @@ def _resident(data, device):
     return img, mn, lab
 
 
-def release_resident():
-    """Frees the device copies of the cached volumes (called by tta_main after each sample)."""
-    _VOLUME_CACHE.clear()
+def release_resident(tensor_list=None):
+    """Frees the device copies of cached volumes: those of `tensor_list` (tta_main, after each sample), or all of them.
+    Entries are never evicted behind a running epoch's back: kernels enqueued on the input-pipeline stream may still
+    read them."""
+    if tensor_list is None:
+        _VOLUME_CACHE.clear()
+        return
+    ids = {id(t) for t in tensor_list}
+    for key in [k for k in _VOLUME_CACHE if k[0] in ids]:
+        del _VOLUME_CACHE[key]
 
 
 def get_batch(tensor_list, batch_idxs, patch_size, fixed_patch_idx=None, device="cuda"):
@@ -52,7 +57,7 @@ def get_batch(tensor_list, batch_idxs, patch_size, fixed_patch_idx=None, device=
     for b in range(len(batch_idxs)):
         data = tensor_list[batch_idxs[b]]
         if fixed_patch_idx != "center":
-            rand_offset = 2.0 * torch.rand(3) - 1.0
+            rand_offset = 2.0 * torch.rand(3, generator=cpu_generator()) - 1.0
             offset_range = ((t_shape - t_patch) / t_shape).clip(min=0.0)
             ranged = rand_offset * offset_range
             patch_affine[:, -1] = torch.cat([ranged.flip(0), torch.tensor([1.0])], dim=0)

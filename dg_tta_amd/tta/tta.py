@@ -13,7 +13,6 @@ no collectives; `shard=(rank, world)`), every (sample, ensemble) unit being inde
 """
 import json
 from contextlib import nullcontext
-from itertools import tee
 from pathlib import Path
 
 import numpy as np
@@ -22,8 +21,10 @@ import torch
 from .. import ops
 from ..gin import gin_aug
 from ..optim import HipAdamW
-from ..sharding import done_marker, mark_rank_done, summary_by_parent, unit_owner, wait_for_files
-from ..utils import disable_internal_augmentation, upload_async
+from ..sharding import (done_marker, failed_marker, mark_rank_done, summary_by_parent, unit_owner,
+                        wait_for_done_markers, wait_for_files)
+from .._state import state_of
+from ..utils import disable_internal_augmentation, numpy_rng, upload_async
 from .augmentation_utils import get_rand_affine
 from .config_log_utils import (get_global_idx, get_parameters_save_path, is_template_modifier, plot_run_results)
 from .model_utils import apply_running_stats, buffer_running_stats, get_model_from_network
@@ -55,10 +56,10 @@ def get_sample_specs(config, smp_idx, tta_data, save_path, across_all_samples=Fa
         for e in tta_data:
             repair_ofilename_and_add_fileextension(config, e)
         return None, [e["data"] for e in tta_data], "all_samples", None, save_path / "tta_output"
-    sample = next(tta_data)
+    sample = next(tta_data)         # a case this rank does not work on arrives as a stub without "data" (not loaded)
     repair_ofilename_and_add_fileextension(config, sample)
     sample_id = sample["ofile"]
-    return sample, [sample["data"]], sample_id, sample["file_extension"], save_path / Path(sample_id).parent
+    return sample, [sample.get("data")], sample_id, sample["file_extension"], save_path / Path(sample_id).parent
 
 
 def calc_branch(branch_id, config, model, intensity_aug_func, identity_grid, patch_size, batch_size, label_mapping,
@@ -174,13 +175,13 @@ def run_both_branches(prepared, config, model, label_mapping, optimized_labels, 
         model.apply(buffer_running_stats)
         model.apply(apply_running_stats)
         if prepared["feat"] is not None:
-            push_features(prepared["feat"])
+            push_features(model, prepared["feat"])
         elif want_noise:
-            push_noise(noise, groups=2 * steps)
+            push_noise(model, noise, groups=2 * steps)
         try:
             both = model(prepared["x"])
         finally:
-            clear_noise()
+            clear_noise(model)
         if isinstance(both, tuple):
             both = both[0]
         per = prepared["per"]
@@ -210,18 +211,6 @@ def run_both_branches(prepared, config, model, label_mapping, optimized_labels, 
                    torch.cat(pieces[steps:], dim=0) if steps > 1 else pieces[1]]
         targets[0]._dgtta_guard_items = targets[1]._dgtta_guard_items = per
     return targets[0], targets[1]
-
-
-_PREP_STREAMS = {}
-
-
-def _prep_stream(device):
-    d = torch.device(device)
-    key = d.index if d.index is not None else torch.cuda.current_device()
-    st = _PREP_STREAMS.get(key)
-    if st is None:
-        st = _PREP_STREAMS[key] = torch.cuda.Stream(device=d)
-    return st
 
 
 def _can_precompute_mind(model, modifier_fn_module):
@@ -280,14 +269,18 @@ def tta_epoch(model, optimizer, config, tta_tens_list, patch_size, label_mapping
     accum = config["patches_to_be_accumulated"]
     optimized_labels = config["optimized_labels"]
     intensity_aug_func = INTENSITY_AUG_FUNCTION_DICT[config["intensity_aug_function"]]
-    # d(loss/accum), times the model's static loss scale (fp16 storage only; HipAdamW divides it out again)
-    inv_accum = torch.full((), float(getattr(model, "loss_scale", 1.0)) / accum, dtype=torch.float32, device=device)
+    # d(loss/accum), times the loss scale of the fp16 storage path (HipAdamW divides it out again and halves it after an
+    # overflow: a step with inf / NaN gradients is skipped on the device and settled here, where the stream is drained)
+    if adapt and hasattr(optimizer, "resolve_overflow") and optimizer.resolve_overflow():
+        print(f"  gradient overflow in 16-bit storage: last optimizer step skipped, loss scale -> {optimizer.grad_scale:g}")
+    scale = float(getattr(optimizer, "grad_scale", getattr(model, "loss_scale", 1.0)))
+    inv_accum = torch.full((), scale / accum, dtype=torch.float32, device=device)
     model.train()
     step_losses = []
 
     def next_imgs():
         with torch.no_grad():
-            imgs, _ = get_batch(tta_tens_list, np.random.choice(range(len(tta_tens_list)), B).tolist(), patch_size,
+            imgs, _ = get_batch(tta_tens_list, numpy_rng().choice(range(len(tta_tens_list)), B).tolist(), patch_size,
                                 fixed_patch_idx=None, device=device)
         return imgs[0] if len(imgs) == 1 else torch.cat(imgs, dim=0)
 
@@ -297,7 +290,8 @@ def tta_epoch(model, optimizer, config, tta_tens_list, patch_size, label_mapping
         # The inputs of pass i+1 (patch sampling, GIN, affine warp, noise draws, MIND) do not depend on the weights or on
         # pass i: they are produced on a side stream while pass i is in its network passes (DGTTA_PIPELINE_PREP=0: in
         # line).  Draw order on both generators is unchanged - the draws happen when the work is enqueued.
-        prep_stream = _prep_stream(device) if (_pipeline_prep() and torch.device(device).type == "cuda") else None
+        prep_stream = state_of(model).stream("prep_stream", device) if (_pipeline_prep() and torch.device(device).type == "cuda") \
+            else None
         mind_ahead = prep_stream is not None and _can_precompute_mind(model, modifier_fn_module)
         main_stream = torch.cuda.current_stream(device) if prep_stream is not None else None
 
@@ -354,7 +348,7 @@ def tta_epoch(model, optimizer, config, tta_tens_list, patch_size, label_mapping
     with torch.inference_mode():
         model.eval()
         for _ in range(config["tta_eval_patches"]):
-            imgs, labels = get_batch(tta_tens_list, np.random.choice(range(len(tta_tens_list)), B).tolist(),
+            imgs, labels = get_batch(tta_tens_list, numpy_rng().choice(range(len(tta_tens_list)), B).tolist(),
                                      patch_size, fixed_patch_idx="center", device=device)
             keep = [i for i, l in enumerate(labels) if l is not None]
             if len(keep) == 0:
@@ -409,7 +403,13 @@ def tta_main(run_name, config, tta_data_dir, save_base_path, label_mapping, modi
              network_bundle=None, tta_data=None, shard=(0, 1), act_dtype=torch.float32, conv_impl=0):
     """Same signature as the reference's tta_main (tta.py:93-102) plus optional injection points:
     network_bundle=(predictor, patch_size, network, parameters) and tta_data=(iterable, num_samples) replace the
-    nnU-Net loaders (used by tests / bench with synthetic data); shard=(rank, world) selects this process's samples."""
+    nnU-Net loaders (used by tests / bench with synthetic data); shard=(rank, world) selects this process's units.
+
+    A rank only ever loads / preprocesses the cases it works on (some ensemble member to adapt, or the case's ensemble
+    prediction), and a case's tensors are dropped as soon as it is predicted: the reference keeps a second iterator over
+    all cases for the inference loop (tta.py:149-155, 379-384); here a case whose members were all adapted by this rank is
+    predicted right after its last member (no draws happen in between, so the results are those of the reference's
+    order), the others after the filesystem barrier on the members' parameter files."""
     from .nnunet_utils import load_network, load_tta_data
     device = torch.device(device)
     if device.type != "cuda":
@@ -419,112 +419,163 @@ def tta_main(run_name, config, tta_data_dir, save_base_path, label_mapping, modi
                                       conv_impl=conv_impl)
     predictor, patch_size, network, parameters = network_bundle
     across = config["tta_across_all_samples"]
-    print("\n# Loading data")
-    if tta_data is None:
-        tta_data = load_tta_data(config, tta_data_dir, predictor, across)
-    tta_data, num_samples = tta_data
-    if not across:
-        tta_data, _inference_data = tee(tta_data)
     ensemble_count = config["ensemble_count"]
     num_epochs = config["epochs"]
+    rank, world = shard
+    do_inference = config.get("run_inference", True) and not across and not debug
+
+    def members_of(smp_idx, n_samples):
+        return [e for e in range(ensemble_count) if unit_owner(smp_idx, e, n_samples, ensemble_count, world) == rank]
+
+    def predicts(smp_idx, n_samples):
+        return do_inference and unit_owner(smp_idx, 0, n_samples, ensemble_count, world) == rank
+
+    print("\n# Loading data")
+    if tta_data is None:
+        tta_data = load_tta_data(config, tta_data_dir, predictor, across,
+                                 wanted=None if across else (lambda i, n: bool(members_of(i, n)) or predicts(i, n)))
+    tta_data, num_samples = tta_data
     save_path = Path(save_base_path) / run_name
     save_path.mkdir(exist_ok=True, parents=False)
+    for stale in (done_marker(save_path, rank), failed_marker(save_path, rank)):
+        stale.unlink(missing_ok=True)       # a resumed run must not pass the barrier on the previous launch's markers
     with open(save_path / "tta_plan.json", "w") as f:
         json.dump({k: v for k, v in config.items()}, f, indent=4)
     disable_internal_augmentation()
-    rank, world = shard
     results = {}
     n_units_samples = 1 if across else num_samples
-    print("\n# Starting TTA")
-    for smp_idx in ([0] if across else range(num_samples)):
-        _, tta_tens_list, sample_id, _ext, sub_dir_tta = get_sample_specs(config, smp_idx, tta_data, save_path, across)
-        mine = [e for e in range(ensemble_count) if unit_owner(smp_idx, e, n_units_samples, ensemble_count, world) == rank]
-        if not mine:
-            continue        # another GPU's units (independent: nothing to exchange)
-        print(f"\nSample {sample_id}")
-        sub_dir_tta.mkdir(exist_ok=True, parents=True)
-        for ensemble_idx in mine:
-            ppath = get_parameters_save_path(sub_dir_tta, sample_id, ensemble_idx)
-            if ppath.is_file():
-                print(f"TTA parameters file already exists. Skipping '{ppath}'")
-                continue
-            if config.get("seed") is not None:      # optional, not a reference key: reproducible units on any GPU count
-                unit = get_global_idx([(smp_idx, max(num_samples, 1)), (ensemble_idx, ensemble_count)])
-                torch.manual_seed(int(config["seed"]) + unit)
-                np.random.seed(int(config["seed"]) + unit)
-            model = get_model_from_network(network, modifier_fn_module, parameters).to(device)
-            fused = _fuse_head_if_possible(model, modifier_fn_module, label_mapping, config["optimized_labels"])
-            if hasattr(model, "accumulate_grads_in_place"):
-                model.accumulate_grads_in_place = True      # this loop owns the gradients (zero_grad once per epoch)
-                model.exact_zero_bias_grad = True           # see HipPlainConvUNet.exact_zero_bias_grad
-            optimizer = HipAdamW(model.parameters(), lr=config["lr"], grad_scale=getattr(model, "loss_scale", 1.0))
+    timeout = float(config.get("barrier_timeout_s", 6 * 3600))
+    try:
+        print("\n# Starting TTA")
+        deferred = []
+        for smp_idx in ([0] if across else range(num_samples)):
+            sample, tta_tens_list, sample_id, _ext, sub_dir_tta = get_sample_specs(config, smp_idx, tta_data, save_path, across)
+            mine = members_of(smp_idx, n_units_samples)
+            predict_here = predicts(smp_idx, n_units_samples)
+            if not mine and not predict_here:
+                continue        # another GPU's case (independent: nothing to exchange); it was not loaded either
+            if mine:
+                print(f"\nSample {sample_id}")
+            sub_dir_tta.mkdir(exist_ok=True, parents=True)
+            for ensemble_idx in mine:
+                ppath = get_parameters_save_path(sub_dir_tta, sample_id, ensemble_idx)
+                if ppath.is_file():
+                    print(f"TTA parameters file already exists. Skipping '{ppath}'")
+                    continue
+                if config.get("seed") is not None:      # optional, not a reference key: reproducible units on any GPU count
+                    unit = get_global_idx([(smp_idx, max(num_samples, 1)), (ensemble_idx, ensemble_count)])
+                    torch.manual_seed(int(config["seed"]) + unit)
+                    np.random.seed(int(config["seed"]) + unit)
+                model = get_model_from_network(network, modifier_fn_module, parameters).to(device)
+                fused = _fuse_head_if_possible(model, modifier_fn_module, label_mapping, config["optimized_labels"])
+                if hasattr(model, "accumulate_grads_in_place"):
+                    model.accumulate_grads_in_place = True      # this loop owns the gradients (zero_grad once per epoch)
+                    model.exact_zero_bias_grad = True           # see HipPlainConvUNet.exact_zero_bias_grad
+                optimizer = HipAdamW(model.parameters(), lr=config["lr"], grad_scale=getattr(model, "loss_scale", 1.0))
 
-            def progress(epoch, loss, dice):
-                print(f"  epoch {epoch}: loss={loss:.3f}, Pseudo-Dice={dice * 100:.1f}%", flush=True)
+                def progress(epoch, loss, dice):
+                    print(f"  epoch {epoch}: loss={loss:.3f}, Pseudo-Dice={dice * 100:.1f}%", flush=True)
 
-            losses, dices = tta_unit(model, optimizer, config, tta_tens_list, patch_size, label_mapping,
-                                     modifier_fn_module, device, fused, debug, progress)
-            if fused:
-                model.set_selected_classes(None)
-            # written under a temporary name and renamed: the owner of the sample polls for the file (filesystem barrier)
-            tmp = ppath.with_name(ppath.name + f".tmp{rank}")
-            torch.save([model.state_dict()], tmp)
-            tmp.replace(ppath)
-            results[(sample_id, ensemble_idx)] = (losses, dices)
-            if num_epochs > 0:
-                plot_run_results(sub_dir_tta, sample_id, ensemble_idx, losses, dices)
-            if debug:
-                break
-        release_resident()      # this sample's volume leaves HBM
-    # ---- ensemble sliding-window inference with the TTA'd parameter sets (reference: tta.py:376-416).  Label maps are
-    # written as <case>.npy (or <case>.nii.gz when the case carries a NIfTI header in data_properties['nifti_header'])
-    # in the preprocessed geometry; the target label channels of the case, mapped to the TTA label set, go to
-    # mapped_target_labels{Ts,Tr}/ and summary_{Ts,Tr}.json is written as tta.py:447-470 does (evaluation.py).
-    # Resampling to the original spacing stays with nnU-Net.
-    if config.get("run_inference", True) and not across and not debug:
-        from .inference import run_inference
-        from .torch_utils import get_imgs
-        print("\n\n# Starting inference")
-        for smp_idx in range(num_samples):
-            sample, _, sample_id, _ext, sub_dir_tta = get_sample_specs(config, smp_idx, _inference_data, save_path, False)
-            if unit_owner(smp_idx, 0, num_samples, ensemble_count, world) != rank:
-                continue        # the rank that owns member 0 predicts the sample
-            paths = [get_parameters_save_path(sub_dir_tta, sample_id, e) for e in range(ensemble_count)]
-            if world > 1:       # members adapted on other GPUs: wait for their files (no collective)
-                wait_for_files(paths, float(config.get("barrier_timeout_s", 24 * 3600)))
-            if not all(p.is_file() for p in paths):
-                continue
-            params = [torch.load(p, map_location=device)[0] for p in paths]
-            model = get_model_from_network(network, modifier_fn_module).to(device)
-            disable_internal_augmentation()
-            image = get_imgs(sample["data"].unsqueeze(0)).squeeze(0)
-            seg = run_inference(image, model, params, patch_size, label_mapping, config["optimized_labels"])
-            nii = (sample.get("data_properties") or {}).get("nifti_header") if isinstance(sample, dict) else None
-            out = Path(str(save_path / sample_id) + (".nii.gz" if nii is not None else ".npy"))
-            out.parent.mkdir(exist_ok=True, parents=True)
-            _save_label_map(out, seg.numpy().astype(np.int16), nii)
-            results[(sample_id, "prediction")] = out
-            # reference labels of this case (one-hot channels of the preprocessed sample = the TTA dataset's label ids),
-            # mapped into the index space of optimized_labels as tta.py:440-447 does (unmapped ids become background)
-            if sample["data"].shape[0] > 1:
-                bucket = "Ts" if "outputTs" in out.parent.name else ("Tr" if "outputTr" in out.parent.name else None)
-                if bucket is not None:
-                    segs = sample["data"][1:]
-                    target = torch.cat([(segs.sum(0, keepdim=True) < 1.0).float(), segs.float()], dim=0).argmax(0)
-                    target = map_label(target[None], get_map_idxs(label_mapping, config["optimized_labels"], "tta_labels"),
-                                       input_format="argmaxed")[0]
-                    ref_path = save_path / f"mapped_target_labels{bucket}" / out.name
-                    ref_path.parent.mkdir(exist_ok=True, parents=True)
-                    _save_label_map(ref_path, target.numpy().astype(np.int16), nii)
-        # ---- evaluation over the whole run directory: only once every rank's predictions are on disk
-        mark_rank_done(save_path, rank)
-        if world == 1:
-            results.update(evaluate_run(save_path, config, modifier_fn_module, device))
-        elif rank == 0 and not summary_by_parent():
-            wait_for_files([done_marker(save_path, r) for r in range(world)],
-                           float(config.get("barrier_timeout_s", 24 * 3600)))
-            results.update(evaluate_run(save_path, config, modifier_fn_module, device))
+                losses, dices = tta_unit(model, optimizer, config, tta_tens_list, patch_size, label_mapping,
+                                         modifier_fn_module, device, fused, debug, progress)
+                if fused:
+                    model.set_selected_classes(None)
+                # written under a temporary name and renamed: the owner of the sample polls for the file (filesystem barrier)
+                tmp = ppath.with_name(ppath.name + f".tmp{rank}")
+                torch.save([model.state_dict()], tmp)
+                tmp.replace(ppath)
+                results[(sample_id, ensemble_idx)] = (losses, dices)
+                if num_epochs > 0:
+                    plot_run_results(sub_dir_tta, sample_id, ensemble_idx, losses, dices)
+                if debug:
+                    break
+            release_resident(tta_tens_list)      # this sample's volume leaves HBM
+            if predict_here:
+                case = (sample, sample_id, sub_dir_tta)
+                if len(mine) == ensemble_count:
+                    _predict_case(case, config, network, predictor, patch_size, label_mapping, modifier_fn_module, device,
+                                  save_path, tta_data_dir, results, world, timeout)
+                else:
+                    deferred.append(case)            # members adapted on other GPUs: predicted after this rank's units
+        # ---- ensemble sliding-window inference with the TTA'd parameter sets (reference: tta.py:376-416)
+        if do_inference:
+            if deferred:
+                print("\n\n# Starting inference")
+            for case in deferred:
+                _predict_case(case, config, network, predictor, patch_size, label_mapping, modifier_fn_module, device,
+                              save_path, tta_data_dir, results, world, timeout)
+            del deferred
+            # ---- evaluation over the whole run directory: only once every rank's predictions are on disk
+            mark_rank_done(save_path, rank)
+            if world == 1:
+                results.update(evaluate_run(save_path, config, modifier_fn_module, device))
+            elif rank == 0 and not summary_by_parent():
+                wait_for_done_markers(save_path, world, timeout)
+                results.update(evaluate_run(save_path, config, modifier_fn_module, device))
+    except BaseException:
+        if world > 1:           # peers waiting in the filesystem barrier stop instead of running into its timeout
+            failed_marker(save_path, rank).write_text("failed\n")
+        raise
     return results
+
+
+def _predict_case(case, config, network, predictor, patch_size, label_mapping, modifier_fn_module, device, save_path,
+                  tta_data_dir, results, world, timeout):
+    """Ensemble prediction of one case + its evaluation target (reference: tta.py:379-446).
+
+    NIfTI cases are exported the way nnU-Net's predictor does it for the reference (nnunet_utils.py:208-230): the
+    ensemble logits are resampled to the shape the case had before preprocessing, argmax'd, pasted into the crop box and
+    transposed back, then written with the image's own header - the prediction is interchangeable with a reference run's
+    and lines up with `labels{Ts,Tr}/<case>`, which is what it is evaluated against (tta.py:420-447).  Array cases
+    (.npy/.npz/.pt: already preprocessed, no geometry) are written as they are."""
+    from .inference import export_segmentation, predict_ensemble_logits
+    from .nifti_io import read_nifti
+    from .torch_utils import get_imgs
+    sample, sample_id, sub_dir_tta = case
+    ensemble_count = config["ensemble_count"]
+    optimized_labels = config["optimized_labels"]
+    paths = [get_parameters_save_path(sub_dir_tta, sample_id, e) for e in range(ensemble_count)]
+    if world > 1:       # members adapted on other GPUs: wait for their files (no collective, SURVEY.md §8e)
+        wait_for_files(paths, timeout, abort_if=[failed_marker(save_path, r) for r in range(world)])
+    if not all(p.is_file() for p in paths):
+        return
+    print(f"\nPredicting {sample_id}")
+    params = [torch.load(p, map_location=device)[0] for p in paths]
+    model = get_model_from_network(network, modifier_fn_module).to(device)
+    disable_internal_augmentation()
+    image = get_imgs(sample["data"].unsqueeze(0)).squeeze(0)
+    props = sample.get("data_properties") or {}
+    nii = props.get("nifti_header")
+    acc, nsum, crop = predict_ensemble_logits(image, model, params, patch_size)
+    plans = getattr(predictor, "plans", None)
+    original = nii is not None and plans is not None and "shape_before_cropping" in props
+    seg = export_segmentation(acc, nsum, crop, props if original else None, plans, getattr(predictor, "configuration", None))
+    del acc, nsum
+    seg = map_label(torch.as_tensor(seg.astype(np.int64))[None],
+                    get_map_idxs(label_mapping, optimized_labels, "pretrain_labels"), input_format="argmaxed")[0]
+    out = Path(str(save_path / sample_id) + (".nii.gz" if nii is not None else ".npy"))
+    out.parent.mkdir(exist_ok=True, parents=True)
+    _save_label_map(out, seg.numpy().astype(np.int16), nii)
+    results[(sample_id, "prediction")] = out
+    bucket = "Ts" if "outputTs" in out.parent.name else ("Tr" if "outputTr" in out.parent.name else None)
+    if bucket is None:
+        return
+    tta_idxs = get_map_idxs(label_mapping, optimized_labels, "tta_labels")
+    ref_path = save_path / f"mapped_target_labels{bucket}" / out.name
+    orig_target = Path(tta_data_dir) / f"labels{bucket}" / out.name if tta_data_dir is not None else None
+    if original and orig_target is not None and orig_target.is_file():
+        # the untouched label file of the case, mapped into the index space of optimized_labels (tta.py:431-446)
+        tgt, tgt_hdr = read_nifti(orig_target)
+        tgt = map_label(torch.as_tensor(tgt.astype(np.int64))[None], tta_idxs, input_format="argmaxed")[0]
+        ref_path.parent.mkdir(exist_ok=True, parents=True)
+        _save_label_map(ref_path, tgt.numpy().astype(np.int16), tgt_hdr)
+    elif sample["data"].shape[0] > 1 and not original:
+        # array cases: the label channels of the preprocessed sample are the only reference there is
+        segs = sample["data"][1:]
+        target = torch.cat([(segs.sum(0, keepdim=True) < 1.0).float(), segs.float()], dim=0).argmax(0)
+        target = map_label(target[None], tta_idxs, input_format="argmaxed")[0]
+        ref_path.parent.mkdir(exist_ok=True, parents=True)
+        _save_label_map(ref_path, target.numpy().astype(np.int16), nii)
 
 
 def evaluate_run(save_path, config, modifier_fn_module, device="cuda"):

@@ -17,24 +17,13 @@ from torch import nn
 
 from . import _lib
 from ._lib import check, ptr, stream_of
+from ._state import state_of
 from .ops import F32, BF16, F16, _ws, dtype_code, is_cl3d
 
 PLANS_3D_FULLRES = dict(features=(32, 64, 128, 256, 320), strides=(1, 2, 2, 2, 2),
                         n_conv_enc=(2, 2, 2, 2, 2), n_conv_dec=(2, 2, 2, 2),
                         in_channels=12, num_classes=105)
 EPS, SLOPE = 1e-5, 1e-2
-
-
-_SIDE_STREAMS = {}
-
-
-def _side_stream(dev):
-    d = torch.device(dev)
-    key = d.index if d.index is not None else torch.cuda.current_device()
-    s_ = _SIDE_STREAMS.get(key)
-    if s_ is None:
-        s_ = _SIDE_STREAMS[key] = torch.cuda.Stream(device=d)
-    return s_
 
 
 def _wgrad_on_side_stream():
@@ -203,14 +192,12 @@ class HipPlainConvUNet(nn.Module):
         return wpack
 
 
-_PROBE = None
-
-
-def set_probe(where):
-    """bench.py hook: record (start, end) events around the forward conv launch of block `where` = (kind, stage, idx)."""
-    global _PROBE
-    _PROBE = None if where is None else dict(where=where, events=[])
-    return _PROBE
+def set_probe(model, where):
+    """bench.py hook: record (start, end) events around the forward conv launch of block `where` = (kind, stage, idx) of
+    `model` (None: stop).  Returns the probe dict (events are appended while the model runs)."""
+    st = state_of(model)
+    st.probe = None if where is None else dict(where=where, events=[])
+    return st.probe
 
 
 def _odim(i, s):
@@ -252,6 +239,7 @@ class _UNetFn(torch.autograd.Function):
             check(lib.dgtta_ncdhw_to_ndhwc(ptr(xs), ptr(xin), B, cin0, D * H * W, cin0p, dt, st), "dgtta_ncdhw_to_ndhwc")
 
         saved = []   # per conv block: dict(u, ldu, y, mr, dims...)
+        probe = state_of(net).probe
         ws_cache = {}
 
         def ws_for(nbytes):
@@ -277,7 +265,7 @@ class _UNetFn(torch.autograd.Function):
             stats = ws_cache.get("stats")
             if stats is None or stats.numel() < sbytes:
                 stats = ws_cache["stats"] = _ws(sbytes, dev)
-            pr = _PROBE if (_PROBE is not None and _PROBE["where"] == where) else None
+            pr = probe if (probe is not None and probe["where"] == where) else None
             if pr is not None:       # bench.py: time this layer's conv launch with events on the launch stream
                 ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 ev0.record()
@@ -402,9 +390,18 @@ class _UNetFn(torch.autograd.Function):
         # only passes dy on): they run on a SIDE STREAM, so that the MFMA-bound weight-gradient kernels overlap the
         # HBM-bound InstanceNorm passes of the main chain instead of queueing between them (DGTTA_WGRAD_STREAM=0: one stream)
         main_stream = torch.cuda.current_stream(dev)
-        side = _side_stream(dev) if _wgrad_on_side_stream() else None
+        side = state_of(net).stream("side_stream", dev) if _wgrad_on_side_stream() else None
         if side is not None:
             side.wait_stream(main_stream)
+
+        def scratch_like(p):
+            """Throw-away gradient buffer (only the bias of this layer wants a gradient): it is written by the kernel on
+            the side stream, so it comes from that stream's pool - a main-stream block could be handed out again while
+            the side kernel still writes to it."""
+            if side is None:
+                return torch.empty_like(p)
+            with torch.cuda.stream(side):
+                return torch.empty_like(p)
 
         V = D * H * W
         g = gout.contiguous(memory_format=torch.channels_last_3d).float()      # [B,nsel,D,H,W] stored NDHWC
@@ -457,7 +454,7 @@ class _UNetFn(torch.autograd.Function):
             # -- weight / bias gradient
             if want(conv.weight) or want(conv.bias):
                 nb = lib.dgtta_conv3d_wgrad_ws_bytes(B, cin, cout, do, ho, wo)
-                dw = gbuf(conv.weight) if want(conv.weight) else torch.empty_like(conv.weight)
+                dw = gbuf(conv.weight) if want(conv.weight) else scratch_like(conv.weight)
                 db = gbuf(conv.bias) if want(conv.bias) else None
                 if net.exact_zero_bias_grad:
                     db = None       # gradient buffer stays exactly zero (see HipPlainConvUNet.exact_zero_bias_grad)
@@ -494,7 +491,7 @@ class _UNetFn(torch.autograd.Function):
                 nb = lib.dgtta_convT3d_bwd_ws_bytes(B, up["cin"], up["cout"], ld0, lh0, lw0)
                 w_ = ws_for(nb)
                 need_w = want(upm.weight) or want(upm.bias)
-                dwu = (gbuf(upm.weight) if want(upm.weight) else torch.empty_like(upm.weight)) if need_w else None
+                dwu = (gbuf(upm.weight) if want(upm.weight) else scratch_like(upm.weight)) if need_w else None
                 dbu = gbuf(upm.bias) if want(upm.bias) else None
                 if side is None or not need_w:
                     check(lib.dgtta_convT3d_k2s2_bwd(up["x"], up["ldx"], ptr(gc), 2 * cskip, ptr(upm.weight), ptr(glow),

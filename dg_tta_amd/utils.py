@@ -1,7 +1,9 @@
 """Environment flags of the reference (dg_tta/utils.py:5-30), same names and semantics."""
 import os
+import threading
 from pathlib import Path
 
+import numpy as np
 import torch
 
 
@@ -57,3 +59,39 @@ def upload_async(cpu_tensors, device):
         stage[o:o + n].copy_(t.reshape(-1))
     dev = stage.to(device, non_blocking=True)
     return [dev[o:o + n].view(t.shape) for t, o, n in zip(cpu_tensors, offs, sizes)]
+
+
+# ---- random draws.  The reference draws from the process-global generators (torch CPU, torch device, numpy legacy), and so
+# does this engine by default.  Two TTA instances in ONE process (threads) would interleave their draws on those; rng_scope
+# gives the calling thread generators of its own, which every draw site of the path uses (GIN, affine, patch offsets,
+# sample choice, MIND noise).
+_RNG = threading.local()
+
+
+class rng_scope:
+    """Context: the calling thread's TTA draws come from these generators instead of the global ones.
+    cpu: torch.Generator (CPU); device: torch.Generator on the GPU; numpy: np.random.RandomState."""
+
+    def __init__(self, cpu=None, device=None, numpy=None):
+        self.new = (cpu, device, numpy)
+
+    def __enter__(self):
+        self.prev = getattr(_RNG, "gens", (None, None, None))
+        _RNG.gens = self.new
+        return self
+
+    def __exit__(self, *exc):
+        _RNG.gens = self.prev
+
+
+def cpu_generator():
+    return getattr(_RNG, "gens", (None, None, None))[0]
+
+
+def device_generator():
+    return getattr(_RNG, "gens", (None, None, None))[1]
+
+
+def numpy_rng():
+    r = getattr(_RNG, "gens", (None, None, None))[2]
+    return np.random if r is None else r

@@ -137,7 +137,12 @@ int dgtta_softdice_probs_bwd(const float *a, const float *b, const float *grad_d
  * ------------------------------------------------------------------------------------------- */
 int dgtta_adamw_step(float *const *h_p, const float *const *h_g, float *const *h_m, float *const *h_v,
                      const int64_t *h_n, int ntensors, float lr, float beta1, float beta2, float eps,
-                     float weight_decay, int step, float grad_scale, void *stream);
+                     float weight_decay, int step, float grad_scale, const int *skip_if_nonzero, void *stream);
+/* Overflow guard of the fp16 storage path (the role torch.cuda.amp.GradScaler's inf check plays for autocast users; the
+ * reference itself runs fp32, dg_tta/tta/tta.py:275-279): *flag (device int, zeroed by the caller) becomes 1 when any
+ * gradient element is inf / NaN.  dgtta_adamw_step(skip_if_nonzero = flag) then leaves parameters and state untouched;
+ * skip_if_nonzero may be NULL. */
+int dgtta_grads_nonfinite(const float *const *h_g, const int64_t *h_n, int ntensors, int *flag, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * nnUNet PlainConvUNet building blocks (third-party dynamic-network-architectures==0.2, built at
@@ -239,6 +244,18 @@ int dgtta_window_accumulate(const float *patch, const float *gauss, float *acc, 
 size_t dgtta_resample_axis_ws_bytes(int64_t outer, int n, int64_t inner, int order);
 int dgtta_resample_axis(const double *src, double *dst, void *ws, size_t ws_bytes, int64_t outer, int n, int m,
                         int64_t inner, int order, void *stream);
+
+/* Export of a prediction in the case's ORIGINAL geometry: nnU-Net's convert_predicted_logits_to_segmentation_with_correct_shape
+ * (third-party nnunetv2==2.2.1), which the reference reaches through predict_from_data_iterator
+ * (dg_tta/tta/nnunet_utils.py:208-230) before sitk_io.write_seg (dg_tta/tta/tta.py:404-413).
+ * dgtta_logits_chunk_f64: dst[x][y][z][j] = acc[x0+x][y0+y][z0+z][c0+j] / nsum[..] as double (classes c0..c0+cg-1 of the
+ * window accumulator, cropped back from the padding to the patch size), the input of the dgtta_resample_axis passes.
+ * dgtta_argmax_merge_f64: running argmax over class groups: vals double [V][cg] holds classes c0..; best_val / best_idx
+ * are initialised when first != 0.  Ties keep the lower class id (argmax semantics). */
+int dgtta_logits_chunk_f64(const float *acc, const float *nsum, double *dst, int C, int X, int Y, int Z, int x0, int y0,
+                           int z0, int xs, int ys, int zs, int c0, int cg, void *stream);
+int dgtta_argmax_merge_f64(const double *vals, int64_t V, int cg, int c0, double *best_val, int *best_idx, int first,
+                           void *stream);
 
 #ifdef __cplusplus
 }

@@ -47,3 +47,28 @@ def ensemble_logits(models, data, patch_size):
         logits = acc / n
         total = logits if total is None else total + logits
     return total / len(models)
+
+
+def convert_logits_to_segmentation_with_correct_shape(logits, properties, plans, configuration):
+    """nnunetv2==2.2.1 inference/export_prediction.py: convert_predicted_logits_to_segmentation_with_correct_shape
+    [third-party; the reference reaches it through predict_from_data_iterator,
+    /root/reference/dg_tta/tta/nnunet_utils.py:208-230], restated from its published behaviour (parity unpinned):
+    logits [C,X,Y,Z] (numpy / tensor, preprocessed geometry) -> resampling_fn_probabilities (resample_data_or_seg_to_shape:
+    is_seg False, order 1, order_z 0, separate-z decided from the spacings) to shape_after_cropping_and_before_resampling
+    -> softmax -> argmax -> zeros(shape_before_cropping)[bbox] = seg -> transpose(transpose_backward)."""
+    from . import preprocessing as op
+    conf = plans["configurations"][configuration]
+    logits = np.asarray(logits, dtype=np.float32)
+    cur_spacing = list(conf["spacing"])
+    if len(cur_spacing) < len(properties["shape_after_cropping_and_before_resampling"]):
+        cur_spacing = [properties["spacing"][0]] + cur_spacing
+    kw = conf.get("resampling_fn_probabilities_kwargs", {"order": 1, "order_z": 0})
+    do_sep, axis = op.separate_z(cur_spacing, properties["spacing"])
+    res = op.resample_data_or_seg(logits, properties["shape_after_cropping_and_before_resampling"], False, axis,
+                                  kw["order"], do_sep, kw["order_z"])
+    probs = torch.softmax(torch.from_numpy(np.ascontiguousarray(res)).float(), 0)
+    seg = probs.argmax(0).numpy()
+    full = np.zeros(properties["shape_before_cropping"], dtype=np.uint8 if logits.shape[0] - 1 < 255 else np.uint16)
+    sl = tuple(slice(int(a), int(b)) for a, b in properties["bbox_used_for_cropping"])
+    full[sl] = seg
+    return full.transpose(plans["transpose_backward"])

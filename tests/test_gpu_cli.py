@@ -24,6 +24,14 @@ def test_prepare_and_run_tta_cli_full_net_64(tmp_path, monkeypatch):
     lab = torch.cat([(case[1:].sum(0, keepdim=True) < 1).float(), case[1:]]).argmax(0).numpy().astype(np.int16)
     write_nifti(raw / "imagesTs" / "mr01_0000.nii.gz", img.astype(np.float32), spacing=(1.5, 1.5, 1.5))
     write_nifti(raw / "labelsTs" / "mr01.nii.gz", lab, spacing=(1.5, 1.5, 1.5))
+    # second case: anisotropic (2.5 x 1.1 x 1.1 mm), with a zero border that preprocessing crops away -> its prediction has to
+    # be resampled back, un-cropped and written in THIS geometry
+    img2 = np.zeros((40, 84, 90), np.float32)
+    lab2 = np.zeros((40, 84, 90), np.int16)
+    img2[3:37, 6:80, 5:83] = img[:34, :74, :78] + 700.0
+    lab2[3:37, 6:80, 5:83] = lab[:34, :74, :78]
+    write_nifti(raw / "imagesTs" / "mr02_0000.nii.gz", img2, spacing=(1.1, 1.1, 2.5))         # (x, y, z)
+    write_nifti(raw / "labelsTs" / "mr02.nii.gz", lab2, spacing=(1.1, 1.1, 2.5))
     json.dump({"labels": {"background": 0, "liver": 1, "spleen": 2, "my_organ": 3}}, open(raw / "dataset.json", "w"))
     root = tmp_path / "dgroot"
     root.mkdir()
@@ -33,7 +41,7 @@ def test_prepare_and_run_tta_cli_full_net_64(tmp_path, monkeypatch):
     DGTTAProgram(["dgtta", "prepare_tta", "TS104_GIN_MIND", "803"])
     plan_dir = root / "plans" / "Pretrained_TS104_GIN_MIND_at_Dataset803_Target" / "nnUNetTrainer_GIN_MIND__3d_fullres" / "fold_0"
     plan = json.load(open(plan_dir / "tta_plan.json"))
-    assert [Path(p).name for p in plan["tta_data_filepaths"]] == ["mr01_0000.nii.gz"]
+    assert sorted(Path(p).name for p in plan["tta_data_filepaths"]) == ["mr01_0000.nii.gz", "mr02_0000.nii.gz"]
     # the model folder: patch 64^3 (config 1), seeded stand-in checkpoint with the real key layout
     weights = Path(plan["pretrained_weights_filepath"])
     mplans = json.load(open(weights.parents[1] / "plans.json"))
@@ -44,7 +52,7 @@ def test_prepare_and_run_tta_cli_full_net_64(tmp_path, monkeypatch):
     # 1 epoch that adapts (start_tta_at_epoch = 0), 4 accumulation steps, one ensemble member
     plan.update(epochs=1, start_tta_at_epoch=0, patches_to_be_accumulated=4, ensemble_count=1)
     json.dump(plan, open(plan_dir / "tta_plan.json", "w"), indent=4)
-    DGTTAProgram(["dgtta", "run_tta", "TS104_GIN_MIND", "803", "--device", "cuda:0", "--dtype", "bf16"])
+    DGTTAProgram(["dgtta", "run_tta", "TS104_GIN_MIND", "803", "--device", "cuda:0"])        # default storage: fp16
     runs = sorted((root / "results" / "Pretrained_TS104_GIN_MIND_at_Dataset803_Target" /
                    "nnUNetTrainer_GIN_MIND__3d_fullres" / "fold_0").iterdir())
     assert len(runs) == 1
@@ -61,4 +69,15 @@ def test_prepare_and_run_tta_cli_full_net_64(tmp_path, monkeypatch):
     tgt, _ = read_nifti(run / "mapped_target_labelsTs" / "mr01.nii.gz")
     assert (tgt == 1).sum() == (lab == 1).sum() and (tgt == 2).sum() == (lab == 2).sum() and (tgt == 3).sum() == 0
     sj = json.loads((run / "summary_Ts.json").read_text())
-    assert len(sj["metric_per_case"]) == 1 and set(sj["mean"]) == {"0", "1", "2"}
+    assert len(sj["metric_per_case"]) == 2 and set(sj["mean"]) == {"0", "1", "2"}
+    # the anisotropic, cropped case comes back in ITS OWN geometry and is evaluated against the untouched label file
+    seg2, hdr2 = read_nifti(out / "mr02.nii.gz")
+    assert seg2.shape == (40, 84, 90) and hdr2["pixdim"] == pytest.approx((1.1, 1.1, 2.5))
+    outside = np.ones(seg2.shape, bool)
+    outside[3:37, 6:80, 5:83] = False
+    assert (seg2[outside] == 0).all() and (seg2 != 0).any()        # zeros outside the crop box, labels inside
+    tgt2, thdr2 = read_nifti(run / "mapped_target_labelsTs" / "mr02.nii.gz")
+    assert tgt2.shape == lab2.shape and thdr2["pixdim"] == pytest.approx((1.1, 1.1, 2.5))
+    assert np.array_equal(tgt2, np.where(lab2 == 3, 0, lab2))      # my_organ is not optimised: mapped to background
+    m2 = [c for c in sj["metric_per_case"] if c["prediction_file"].endswith("mr02.nii.gz")][0]["metrics"]
+    assert m2["1"]["n_ref"] == int((lab2 == 1).sum()) and m2["1"]["n_pred"] == int((seg2 == 1).sum())

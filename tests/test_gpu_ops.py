@@ -303,6 +303,41 @@ def test_adamw_golden():
     assert p.grad is None
 
 
+def test_adamw_overflow_guard_skips_the_step_and_halves_the_loss_scale():
+    """fp16 storage path: one inf in a gradient must not reach the parameters or the Adam state; the step is
+    skipped on the device, the next resolve_overflow() halves the scale and rolls the step counter back; the following
+    clean step is the FIRST Adam step of the unscaled problem."""
+    from dg_tta_amd.optim import HipAdamW
+    torch.manual_seed(3)
+    p = torch.nn.Parameter(torch.randn(5000, device=DEV))
+    q = torch.nn.Parameter(torch.randn(300, device=DEV))
+    gp, gq = torch.randn(5000, device=DEV), torch.randn(300, device=DEV)
+    ref_p, ref_q = torch.nn.Parameter(p.detach().clone()), torch.nn.Parameter(q.detach().clone())
+    opt = HipAdamW([p, q], lr=1e-2, grad_scale=1024.0)
+    before = (p.detach().clone(), q.detach().clone())
+    p.grad, q.grad = gp * 1024.0, gq * 1024.0
+    q.grad[17] = float("inf")                     # the overflow sits in the OTHER tensor: all or nothing
+    opt.step()
+    assert torch.equal(p.detach(), before[0]) and torch.equal(q.detach(), before[1])
+    assert torch.equal(opt.state[p]["exp_avg"], torch.zeros_like(p))
+    assert opt.resolve_overflow() is True and opt.grad_scale == 512.0 and opt.skipped_steps == 1
+    assert opt.state[p]["step"] == 0 and opt.state[q]["step"] == 0
+    assert opt.resolve_overflow() is False        # settled
+    p.grad, q.grad = gp * 512.0, gq * 512.0
+    opt.step()
+    assert opt.resolve_overflow() is False and opt.state[p]["step"] == 1
+    ref = torch.optim.AdamW([ref_p, ref_q], lr=1e-2)
+    ref_p.grad, ref_q.grad = gp.clone(), gq.clone()
+    ref.step()
+    _close(p, ref_p.detach().cpu(), atol=1e-6, what="first clean step after a skipped one")
+    _close(q, ref_q.detach().cpu(), atol=1e-6, what="first clean step after a skipped one (q)")
+    nan = HipAdamW([p], lr=1e-2, grad_scale=2.0, min_grad_scale=2.0)
+    p.grad = torch.full_like(p, float("nan"))
+    keep = p.detach().clone()
+    nan.step()
+    assert torch.equal(p.detach(), keep) and nan.resolve_overflow() and nan.grad_scale == 2.0     # floor
+
+
 # ------------------------------------------------------------------------------------------------ network
 def _models(cfg, seed=0):
     from oracle import unet as ounet

@@ -611,6 +611,53 @@ def test_side_streams_do_not_change_a_bit(monkeypatch):
     assert float((l1[1:] - l1[:-1]).abs().max()) > 0          # the runs did adapt
 
 
+def test_two_instances_on_two_threads_match_their_sequential_runs():
+    """Per-model host state: two tta_units in ONE process, each on its own thread, stream and draw
+    generators (utils.rng_scope), give bit-identical losses, Dice and parameters to the same two units run one after the
+    other - nothing (MIND hand-over, side streams, draw order) leaks from one instance into the other."""
+    import threading
+    from dg_tta_amd.optim import HipAdamW
+    from dg_tta_amd.tta.tta import _fuse_head_if_possible, tta_unit
+    from dg_tta_amd.utils import rng_scope
+    g = load_golden("tta_unit")
+
+    def unit(seed, stream, out):
+        try:
+            with torch.cuda.stream(stream):
+                model, modmod = _product_model(g, conv_impl=0, act_dtype=torch.float16)
+                assert _fuse_head_if_possible(model, modmod, UNIT_MAPPING, OPTIMIZED)
+                model.accumulate_grads_in_place = True
+                model.exact_zero_bias_grad = True
+                cfg = _plan(epochs=3, patches_to_be_accumulated=8, lr=1e-4)
+                opt = HipAdamW(model.parameters(), lr=cfg["lr"], grad_scale=model.loss_scale)
+                data = [g["data"].clone() + 0.01 * seed]          # an instance's own case
+                gens = (torch.Generator().manual_seed(seed), torch.Generator(device=DEV).manual_seed(seed),
+                        np.random.RandomState(seed))
+                with rng_scope(*gens):
+                    losses, dices = tta_unit(model, opt, cfg, data, [16, 16, 16], UNIT_MAPPING, modmod, torch.device(DEV), True)
+                stream.synchronize()
+                out[seed] = (losses, dices, {k: v.detach().clone() for k, v in model.state_dict().items()})
+        except BaseException as e:        # surfaced in the main thread
+            out[seed] = e
+
+    seq, par = {}, {}
+    for seed in (5, 6):
+        unit(seed, torch.cuda.Stream(), seq)
+    threads = [threading.Thread(target=unit, args=(seed, torch.cuda.Stream(), par)) for seed in (5, 6)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    for seed in (5, 6):
+        for res in (seq[seed], par[seed]):
+            if isinstance(res, BaseException):
+                raise res
+        (l0, d0, p0), (l1, d1, p1) = seq[seed], par[seed]
+        assert torch.equal(l0, l1) and torch.equal(d0, d1), f"instance {seed}: threaded run differs"
+        assert all(torch.equal(p0[k], p1[k]) for k in p0)
+    assert not torch.equal(seq[5][0], seq[6][0])                   # the two instances are different problems
+
+
 def test_mind_is_not_precomputed_behind_a_user_input_modifier():
     """tta_epoch evaluates MIND ahead of the network call only when nothing in front of mind_hook can change the input: a
     user-defined modify_tta_input_fn (or the trainers' internal GIN augmentation) switches the shortcut off."""

@@ -8,6 +8,7 @@ import subprocess
 import sys
 from pathlib import Path
 
+import numpy as np
 import pytest
 import torch
 
@@ -247,3 +248,87 @@ def test_upload_async_cpu_passthrough():
     a, b = torch.arange(6.0).reshape(2, 3), torch.ones(5)
     out = upload_async([a, b], "cpu")
     assert torch.equal(out[0], a) and torch.equal(out[1], b) and out[0].shape == a.shape
+
+
+def test_data_iterator_loads_only_wanted_cases(tmp_path, monkeypatch):
+    """Multi-GPU runs: every rank walks the same file list but reads / preprocesses only the cases it works on
+    (VERDICT r2 weak #9); the others arrive as stubs so the indexing stays that of the plan's file list."""
+    raw, root, env = _make_nnunet_tree(tmp_path)
+    from dg_tta_amd.tta import nnunet_utils as nu
+    files = sorted(str(p) for p in (raw / "imagesTs").iterdir())
+    read = []
+    real = nu.preprocess_fromfile
+    monkeypatch.setattr(nu, "preprocess_fromfile", lambda f, *a, **k: (read.append(Path(f).name), real(f, *a, **k))[1])
+    asked = []
+    it, n = nu.load_tta_data({"tta_data_filepaths": files}, raw, wanted=lambda i, tot: (asked.append((i, tot)), i % 2 == 1)[1])
+    items = list(it)
+    assert n == 2 and asked == [(0, 2), (1, 2)]
+    assert len(read) == 1 and read[0].startswith("caseB")
+    assert items[0].get("skipped") and "data" not in items[0] and items[0]["ofile"] == "tta_outputTs/caseA"
+    assert items[1]["data"].shape[0] == 3
+    # stubs go through the sample bookkeeping of tta_main unharmed
+    from dg_tta_amd.tta.tta import get_sample_specs
+    sample, tens, sid, ext, sub = get_sample_specs({"tta_data_filepaths": files}, 0, iter(items), tmp_path)
+    assert sid == "tta_outputTs/caseA" and tens == [None]
+
+
+def test_rng_scope_gives_a_thread_its_own_draw_stream():
+    """Two TTA instances in one process: inside rng_scope every host-side draw of the path comes from the
+    scope's generators; outside, from the global ones exactly as the reference draws."""
+    import threading
+    from dg_tta_amd.gin import draw_gin_params
+    from dg_tta_amd.tta.augmentation_utils import get_rand_affine
+    from dg_tta_amd.utils import numpy_rng, rng_scope
+
+    def draws():
+        a, ks, kers, shifts = draw_gin_params(1, "cpu")
+        r, _ = get_rand_affine(1)
+        return [a] + kers + shifts + [r, torch.as_tensor(numpy_rng().choice(range(100), 4))], ks
+
+    torch.manual_seed(5)
+    np.random.seed(5)
+    ref, ref_ks = draws()
+    torch.manual_seed(5)
+    np.random.seed(5)
+    again, _ = draws()
+    assert all(torch.equal(x, y) for x, y in zip(ref, again))
+    out = {}
+
+    def worker(name, seed):
+        g = torch.Generator().manual_seed(seed)
+        with rng_scope(cpu=g, device=g, numpy=np.random.RandomState(seed)):
+            out[name] = [draws() for _ in range(3)]
+
+    threads = [threading.Thread(target=worker, args=(n, s)) for n, s in (("a", 11), ("b", 12), ("a2", 11))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    for (xa, ka), (xb, kb) in zip(out["a"], out["a2"]):          # same seeds -> same stream, whatever the interleaving
+        assert ka == kb and all(torch.equal(p, q) for p, q in zip(xa, xb))
+    assert not all(torch.equal(p, q) for p, q in zip(out["a"][0][0], out["b"][0][0]) if p.shape == q.shape)
+    torch.manual_seed(5)
+    np.random.seed(5)
+    after, _ = draws()                                            # the global generators were not touched by the scopes
+    assert all(torch.equal(x, y) for x, y in zip(ref, after))
+
+
+def test_mind_hand_over_is_per_model():
+    from dg_tta_amd import mind as hmind
+    from dg_tta_amd._state import state_of
+    m1, m2 = torch.nn.Identity(), torch.nn.Identity()
+    for m in (m1, m2):
+        m.register_forward_pre_hook(hmind.mind_hook)
+    n1, n2 = torch.zeros(2, 12, 4, 4, 4), torch.ones(2, 12, 4, 4, 4)
+    hmind.push_noise(m1, n1, groups=2)
+    hmind.push_features(m2, n2)
+    assert state_of(m1).noise[0][0] is n1 and not state_of(m2).noise and state_of(m2).features[0] is n2
+    out = hmind.mind_hook(m2, (torch.zeros(2, 1, 4, 4, 4),))      # m2 takes ITS descriptor, m1's noise stays queued
+    assert out is n2 and len(state_of(m1).noise) == 1
+    hmind.clear_noise(m1)
+    assert not state_of(m1).noise
+    with hmind.mind_groups(m1, 3):
+        assert state_of(m1).forced_groups == 3 and state_of(m2).forced_groups is None
+    assert state_of(m1).forced_groups is None
+    import copy
+    assert state_of(copy.deepcopy(m1)) is not state_of(m1)         # a per-member copy starts with fresh state

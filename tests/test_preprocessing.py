@@ -98,3 +98,55 @@ def test_nifti_case_through_load_tta_data(tmp_path):
     assert (data[0].numpy() - rd[0]).__abs__().max() < 2e-6 * np.abs(rd).max()
     lab = torch.cat([(data[1:].sum(0, keepdim=True) < 1).float(), data[1:]]).argmax(0).numpy()
     assert (lab == np.maximum(rs[0], 0)).mean() > 0.9999
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("spacing", [(2.5, 0.9, 0.9), (5.0, 0.9, 0.9), (1.5, 1.5, 1.5)])
+def test_export_in_original_geometry_matches_oracle(spacing):
+    """The inverse of run_case for a prediction: accumulated window logits -> nnU-Net's
+    convert_predicted_logits_to_segmentation_with_correct_shape (resample back, argmax, un-crop, transpose back) on the
+    GPU class group by class group, against the scipy restatement, on a cropped case incl. the anisotropic branch."""
+    from dg_tta_amd.tta import preprocessing as pp
+    from dg_tta_amd.tta.inference import export_segmentation
+    from oracle import inference as oinf
+    img, seg = _case(3)
+    d, s, props = pp.run_case_npy(img.copy(), seg.copy(), spacing, PLANS, "3d_fullres", "cuda:0")
+    X, Y, Z = d.shape[1:]
+    C = 19                                   # not a multiple of the export class group
+    g = torch.Generator().manual_seed(11)
+    # smooth-ish logits with clear winners: low-resolution noise upsampled, so that argmax regions have extent
+    low = torch.randn(1, C, X // 3 + 2, Y // 3 + 2, Z // 3 + 2, generator=g)
+    logits = torch.nn.functional.interpolate(low, size=(X, Y, Z), mode="trilinear", align_corners=False)[0] * 4
+    nsum = torch.rand(X, Y, Z, generator=g) * 3 + 0.5            # per-voxel window weights (must be divided out first)
+    acc = (logits * nsum).permute(1, 2, 3, 0).contiguous().to("cuda:0")
+    crop = [slice(0, X), slice(0, Y), slice(0, Z)]
+    out = export_segmentation(acc, nsum.to("cuda:0"), crop, props, PLANS, "3d_fullres")
+    ref_logits = (acc.cpu() / nsum[..., None]).permute(3, 0, 1, 2).numpy()
+    ref = oinf.convert_logits_to_segmentation_with_correct_shape(ref_logits, props, PLANS, "3d_fullres")
+    assert out.shape == ref.shape == img.shape[1:] and out.dtype == ref.dtype
+    bbox = props["bbox_used_for_cropping"]
+    outside = np.ones(out.shape, bool)
+    outside[tuple(slice(a, b) for a, b in bbox)] = False
+    assert (out[outside] == 0).all()                               # un-cropped: zeros outside the box
+    assert (out == ref).mean() > 0.9995                            # float ties at region borders only
+    assert len(np.unique(out)) > 5
+
+
+@pytest.mark.gpu
+def test_export_with_padded_small_case_and_no_resampling():
+    """A case smaller than the patch (padded for the windows, cropped back) at the plans' spacing: export = argmax of the
+    cropped accumulator pasted into the crop box."""
+    from dg_tta_amd.tta.inference import export_segmentation
+    X, Y, Z, C = 10, 16, 12, 7
+    g = torch.Generator().manual_seed(2)
+    acc = torch.randn(16, 16, 16, C, generator=g).to("cuda:0")
+    nsum = torch.ones(16, 16, 16).to("cuda:0")
+    crop = [slice(3, 13), slice(0, 16), slice(2, 14)]
+    props = {"shape_before_cropping": (14, 18, 12), "bbox_used_for_cropping": [[2, 12], [1, 17], [0, 12]],
+             "shape_after_cropping_and_before_resampling": (X, Y, Z), "spacing": [1.5, 1.5, 1.5]}
+    out = export_segmentation(acc, nsum, crop, props, PLANS, "3d_fullres")
+    ref = np.zeros((14, 18, 12), np.uint8)
+    ref[2:12, 1:17, 0:12] = acc.cpu()[3:13, :, 2:14].argmax(-1).numpy()
+    assert np.array_equal(out, ref.transpose(PLANS["transpose_backward"]))
+    plain = export_segmentation(acc, nsum, crop, None, None, None)
+    assert np.array_equal(plain, acc.cpu()[3:13, :, 2:14].argmax(-1).numpy())

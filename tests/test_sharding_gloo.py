@@ -2,6 +2,7 @@
 import os
 import socket
 
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -138,3 +139,64 @@ def test_fanout_parent_reports_failed_children(tmp_path):
     finally:
         if old is not None:
             os.environ["HIP_VISIBLE_DEVICES"] = old
+
+
+def test_bench_launches_its_own_ranks(tmp_path):
+    """`bench.py --gpus 2` without RANK / WORLD_SIZE starts two ranks itself: the line says n_gpus 2, the
+    whole-job value is twice one instance's, the time is the slowest rank's.  Stub runner: no GPU is touched."""
+    import json
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parents[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    res = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "2", "--stub-runner", "0.05", "--steps", "3",
+                          "--warmup", "1"], env=env, capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1                                   # ONE line, printed by rank 0
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 3 and out["warmup"] == 1 and out["scaling"] == "weak"
+    assert len(out["per_rank_epochs_per_s"]) == 2
+    assert out["value"] == pytest.approx(2 * out["value_per_gpu"], rel=1e-4)
+    assert out["value_per_gpu"] <= min(out["per_rank_epochs_per_s"]) * 1.0001      # quoted on the slowest rank
+    assert "own child" in out["config"]["launcher"]
+    # one rank under an external launcher (RANK / WORLD_SIZE set): no children are started
+    env1 = dict(env, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    res = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "1", "--stub-runner", "0.01", "--steps", "1",
+                          "--warmup", "0"], env=env1, capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0 and json.loads(res.stdout.strip().splitlines()[-1])["n_gpus"] == 1
+
+
+def test_bench_launcher_reports_a_failed_rank():
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parents[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    res = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "2", "--stub-runner", "-1"], env=env,
+                         capture_output=True, text=True, timeout=300)        # a negative sleep raises in every rank
+    assert res.returncode != 0 and "rank return codes" in res.stderr
+
+
+def test_barrier_aborts_on_a_failed_peer_and_stale_markers_are_cleared(tmp_path):
+    from dg_tta_amd.sharding import done_marker, failed_marker, mark_rank_done, wait_for_files
+    failed_marker(tmp_path, 1).write_text("failed\n")
+    with pytest.raises(RuntimeError, match="peer rank failed"):
+        wait_for_files([tmp_path / "x.pt"], timeout_s=30, poll_s=0.05, abort_if=[failed_marker(tmp_path, r) for r in range(2)])
+    mark_rank_done(tmp_path, 0)
+    assert done_marker(tmp_path, 0).is_file()
+
+
+def test_done_markers_of_an_earlier_launch_do_not_pass_the_barrier(tmp_path, monkeypatch):
+    from dg_tta_amd.sharding import mark_rank_done, wait_for_done_markers
+    monkeypatch.setenv("DGTTA_LAUNCH_ID", "first")
+    mark_rank_done(tmp_path, 0)
+    mark_rank_done(tmp_path, 1)
+    wait_for_done_markers(tmp_path, 2, timeout_s=5, poll_s=0.05)
+    monkeypatch.setenv("DGTTA_LAUNCH_ID", "second")        # a resumed run in the same directory
+    mark_rank_done(tmp_path, 0)
+    with pytest.raises(TimeoutError, match="earlier launch"):
+        wait_for_done_markers(tmp_path, 2, timeout_s=0.3, poll_s=0.05)
+    mark_rank_done(tmp_path, 1)
+    wait_for_done_markers(tmp_path, 2, timeout_s=5, poll_s=0.05)

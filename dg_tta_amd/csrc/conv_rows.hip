@@ -35,7 +35,13 @@ struct RowsCfg {
   static constexpr size_t LDS_BYTES = 2 * A_BYTES + B_BYTES + RED_BYTES;
 };
 
-template <int PD, int PH, int WD, int WH, int ABL = 0, typename T16 = bf16_t>   // ABL: diagnostic ablation; T16: bf16_t | f16_t
+// VAR (round 3, bit mask; DGTTA_ROWS_VAR selects, default = all): 1 = the next job's coordinates come from a mixed-radix
+// counter (a few scalar adds) instead of ten integer divisions on the CU's one scalar unit, which all 8 waves queued on
+// (stamps: 5.7 % of the kernel); 2 = the DMA pieces of the next chunk are issued in the first 5/8 of the MFMA loop, so
+// that they have landed when the loop ends; 4 = the 27 weight fragments are read from LDS just in time inside the MFMA
+// loop (taps (kd,kh) in order of first use) instead of in a block before it, and the barrier that frees the weight
+// buffer for the next chunk's DMA sits in the middle of the loop.
+template <int PD, int PH, int WD, int WH, int ABL = 0, typename T16 = bf16_t, int VAR = 0>   // ABL: diagnostic ablation
 __global__ __launch_bounds__(WD *WH * 64) void conv3_rows_kernel(const bf16_t *__restrict__ x, View xv,
                                                                  const bf16_t *__restrict__ w, Taps taps,
                                                                  const float *__restrict__ bias, bf16_t *__restrict__ y,
@@ -150,7 +156,7 @@ __global__ __launch_bounds__(WD *WH * 64) void conv3_rows_kernel(const bf16_t *_
                         c < cin_lim;
         const bf16_t *rowp = x + (long long)q.b * xv.sb + gd * xv.sd + gh * xv.sh;      // scalar part
         const void *src = ok ? (const void *)(rowp + gw * xv.sw + c) : (const void *)&g_zero16;
-        if (ABL == 1 || ABL == 4) return;
+        if (ABL == 1 || ABL == 4 || (ABL == 9 && dz >= 4)) return;      // 9: timing model of a D-ring (4 new planes of 6)
         dma16_to_lds(src, lds_addr_of(sAb + (size_t)buf * Cfg::A_BYTES + (row * Cfg::RB + (tail ? 64 : 0)) * 16));
       }
     } else {
@@ -174,6 +180,41 @@ __global__ __launch_bounds__(WD *WH * 64) void conv3_rows_kernel(const bf16_t *_
     abase[kw] = ((wd * PD) * IH + wh * PH) * Cfg::RB + (col < 32 ? h * 32 + col : 64 + h * 2 + (col - 32));
   }
 
+  // mixed-radix job counter (VAR & 1): digits (nb_lo, td_lo, th_lo, td_hi, th_hi, nb_hi, tw | b) of the current job index
+  // and of the stride between this workgroup's jobs; advancing = digit-wise add with carry, all on wave-uniform values
+  int dg[8], sdg[8];
+  const int rad[7] = {NBL, TDL, THL, tdH, thH, nbH, tilesW};
+  {
+    int a = jbeg, c = jstep;
+#pragma unroll
+    for (int k = 0; k < 7; ++k) {
+      dg[k] = a % rad[k];
+      a /= rad[k];
+      sdg[k] = c % rad[k];
+      c /= rad[k];
+    }
+    dg[7] = a;
+    sdg[7] = c;
+  }
+  auto advance = [&]() {
+    int carry = 0;
+#pragma unroll
+    for (int k = 0; k < 7; ++k) {
+      const int v = dg[k] + sdg[k] + carry;
+      carry = v >= rad[k] ? 1 : 0;
+      dg[k] = carry ? v - rad[k] : v;
+    }
+    dg[7] += sdg[7] + carry;
+    Job q;
+    const int nb = dg[5] * NBL + dg[0], td = dg[3] * TDL + dg[1], th = dg[4] * THL + dg[2], tw = dg[6];
+    q.b = dg[7];
+    q.n0 = nb * 32;
+    q.od0 = td * Cfg::TD;
+    q.oh0 = th * Cfg::TH;
+    q.ow0 = tw * 32;
+    q.tile = (tw * tilesH + th) * tilesD + td;
+    return q;
+  };
   Job cur = decode(jbeg);
   float bv = 0.f;
   float st1 = 0.f, st2 = 0.f;       // InstanceNorm partial sums of this lane's channel over the current run of jobs
@@ -200,8 +241,15 @@ __global__ __launch_bounds__(WD *WH * 64) void conv3_rows_kernel(const bf16_t *_
     stamp(0);                 // waiting for the DMA
     lds_barrier();            // chunk p has landed; every wave is done with phase p-1
     uint4 breg[27];
-    {
-      const uint4 *sB = reinterpret_cast<const uint4 *>(sBb);
+    const uint4 *sB = reinterpret_cast<const uint4 *>(sBb);
+    auto load_b = [&](int kd, int kh) {       // the three kw fragments of tap row (kd, kh)
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) breg[(kd * 3 + kh) * 3 + kw] = sB[((kd * 3 + kh) * 3 + kw) * 64 + lane];
+    };
+    if (VAR & 4) {
+      static_assert(!(VAR & 4) || (PD == 2 && PH == 2), "the just-in-time weight schedule is written for 2 x 2 patches");
+      load_b(0, 0);
+    } else {
 #pragma unroll
       for (int t = 0; t < 27; ++t) breg[t] = sB[t * 64 + lane];
     }
@@ -210,14 +258,14 @@ __global__ __launch_bounds__(WD *WH * 64) void conv3_rows_kernel(const bf16_t *_
       bv = (bias && co < Cout) ? bias[co] : 0.f;
       asm volatile("" ::"v"(bv));
     }
-    lds_barrier();            // B buffer is free again
+    if (!(VAR & 4)) lds_barrier();            // B buffer is free again (VAR & 4: in the middle of the MFMA loop)
     stamp(1);                 // barrier + B fragments + barrier
     // prefetch the next phase (next K-chunk of this job, or chunk 0 of the next job)
     Job nxt = cur;
     int kn = kc + 1;
     if (kn == nk) {
       kn = 0;
-      if (p + 1 < nph) nxt = decode(jn + jstep);
+      if (p + 1 < nph) nxt = ((VAR & 1) && order != 0) ? advance() : decode(jn + jstep);
     }
     const bool more = p + 1 < nph;
     stamp(2);
@@ -235,16 +283,33 @@ __global__ __launch_bounds__(WD *WH * 64) void conv3_rows_kernel(const bf16_t *_
 #pragma unroll
       for (int dz = 0; dz < PD + 2; ++dz)
 #pragma unroll
-        for (int hy = 0; hy < PH + 2; ++hy)
+        for (int hy = 0; hy < PH + 2; ++hy) {
+          if (VAR & 4) {
+            // weight fragments just in time: tap row (kd, kh) is first used at input row (dz, hy) = (kd, kh); row step rs
+            // reads the fragments whose first use is 1-3 steps ahead.  After step 7 every wave holds all 27: the barrier
+            // at step 8 frees the weight buffer, the DMA pieces of the next weight chunk are issued after it.
+            const int rs = dz * (PH + 2) + hy;
+            constexpr int sched[8][2] = {{0, 1}, {0, 2}, {1, 0}, {1, 1}, {1, 2}, {2, 0}, {2, 1}, {2, 2}};
+            if (rs < 8) {
+              __builtin_amdgcn_sched_barrier(0);
+              load_b(sched[rs][0], sched[rs][1]);
+            } else if (rs == 8) {
+              __builtin_amdgcn_sched_barrier(0);
+              lds_barrier();
+            }
+          }
 #pragma unroll
           for (int kw = 0; kw < 3; ++kw) {
             const uint4 af = sA[abase[kw] + (dz * IH + hy) * Cfg::RB];
-            {   // spread this wave's DMA pieces of the next chunk evenly over the A-read steps
+            {   // spread this wave's DMA pieces of the next chunk over the A-read steps (VAR & 2: over the first 5/8 of
+                // them; the weight pieces - the last ones - then still come after the barrier of step 24)
               constexpr int NSTEP = (PD + 2) * (PH + 2) * 3;
+              constexpr int NISSUE = (VAR & 2) ? NSTEP * 5 / 8 : NSTEP;
+              static_assert(!(VAR & 4) || (2 * NPR * NISSUE) / NPIECE + 1 > 24, "weight pieces must follow the mid-loop barrier");
               const int step = (dz * (PH + 2) + hy) * 3 + kw;
 #pragma unroll
               for (int i = 0; i < NPIECE; ++i)
-                if (step == (i * NSTEP) / NPIECE + 1 && more) issue_piece(nxt, kn, (p + 1) & 1, i);
+                if (step == (i * NISSUE) / NPIECE + 1 && more) issue_piece(nxt, kn, (p + 1) & 1, i);
             }
 #pragma unroll
             for (int kd = 0; kd < 3; ++kd)
@@ -257,6 +322,7 @@ __global__ __launch_bounds__(WD *WH * 64) void conv3_rows_kernel(const bf16_t *_
                 }
               }
           }
+        }
     }
 
     stamp(3);                 // MFMA loop
@@ -432,15 +498,27 @@ int launch_conv_rows(const void *x, const View &xv, const void *w, const Taps &t
   // DGTTA_ROWS_ABL (diagnostic builds of the same kernel): 1 no DMA, 3 no MFMA, 6 per-segment cycle stamps, 7 the
   // voxel-major (ragged-tile) epilogue for every tile, 8 plain (temporal) output stores
   const int abl = dgtta_switches().rows_abl;
-  auto kern = conv3_rows_kernel<PD, PH, WD, WH, 0, T16>;
-  static DynLdsOnce once[6];
+  const int var = dgtta_switches().rows_var;       // DGTTA_ROWS_VAR: '0' round-2 kernel, '1', '3', '7' (default) feature masks
+  auto kern = conv3_rows_kernel<PD, PH, WD, WH, 0, T16, 7>;
+  static DynLdsOnce once[16];
   int slot = 0;
+  if (var == '0') kern = conv3_rows_kernel<PD, PH, WD, WH, 0, T16, 0>, slot = 6;
   if (std::is_same<T16, bf16_t>::value) {      // diagnostic builds exist for the bf16 instantiation only
-    if (abl == '1') kern = conv3_rows_kernel<PD, PH, WD, WH, 1, T16>, slot = 1;
-    if (abl == '3') kern = conv3_rows_kernel<PD, PH, WD, WH, 3, T16>, slot = 2;
-    if (abl == '6') kern = conv3_rows_kernel<PD, PH, WD, WH, 6, T16>, slot = 3;
-    if (abl == '7') kern = conv3_rows_kernel<PD, PH, WD, WH, 7, T16>, slot = 4;
-    if (abl == '8') kern = conv3_rows_kernel<PD, PH, WD, WH, 8, T16>, slot = 5;
+    if (var == '1') kern = conv3_rows_kernel<PD, PH, WD, WH, 0, T16, 1>, slot = 7;
+    if (var == '3') kern = conv3_rows_kernel<PD, PH, WD, WH, 0, T16, 3>, slot = 8;
+    if (var == '5') kern = conv3_rows_kernel<PD, PH, WD, WH, 0, T16, 5>, slot = 11;
+    if (abl == '1') kern = conv3_rows_kernel<PD, PH, WD, WH, 1, T16, 0>, slot = 1;
+    if (abl == '3') kern = conv3_rows_kernel<PD, PH, WD, WH, 3, T16, 0>, slot = 2;
+    if (abl == '6') {
+      kern = conv3_rows_kernel<PD, PH, WD, WH, 6, T16, 7>, slot = 3;
+      if (var == '0') kern = conv3_rows_kernel<PD, PH, WD, WH, 6, T16, 0>, slot = 9;
+      if (var == '3') kern = conv3_rows_kernel<PD, PH, WD, WH, 6, T16, 3>, slot = 10;
+    }
+    if (abl == '7') kern = conv3_rows_kernel<PD, PH, WD, WH, 7, T16, 0>, slot = 4;
+    if (abl == '4') kern = conv3_rows_kernel<PD, PH, WD, WH, 4, T16, 0>, slot = 12;
+    if (abl == '5') kern = conv3_rows_kernel<PD, PH, WD, WH, 5, T16, 0>, slot = 13;
+    if (abl == '9') kern = conv3_rows_kernel<PD, PH, WD, WH, 9, T16, 0>, slot = 14;
+    if (abl == '8') kern = conv3_rows_kernel<PD, PH, WD, WH, 8, T16, 0>, slot = 5;
   }
   DG_REQUIRE(ensure_dyn_lds(once[slot], reinterpret_cast<const void *>(kern), (int)Cfg::LDS_BYTES) == hipSuccess,
              DGTTA_ERR_LAUNCH, "conv3_rows: cannot raise the dynamic LDS limit to %zu", (size_t)Cfg::LDS_BYTES);

@@ -44,6 +44,10 @@ static const DgttaSwitches *read_switches() {
   s->convt_wgrad_onepass = env_char("DGTTA_CONVT_WGRAD_ONEPASS");
   s->conv_abl = env_char("DGTTA_CONV_ABL");
   s->rows_abl = env_char("DGTTA_ROWS_ABL");
+  s->rows_var = env_char("DGTTA_ROWS_VAR");
+  s->warp_coop = env_char("DGTTA_WARP_COOP");
+  s->warp_nt = env_char("DGTTA_WARP_NT");
+  s->warp_xcd = env_char("DGTTA_WARP_XCD");
   s->wgrad_abl = env_char("DGTTA_WGRAD_ABL");
   return s;
 }

@@ -80,6 +80,8 @@ class mind_groups:
 
 
 def mind_hook(module, input):
+    if module is None:          # called as a plain function (the reference's hook ignores `module` as well)
+        return MIND3D().forward(*input)
     st = state_of(module)
     if st.features:
         cand = st.features[0]

@@ -97,12 +97,14 @@ def test_one_pass_batch8_128_every_storage_type_vs_fp32_valu():
     del ref_r
     torch.cuda.empty_cache()
     rng = float(ref_logits.max() - ref_logits.min())
-    assert len(ref_grads) > 100 and ref_logits.shape == (8, 16, 128, 128, 128)
+    assert len(ref_grads) > 60 and ref_logits.shape == (8, 16, 128, 128, 128)
     report = {"fp32_valu_seconds": round(t_ref, 1), "loss_fp32_valu": ref_loss, "logit_range": rng}
     # bias gradients in front of InstanceNorm are exact zeros in the product setting: excluded by _grad_stats (max == 0)
-    limits = {"fp32": dict(logit=2e-4, loss=2e-5, cos=0.999, sign=0.99),
-              "fp16": dict(logit=6e-3, loss=2e-4, cos=0.97, sign=0.93),
-              "bf16": dict(logit=4e-2, loss=1e-3, cos=0.80, sign=0.75)}
+    # measured (profiles/r03_at_size_parity.json): fp32 MFMA 3.4e-6 / 6e-8 / 0.99997 / 0.992, fp16 1.6e-3 / 3e-7 / 0.987 /
+    # 0.943, bf16 1.3e-2 / 1.5e-5 / 0.901 / 0.827 (logit error over range / loss delta / min gradient cosine / min sign agreement)
+    limits = {"fp32": dict(logit=2e-5, loss=2e-6, cos=0.9999, sign=0.98),
+              "fp16": dict(logit=5e-3, loss=2e-5, cos=0.97, sign=0.92),
+              "bf16": dict(logit=4e-2, loss=2e-4, cos=0.85, sign=0.78)}
     for dtype in ("fp32", "fp16", "bf16"):
         r = _runner(dtype, impl=0)
         logits, loss, dice, grads = _one_pass(r, 77)
@@ -164,5 +166,98 @@ def test_adaptation_epochs_128_dice_delta_of_the_default_storage_type():
         assert max(d["pseudo_dice_delta_per_epoch"]) < TOL
         assert d["hard_dice_mean_delta"] < TOL
         assert d["skipped_steps"] == 0
+        assert d["label_agreement"] > 0.99          # measured 0.9967 for fp16 (bf16: 0.9765) on He-init, near-tied logits
     # bf16 (8 mantissa bits) is reported, and must at least track the soft quantities
     assert max(report["bf16"]["loss_delta_per_epoch"]) < 5e-3
+
+
+def _volume_512(k=15):
+    """BASELINE config 3's input: a 512^3 "CT" with k label channels, [1+k, 512, 512, 512] fp32 on the host (8.6 GB)."""
+    g = torch.Generator().manual_seed(33)
+    n = 512
+    low = torch.randn(1, 1, 34, 34, 34, generator=g)
+    img = torch.nn.functional.interpolate(low, size=(n, n, n), mode="trilinear", align_corners=False)[0, 0]
+    data = torch.empty((1 + k, n, n, n), dtype=torch.float32)
+    data[0] = img
+    # labels: 64^3 blocks numbered 0..k in a fixed pattern (every label present in every 128^3 patch neighbourhood)
+    ax = torch.arange(n) // 64
+    lab = ((ax[:, None, None] * 5 + ax[None, :, None] * 3 + ax[None, None, :]) % (k + 1)).to(torch.int16)
+    for i in range(k):
+        data[1 + i] = (lab == i + 1)
+    return data, lab
+
+
+def test_config3_tta_epoch_from_a_512_cubed_resident_volume():
+    """BASELINE config 3 at size, TTA side: patches sampled from a 512^3 volume with 15 label channels that stays
+    resident in HBM (0.5 GB image + label map), one adaptation epoch of the product's tta_epoch (full net, 128^3 patches,
+    16 accumulation steps) and its evaluation against the label channels."""
+    bench = _bench()
+    from dg_tta_amd.tta.torch_utils import _VOLUME_CACHE, get_batch, release_resident
+    data, lab = _volume_512()
+    r = _runner(bench.parse_args([]).dtype)
+    r.data = [data]
+    torch.manual_seed(5)
+    np.random.seed(5)
+    # the sampler: label patches are bit-exact crops for the centre patch (nearest sampling of an aligned grid)
+    imgs, labels = get_batch(r.data, [0], r.patch, fixed_patch_idx="center", device=DEV)
+    assert tuple(imgs[0].shape) == (1, 1, 128, 128, 128) and labels[0].dtype == torch.int64
+    assert torch.equal(labels[0][0, 0].cpu(), lab[192:320, 192:320, 192:320].long())
+    assert torch.allclose(imgs[0][0, 0].cpu(), data[0, 192:320, 192:320, 192:320], atol=1e-5)
+    assert len(_VOLUME_CACHE) == 1
+    before = {n: p.detach().clone() for n, p in list(r.model.named_parameters())[:4]}
+    r.epoch()
+    r.epoch()
+    assert np.isfinite(r.losses).all() and 0.0 < r.losses[-1] < 1.0 and np.isfinite(r.dices).all()
+    assert any(not torch.equal(before[n], p.detach()) for n, p in list(r.model.named_parameters())[:4])
+    assert len(_VOLUME_CACHE) == 1               # uploaded once, sampled 2 x (16 + 1) times
+    release_resident(r.data)
+    assert len(_VOLUME_CACHE) == 0
+
+
+def test_config3_sliding_window_512_cubed_properties():
+    """BASELINE config 3 at size, inference side: 512^3 volume, 128^3 Gaussian windows at step 0.5 -> 7^3 = 343 windows, all
+    105 classes accumulated in fp32 (52.5 GiB).  Size-independent properties: the accumulated weight map is the sum of the
+    window Gaussians; a region covered by ONE window equals the plain forward of that window; the label map is the argmax
+    over all 105 classes of the accumulator."""
+    from dg_tta_amd import ops
+    from dg_tta_amd.mind import MIND3D
+    from dg_tta_amd.run import DEFAULT_DTYPE
+    from dg_tta_amd.synthetic import he_init_
+    from dg_tta_amd.tta.inference import (compute_gaussian, compute_steps_for_sliding_window, export_segmentation,
+                                          predict_sliding_window_return_logits)
+    from dg_tta_amd.unet import HipPlainConvUNet
+    adt = {"fp16": torch.float16, "bf16": torch.bfloat16, "fp32": torch.float32}[DEFAULT_DTYPE]
+    net = he_init_(HipPlainConvUNet(act_dtype=adt), seed=7).to(DEV)
+    net.register_forward_pre_hook(lambda mod, inp: MIND3D(randn_weighting=0.0).forward(*inp, out_dtype=adt))
+    patch = [128, 128, 128]
+    vol = torch.randn(1, 512, 512, 512, generator=torch.Generator().manual_seed(3)).to(DEV)
+    acc, nsum, crop = predict_sliding_window_return_logits(net, vol, patch)
+    assert tuple(acc.shape) == (512, 512, 512, 105) and acc.dtype == torch.float32
+    steps = compute_steps_for_sliding_window((512, 512, 512), patch)
+    assert steps == [[0, 64, 128, 192, 256, 320, 384]] * 3
+    # (a) weight map: separable check - the Gaussian is a product of 1-D profiles only approximately (it is a 3-D filter of
+    # a delta), so the reference map is accumulated on the GPU from the same window origins
+    g = compute_gaussian(tuple(patch)).to(DEV)
+    ref_n = torch.zeros((512, 512, 512), device=DEV)
+    for sx in steps[0]:
+        for sy in steps[1]:
+            for sz in steps[2]:
+                ref_n[sx:sx + 128, sy:sy + 128, sz:sz + 128] += g
+    assert float((nsum - ref_n).abs().max()) < 1e-4 * float(ref_n.max())
+    del ref_n
+    # (b) the corner [0:64]^3 is covered by the first window only
+    with torch.no_grad():
+        first = net(vol[None, :, :128, :128, :128]).float()[0]
+    corner = (acc[:64, :64, :64] / nsum[:64, :64, :64, None]).permute(3, 0, 1, 2)
+    assert float((corner - first[:, :64, :64, :64]).abs().max()) < 1.5e-2 * float(first.abs().max())
+    del corner, first
+    # (c) label map = argmax over all 105 classes (checked on a slab: the full top-2 of 52 GiB is not needed for the point)
+    seg = export_segmentation(acc, nsum, crop, None, None, None)
+    assert seg.shape == (512, 512, 512)
+    slab = acc[200:232]
+    am = slab.argmax(-1).cpu()
+    top2 = slab.topk(2, dim=-1).values
+    safe = ((top2[..., 0] - top2[..., 1]) > 1e-3 * nsum[200:232]).cpu()
+    got = torch.from_numpy(seg[200:232].astype(np.int64))
+    assert torch.equal(got[safe], am[safe]) and float((got == am).float().mean()) > 0.999
+    assert len(np.unique(seg[::16, ::16, ::16])) > 20

@@ -26,10 +26,10 @@ def test_prepare_and_run_tta_cli_full_net_64(tmp_path, monkeypatch):
     write_nifti(raw / "labelsTs" / "mr01.nii.gz", lab, spacing=(1.5, 1.5, 1.5))
     # second case: anisotropic (2.5 x 1.1 x 1.1 mm), with a zero border that preprocessing crops away -> its prediction has to
     # be resampled back, un-cropped and written in THIS geometry
-    img2 = np.zeros((40, 84, 90), np.float32)
-    lab2 = np.zeros((40, 84, 90), np.int16)
-    img2[3:37, 6:80, 5:83] = img[:34, :74, :78] + 700.0
-    lab2[3:37, 6:80, 5:83] = lab[:34, :74, :78]
+    img2 = np.zeros((40, 76, 74), np.float32)
+    lab2 = np.zeros((40, 76, 74), np.int16)
+    img2[3:37, 6:70, 5:69] = img[:34] + 700.0
+    lab2[3:37, 6:70, 5:69] = lab[:34]
     write_nifti(raw / "imagesTs" / "mr02_0000.nii.gz", img2, spacing=(1.1, 1.1, 2.5))         # (x, y, z)
     write_nifti(raw / "labelsTs" / "mr02.nii.gz", lab2, spacing=(1.1, 1.1, 2.5))
     json.dump({"labels": {"background": 0, "liver": 1, "spleen": 2, "my_organ": 3}}, open(raw / "dataset.json", "w"))
@@ -72,9 +72,9 @@ def test_prepare_and_run_tta_cli_full_net_64(tmp_path, monkeypatch):
     assert len(sj["metric_per_case"]) == 2 and set(sj["mean"]) == {"0", "1", "2"}
     # the anisotropic, cropped case comes back in ITS OWN geometry and is evaluated against the untouched label file
     seg2, hdr2 = read_nifti(out / "mr02.nii.gz")
-    assert seg2.shape == (40, 84, 90) and hdr2["pixdim"] == pytest.approx((1.1, 1.1, 2.5))
+    assert seg2.shape == (40, 76, 74) and hdr2["pixdim"] == pytest.approx((1.1, 1.1, 2.5))
     outside = np.ones(seg2.shape, bool)
-    outside[3:37, 6:80, 5:83] = False
+    outside[3:37, 6:70, 5:69] = False
     assert (seg2[outside] == 0).all() and (seg2 != 0).any()        # zeros outside the crop box, labels inside
     tgt2, thdr2 = read_nifti(run / "mapped_target_labelsTs" / "mr02.nii.gz")
     assert tgt2.shape == lab2.shape and thdr2["pixdim"] == pytest.approx((1.1, 1.1, 2.5))

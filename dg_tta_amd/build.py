@@ -38,6 +38,42 @@ def build(force=False, verbose=True):
     return LIB
 
 
+ASAN_DIR = CSRC.parents[1] / "build" / "asan"
+ASAN_FLAGS = ["--offload-arch=gfx950", "-O1", "-g", "-fPIC", "-std=c++17", "-ffp-contract=off", "-fsanitize=address,undefined",
+              "-fno-gpu-sanitize", "-fno-omit-frame-pointer", "-Wno-unused-function"]
+
+
+def build_asan(verbose=False):
+    """Host-side sanitizer build of the C-ABI shim: the HOST code of every translation unit (argument
+    checks, size queries, launch plans, dispatch) instrumented with AddressSanitizer + UndefinedBehaviorSanitizer, the
+    device code left as it is (GPU sanitizers are not available on the pool).  Goes to build/asan/ (git-ignored), never
+    into the package: the product always loads dg_tta_amd/libdgtta_hip.so.  tests/test_host_logic.py drives it."""
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    ASAN_DIR.mkdir(parents=True, exist_ok=True)
+    hdrs = list(CSRC.glob("*.h")) + [CSRC.parents[1] / "include" / "dgtta.h"]
+    lib = ASAN_DIR / "libdgtta_hip_asan.so"
+    objs, jobs = [], []
+    for s in SOURCES:
+        src, obj = CSRC / s, ASAN_DIR / (s + ".o")
+        objs.append(obj)
+        if _stale(obj, [src] + hdrs):
+            jobs.append([hipcc, *ASAN_FLAGS, "-c", str(src), "-o", str(obj)])
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True, capture_output=not verbose)
+
+    with ThreadPoolExecutor(max_workers=6) as ex:
+        list(ex.map(run, jobs))
+    if jobs or _stale(lib, objs):
+        run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-fsanitize=address,undefined", "-o", str(lib), *map(str, objs)])
+    return lib
+
+
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
-    print(LIB)
+    if "--asan" in sys.argv:
+        print(build_asan(verbose=True))
+    else:
+        build(force="--force" in sys.argv)
+        print(LIB)

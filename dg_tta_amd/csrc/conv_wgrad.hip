@@ -968,7 +968,7 @@ WgradPlan wgrad_plan(int B, int Cin, int Cout, int D, int H, int W, int ncls = 1
   p.cibs = cdiv(Cin, 32);
   p.cobs = cdiv(Cout, 32);
   const int64_t base = (int64_t)B * p.tW * p.tH * p.cibs * p.cobs * ncls;
-  int want = (int)cdiv64(512, base);                  // aim for >= ~512 workgroups (2 per CU) over all classes
+  int want = (int)cdiv64(512, base > 0 ? base : 1);   // aim for >= ~512 workgroups (2 per CU) over all classes
   int maxsplit = D / 4 > 0 ? D / 4 : 1;
   p.nsd = want < 1 ? 1 : (want > maxsplit ? maxsplit : want);
   p.DR = cdiv(D, p.nsd);
@@ -987,7 +987,7 @@ static WgradPlan wgrad_plan_s2(int B, int Cin, int Cout, int D, int H, int W) {
   p.cibs = cdiv(Cin, 32);
   p.cobs = cdiv(Cout, 32);
   const int64_t base = (int64_t)B * p.tW * p.tH * p.cibs * p.cobs;
-  int want = (int)cdiv64(512, base);
+  int want = (int)cdiv64(512, base > 0 ? base : 1);
   int maxsplit = D / 4 > 0 ? D / 4 : 1;
   p.nsd = want < 1 ? 1 : (want > maxsplit ? maxsplit : want);
   p.DR = cdiv(D, p.nsd);
@@ -1267,7 +1267,7 @@ __global__ void f32_to_16_rows_kernel(const float *__restrict__ src, int lds_, u
 }  // namespace
 
 size_t head_wgrad_mfma_ws_bytes(int Cin, int nsel, int64_t rows) {
-  if (rows % 128) return 0;
+  if (rows <= 0 || rows % 128 || rows / 128 >= (1ll << 30)) return 0;      // the MFMA plan does not apply (as head_wgrad_mfma)
   const int D = (int)(rows / 128);
   return conv3_wgrad_mfma_ws_bytes(1, Cin, nsel, D, 4, 32) + align_up((size_t)rows * nsel * 2, 256);
 }

@@ -306,6 +306,7 @@ __global__ void gin_scale_kernel(float *__restrict__ out, const float *__restric
 }  // namespace
 
 extern "C" size_t dgtta_gin_ws_bytes(int B, int D, int H, int W) {
+  if (B <= 0 || D <= 0 || H <= 0 || W <= 0) return 0;      // a size query of an empty problem (the launchers reject it with DGTTA_ERR_BADARG)
   size_t per = (size_t)cdiv(D, TD) * cdiv(H, TH) * cdiv(W, TW);
   return align_up((size_t)B * per * 2 * sizeof(double), 256) + align_up((size_t)B * 2 * sizeof(float), 256) +
          align_up((size_t)B * WTAB * sizeof(float), 256);

@@ -352,6 +352,7 @@ void tile_counts(int D, int H, int W, int &td, int &th, int &tw) {
 }  // namespace
 
 extern "C" size_t dgtta_mind3d_ws_bytes(int B, int D, int H, int W) {
+  if (B <= 0 || D <= 0 || H <= 0 || W <= 0) return 0;      // a size query of an empty problem (the launchers reject it with DGTTA_ERR_BADARG)
   int td, th, tw;
   tile_counts(D, H, W, td, th, tw);
   size_t m = align_up((size_t)B * D * H * W * 12 * sizeof(float), 256);

@@ -158,6 +158,7 @@ extern "C" int dgtta_argmax_merge_f64(const double *vals, int64_t V, int cg, int
 }
 
 extern "C" size_t dgtta_resample_axis_ws_bytes(int64_t outer, int n, int64_t inner, int order) {
+  if (outer <= 0 || n <= 0 || inner <= 0) return 0;      // a size query of an empty problem (the launchers reject it with DGTTA_ERR_BADARG)
   return order == 3 ? (size_t)outer * (size_t)inner * (size_t)(n + 2 * NPAD) * sizeof(double) : 256;
 }
 

@@ -346,6 +346,7 @@ int allow_big_lds() {      // per device, once (common.h: DynLdsOnce)
 
 // ws layout: [partials: B*nblk*C*2 double][coef: B*C*2 float]
 extern "C" size_t dgtta_softdice_ws_bytes(int B, int C, int64_t V) {
+  if (B <= 0 || C <= 0 || V <= 0) return 0;      // a size query of an empty problem (the launchers reject it with DGTTA_ERR_BADARG)
   return align_up((size_t)B * nblocks_for(V) * C * 2 * sizeof(double), 256) +
          align_up((size_t)B * C * 2 * sizeof(float), 256) + 256 /* scratch scalar of the stand-alone op */;
 }

@@ -964,6 +964,7 @@ static const void *imgB_of(const void *wpack, int CinP, int CoutP, int dtype) {
 }
 
 extern "C" size_t dgtta_conv3d_packed_bytes(int CinP, int CoutP, int dtype) {
+  if (CinP <= 0 || CoutP <= 0) return 0;      // a size query of an empty problem (the launchers reject it with DGTTA_ERR_BADARG)
   return (size_t)2 * 27 * CinP * CoutP * esize(dtype) + conv_image_bytes(CinP, CoutP, dtype);
 }
 
@@ -987,6 +988,7 @@ static int out_dim(int i, int s) { return (i + 2 - 3) / s + 1; }
 
 // statistics buffer: [256-byte header: int64 nblk][partial sums: B x nblk x Cout x 2 doubles]
 extern "C" size_t dgtta_conv3d_stats_bytes(int B, int Cout, int Do, int Ho, int Wo) {
+  if (B <= 0 || Cout <= 0 || Do <= 0 || Ho <= 0 || Wo <= 0) return 0;      // a size query of an empty problem (the launchers reject it with DGTTA_ERR_BADARG)
   int64_t nb = conv3_mfma_max_tiles(Do, Ho, Wo);
   const int64_t rb = reduce_blocks((int64_t)Do * Ho * Wo, B);
   if (rb > nb) nb = rb;
@@ -1070,6 +1072,7 @@ static size_t wgrad_bias_bytes(int B, int Cout, int Do, int Ho, int Wo) {
 }
 
 extern "C" size_t dgtta_conv3d_wgrad_ws_bytes(int B, int Cin, int Cout, int Do, int Ho, int Wo) {
+  if (B <= 0 || Cin <= 0 || Cout <= 0 || Do <= 0 || Ho <= 0 || Wo <= 0) return 0;      // a size query of an empty problem (the launchers reject it with DGTTA_ERR_BADARG)
   const int64_t nvox = (int64_t)B * Do * Ho * Wo;
   size_t a = align_up((size_t)wgrad_splits(nvox) * Cout * Cin * 27 * sizeof(float), 256);
   size_t c = align_up(conv3_wgrad_mfma_ws_bytes(B, Cin, Cout, Do, Ho, Wo), 256);   // stride 1: input dims == output dims
@@ -1124,6 +1127,7 @@ extern "C" int dgtta_conv3d_k3_wgrad(const void *x, int ldx, const void *dy, int
 }
 
 extern "C" size_t dgtta_instnorm_ws_bytes(int B, int C, int64_t V) {
+  if (B <= 0 || C <= 0 || V <= 0) return 0;      // a size query of an empty problem (the launchers reject it with DGTTA_ERR_BADARG)
   return align_up((size_t)B * reduce_blocks(V, B) * C * 2 * sizeof(double), 256) +
          align_up((size_t)B * C * 2 * sizeof(float), 256);
 }
@@ -1206,7 +1210,10 @@ static size_t convT_pack_region(int Cin, int Cout, int dtype) {
   return align_up(convT_packed_bytes((Cin + g - 1) / g * g, (Cout + g - 1) / g * g, dtype), 256);
 }
 
-extern "C" size_t dgtta_convT3d_fwd_ws_bytes(int Cin, int Cout, int dtype) { return convT_pack_region(Cin, Cout, dtype); }
+extern "C" size_t dgtta_convT3d_fwd_ws_bytes(int Cin, int Cout, int dtype) {
+  if (Cin <= 0 || Cout <= 0) return 0;
+  return convT_pack_region(Cin, Cout, dtype);
+}
 
 extern "C" int dgtta_convT3d_k2s2_fwd(const void *x, int ldx, const float *w_t, const float *bias, void *out, int ldo,
                                       void *ws, size_t ws_bytes, int B, int Cin, int Cout, int Di, int Hi, int Wi,
@@ -1233,6 +1240,7 @@ static size_t convT_bias_region(int B, int Cout, int Di, int Hi, int Wi) {
 }
 
 extern "C" size_t dgtta_convT3d_bwd_ws_bytes(int B, int Cin, int Cout, int Di, int Hi, int Wi) {
+  if (B <= 0 || Cin <= 0 || Cout <= 0 || Di <= 0 || Hi <= 0 || Wi <= 0) return 0;      // a size query of an empty problem (the launchers reject it with DGTTA_ERR_BADARG)
   const int64_t nvox = (int64_t)B * Di * Hi * Wi;
   size_t a = align_up((size_t)wgrad_splits(nvox) * Cin * Cout * 8 * sizeof(float), 256);
   size_t c = align_up(conv3_wgrad_mfma_ws_bytes(B, Cin, Cout, Di, Hi, Wi), 256);
@@ -1342,6 +1350,7 @@ static size_t head_bias_region(int B, int nsel, int64_t V) {
 }
 
 extern "C" size_t dgtta_seghead_bwd_ws_bytes(int B, int Cin, int nsel, int64_t V) {
+  if (B <= 0 || Cin <= 0 || nsel <= 0 || V <= 0) return 0;      // a size query of an empty problem (the launchers reject it with DGTTA_ERR_BADARG)
   size_t a = align_up((size_t)head_splits((int64_t)B * V) * nsel * Cin * sizeof(float), 256);
   size_t c = align_up(head_wgrad_mfma_ws_bytes(Cin, nsel, (int64_t)B * V), 256);
   return head_bias_region(B, nsel, V) + (a > c ? a : c);

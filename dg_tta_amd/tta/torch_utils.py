@@ -14,11 +14,13 @@ _VOLUME_CACHE = {}
 def _resident(data, device):
     """Uploads a preprocessed case once and keeps it in HBM (the reference re-uploads it on every call,
     torch_utils.py:60).  Returns (image [1,1,Dv,Hv,Wv] fp32, min scalar [1], label map [1,1,Dv,Hv,Wv] fp32 or None).
-    An entry holds its source tensor, so a hit requires the SAME tensor object at the same version (an address can be
-    reused by a later case of the same shape); tta_main drops the entries of a sample when it is done."""
+    An entry is tied to its source tensor: a hit requires the SAME tensor object at the same version (an address can be
+    reused by a later case of the same shape), and the device copy is dropped when the host tensor is collected or when
+    tta_main releases the sample - never behind a running epoch's back."""
+    import weakref
     key = (id(data), str(device))
     hit = _VOLUME_CACHE.get(key)
-    if hit is not None and hit[0] is data and hit[1] == data._version:
+    if hit is not None and hit[0]() is data and hit[1] == data._version:
         return hit[2]
     img = data[0][None, None].float().contiguous().to(device)
     mn = data[0].min().reshape(1).float().to(device)                  # torch_utils.py:58
@@ -28,7 +30,8 @@ def _resident(data, device):
         # get_argmaxed_segs (torch_utils.py:79-82) commutes with nearest sampling: apply it once to the volume
         lab = torch.cat([(segs.sum(1, keepdim=True) < 1.0).float(), segs.float()], dim=1).argmax(1, keepdim=True)
         lab = lab.float().contiguous().to(device)
-    _VOLUME_CACHE[key] = (data, data._version, (img, mn, lab))
+    _VOLUME_CACHE[key] = (weakref.ref(data), data._version, (img, mn, lab))
+    weakref.finalize(data, _VOLUME_CACHE.pop, key, None)
     return img, mn, lab
 
 

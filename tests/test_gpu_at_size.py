@@ -193,6 +193,7 @@ def test_config3_tta_epoch_from_a_512_cubed_resident_volume():
     16 accumulation steps) and its evaluation against the label channels."""
     bench = _bench()
     from dg_tta_amd.tta.torch_utils import _VOLUME_CACHE, get_batch, release_resident
+    release_resident()
     data, lab = _volume_512()
     r = _runner(bench.parse_args([]).dtype)
     r.data = [data]

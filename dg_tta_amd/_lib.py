@@ -48,6 +48,10 @@ SIGNATURES = {
     "dgtta_seghead_fwd": (I, [P, I, P, P, P, I, P, I, I, I, I, I64, I, P]),
     "dgtta_seghead_bwd_ws_bytes": (SZ, [I, I, I, I64]),
     "dgtta_seghead_bwd": (I, [P, I, P, I, P, P, I, P, I, P, P, P, SZ, I, I, I64, I, I, P]),
+    "dgtta_seghead_warp_supported": (I, [P, I, I, I, I, I, I, I]),
+    "dgtta_seghead_warp_bwd_ws_bytes": (SZ, [I, I, I, I, I, I]),
+    "dgtta_seghead_warp_fwd": (I, [P, P, P, P, I, P, P, I, I, I, I, I, I, I, P]),
+    "dgtta_seghead_warp_bwd": (I, [P, P, P, P, P, P, I, P, P, P, P, SZ, I, I, I, I, I, I, I, I, P]),
     "dgtta_ncdhw_to_ndhwc": (I, [P, P, I, I, I64, I, I, P]),
     "dgtta_ndhwc_to_ncdhw": (I, [P, P, I, I, I64, I, I, P]),
     "dgtta_argmax_dice": (I, [P, I, I, P, P, P, I, I64, P]),

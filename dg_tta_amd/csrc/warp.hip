@@ -601,6 +601,280 @@ __global__ __launch_bounds__(256) void warp_fwd_rows4_kernel(const float *__rest
   }
 }
 
+// =====================================================================================================================
+// Segmentation head fused with the inverse warp of the logits (round 3).
+//
+// The reference maps a branch's logits back to the common frame with grid_sample (tta.py:572-575) after the 1x1x1 head of
+// the network ([3P] PlainConvUNet seg layer) and map_label (torch_utils.py:214-221).  Both are linear and the head acts
+// per voxel, so  warp(head(z)) = head(warp(z)) + bias * (sum of the in-bounds corner weights):  the forward kernel gathers
+// the 8 corners of the 32-channel 16-bit feature map z (64 B per voxel, the size of the 16 fp32 logits it replaces),
+// blends them and applies the selected head rows; the backward kernel gathers the logit gradient like
+// warp_bwd_gather_kernel, and applies W^T to its 16 accumulators before storing.  The un-warped logits and their
+// gradient (1 GB each per 8 x 128^3 pass) are never written or read: one launch each way instead of two.  Both gathers wait
+// on L2 round trips with the vector ALU ~14 % busy (PMC), so the head's FMAs ride along.
+// Numerics: same terms, associated differently (blend first, then the dot product) - fp32 rounding level.
+constexpr int HW_CIN = 32, HW_NS = 16;
+
+__device__ __forceinline__ float quad_xor_add(float v, int which) {     // v + (value of lane ^ 1) or (lane ^ 2): DPP quad_perm
+  const int iv = __float_as_int(v);
+  const int o = which == 1 ? __builtin_amdgcn_update_dpp(0, iv, 0xB1, 0xf, 0xf, false)
+                           : __builtin_amdgcn_update_dpp(0, iv, 0x4E, 0xf, 0xf, false);
+  return v + __int_as_float(o);
+}
+
+template <typename T>
+__device__ __forceinline__ void unpack8_16(const uint4 &v, float *f) {
+  const unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) unpack2_16<T>(w[i], f[2 * i], f[2 * i + 1]);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void head_warp_fwd_kernel(const T *__restrict__ z, const float *__restrict__ theta,
+                                                            const float *__restrict__ w, const float *__restrict__ bias,
+                                                            const int *__restrict__ sel, int nsel, float *__restrict__ out,
+                                                            int D, int H, int W, int algebra, int gx, int gy) {
+  __shared__ float sw[HW_NS * HW_CIN];
+  __shared__ float sb[HW_NS];
+  for (int i = threadIdx.x; i < HW_NS * HW_CIN; i += 256) {
+    const int k = i / HW_CIN;
+    sw[i] = k < nsel ? w[(int64_t)(sel ? sel[k] : k) * HW_CIN + i % HW_CIN] : 0.f;
+  }
+  if (threadIdx.x < HW_NS) sb[threadIdx.x] = (int)threadIdx.x < nsel ? bias[sel ? sel[threadIdx.x] : threadIdx.x] : 0.f;
+  __syncthreads();
+  const int tile = (int)blockIdx.x;
+  const int bx = tile % gx, by = (tile / gx) % gy, bz = tile / (gx * gy);
+  const int d = bz % D, b = bz / D;
+  const int64_t V = (int64_t)D * H * W;
+  const T *zb = z + (int64_t)b * V * HW_CIN;
+  const int i = bx * 256 + threadIdx.x;
+  const int wv = i >> 2, g = i & 3;              // 4 lanes per voxel: channels 8 g .. 8 g + 7 in, classes 4 g .. 4 g + 3 out
+  const bool live = wv < W;
+  const int h0 = by * WARP_ROWS;
+  for (int h = h0; h < min(h0 + WARP_ROWS, H); ++h) {
+    float zbl[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float wsum = 0.f;
+    if (live) {
+      const Sample s = sample_pos(theta + b * 12, d, h, wv, D, H, W, D, H, W, algebra, DGTTA_PAD_ZEROS);
+      const Corners cr = corners(s);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int xx = cr.x0 + (k & 1), yy = cr.y0 + ((k >> 1) & 1), zz = cr.z0 + (k >> 2);
+        if ((unsigned)xx < (unsigned)W && (unsigned)yy < (unsigned)H && (unsigned)zz < (unsigned)D) {
+          const uint4 t = *reinterpret_cast<const uint4 *>(zb + (((int64_t)zz * H + yy) * W + xx) * HW_CIN + g * 8);
+          float f[8];
+          unpack8_16<T>(t, f);
+#pragma unroll
+          for (int c = 0; c < 8; ++c) zbl[c] += f[c] * cr.w[k];
+          wsum += cr.w[k];
+        }
+      }
+    }
+    // partial logits over this lane's 8 channels, summed over the voxel's 4 lanes.  The weight slice is re-read from LDS
+    // for every row on purpose: its offset is laundered, otherwise the compiler hoists the 32 reads out of the row loop
+    // and keeps 128 registers live (190 VGPRs, 2 waves per SIMD - this kernel lives on occupancy)
+    float pl[HW_NS];
+    int goff = g * 8;
+    asm volatile("" : "+v"(goff));
+#pragma unroll
+    for (int k = 0; k < HW_NS; ++k) {
+      const float4 w0 = *reinterpret_cast<const float4 *>(sw + k * HW_CIN + goff);
+      const float4 w1 = *reinterpret_cast<const float4 *>(sw + k * HW_CIN + goff + 4);
+      float a = zbl[0] * w0.x;
+      a = __builtin_fmaf(zbl[1], w0.y, a);
+      a = __builtin_fmaf(zbl[2], w0.z, a);
+      a = __builtin_fmaf(zbl[3], w0.w, a);
+      a = __builtin_fmaf(zbl[4], w1.x, a);
+      a = __builtin_fmaf(zbl[5], w1.y, a);
+      a = __builtin_fmaf(zbl[6], w1.z, a);
+      a = __builtin_fmaf(zbl[7], w1.w, a);
+      a = quad_xor_add(a, 1);
+      pl[k] = quad_xor_add(a, 2);
+    }
+    if (live && 4 * g < nsel) {
+      float o[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float v = g == 0 ? pl[j] : (g == 1 ? pl[4 + j] : (g == 2 ? pl[8 + j] : pl[12 + j]));
+        o[j] = v + sb[4 * g + j] * wsum;
+      }
+      float *op = out + ((int64_t)b * V + ((int64_t)d * H + h) * W + wv) * nsel + 4 * g;
+      *reinterpret_cast<float4 *>(op) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+  }
+}
+
+template <typename T>
+__device__ __forceinline__ uint4 pack8_16(const float *f) {
+  return make_uint4(pack2_16<T>(f[0], f[1]), pack2_16<T>(f[2], f[3]), pack2_16<T>(f[4], f[5]), pack2_16<T>(f[6], f[7]));
+}
+
+// backward: one thread owns one voxel of the feature-map lattice; candidate search and accumulation exactly as
+// warp_bwd_gather_kernel<16, true> (same order), then d16 = 16-bit copy of the gathered logit gradient (operand of the
+// head's MFMA weight gradient), gz = W^T acc in the network's storage type, and the block's partial sums for the bias gradient
+template <typename T>
+__global__ __launch_bounds__(256, 6) void head_warp_bwd_kernel(const float *__restrict__ gdst, const float *__restrict__ theta,
+                                                            const float *__restrict__ w, const int *__restrict__ sel,
+                                                            int nsel, T *__restrict__ gz, unsigned short *__restrict__ d16,
+                                                            double *__restrict__ bias_partial, int D, int H, int W,
+                                                            int algebra, int gx, int gy) {
+  __shared__ float sw[HW_NS * HW_CIN];
+  __shared__ InvMap s_im;
+  __shared__ float sred[4][HW_NS];
+  for (int i = threadIdx.x; i < HW_NS * HW_CIN; i += 256) {
+    const int k = i / HW_CIN;
+    sw[i] = k < nsel ? w[(int64_t)(sel ? sel[k] : k) * HW_CIN + i % HW_CIN] : 0.f;
+  }
+  const int64_t V = (int64_t)D * H * W;
+  const int tilesX = (W + 15) >> 4, tilesZ = (D + 3) >> 2;
+  const int tile = (int)blockIdx.x;
+  const int bx = tile % gx, by = (tile / gx) % gy, bz = tile / (gx * gy);
+  const int b = bz / tilesZ;
+  const int x = bx * 16 + (threadIdx.x & 15), y = by * 4 + ((threadIdx.x >> 4) & 3), zc_ = (bz % tilesZ) * 4 + (threadIdx.x >> 6);
+  const float *th = theta + b * 12;
+  if (threadIdx.x == 0) s_im = inverse_map(th, D, H, W, D, H, W, algebra);
+  __syncthreads();
+  const InvMap im = s_im;           // the launcher has checked on the host that every map of the batch is accepted
+  float acc[HW_NS];
+#pragma unroll
+  for (int q = 0; q < HW_NS; ++q) acc[q] = 0.f;
+  const bool inside = x < W && y < H && zc_ < D;
+  if (inside && im.ok) {
+    const float rel[3] = {(float)x - im.s0[0], (float)y - im.s0[1], (float)zc_ - im.s0[2]};
+    int lo[3], hi[3];
+    const int dims[3] = {W, H, D};
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      const float c = im.inv[a][0] * rel[0] + im.inv[a][1] * rel[1] + im.inv[a][2] * rel[2];
+      const float slack = im.e[a] + 0.02f;
+      lo[a] = max(0, (int)fmaxf(ceilf(c - slack), -1.0f));
+      hi[a] = min(dims[a] - 1, (int)fminf(floorf(c + slack), (float)dims[a]));
+    }
+    float rcp0[3];
+    bool bounds_w[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      bounds_w[j] = fabsf(im.m[j][0]) > 1e-6f;
+      rcp0[j] = bounds_w[j] ? 1.0f / im.m[j][0] : 0.f;
+    }
+    for (int d = lo[2]; d <= hi[2]; ++d) {
+      const float zc = base_coord(d, D);
+      for (int h = lo[1]; h <= hi[1]; ++h) {
+        const float yc = base_coord(h, H);
+        float wl = (float)lo[0], wh = (float)hi[0];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+          const float r = -rel[j] + im.m[j][1] * (float)h + im.m[j][2] * (float)d;
+          if (bounds_w[j]) {
+            const float a = (-1.02f - r) * rcp0[j], bq = (1.02f - r) * rcp0[j];
+            wl = fmaxf(wl, fminf(a, bq));
+            wh = fminf(wh, fmaxf(a, bq));
+          } else if (fabsf(r) > 1.02f) {
+            wh = wl - 1.0f;
+          }
+        }
+        const int w1 = (int)floorf(wh);
+        for (int wq = (int)ceilf(wl); wq <= w1; ++wq) {
+          const Sample s = sample_from_base(th, base_coord(wq, W), yc, zc, D, H, W, algebra, DGTTA_PAD_ZEROS);
+          const float fx = floorf(s.ix), fy = floorf(s.iy), fz = floorf(s.iz);
+          const float dx = (float)x - fx, dy = (float)y - fy, dz = (float)zc_ - fz;
+          if (!((dx == 0.f || dx == 1.f) && (dy == 0.f || dy == 1.f) && (dz == 0.f || dz == 1.f))) continue;
+          const float wx = dx == 0.f ? (fx + 1.0f) - s.ix : s.ix - fx;
+          const float wy = dy == 0.f ? (fy + 1.0f) - s.iy : s.iy - fy;
+          const float wz = dz == 0.f ? (fz + 1.0f) - s.iz : s.iz - fz;
+          const float wt = wx * wy * wz;
+          const float *gp = gdst + ((int64_t)b * V + ((int64_t)d * H + h) * W + wq) * nsel;
+#pragma unroll
+          for (int q = 0; q < HW_NS; q += 4) {
+            if (q < nsel) {
+              const float4 g = *reinterpret_cast<const float4 *>(gp + q);
+              acc[q] += g.x * wt;
+              acc[q + 1] += g.y * wt;
+              acc[q + 2] += g.z * wt;
+              acc[q + 3] += g.w * wt;
+            }
+          }
+        }
+      }
+    }
+  }
+  if (inside) {
+    const int64_t u = (int64_t)b * V + ((int64_t)zc_ * H + y) * W + x;
+    // 16-bit copy of the gathered gradient, rows of nsel
+    unsigned short *dp = d16 + u * nsel;
+#pragma unroll
+    for (int q = 0; q < HW_NS; q += 4)
+      if (q < nsel) *reinterpret_cast<uint2 *>(dp + q) = make_uint2(pack2_16<T>(acc[q], acc[q + 1]), pack2_16<T>(acc[q + 2], acc[q + 3]));
+    // gz = W^T acc, a quarter (8 channels) at a time to keep the register footprint of the gather phase
+    T *gp = gz + u * HW_CIN;
+#pragma unroll
+    for (int qt = 0; qt < 4; ++qt) {
+      float o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int k = 0; k < HW_NS; ++k) {
+        const float4 w0 = *reinterpret_cast<const float4 *>(sw + k * HW_CIN + qt * 8);
+        const float4 w1 = *reinterpret_cast<const float4 *>(sw + k * HW_CIN + qt * 8 + 4);
+        o[0] = __builtin_fmaf(acc[k], w0.x, o[0]);
+        o[1] = __builtin_fmaf(acc[k], w0.y, o[1]);
+        o[2] = __builtin_fmaf(acc[k], w0.z, o[2]);
+        o[3] = __builtin_fmaf(acc[k], w0.w, o[3]);
+        o[4] = __builtin_fmaf(acc[k], w1.x, o[4]);
+        o[5] = __builtin_fmaf(acc[k], w1.y, o[5]);
+        o[6] = __builtin_fmaf(acc[k], w1.z, o[6]);
+        o[7] = __builtin_fmaf(acc[k], w1.w, o[7]);
+      }
+      *reinterpret_cast<uint4 *>(reinterpret_cast<unsigned short *>(gp) + qt * 8) = pack8_16<T>(o);
+    }
+  }
+  // bias gradient: sum of the gathered gradient over the block (threads outside the volume hold zeros), fixed order
+  if (bias_partial) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < HW_NS; ++k) {
+      const float v = wave_sum(acc[k]);
+      if (lane == 0) sred[wave][k] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < HW_NS) {
+      const double t = ((double)sred[0][threadIdx.x] + (double)sred[1][threadIdx.x]) +
+                       ((double)sred[2][threadIdx.x] + (double)sred[3][threadIdx.x]);
+      bias_partial[(int64_t)blockIdx.x * HW_NS + threadIdx.x] = t;
+    }
+  }
+}
+
+__global__ void head_warp_bias_finalize_kernel(const double *__restrict__ partial, int nblk, int nsel, float *__restrict__ db,
+                                               int accumulate) {
+  const int k = blockIdx.x;   // one wave per class; blocks in index order
+  double s = 0.0;
+  for (int i = threadIdx.x; i < nblk; i += 64) s += partial[(int64_t)i * HW_NS + k];
+  s = wave_sum_d(s);
+  if (threadIdx.x == 0 && k < nsel) db[k] = accumulate ? db[k] + (float)s : (float)s;
+}
+
+// host copy of inverse_map()'s acceptance test (same arithmetic in float): the fused backward has no scatter fallback
+bool host_map_ok(const float *th, int D, int H, int W) {
+  const float m00 = th[0], m01 = th[1] * W / H, m02 = th[2] * W / D;
+  const float m10 = th[4] * H / W, m11 = th[5], m12 = th[6] * H / D;
+  const float m20 = th[8] * D / W, m21 = th[9] * D / H, m22 = th[10];
+  const float c00 = m11 * m22 - m12 * m21, c01 = m12 * m20 - m10 * m22, c02 = m10 * m21 - m11 * m20;
+  const float det = m00 * c00 + m01 * c01 + m02 * c02;
+  if (det == 0.f) return false;
+  const float idet = 1.0f / det;
+  const float inv[3][3] = {{c00 * idet, (m02 * m21 - m01 * m22) * idet, (m01 * m12 - m02 * m11) * idet},
+                           {c01 * idet, (m00 * m22 - m02 * m20) * idet, (m02 * m10 - m00 * m12) * idet},
+                           {c02 * idet, (m01 * m20 - m00 * m21) * idet, (m00 * m11 - m01 * m10) * idet}};
+  float vol = 1.f;
+  for (int i = 0; i < 3; ++i) {
+    const float e = fabsf(inv[i][0]) + fabsf(inv[i][1]) + fabsf(inv[i][2]);
+    if (!(e < 1e30f)) return false;
+    vol *= 2.0f * e + 1.0f;
+  }
+  for (int i = 0; i < 12; ++i)
+    if (!(fabsf(th[i]) < 1e30f)) return false;
+  return vol <= 256.0f;        // (the device test accepts up to 512: a margin for the differences in rounding)
+}
+
 int check_common(const char *name, const void *a, const void *t, const void *o, int B, int C, int Ds, int Hs, int Ws,
                  int Dd, int Hd, int Wd, int ndhwc, int src_ldc, int dst_ldc) {
   DG_REQUIRE(a && t && o, DGTTA_ERR_BADARG, "%s: null pointer", name);
@@ -712,6 +986,100 @@ extern "C" int dgtta_affine_warp3d_bwd(const float *grad_dst, const float *theta
                        Ds, Hs, Ws, Dd, Hd, Wd, src_ldc, dst_ldc, pad_mode, tta_grid_algebra, 0, B, total);
   }
   DG_CHECK_LAUNCH("warp_bwd_kernel");
+  return DGTTA_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// fused head + inverse warp (see head_warp_fwd_kernel)
+size_t head_wgrad_mfma_ws_bytes(int Cin, int nsel, int64_t rows);
+int head_wgrad_mfma(const void *x, int ldx, const float *dout, int lddo, float *dw_sel, void *ws, size_t ws_bytes, int Cin,
+                    int nsel, int64_t rows, int accumulate, int dtype, hipStream_t st, bool have_d16);
+
+static bool head_warp_shape_ok(int Cin, int nsel, int dtype) {
+  return Cin == HW_CIN && nsel >= 4 && nsel <= HW_NS && nsel % 4 == 0 && (dtype == DGTTA_BF16 || dtype == DGTTA_F16);
+}
+
+static size_t head_warp_bias_region(int B, int D, int H, int W) {
+  const int64_t nblk = (int64_t)cdiv(W, 16) * cdiv(H, 4) * cdiv(D, 4) * B;
+  return align_up((size_t)nblk * HW_NS * sizeof(double), 256);
+}
+
+extern "C" int dgtta_seghead_warp_supported(const float *h_theta, int B, int Cin, int nsel, int D, int H, int W, int dtype) {
+  if (!h_theta || B <= 0 || B > 16 || D <= 0 || H <= 0 || W <= 0 || !head_warp_shape_ok(Cin, nsel, dtype)) return 0;
+  if (head_wgrad_mfma_ws_bytes(Cin, nsel, (int64_t)B * D * H * W) == 0) return 0;
+  for (int b = 0; b < B; ++b)
+    if (!host_map_ok(h_theta + 12 * b, D, H, W)) return 0;
+  return 1;
+}
+
+extern "C" size_t dgtta_seghead_warp_bwd_ws_bytes(int B, int Cin, int nsel, int D, int H, int W) {
+  if (B <= 0 || Cin <= 0 || nsel <= 0 || D <= 0 || H <= 0 || W <= 0) return 0;
+  const int64_t rows = (int64_t)B * D * H * W;
+  const size_t wg = head_wgrad_mfma_ws_bytes(Cin, nsel, rows);
+  if (wg == 0) return 0;                       // the MFMA weight-gradient plan does not apply: the fused path is not offered
+  return head_warp_bias_region(B, D, H, W) + align_up(wg, 256);
+}
+
+extern "C" int dgtta_seghead_warp_fwd(const void *z, const float *w, const float *bias, const int *sel, int nsel,
+                                      const float *theta, float *out, int B, int Cin, int D, int H, int W,
+                                      int tta_grid_algebra, int dtype, void *stream) {
+  DG_REQUIRE(z && w && bias && theta && out, DGTTA_ERR_BADARG, "seghead_warp_fwd: null pointer");
+  DG_REQUIRE(B > 0 && D > 0 && H > 0 && W > 0, DGTTA_ERR_BADARG, "seghead_warp_fwd: bad dims");
+  DG_REQUIRE(head_warp_shape_ok(Cin, nsel, dtype), DGTTA_ERR_UNSUPPORTED,
+             "seghead_warp_fwd: built for 32 input channels, 4/8/12/16 selected classes and 16-bit storage (Cin %d, nsel %d, "
+             "dtype %d)", Cin, nsel, dtype);
+  DG_REQUIRE(((uintptr_t)z & 15) == 0 && ((uintptr_t)out & 15) == 0, DGTTA_ERR_BADARG, "seghead_warp_fwd: unaligned operand");
+  const int gx = cdiv(W * 4, 256), gy = cdiv(H, WARP_ROWS);
+  const int64_t nblk = (int64_t)gx * gy * D * B;
+  DG_REQUIRE(nblk < (1ll << 31), DGTTA_ERR_UNSUPPORTED, "seghead_warp_fwd: too many tiles");
+  if (dtype == DGTTA_BF16)
+    hipLaunchKernelGGL(head_warp_fwd_kernel<bf16_t>, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, (const bf16_t *)z,
+                       theta, w, bias, sel, nsel, out, D, H, W, tta_grid_algebra, gx, gy);
+  else
+    hipLaunchKernelGGL(head_warp_fwd_kernel<f16_t>, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, (const f16_t *)z,
+                       theta, w, bias, sel, nsel, out, D, H, W, tta_grid_algebra, gx, gy);
+  DG_CHECK_LAUNCH("head_warp_fwd_kernel");
+  return DGTTA_OK;
+}
+
+extern "C" int dgtta_seghead_warp_bwd(const void *z, const float *gout, const float *theta, const float *h_theta,
+                                      const float *w, const int *sel, int nsel, void *gz, float *dw_sel, float *db_sel,
+                                      void *ws, size_t ws_bytes, int B, int Cin, int D, int H, int W, int tta_grid_algebra,
+                                      int accumulate, int dtype, void *stream) {
+  DG_REQUIRE(z && gout && theta && h_theta && w && gz && ws, DGTTA_ERR_BADARG, "seghead_warp_bwd: null pointer");
+  DG_REQUIRE(B > 0 && B <= 16 && D > 0 && H > 0 && W > 0, DGTTA_ERR_BADARG, "seghead_warp_bwd: bad dims");
+  DG_REQUIRE(head_warp_shape_ok(Cin, nsel, dtype), DGTTA_ERR_UNSUPPORTED, "seghead_warp_bwd: unsupported shape / dtype");
+  const size_t need = dgtta_seghead_warp_bwd_ws_bytes(B, Cin, nsel, D, H, W);
+  DG_REQUIRE(need > 0, DGTTA_ERR_UNSUPPORTED, "seghead_warp_bwd: voxel count must be a multiple of 128");
+  DG_REQUIRE(ws_bytes >= need, DGTTA_ERR_WORKSPACE, "seghead_warp_bwd: workspace too small");
+  for (int b = 0; b < B; ++b)
+    DG_REQUIRE(host_map_ok(h_theta + 12 * b, D, H, W), DGTTA_ERR_UNSUPPORTED,
+               "seghead_warp_bwd: sample %d's map is singular or strongly minifying (use the unfused path)", b);
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t rows = (int64_t)B * D * H * W;
+  double *bias_partial = (double *)ws;
+  void *ws_main = (char *)ws + head_warp_bias_region(B, D, H, W);
+  const size_t main_bytes = ws_bytes - head_warp_bias_region(B, D, H, W);
+  unsigned short *d16 = (unsigned short *)ws_main;           // first region of head_wgrad_mfma's workspace
+  const int gx = cdiv(W, 16), gy = cdiv(H, 4);
+  const int64_t nblk = (int64_t)gx * gy * cdiv(D, 4) * B;
+  DG_REQUIRE(nblk < (1ll << 31), DGTTA_ERR_UNSUPPORTED, "seghead_warp_bwd: too many tiles");
+  if (dtype == DGTTA_BF16)
+    hipLaunchKernelGGL(head_warp_bwd_kernel<bf16_t>, dim3((unsigned)nblk), dim3(256), 0, st, gout, theta, w, sel, nsel,
+                       (bf16_t *)gz, d16, db_sel ? bias_partial : nullptr, D, H, W, tta_grid_algebra, gx, gy);
+  else
+    hipLaunchKernelGGL(head_warp_bwd_kernel<f16_t>, dim3((unsigned)nblk), dim3(256), 0, st, gout, theta, w, sel, nsel,
+                       (f16_t *)gz, d16, db_sel ? bias_partial : nullptr, D, H, W, tta_grid_algebra, gx, gy);
+  DG_CHECK_LAUNCH("head_warp_bwd_kernel");
+  if (dw_sel) {
+    const int rc = head_wgrad_mfma(z, Cin, nullptr, nsel, dw_sel, ws_main, main_bytes, Cin, nsel, rows, accumulate, dtype, st, true);
+    DG_REQUIRE(rc == DGTTA_OK, rc, "seghead_warp_bwd: head weight gradient failed (%d)", rc);
+  }
+  if (db_sel) {
+    hipLaunchKernelGGL(head_warp_bias_finalize_kernel, dim3(HW_NS), dim3(64), 0, st, bias_partial, (int)nblk, nsel, db_sel,
+                       accumulate);
+    DG_CHECK_LAUNCH("head_warp_bias_finalize_kernel");
+  }
   return DGTTA_OK;
 }
 

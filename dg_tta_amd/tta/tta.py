@@ -126,7 +126,7 @@ def prepare_both_branches(config, model, intensity_aug_func, batch_size, imgs, d
     evaluate the MIND descriptor here (it is handed to the model's mind_hook by run_both_branches)."""
     from ..mind import MIND3D, draw_noise_, uses_mind_hook
     with torch.no_grad():
-        augs, inverses = [[], []], [[], []]
+        augs, inverses, inverses_cpu = [[], []], [[], []], [[], []]
         want_noise = uses_mind_hook(model)
         noise = None
         for step in range(steps):
@@ -135,11 +135,12 @@ def prepare_both_branches(config, model, intensity_aug_func, batch_size, imgs, d
                 imgs_aug = step_imgs
                 if config["do_intensity_aug_in"] in [branch_id, "both"]:
                     imgs_aug = intensity_aug_func(imgs_aug)
-                R_inverse = None
+                R_inverse = R_inverse_cpu = None
                 if config["do_spatial_aug_in"] in [branch_id, "both"]:
                     if config["spatial_aug_type"] == "affine":
                         R, R_inverse = get_rand_affine(batch_size, flip=False)
-                        R, R_inverse = upload_async([R.float().contiguous(), R_inverse.float().contiguous()], device)
+                        R_inverse_cpu = R_inverse.float().contiguous()
+                        R, R_inverse = upload_async([R.float().contiguous(), R_inverse_cpu], device)
                     elif config["spatial_aug_type"] == "deformable":
                         from .augmentation_utils import get_disp_field
                         get_disp_field()
@@ -148,6 +149,7 @@ def prepare_both_branches(config, model, intensity_aug_func, batch_size, imgs, d
                     imgs_aug = ops.affine_warp(imgs_aug, R, padding_mode="border", tta_grid_algebra=True)
                 augs[k].append(imgs_aug)
                 inverses[k].append(R_inverse)
+                inverses_cpu[k].append(R_inverse_cpu)
                 if want_noise:      # this branch's torch.randn(...) of mind.py:150, drawn in place into its slot of the batch
                     nb_ = imgs_aug.shape[0]
                     if noise is None:
@@ -160,8 +162,8 @@ def prepare_both_branches(config, model, intensity_aug_func, batch_size, imgs, d
         if want_noise and precompute_mind:
             feat = MIND3D().forward(x, noise=noise, out_dtype=getattr(model, "act_dtype", torch.float32), groups=2 * steps)
             noise = None
-    return {"x": x, "inverses": inverses[0] + inverses[1], "noise": noise, "feat": feat, "per": augs[0][0].shape[0],
-            "want_noise": want_noise}
+    return {"x": x, "inverses": inverses[0] + inverses[1], "inverses_cpu": inverses_cpu[0] + inverses_cpu[1], "noise": noise,
+            "feat": feat, "per": augs[0][0].shape[0], "want_noise": want_noise}
 
 
 def run_both_branches(prepared, config, model, label_mapping, optimized_labels, modifier_fn_module, head_is_fused=False,
@@ -178,19 +180,29 @@ def run_both_branches(prepared, config, model, label_mapping, optimized_labels, 
             push_features(model, prepared["feat"])
         elif want_noise:
             push_noise(model, noise, groups=2 * steps)
+        per = prepared["per"]
+        nb = steps * per
+        template_after = is_template_modifier(after_mapping, "modify_tta_output_after_mapping_fn")
+        fast = head_is_fused and template_after and all(r is not None for r in inverses)
+        # fast path: one inverse warp over the batch, targets are views of one tensor (the loss then runs on it directly and
+        # returns one gradient buffer); where the network offers it, that warp is fused into the head (no un-warped logits)
+        warp_in_head = nullcontext()
+        cpu_inv = prepared.get("inverses_cpu")
+        if fast and hasattr(model, "can_fuse_output_warp") and cpu_inv and all(r is not None for r in cpu_inv):
+            theta_host = torch.cat(cpu_inv, dim=0)
+            if model.can_fuse_output_warp(prepared["x"].shape, theta_host):
+                warp_in_head = model.fuse_output_warp(torch.cat(inverses, dim=0), theta_host)
+        fused_warp = not isinstance(warp_in_head, nullcontext)
         try:
-            both = model(prepared["x"])
+            with warp_in_head:
+                both = model(prepared["x"])
         finally:
             clear_noise(model)
         if isinstance(both, tuple):
             both = both[0]
-        per = prepared["per"]
-        nb = steps * per
-        template_after = is_template_modifier(after_mapping, "modify_tta_output_after_mapping_fn")
-        if head_is_fused and template_after and all(r is not None for r in inverses):
-            # fast path: one inverse warp over the batch, targets are views of one tensor (the loss then runs on it
-            # directly and returns one gradient buffer)
-            both = ops.affine_warp(both, torch.cat(inverses, dim=0), padding_mode="zeros", tta_grid_algebra=True)
+        if fast:
+            if not fused_warp:
+                both = ops.affine_warp(both, torch.cat(inverses, dim=0), padding_mode="zeros", tta_grid_algebra=True)
             ta, tb = both[:nb], both[nb:]
             ta._dgtta_pair = tb._dgtta_pair = both
             ta._dgtta_guard_items = tb._dgtta_guard_items = per

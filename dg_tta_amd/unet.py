@@ -146,6 +146,7 @@ class HipPlainConvUNet(nn.Module):
         self.loss_scale = 16384.0 if act_dtype == torch.float16 else 1.0
         self._packed = {}        # id(weight) -> (version, wf, wb)
         self.selected_classes = None   # optional LongTensor: evaluate only these head rows (== map_label 'logits')
+        self._fused_warp = None        # (theta on the device, theta on the host) while fuse_output_warp() is active
 
     def __deepcopy__(self, memo):
         # get_model_from_network deep-copies the network per ensemble member: do not drag the packed-weight cache along
@@ -165,6 +166,36 @@ class HipPlainConvUNet(nn.Module):
     def set_selected_classes(self, idx):
         """Fuses map_label(..., 'logits') (torch_utils.py:214-221) into the head: forward returns only these rows."""
         self.selected_classes = None if idx is None else torch.as_tensor(idx, dtype=torch.int32)
+
+    # -- head fused with the inverse warp of its logits (csrc/warp.hip: head_warp_*_kernel)
+    def can_fuse_output_warp(self, x_shape, theta_host):
+        """True when `forward` can hand back the logits already warped by theta (R_inverse, zeros padding, the TTA grid
+        algebra): 16-bit storage, 32 head input channels, 4 / 8 / 12 / 16 selected classes, maps the gather kernel accepts."""
+        import os
+        if os.environ.get("DGTTA_FUSE_HEAD_WARP", "1") == "0" or self.selected_classes is None:
+            return False
+        if self.act_dtype not in (torch.float16, torch.bfloat16):
+            return False
+        b, _, d, h, w = x_shape
+        th = theta_host.detach().float().contiguous()
+        if tuple(th.shape) != (b, 3, 4) or th.is_cuda:
+            return False
+        head = self.decoder.seg_layers[-1]
+        return bool(_lib.load().dgtta_seghead_warp_supported(th.data_ptr(), b, head.in_channels, int(self.selected_classes.numel()),
+                                                             d, h, w, dtype_code(self.act_dtype)))
+
+    def fuse_output_warp(self, theta_dev, theta_host):
+        """Context: the next forward returns affine_warp(logits, theta, zeros, tta_grid_algebra) computed by the fused
+        head + warp kernels (and its backward runs the fused gather).  Check can_fuse_output_warp first."""
+        net = self
+
+        class _Ctx:
+            def __enter__(self_):
+                net._fused_warp = (theta_dev.float().contiguous(), theta_host.detach().float().contiguous())
+
+            def __exit__(self_, *exc):
+                net._fused_warp = None
+        return _Ctx()
 
     def forward(self, x):
         sel = self.selected_classes
@@ -339,12 +370,19 @@ class _UNetFn(torch.autograd.Function):
         nsel = ncls if sel is None else int(sel.numel())
         V = D * H * W
         out = torch.empty((B, D, H, W, nsel), dtype=torch.float32, device=dev)
-        check(lib.dgtta_seghead_fwd(u_ptr, ldu, ptr(head.weight), ptr(head.bias), ptr(sel), nsel, ptr(out), 1, nsel, B,
-                                    head.in_channels, V, dt, st), "dgtta_seghead_fwd")
+        fw = net._fused_warp
+        if fw is not None:
+            assert ldu == head.in_channels and tuple(fw[0].shape) == (B, 3, 4), "fuse_output_warp: shape mismatch"
+            check(lib.dgtta_seghead_warp_fwd(u_ptr, ptr(head.weight), ptr(head.bias), ptr(sel), nsel, ptr(fw[0]), ptr(out), B,
+                                             head.in_channels, D, H, W, 1, dt, st), "dgtta_seghead_warp_fwd")
+        else:
+            check(lib.dgtta_seghead_fwd(u_ptr, ldu, ptr(head.weight), ptr(head.bias), ptr(sel), nsel, ptr(out), 1, nsel, B,
+                                        head.in_channels, V, dt, st), "dgtta_seghead_fwd")
         if need_grad:
             ctx.net, ctx.sel, ctx.saved, ctx.ups, ctx.keep, ctx.cat_bufs = net, sel, saved, ups, keep, cat_bufs
             ctx.meta = (B, D, H, W, dt, impl, nsel, u_ptr, ldu)
             ctx.params = params
+            ctx.fused_warp = fw
         return out.permute(0, 4, 1, 2, 3)
 
     @staticmethod
@@ -409,13 +447,21 @@ class _UNetFn(torch.autograd.Function):
         cin_h = head.in_channels
         # ---- head backward
         gz = torch.empty((B, D, H, W, cin_h), dtype=adt, device=dev)
-        nb = lib.dgtta_seghead_bwd_ws_bytes(B, cin_h, nsel, V)
-        w_ = ws_for(nb)
         need_hw = want(head.weight) or want(head.bias)
         dws = torch.empty((nsel, cin_h), dtype=torch.float32, device=dev) if need_hw else None
         dbs = torch.empty((nsel,), dtype=torch.float32, device=dev) if need_hw else None
-        check(lib.dgtta_seghead_bwd(zlast_ptr, zlast_ld, ptr(g), nsel, ptr(head.weight), ptr(sel), nsel, ptr(gz), cin_h,
-                                    ptr(dws), ptr(dbs), ptr(w_), nb, B, cin_h, V, 0, dt, st), "dgtta_seghead_bwd")
+        fw = ctx.fused_warp
+        if fw is not None:      # g is the gradient of the WARPED logits: fused gather + W^T (+ weight / bias gradient)
+            nb = lib.dgtta_seghead_warp_bwd_ws_bytes(B, cin_h, nsel, D, H, W)
+            w_ = ws_for(nb)
+            check(lib.dgtta_seghead_warp_bwd(zlast_ptr, ptr(g), ptr(fw[0]), ptr(fw[1]), ptr(head.weight), ptr(sel), nsel,
+                                             ptr(gz), ptr(dws), ptr(dbs), ptr(w_), nb, B, cin_h, D, H, W, 1, 0, dt, st),
+                  "dgtta_seghead_warp_bwd")
+        else:
+            nb = lib.dgtta_seghead_bwd_ws_bytes(B, cin_h, nsel, V)
+            w_ = ws_for(nb)
+            check(lib.dgtta_seghead_bwd(zlast_ptr, zlast_ld, ptr(g), nsel, ptr(head.weight), ptr(sel), nsel, ptr(gz), cin_h,
+                                        ptr(dws), ptr(dbs), ptr(w_), nb, B, cin_h, V, 0, dt, st), "dgtta_seghead_bwd")
         if need_hw:
             gw, gb = gbuf(head.weight), gbuf(head.bias)
             if sel is None:

@@ -218,6 +218,26 @@ int dgtta_seghead_bwd(const void *x, int ldx, const float *dout, int lddo, const
                       int nsel, void *dx, int lddx, float *dw_sel, float *db_sel, void *ws, size_t ws_bytes,
                       int B, int Cin, int64_t V, int accumulate, int dtype, void *stream);
 
+/* Segmentation head fused with the inverse warp of its logits: the two steps at the end of calc_branch
+ * (dg_tta/tta/tta.py:560-575: model() -> map_label(logits) -> grid_sample(..., R_inverse grid, zeros padding)) in one launch
+ * each way.  Both are linear and the head is per voxel, so warp(head(z)) = head(warp(z)) + bias * (in-bounds corner weight):
+ * the un-warped logits and their gradient are never materialised.  z: NDHWC [B][D][H][W][32] in `dtype` (bf16 / fp16 only);
+ * w / bias: the head's fp32 parameters, sel: the nsel (4, 8, 12 or 16) selected class rows; theta [B][3][4] = R_inverse.
+ * fwd: out [B][D][H][W][nsel] fp32 = the branch's logits in the common frame.
+ * bwd: gout = gradient of that tensor; gz [B][D][H][W][32] (dtype) = gradient of z; dw_sel [nsel][32], db_sel [nsel] fp32
+ * (either may be NULL; accumulate != 0 adds).  h_theta: HOST copy of theta - the owner-computes gather has no scatter
+ * fallback here, so maps it would decline (singular / strongly minifying) are rejected with DGTTA_ERR_UNSUPPORTED before
+ * anything is launched and the caller uses dgtta_seghead_* + dgtta_affine_warp3d_*.  ws: dgtta_seghead_warp_bwd_ws_bytes
+ * (0 = shape not offered: B*D*H*W must be a multiple of 128). */
+/* 1 when the fused pair applies to this shape / dtype and to every map of the HOST array h_theta [B][3][4], else 0. */
+int dgtta_seghead_warp_supported(const float *h_theta, int B, int Cin, int nsel, int D, int H, int W, int dtype);
+size_t dgtta_seghead_warp_bwd_ws_bytes(int B, int Cin, int nsel, int D, int H, int W);
+int dgtta_seghead_warp_fwd(const void *z, const float *w, const float *bias, const int *sel, int nsel, const float *theta,
+                           float *out, int B, int Cin, int D, int H, int W, int tta_grid_algebra, int dtype, void *stream);
+int dgtta_seghead_warp_bwd(const void *z, const float *gout, const float *theta, const float *h_theta, const float *w,
+                           const int *sel, int nsel, void *gz, float *dw_sel, float *db_sel, void *ws, size_t ws_bytes, int B,
+                           int Cin, int D, int H, int W, int tta_grid_algebra, int accumulate, int dtype, void *stream);
+
 /* Layout / dtype converters between the reference's NCDHW fp32 and internal NDHWC. */
 int dgtta_ncdhw_to_ndhwc(const float *src, void *dst, int B, int C, int64_t V, int ldc, int dtype, void *stream);
 int dgtta_ndhwc_to_ncdhw(const void *src, float *dst, int B, int C, int64_t V, int ldc, int dtype, void *stream);

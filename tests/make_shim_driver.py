@@ -46,7 +46,7 @@ def main(header, out):
         else:
             lines.append(f'  {{ int rc = {call(name, params, {})}; const char *m = dgtta_last_error();')
             lines.append(f'    printf("{name} -> %d: %s\\n", rc, m);')
-            if params and name not in ("dgtta_reload_env",):
+            if params and name not in ("dgtta_reload_env",) and not name.endswith("_supported"):      # (predicates answer 0 / 1)
                 lines.append(f'    if (rc >= 0 || !m || !m[0]) {{ printf("NOT REJECTED: {name}\\n"); bad = 1; }} }}')
             else:
                 lines.append("  }")

@@ -198,3 +198,51 @@ def test_noncubic_batch_16bit_kernels_vs_reference_kernels(dtype):
         cosines[n] = float(torch.nn.functional.cosine_similarity(gr.flatten().double(), grads[1][n].flatten().double(), dim=0))
     bad = {n: round(c, 4) for n, c in cosines.items() if c < (0.85 if dtype == "bf16" else 0.97)}
     assert not bad, bad
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("nsel", [16, 8])
+def test_head_fused_with_the_inverse_warp_matches_head_then_warp(dtype, nsel):
+    """Round 3: dgtta_seghead_warp_fwd / _bwd (head + inverse logit warp in one launch each way, csrc/warp.hip) against the
+    two-step path (dgtta_seghead_* then dgtta_affine_warp3d_*) on the full 3d_fullres net: same logits up to fp32
+    association, the SAME feature-map gradient and head weight gradient bit for bit (identical gather order and FMA chain),
+    the bias gradient up to its reduction order; every other parameter gradient follows from gz and must be identical too."""
+    from dg_tta_amd import ops
+    from dg_tta_amd.synthetic import he_init_
+    from dg_tta_amd.unet import HipPlainConvUNet
+    from oracle import tta as otta
+    torch.manual_seed(3)
+    net = he_init_(HipPlainConvUNet(act_dtype=dtype), seed=7)
+    net.decoder.seg_layers[-1].bias.data.normal_()
+    net = net.to(DEV)
+    net.set_selected_classes(torch.arange(nsel) * 5 + 1)
+    x = torch.rand(2, 12, 32, 32, 32, device=DEV)
+    _, rinv = otta.rand_affine_from_draw(torch.randn(2, 3, 4), 0.08)
+    rinv = rinv.float().contiguous()
+    gout = torch.randn(2, nsel, 32, 32, 32, device=DEV).contiguous(memory_format=torch.channels_last_3d)
+    assert net.can_fuse_output_warp(x.shape, rinv)
+
+    def run(fused):
+        net.zero_grad()
+        if fused:
+            with net.fuse_output_warp(rinv.to(DEV), rinv):
+                y = net(x)
+        else:
+            y = ops.affine_warp(net(x), rinv.to(DEV), padding_mode="zeros", tta_grid_algebra=True)
+        y.backward(gout)
+        torch.cuda.synchronize()
+        return y.detach().clone(), {n: p.grad.detach().clone() for n, p in net.named_parameters() if p.grad is not None}
+
+    y0, g0 = run(False)
+    y1, g1 = run(True)
+    rng = float(y0.max() - y0.min())
+    assert tuple(y1.shape) == tuple(y0.shape) and float((y1 - y0).abs().max()) < 2e-6 * rng + 1e-6
+    assert set(g0) == set(g1)
+    for n in g0:
+        if n == "decoder.seg_layers.3.bias":
+            assert float((g0[n] - g1[n]).abs().max()) < 1e-4 * float(g0[n].abs().max()) + 1e-6, n
+        else:
+            assert torch.equal(g0[n], g1[n]), f"{n}: fused backward differs"
+    # maps the owner-computes gather declines are not offered the fused pair
+    assert not net.can_fuse_output_warp(x.shape, torch.zeros(2, 3, 4))
+    assert not net.can_fuse_output_warp(x.shape, rinv * 0.05)

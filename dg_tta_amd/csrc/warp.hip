@@ -838,18 +838,27 @@ __global__ __launch_bounds__(256, 6) void head_warp_bwd_kernel(const float *__re
     if (threadIdx.x < HW_NS) {
       const double t = ((double)sred[0][threadIdx.x] + (double)sred[1][threadIdx.x]) +
                        ((double)sred[2][threadIdx.x] + (double)sred[3][threadIdx.x]);
-      bias_partial[(int64_t)blockIdx.x * HW_NS + threadIdx.x] = t;
+      bias_partial[(int64_t)threadIdx.x * gridDim.x + blockIdx.x] = t;      // [class][block]: the finalize reads rows
     }
   }
 }
 
-__global__ void head_warp_bias_finalize_kernel(const double *__restrict__ partial, int nblk, int nsel, float *__restrict__ db,
-                                               int accumulate) {
-  const int k = blockIdx.x;   // one wave per class; blocks in index order
+__global__ __launch_bounds__(1024) void head_warp_bias_finalize_kernel(const double *__restrict__ partial, int nblk, int nsel,
+                                                                       float *__restrict__ db, int accumulate) {
+  // one workgroup per class over its row of block sums; fixed order: per-thread strided sums, butterfly per wave, waves in order
+  __shared__ double red[16];
+  const int k = blockIdx.x;
+  const double *row = partial + (int64_t)k * nblk;
   double s = 0.0;
-  for (int i = threadIdx.x; i < nblk; i += 64) s += partial[(int64_t)i * HW_NS + k];
+  for (int i = threadIdx.x; i < nblk; i += 1024) s += row[i];
   s = wave_sum_d(s);
-  if (threadIdx.x == 0 && k < nsel) db[k] = accumulate ? db[k] + (float)s : (float)s;
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0 && k < nsel) {
+    double t = 0.0;
+    for (int wv = 0; wv < 16; ++wv) t += red[wv];
+    db[k] = accumulate ? db[k] + (float)t : (float)t;
+  }
 }
 
 // host copy of inverse_map()'s acceptance test (same arithmetic in float): the fused backward has no scatter fallback
@@ -1076,7 +1085,7 @@ extern "C" int dgtta_seghead_warp_bwd(const void *z, const float *gout, const fl
     DG_REQUIRE(rc == DGTTA_OK, rc, "seghead_warp_bwd: head weight gradient failed (%d)", rc);
   }
   if (db_sel) {
-    hipLaunchKernelGGL(head_warp_bias_finalize_kernel, dim3(HW_NS), dim3(64), 0, st, bias_partial, (int)nblk, nsel, db_sel,
+    hipLaunchKernelGGL(head_warp_bias_finalize_kernel, dim3(HW_NS), dim3(1024), 0, st, bias_partial, (int)nblk, nsel, db_sel,
                        accumulate);
     DG_CHECK_LAUNCH("head_warp_bias_finalize_kernel");
   }

@@ -35,12 +35,16 @@ struct RowsCfg {
   static constexpr size_t LDS_BYTES = 2 * A_BYTES + B_BYTES + RED_BYTES;
 };
 
-// VAR (round 3, bit mask; DGTTA_ROWS_VAR selects, default = all): 1 = the next job's coordinates come from a mixed-radix
+// VAR (round 3, bit mask; default 5 = 1 | 4, DGTTA_ROWS_VAR=0: the round-2 kernel): 1 = the next job's coordinates come from a mixed-radix
 // counter (a few scalar adds) instead of ten integer divisions on the CU's one scalar unit, which all 8 waves queued on
 // (stamps: 5.7 % of the kernel); 2 = the DMA pieces of the next chunk are issued in the first 5/8 of the MFMA loop, so
-// that they have landed when the loop ends; 4 = the 27 weight fragments are read from LDS just in time inside the MFMA
+// that they have landed when the loop ends (measured: no gain, not in the default); 4 = the 27 weight fragments are read from LDS just in time inside the MFMA
 // loop (taps (kd,kh) in order of first use) instead of in a block before it, and the barrier that frees the weight
-// buffer for the next chunk's DMA sits in the middle of the loop.
+// buffer for the next chunk's DMA sits in the middle of the loop.  Stamps (128^3 32->32): each feature shortens its own
+// segment (job decode 13.7 k -> 8.6 k cycles per wave, weight reload + barriers 31.9 k -> 17.1 k of 238 k) and the MFMA
+// loop of the lock-stepped waves absorbs most of it; net 1.5-2.5 % per launch.  Also tried in round 3 and dropped: the A image
+// filled as flat 1-KiB pieces crossing row boundaries (12 instead of 20 piece issues per wave and phase): 8 % SLOWER -
+// the per-lane row select and address arithmetic cost more than the issue slots they save.
 template <int PD, int PH, int WD, int WH, int ABL = 0, typename T16 = bf16_t, int VAR = 0>   // ABL: diagnostic ablation
 __global__ __launch_bounds__(WD *WH * 64) void conv3_rows_kernel(const bf16_t *__restrict__ x, View xv,
                                                                  const bf16_t *__restrict__ w, Taps taps,
@@ -498,21 +502,18 @@ int launch_conv_rows(const void *x, const View &xv, const void *w, const Taps &t
   // DGTTA_ROWS_ABL (diagnostic builds of the same kernel): 1 no DMA, 3 no MFMA, 6 per-segment cycle stamps, 7 the
   // voxel-major (ragged-tile) epilogue for every tile, 8 plain (temporal) output stores
   const int abl = dgtta_switches().rows_abl;
-  const int var = dgtta_switches().rows_var;       // DGTTA_ROWS_VAR: '0' round-2 kernel, '1', '3', '7' (default) feature masks
-  auto kern = conv3_rows_kernel<PD, PH, WD, WH, 0, T16, 7>;
+  const int var = dgtta_switches().rows_var;       // DGTTA_ROWS_VAR: '0' = the round-2 kernel; default = feature mask 5
+  auto kern = conv3_rows_kernel<PD, PH, WD, WH, 0, T16, 5>;
   static DynLdsOnce once[16];
   int slot = 0;
   if (var == '0') kern = conv3_rows_kernel<PD, PH, WD, WH, 0, T16, 0>, slot = 6;
   if (std::is_same<T16, bf16_t>::value) {      // diagnostic builds exist for the bf16 instantiation only
-    if (var == '1') kern = conv3_rows_kernel<PD, PH, WD, WH, 0, T16, 1>, slot = 7;
-    if (var == '3') kern = conv3_rows_kernel<PD, PH, WD, WH, 0, T16, 3>, slot = 8;
-    if (var == '5') kern = conv3_rows_kernel<PD, PH, WD, WH, 0, T16, 5>, slot = 11;
+    if (var == '7') kern = conv3_rows_kernel<PD, PH, WD, WH, 0, T16, 7>, slot = 7;
     if (abl == '1') kern = conv3_rows_kernel<PD, PH, WD, WH, 1, T16, 0>, slot = 1;
     if (abl == '3') kern = conv3_rows_kernel<PD, PH, WD, WH, 3, T16, 0>, slot = 2;
     if (abl == '6') {
-      kern = conv3_rows_kernel<PD, PH, WD, WH, 6, T16, 7>, slot = 3;
+      kern = conv3_rows_kernel<PD, PH, WD, WH, 6, T16, 5>, slot = 3;
       if (var == '0') kern = conv3_rows_kernel<PD, PH, WD, WH, 6, T16, 0>, slot = 9;
-      if (var == '3') kern = conv3_rows_kernel<PD, PH, WD, WH, 6, T16, 3>, slot = 10;
     }
     if (abl == '7') kern = conv3_rows_kernel<PD, PH, WD, WH, 7, T16, 0>, slot = 4;
     if (abl == '4') kern = conv3_rows_kernel<PD, PH, WD, WH, 4, T16, 0>, slot = 12;

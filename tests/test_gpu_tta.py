@@ -688,3 +688,46 @@ def test_mind_is_not_precomputed_behind_a_user_input_modifier():
         else:
             os.environ["DG_TTA_INTERNAL_AUGMENTATION"] = old
     utils.disable_internal_augmentation()
+
+
+def test_each_rank_loads_only_the_cases_it_works_on(tmp_path, monkeypatch):
+    """Sharded tta_main through the REAL data iterator: 3 cases on 2 ranks - a rank reads and
+    preprocesses only its own cases (the others arrive as stubs), predicts each case right after its last ensemble member
+    and drops it; the summary written after both ranks covers all three."""
+    import json
+    from types import SimpleNamespace as NS
+    from dg_tta_amd.tta import nnunet_utils as nu
+    from dg_tta_amd.tta.config_log_utils import ModifierFunctions
+    from dg_tta_amd.tta.tta import tta_main
+    raw = tmp_path / "raw"
+    (raw / "imagesTs").mkdir(parents=True)
+    (raw / "labelsTs").mkdir()
+    files = []
+    for s in (1, 2, 3):
+        case = _synthetic_case(s)
+        np.save(raw / "imagesTs" / f"c{s}_0000.npy", case[:1].numpy())
+        lab = torch.cat([(case[1:].sum(0, keepdim=True) < 1).float(), case[1:]]).argmax(0)
+        np.save(raw / "labelsTs" / f"c{s}.npy", lab.numpy().astype(np.int16))
+        files.append(str(raw / "imagesTs" / f"c{s}_0000.npy"))
+    g = load_golden("calc_branch")
+    net = _network_with_hooks(g, conv_impl=0)
+    modmod = SimpleNamespace(ModifierFunctions=ModifierFunctions)
+    mapping = {"background": (0, 0), "a": (2, 1), "b": (3, 2), "c": (5, 3)}
+    cfg = _plan(epochs=1, start_tta_at_epoch=0, ensemble_count=2, patches_to_be_accumulated=2, tta_data_filepaths=files, seed=3,
+                pretrained_weights_filepath="unused", lr=1e-4, optimized_labels=["background", "a", "b", "c"],
+                barrier_timeout_s=60.0)
+    bundle = (NS(), [16, 16, 16], net, [{k: v.clone() for k, v in net.state_dict().items()}])
+    read = []
+    real = nu.preprocess_fromfile
+    monkeypatch.setattr(nu, "preprocess_fromfile", lambda f, *a, **k: (read.append(Path(f).name), real(f, *a, **k))[1])
+    out = tmp_path / "out"
+    out.mkdir()
+    r1 = tta_main("run", cfg, raw, out, mapping, modmod, DEV, network_bundle=bundle, shard=(1, 2))
+    assert read == ["c2_0000.npy"]                                        # rank 1 of 2: sample index 1 only
+    assert ("tta_outputTs/c2", "prediction") in r1 and not any(k[0] == "summary" for k in r1)
+    read.clear()
+    r0 = tta_main("run", cfg, raw, out, mapping, modmod, DEV, network_bundle=bundle, shard=(0, 2))
+    assert read == ["c1_0000.npy", "c3_0000.npy"]                         # rank 0: indices 0 and 2, each read once
+    assert ("summary", "Ts") in r0
+    sj = json.loads((out / "run" / "summary_Ts.json").read_text())
+    assert sorted(Path(c["prediction_file"]).name for c in sj["metric_per_case"]) == ["c1.npy", "c2.npy", "c3.npy"]

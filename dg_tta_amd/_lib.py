@@ -41,6 +41,8 @@ SIGNATURES = {
     "dgtta_instnorm_ws_bytes": (SZ, [I, I, I64]),
     "dgtta_instnorm_lrelu_fwd": (I, [P, I, P, P, P, P, P, I, P, SZ, I, I, I64, F, F, I, P]),
     "dgtta_instnorm_lrelu_bwd": (I, [P, I, P, I, P, P, P, P, I, P, P, P, SZ, I, I, I64, F, I, I, P]),
+    "dgtta_conv3d_k3_dgrad_gstats": (I, [P, I, P, P, I, I, I, I, I, I, I, I, I, P, I, P, P, P, F, P, SZ, C.POINTER(I), I, I, P]),
+    "dgtta_instnorm_lrelu_bwd_gstats": (I, [P, I, P, I, P, P, P, P, I, P, P, P, P, SZ, I, I, I64, F, I, I, P]),
     "dgtta_convT3d_fwd_ws_bytes": (SZ, [I, I, I]),
     "dgtta_convT3d_k2s2_fwd": (I, [P, I, P, P, P, I, P, SZ, I, I, I, I, I, I, I, I, P]),
     "dgtta_convT3d_bwd_ws_bytes": (SZ, [I, I, I, I, I, I]),

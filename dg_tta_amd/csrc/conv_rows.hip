@@ -31,7 +31,7 @@ struct RowsCfg {
   static constexpr int NROW = ID * IH, RB = 68;
   static constexpr size_t A_BYTES = ((size_t)NROW * RB * 16 + 1023) / 1024 * 1024;
   static constexpr size_t B_BYTES = 27 * 1024;
-  static constexpr size_t RED_BYTES = (size_t)NW * 32 * 2 * sizeof(float);
+  static constexpr size_t RED_BYTES = (size_t)NW * 32 * 2 * sizeof(float) + 32 * 2 * sizeof(float);     // + GST constants
   static constexpr size_t LDS_BYTES = 2 * A_BYTES + B_BYTES + RED_BYTES;
 };
 
@@ -45,19 +45,35 @@ struct RowsCfg {
 // loop of the lock-stepped waves absorbs most of it; net 1.5-2.5 % per launch.  Also tried in round 3 and dropped: the A image
 // filled as flat 1-KiB pieces crossing row boundaries (12 instead of 20 piece issues per wave and phase): 8 % SLOWER -
 // the per-lane row select and address arithmetic cost more than the issue slots they save.
-template <int PD, int PH, int WD, int WH, int ABL = 0, typename T16 = bf16_t, int VAR = 0>   // ABL: diagnostic ablation
+// GST (round 3): the launch is the DATA GRADIENT of a conv whose input was z = LeakyReLU(InstanceNorm(y_prev)): the
+// epilogue also accumulates the statistics the InstanceNorm backward of that previous layer needs,
+//   sum_v g'  and  sum_v g' * y_prev   with  g' = gz * lrelu'(A y_prev + B),  A = gamma * rstd,  B = beta - mean * A
+// (sum g' xhat = rstd (sum g' y - mean sum g')), from the gz values it is about to store (rounded, as the apply pass reads
+// them) and the y_prev tile read with the stores' own address pattern.  Replaces the reduction pass over y_prev and gz
+// (chan_reduce_vec_kernel<., 1>) for that layer; same partial-sum layout and finalize order as the forward statistics.
+struct GstArgs {
+  const bf16_t *y;          // y_prev, same lattice as the output
+  View v;
+  const float *mr, *gamma, *beta;
+  float slope;
+};
+
+template <int PD, int PH, int WD, int WH, int ABL = 0, typename T16 = bf16_t, int VAR = 0, bool GST = false>   // ABL: diagnostic ablation
 __global__ __launch_bounds__(WD *WH * 64) void conv3_rows_kernel(const bf16_t *__restrict__ x, View xv,
                                                                  const bf16_t *__restrict__ w, Taps taps,
                                                                  const float *__restrict__ bias, bf16_t *__restrict__ y,
                                                                  View yv, int Cin, int Cout, int CinP, int tilesW,
                                                                  int tilesH, int tilesD, int nblkN, int njobs,
-                                                                 double *__restrict__ stats, int ntaps_src, int order) {
+                                                                 double *__restrict__ stats, int ntaps_src, int order,
+                                                                 GstArgs gst) {
   typedef RowsCfg<PD, PH, WD, WH> Cfg;
   constexpr int NW = Cfg::NW, IH = Cfg::IH;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char *sAb = smem;                                   // two A buffers
   unsigned char *sBb = smem + 2 * Cfg::A_BYTES;                // [27][2][32] x 16 B
   float *red = reinterpret_cast<float *>(smem + 2 * Cfg::A_BYTES + Cfg::B_BYTES);
+  float *gcst = red + NW * 32 * 2;                             // GST: (A, B) of the run's 32 channels
+  bool gst_newrun = true;
 
   // the wave id is made explicitly scalar: derived from threadIdx it is a 'divergent' VGPR value to the compiler, and
   // every per-row address of a DMA piece (64-bit multiplies and adds) was computed per lane - ~25 VALU per piece, 20
@@ -261,6 +277,17 @@ __global__ __launch_bounds__(WD *WH * 64) void conv3_rows_kernel(const bf16_t *_
       const int co = cur.n0 + r;
       bv = (bias && co < Cout) ? bias[co] : 0.f;
       asm volatile("" ::"v"(bv));
+      if (GST && gst_newrun) {      // a new (sample, channel block) run: its constants, and zeroed per-wave accumulators
+        if (tid < 32) {
+          const int c = cur.n0 + tid;
+          const float mu = gst.mr[((long long)cur.b * Cout + c) * 2], rs = gst.mr[((long long)cur.b * Cout + c) * 2 + 1];
+          const float a = gst.gamma[c] * rs;
+          gcst[tid * 2] = a;
+          gcst[tid * 2 + 1] = gst.beta[c] - mu * a;
+        }
+        for (int i = tid; i < NW * 32 * 2; i += Cfg::NT) red[i] = 0.f;
+        gst_newrun = false;         // (published by the barriers between here and the epilogue)
+      }
     }
     if (!(VAR & 4)) lds_barrier();            // B buffer is free again (VAR & 4: in the middle of the MFMA loop)
     stamp(1);                 // barrier + B fragments + barrier
@@ -356,6 +383,25 @@ __global__ __launch_bounds__(WD *WH * 64) void conv3_rows_kernel(const bf16_t *_
         // lane 4 q + p of a group supplies the address of block row q, voxels 4 p .. 4 p + 3
         const int cq = le >> 4, li = le & 15, rq = li >> 2, rp = li & 3;
         f32x2_t s1v = {0.f, 0.f}, s2v = {0.f, 0.f};       // packed fp32 math: two voxels per instruction
+        // GST: this lane's y_prev values (8 channels of each of its 8 output voxels), fetched with the stores' pattern
+        uint4 gy[GST ? PD * PH * 2 : 1];
+        float gs1[8], gs2[8], gA[8], gB[8];
+        if (GST) {
+#pragma unroll
+          for (int k = 0; k < PD * PH; ++k) {
+            const int od = cur.od0 + wd * PD + k / PH, oh = cur.oh0 + wh * PH + k % PH;
+            const bf16_t *yrow = gst.y + (long long)cur.b * gst.v.sb + od * gst.v.sd + oh * gst.v.sh + cur.n0 + cq * 8;
+#pragma unroll
+            for (int vb = 0; vb < 2; ++vb)
+              gy[k * 2 + vb] = *reinterpret_cast<const uint4 *>(yrow + (long long)(cur.ow0 + 16 * vb + li) * gst.v.sw);
+          }
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            gs1[e] = gs2[e] = 0.f;
+            gA[e] = gcst[(cq * 8 + e) * 2];
+            gB[e] = gcst[(cq * 8 + e) * 2 + 1];
+          }
+        }
         auto part1 = [&](int i, int j) {
           unsigned char *sl = slabb + (i * PH + j) * 2048 + re * 64;
 #pragma unroll
@@ -387,6 +433,22 @@ __global__ __launch_bounds__(WD *WH * 64) void conv3_rows_kernel(const bf16_t *_
             val.y = (unsigned)(unsigned short)lo[2] | ((unsigned)(unsigned short)lo[3] << 16);
             val.z = (unsigned)(unsigned short)hi[0] | ((unsigned)(unsigned short)hi[1] << 16);
             val.w = (unsigned)(unsigned short)hi[2] | ((unsigned)(unsigned short)hi[3] << 16);
+            if (GST) {
+              const uint4 yq = gy[(i * PH + j) * 2 + vb];
+              const unsigned gw[4] = {val.x, val.y, val.z, val.w}, yw[4] = {yq.x, yq.y, yq.z, yq.w};
+#pragma unroll
+              for (int t = 0; t < 4; ++t) {
+                float g0, g1, y0, y1;
+                unpack2_16<T16>(gw[t], g0, g1);
+                unpack2_16<T16>(yw[t], y0, y1);
+                const float a0 = __builtin_fmaf(gA[2 * t], y0, gB[2 * t]), a1 = __builtin_fmaf(gA[2 * t + 1], y1, gB[2 * t + 1]);
+                const float q0 = a0 > 0.f ? g0 : g0 * gst.slope, q1 = a1 > 0.f ? g1 : g1 * gst.slope;
+                gs1[2 * t] += q0;
+                gs1[2 * t + 1] += q1;
+                gs2[2 * t] = __builtin_fmaf(q0, y0, gs2[2 * t]);
+                gs2[2 * t + 1] = __builtin_fmaf(q1, y1, gs2[2 * t + 1]);
+              }
+            }
             const int ow = cur.ow0 + 16 * vb + li;
             // NON-TEMPORAL store: the output streams through L2 instead of displacing the input lines, whose second
             // 16-channel half is fetched one phase later.  PMC, 128^3 32->32, one sample: FETCH 353 -> 197 MB (134 MB
@@ -408,6 +470,29 @@ __global__ __launch_bounds__(WD *WH * 64) void conv3_rows_kernel(const bf16_t *_
         }
         st1 += s1v[0] + s1v[1];
         st2 += s2v[0] + s2v[1];
+        if (GST) {
+          // sum over the 16 lanes (voxels) that share this lane's channel group: quad swaps, half-row and row mirrors (DPP);
+          // lane li == 0 adds the job's sums to this wave's accumulators (one writer per slot: fixed order)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            float a = gs1[e], c2 = gs2[e];
+            a += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(a), 0xB1, 0xf, 0xf, false));
+            c2 += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(c2), 0xB1, 0xf, 0xf, false));
+            a += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(a), 0x4E, 0xf, 0xf, false));
+            c2 += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(c2), 0x4E, 0xf, 0xf, false));
+            a += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(a), 0x141, 0xf, 0xf, false));
+            c2 += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(c2), 0x141, 0xf, 0xf, false));
+            a += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(a), 0x140, 0xf, 0xf, false));
+            c2 += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(c2), 0x140, 0xf, 0xf, false));
+            if (li == 0) {
+              float2 *slot = reinterpret_cast<float2 *>(red + (wave * 32 + cq * 8 + e) * 2);
+              float2 cur2 = *slot;
+              cur2.x += a;
+              cur2.y += c2;
+              *slot = cur2;
+            }
+          }
+        }
         stamp(7);               // (diagnostic) slab reads + global stores
       } else {
         // ragged tile: voxel-major slab [32 voxels][32 ch] with 2-byte writes and per-element bounds
@@ -454,10 +539,14 @@ __global__ __launch_bounds__(WD *WH * 64) void conv3_rows_kernel(const bf16_t *_
         const int tiles_per_b = tilesW * tilesH * tilesD;
         double *pp = stats + 32 + (((int64_t)cur.b * tiles_per_b + cur.tile) * Cout + cur.n0 + tid) * 2;
         if (flush) {
-          const float a = st1 + __shfl_xor(st1, 32, 64), c2 = st2 + __shfl_xor(st2, 32, 64);
-          if (he == 0) {
-            red[(wave * 32 + re) * 2 + 0] = a;
-            red[(wave * 32 + re) * 2 + 1] = c2;
+          if (!GST) {
+            const float a = st1 + __shfl_xor(st1, 32, 64), c2 = st2 + __shfl_xor(st2, 32, 64);
+            if (he == 0) {
+              red[(wave * 32 + re) * 2 + 0] = a;
+              red[(wave * 32 + re) * 2 + 1] = c2;
+            }
+          } else {
+            gst_newrun = true;      // (the per-wave accumulators already hold the run's sums)
           }
           st1 = st2 = 0.f;
           lds_barrier();
@@ -494,11 +583,43 @@ __global__ __launch_bounds__(WD *WH * 64) void conv3_rows_kernel(const bf16_t *_
   }
 }
 
+}  // namespace
+
+// context of a data-gradient launch that also produces the InstanceNorm backward statistics (set by
+// dgtta_conv3d_k3_dgrad_gstats around the dispatcher call, consumed here: the generic kernels know nothing about it)
+struct RowsGstCtx {
+  const void *y;
+  long long ldy;
+  const float *mr, *gamma, *beta;
+  float slope;
+  double *out;
+  int produced;
+};
+thread_local RowsGstCtx *g_rows_gst = nullptr;
+
+namespace {
+
 template <int PD, int PH, int WD, int WH, typename T16>
 int launch_conv_rows(const void *x, const View &xv, const void *w, const Taps &taps, const float *bias, void *y,
                      const View &yv, int B, int Cin, int Cout, int CinP, int CoutP, double *stats, int ntaps_src,
                      hipStream_t st) {
   typedef RowsCfg<PD, PH, WD, WH> Cfg;
+  GstArgs ga{};
+  RowsGstCtx *gctx = g_rows_gst;
+  g_rows_gst = nullptr;       // one launch per context
+  // eligible: no forward statistics asked for, every tile whole, whole 32-channel blocks
+  const bool gst_on = gctx && !stats && !bias && yv.D % Cfg::TD == 0 && yv.H % Cfg::TH == 0 && yv.W % 32 == 0 && Cout % 32 == 0 &&
+                      CoutP == Cout && gctx->ldy % 8 == 0 && ((uintptr_t)gctx->y & 15) == 0 && dgtta_switches().rows_abl < 0;
+  if (gst_on) {
+    ga.y = (const bf16_t *)gctx->y;
+    ga.v = dense_view(B, yv.D, yv.H, yv.W, (int)gctx->ldy);
+    ga.mr = gctx->mr;
+    ga.gamma = gctx->gamma;
+    ga.beta = gctx->beta;
+    ga.slope = gctx->slope;
+    stats = gctx->out;
+    gctx->produced = 1;
+  }
   // DGTTA_ROWS_ABL (diagnostic builds of the same kernel): 1 no DMA, 3 no MFMA, 6 per-segment cycle stamps, 7 the
   // voxel-major (ragged-tile) epilogue for every tile, 8 plain (temporal) output stores
   const int abl = dgtta_switches().rows_abl;
@@ -507,6 +628,7 @@ int launch_conv_rows(const void *x, const View &xv, const void *w, const Taps &t
   static DynLdsOnce once[16];
   int slot = 0;
   if (var == '0') kern = conv3_rows_kernel<PD, PH, WD, WH, 0, T16, 0>, slot = 6;
+  if (gst_on) kern = conv3_rows_kernel<PD, PH, WD, WH, 0, T16, 5, true>, slot = 15;
   if (std::is_same<T16, bf16_t>::value) {      // diagnostic builds exist for the bf16 instantiation only
     if (var == '7') kern = conv3_rows_kernel<PD, PH, WD, WH, 0, T16, 7>, slot = 7;
     if (abl == '1') kern = conv3_rows_kernel<PD, PH, WD, WH, 1, T16, 0>, slot = 1;
@@ -535,7 +657,7 @@ int launch_conv_rows(const void *x, const View &xv, const void *w, const Taps &t
   const int grid = (int)(njobs < (long long)ncu * wg_per_cu ? njobs : (long long)ncu * wg_per_cu);
   hipLaunchKernelGGL(kern, dim3(grid), dim3(Cfg::NT), Cfg::LDS_BYTES, st, (const bf16_t *)x, xv, (const bf16_t *)w, taps,
                      bias, (bf16_t *)y, yv, Cin, Cout, CinP, tW, tH, tD, nblkN, (int)njobs, stats, ntaps_src,
-                     dgtta_switches().rows_order == '0' ? 0 : 1);
+                     dgtta_switches().rows_order == '0' ? 0 : 1, ga);
   DG_CHECK_LAUNCH("conv3_rows_kernel");
   return DGTTA_OK;
 }

@@ -48,6 +48,7 @@ static const DgttaSwitches *read_switches() {
   s->warp_coop = env_char("DGTTA_WARP_COOP");
   s->warp_nt = env_char("DGTTA_WARP_NT");
   s->warp_xcd = env_char("DGTTA_WARP_XCD");
+  s->in_gstats = env_char("DGTTA_IN_GSTATS");
   s->wgrad_abl = env_char("DGTTA_WGRAD_ABL");
   return s;
 }

@@ -550,6 +550,39 @@ __global__ void in_bwd_finalize_kernel(const double *__restrict__ partial, int n
   }
 }
 
+// The same from the partial sums the data-gradient kernel left (conv_rows.hip, GST): per (sample, tile) sums of g' and
+// g' * y in the layout of the forward statistics (header = tiles per sample); sum g' xhat = rstd (sum g' y - mean sum g').
+__global__ void in_bwd_finalize_gstats_kernel(const double *__restrict__ stats, int B, int C, int64_t V,
+                                              const float *__restrict__ mean_rstd, float *__restrict__ c12,
+                                              float *__restrict__ dgamma, float *__restrict__ dbeta, int accumulate) {
+  const int c = blockIdx.x;
+  __shared__ double red[8];
+  const int nblk = (int)reinterpret_cast<const long long *>(stats)[0];
+  const double *partial = stats + 32;
+  double g_acc = 0.0, b_acc = 0.0;
+  for (int b = 0; b < B; ++b) {
+    double s0 = 0.0, s1 = 0.0;
+    for (int k = threadIdx.x; k < nblk; k += 256) {
+      const double2 v = *reinterpret_cast<const double2 *>(partial + ((((int64_t)b * nblk + k) * C) + c) * 2);
+      s0 += v.x;
+      s1 += v.y;
+    }
+    block_sum2_d(s0, s1, red);
+    const double mu = (double)mean_rstd[((int64_t)b * C + c) * 2], rs = (double)mean_rstd[((int64_t)b * C + c) * 2 + 1];
+    const double s1x = rs * (s1 - mu * s0);
+    if (threadIdx.x == 0) {
+      c12[((int64_t)b * C + c) * 2] = (float)(s0 / (double)V);
+      c12[((int64_t)b * C + c) * 2 + 1] = (float)(s1x / (double)V);
+    }
+    b_acc += s0;
+    g_acc += s1x;
+  }
+  if (threadIdx.x == 0) {
+    dgamma[c] = accumulate ? dgamma[c] + (float)g_acc : (float)g_acc;
+    dbeta[c] = accumulate ? dbeta[c] + (float)b_acc : (float)b_acc;
+  }
+}
+
 // dy = gamma*rstd*(da - c1 - xhat*c2)
 template <typename T>
 __global__ void in_lrelu_bwd_apply_kernel(const T *__restrict__ gz, int ldgz, const T *__restrict__ y, int ldy,
@@ -1064,6 +1097,37 @@ extern "C" int dgtta_conv3d_k3_dgrad(const void *dy, int lddy, const void *wpack
   return DGTTA_OK;
 }
 
+// conv_rows.hip: context of a data-gradient launch that also produces InstanceNorm backward statistics
+struct RowsGstCtx {
+  const void *y;
+  long long ldy;
+  const float *mr, *gamma, *beta;
+  float slope;
+  double *out;
+  int produced;
+};
+extern thread_local RowsGstCtx *g_rows_gst;
+
+extern "C" int dgtta_conv3d_k3_dgrad_gstats(const void *dy, int lddy, const void *wpack, void *dx, int lddx, int B, int Cin,
+                                            int Cout, int CinP, int CoutP, int Di, int Hi, int Wi, const void *y_prev,
+                                            int ldy_prev, const float *mean_rstd_prev, const float *gamma_prev,
+                                            const float *beta_prev, float slope, void *gstats, size_t gstats_bytes,
+                                            int *h_produced, int dtype, int impl, void *stream) {
+  DG_REQUIRE(y_prev && mean_rstd_prev && gamma_prev && beta_prev && gstats && h_produced, DGTTA_ERR_BADARG,
+             "conv3d_k3_dgrad_gstats: null pointer");
+  DG_REQUIRE(ldy_prev >= Cin, DGTTA_ERR_BADARG, "conv3d_k3_dgrad_gstats: ldy_prev < Cin");
+  DG_REQUIRE(B > 0 && Cin > 0 && Di > 0 && Hi > 0 && Wi > 0 && gstats_bytes >= dgtta_conv3d_stats_bytes(B, Cin, Di, Hi, Wi),
+             DGTTA_ERR_WORKSPACE, "conv3d_k3_dgrad_gstats: statistics buffer too small");
+  RowsGstCtx ctx{y_prev, ldy_prev, mean_rstd_prev, gamma_prev, beta_prev, slope, (double *)gstats, 0};
+  // only the row-reuse kernel (16-bit storage, large whole-tile volumes) knows the fused form; any other dispatch ignores
+  // the context and *h_produced stays 0: the caller then runs the plain dgtta_instnorm_lrelu_bwd
+  if (dtype != DGTTA_F32 && impl != 1 && dgtta_switches().in_gstats != '0') g_rows_gst = &ctx;
+  const int rc = dgtta_conv3d_k3_dgrad(dy, lddy, wpack, dx, lddx, B, Cin, Cout, CinP, CoutP, Di, Hi, Wi, 1, 0, dtype, impl, stream);
+  g_rows_gst = nullptr;
+  *h_produced = rc == DGTTA_OK ? ctx.produced : 0;
+  return rc;
+}
+
 size_t conv3_wgrad_mfma_ws_bytes(int B, int Cin, int Cout, int D, int H, int W);
 
 // workspace layout: [bias partials][main: split partials of the VALU kernel | slabs of the MFMA kernel]
@@ -1168,24 +1232,28 @@ extern "C" int dgtta_instnorm_lrelu_fwd(const void *y, int ldy, const void *stat
   return DGTTA_OK;
 }
 
-extern "C" int dgtta_instnorm_lrelu_bwd(const void *gz, int ldgz, const void *y, int ldy, const float *gamma,
-                                        const float *beta, const float *mean_rstd, void *dy, int lddy, float *dgamma,
-                                        float *dbeta, void *ws, size_t ws_bytes, int B, int C, int64_t V, float slope,
-                                        int accumulate, int dtype, void *stream) {
-  DG_REQUIRE(gz && y && gamma && beta && mean_rstd && dy && dgamma && dbeta && ws, DGTTA_ERR_BADARG,
-             "instnorm_lrelu_bwd: null pointer");
-  DG_REQUIRE(B > 0 && C > 0 && V > 0 && ldy >= C && ldgz >= C && lddy >= C, DGTTA_ERR_BADARG,
-             "instnorm_lrelu_bwd: bad dims");
-  DG_REQUIRE(ws_bytes >= dgtta_instnorm_ws_bytes(B, C, V), DGTTA_ERR_WORKSPACE, "instnorm_lrelu_bwd: workspace too small");
+static int instnorm_bwd_impl(const void *gz, int ldgz, const void *y, int ldy, const float *gamma, const float *beta,
+                             const float *mean_rstd, void *dy, int lddy, float *dgamma, float *dbeta, const void *gstats,
+                             void *ws, size_t ws_bytes, int B, int C, int64_t V, float slope, int accumulate, int dtype,
+                             void *stream, const char *name) {
+  DG_REQUIRE(gz && y && gamma && beta && mean_rstd && dy && dgamma && dbeta && ws, DGTTA_ERR_BADARG, "%s: null pointer", name);
+  DG_REQUIRE(B > 0 && C > 0 && V > 0 && ldy >= C && ldgz >= C && lddy >= C, DGTTA_ERR_BADARG, "%s: bad dims", name);
+  DG_REQUIRE(ws_bytes >= dgtta_instnorm_ws_bytes(B, C, V), DGTTA_ERR_WORKSPACE, "%s: workspace too small", name);
   hipStream_t st = (hipStream_t)stream;
   const int nblk = reduce_blocks(V, B);
   double *partial = (double *)ws;
   float *c12 = (float *)((char *)ws + align_up((size_t)B * nblk * C * 2 * sizeof(double), 256));
-  DISPATCH_T(dtype, (launch_chan_reduce<T, 1>(y, ldy, gz, ldgz, mean_rstd, gamma, beta, slope, partial, nblk, B, C, V, st)));
-  DG_CHECK_LAUNCH("chan_reduce_kernel<1>");
-  hipLaunchKernelGGL(in_bwd_finalize_kernel, dim3(C), dim3(256), 0, st, partial, nblk, B, C, V, c12, dgamma, dbeta,
-                     accumulate);
-  DG_CHECK_LAUNCH("in_bwd_finalize_kernel");
+  if (gstats) {     // the sums came out of the data-gradient kernel that produced gz: no pass over y and gz
+    hipLaunchKernelGGL(in_bwd_finalize_gstats_kernel, dim3(C), dim3(256), 0, st, (const double *)gstats, B, C, V, mean_rstd, c12,
+                       dgamma, dbeta, accumulate);
+    DG_CHECK_LAUNCH("in_bwd_finalize_gstats_kernel");
+  } else {
+    DISPATCH_T(dtype, (launch_chan_reduce<T, 1>(y, ldy, gz, ldgz, mean_rstd, gamma, beta, slope, partial, nblk, B, C, V, st)));
+    DG_CHECK_LAUNCH("chan_reduce_kernel<1>");
+    hipLaunchKernelGGL(in_bwd_finalize_kernel, dim3(C), dim3(256), 0, st, partial, nblk, B, C, V, c12, dgamma, dbeta,
+                       accumulate);
+    DG_CHECK_LAUNCH("in_bwd_finalize_kernel");
+  }
   const int64_t total = (int64_t)B * V * C;
   const int esz = dtype == DGTTA_F32 ? 4 : 2, epv = 16 / esz;
   if (C % epv == 0 && ldy % epv == 0 && ldgz % epv == 0 && lddy % epv == 0 && !((uintptr_t)y & 15) && !((uintptr_t)gz & 15) &&
@@ -1203,6 +1271,24 @@ extern "C" int dgtta_instnorm_lrelu_bwd(const void *gz, int ldgz, const void *y,
                                        C, V, slope, total));
   DG_CHECK_LAUNCH("in_lrelu_bwd_apply_kernel");
   return DGTTA_OK;
+}
+
+extern "C" int dgtta_instnorm_lrelu_bwd(const void *gz, int ldgz, const void *y, int ldy, const float *gamma,
+                                        const float *beta, const float *mean_rstd, void *dy, int lddy, float *dgamma,
+                                        float *dbeta, void *ws, size_t ws_bytes, int B, int C, int64_t V, float slope,
+                                        int accumulate, int dtype, void *stream) {
+  return instnorm_bwd_impl(gz, ldgz, y, ldy, gamma, beta, mean_rstd, dy, lddy, dgamma, dbeta, nullptr, ws, ws_bytes, B, C, V,
+                           slope, accumulate, dtype, stream, "instnorm_lrelu_bwd");
+}
+
+extern "C" int dgtta_instnorm_lrelu_bwd_gstats(const void *gz, int ldgz, const void *y, int ldy, const float *gamma,
+                                               const float *beta, const float *mean_rstd, void *dy, int lddy,
+                                               float *dgamma, float *dbeta, const void *gstats, void *ws, size_t ws_bytes,
+                                               int B, int C, int64_t V, float slope, int accumulate, int dtype,
+                                               void *stream) {
+  DG_REQUIRE(gstats, DGTTA_ERR_BADARG, "instnorm_lrelu_bwd_gstats: null statistics");
+  return instnorm_bwd_impl(gz, ldgz, y, ldy, gamma, beta, mean_rstd, dy, lddy, dgamma, dbeta, gstats, ws, ws_bytes, B, C, V,
+                           slope, accumulate, dtype, stream, "instnorm_lrelu_bwd_gstats");
 }
 
 static size_t convT_pack_region(int Cin, int Cout, int dtype) {

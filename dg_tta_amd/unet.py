@@ -476,6 +476,7 @@ class _UNetFn(torch.autograd.Function):
 
         gz_ptr, gz_ld = gz.data_ptr(), cin_h
         keep_alive = [gz]
+        gstats = None       # InstanceNorm backward sums left by the data gradient that produced the current gz
         first_rec = saved[0]
         # walk blocks in reverse order
         idx = len(saved) - 1
@@ -494,9 +495,16 @@ class _UNetFn(torch.autograd.Function):
             w_ = ws_for(nb)
             dgam = gbuf(norm.weight) if want(norm.weight) else torch.empty_like(norm.weight)
             dbet = gbuf(norm.bias) if want(norm.bias) else torch.empty_like(norm.bias)
-            check(lib.dgtta_instnorm_lrelu_bwd(gz_ptr, gz_ld, ptr(rec["y"]), cout, ptr(norm.weight), ptr(norm.bias),
-                                               ptr(rec["mr"]), ptr(dy), cout, ptr(dgam), ptr(dbet), ptr(w_), nb, B, cout,
-                                               v, SLOPE, ACC, dt, st), "dgtta_instnorm_lrelu_bwd")
+            if gstats is not None:      # the data gradient that produced gz also left the reduction's sums
+                check(lib.dgtta_instnorm_lrelu_bwd_gstats(gz_ptr, gz_ld, ptr(rec["y"]), cout, ptr(norm.weight),
+                                                          ptr(norm.bias), ptr(rec["mr"]), ptr(dy), cout, ptr(dgam), ptr(dbet),
+                                                          ptr(gstats), ptr(w_), nb, B, cout, v, SLOPE, ACC, dt, st),
+                      "dgtta_instnorm_lrelu_bwd_gstats")
+                gstats = None
+            else:
+                check(lib.dgtta_instnorm_lrelu_bwd(gz_ptr, gz_ld, ptr(rec["y"]), cout, ptr(norm.weight), ptr(norm.bias),
+                                                   ptr(rec["mr"]), ptr(dy), cout, ptr(dgam), ptr(dbet), ptr(w_), nb, B, cout,
+                                                   v, SLOPE, ACC, dt, st), "dgtta_instnorm_lrelu_bwd")
             # -- weight / bias gradient
             if want(conv.weight) or want(conv.bias):
                 nb = lib.dgtta_conv3d_wgrad_ws_bytes(B, cin, cout, do, ho, wo)
@@ -572,9 +580,23 @@ class _UNetFn(torch.autograd.Function):
                 gz_ptr, gz_ld = gptr, 2 * cskip
                 keep_alive = [gc]
             else:
+                # input was the previous block's activation z = LeakyReLU(InstanceNorm(y_prev)), consumed by this conv only:
+                # the data gradient can leave the sums of that block's InstanceNorm backward (csrc/conv_rows.hip, GST)
                 gin = torch.empty((B, di, hi, wi, cin), dtype=adt, device=dev)
-                check(lib.dgtta_conv3d_k3_dgrad(ptr(dy), cout, ptr(wb), ptr(gin), cin, B, cin, cout, rec["cinp"],
-                                                rec["coutp"], di, hi, wi, s, 0, dt, impl, st), "dgtta_conv3d_k3_dgrad")
+                prev = saved[idx - 1]
+                if s == 1 and dt != F32 and prev["cout"] == cin and prev["dout"] == (di, hi, wi):
+                    pn = prev["mod"].norm
+                    gbytes = lib.dgtta_conv3d_stats_bytes(B, cin, di, hi, wi)
+                    gbuf_ = ws_for(gbytes, "gstats")
+                    produced = C.c_int(0)
+                    check(lib.dgtta_conv3d_k3_dgrad_gstats(ptr(dy), cout, ptr(wb), ptr(gin), cin, B, cin, cout, rec["cinp"],
+                                                           rec["coutp"], di, hi, wi, ptr(prev["y"]), cin, ptr(prev["mr"]),
+                                                           ptr(pn.weight), ptr(pn.bias), SLOPE, ptr(gbuf_), gbytes,
+                                                           C.byref(produced), dt, impl, st), "dgtta_conv3d_k3_dgrad_gstats")
+                    gstats = gbuf_ if produced.value else None
+                else:
+                    check(lib.dgtta_conv3d_k3_dgrad(ptr(dy), cout, ptr(wb), ptr(gin), cin, B, cin, cout, rec["cinp"],
+                                                    rec["coutp"], di, hi, wi, s, 0, dt, impl, st), "dgtta_conv3d_k3_dgrad")
                 gz_ptr, gz_ld = gin.data_ptr(), cin
                 keep_alive = [gin]
             idx -= 1

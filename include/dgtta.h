@@ -196,6 +196,21 @@ int dgtta_instnorm_lrelu_bwd(const void *gz, int ldgz, const void *y, int ldy, c
                              float *dbeta, void *ws, size_t ws_bytes, int B, int C, int64_t V, float slope,
                              int accumulate, int dtype, void *stream);
 
+/* Data gradient of a stride-1 conv whose INPUT was z = LeakyReLU(InstanceNorm(y_prev)) (the blocks built at
+ * dg_tta/pretraining/nnUNetTrainer_GIN_MIND.py:46-53; autograd of tta.py:275), fused with the reduction pass of that
+ * previous layer's InstanceNorm backward: besides dx = gz it leaves, in `gstats` (size dgtta_conv3d_stats_bytes(B, Cin,
+ * Di, Hi, Wi)), the per-tile sums of g' and g' * y_prev (g' = gz * lrelu'(pre-activation)).  *h_produced (HOST int) = 1 when
+ * the statistics were produced (16-bit storage on the row-reuse kernel, whole tiles); 0: plain dgtta_conv3d_k3_dgrad ran.
+ * dgtta_instnorm_lrelu_bwd_gstats = dgtta_instnorm_lrelu_bwd without its own pass over y and gz. */
+int dgtta_conv3d_k3_dgrad_gstats(const void *dy, int lddy, const void *wpack, void *dx, int lddx, int B, int Cin, int Cout,
+                                 int CinP, int CoutP, int Di, int Hi, int Wi, const void *y_prev, int ldy_prev,
+                                 const float *mean_rstd_prev, const float *gamma_prev, const float *beta_prev, float slope,
+                                 void *gstats, size_t gstats_bytes, int *h_produced, int dtype, int impl, void *stream);
+int dgtta_instnorm_lrelu_bwd_gstats(const void *gz, int ldgz, const void *y, int ldy, const float *gamma, const float *beta,
+                                    const float *mean_rstd, void *dy, int lddy, float *dgamma, float *dbeta,
+                                    const void *gstats, void *ws, size_t ws_bytes, int B, int C, int64_t V, float slope,
+                                    int accumulate, int dtype, void *stream);
+
 /* ConvTranspose3d(Cin, Cout, kernel 2, stride 2, bias): w_t torch layout [Cin][Cout][2][2][2] fp32.
  * out[b][2v+o][co] = bias[co] + sum_ci x[b][v][ci] * w[ci][co][o]. */
 size_t dgtta_convT3d_fwd_ws_bytes(int Cin, int Cout, int dtype);

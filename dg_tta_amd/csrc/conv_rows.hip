@@ -385,7 +385,7 @@ __global__ __launch_bounds__(WD *WH * 64) void conv3_rows_kernel(const bf16_t *_
         f32x2_t s1v = {0.f, 0.f}, s2v = {0.f, 0.f};       // packed fp32 math: two voxels per instruction
         // GST: this lane's y_prev values (8 channels of each of its 8 output voxels), fetched with the stores' pattern
         uint4 gy[GST ? PD * PH * 2 : 1];
-        float gs1[8], gs2[8], gA[8], gB[8];
+        f32x2_t gs1[4], gs2[4], gA[4], gB[4];       // channel pairs: packed fp32 math (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32)
         if (GST) {
 #pragma unroll
           for (int k = 0; k < PD * PH; ++k) {
@@ -396,10 +396,11 @@ __global__ __launch_bounds__(WD *WH * 64) void conv3_rows_kernel(const bf16_t *_
               gy[k * 2 + vb] = *reinterpret_cast<const uint4 *>(yrow + (long long)(cur.ow0 + 16 * vb + li) * gst.v.sw);
           }
 #pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            gs1[e] = gs2[e] = 0.f;
-            gA[e] = gcst[(cq * 8 + e) * 2];
-            gB[e] = gcst[(cq * 8 + e) * 2 + 1];
+          for (int t = 0; t < 4; ++t) {
+            const float4 c4 = *reinterpret_cast<const float4 *>(gcst + (cq * 8 + 2 * t) * 2);      // (A, B) of two channels
+            gs1[t] = gs2[t] = f32x2_t{0.f, 0.f};
+            gA[t] = f32x2_t{c4.x, c4.z};
+            gB[t] = f32x2_t{c4.y, c4.w};
           }
         }
         auto part1 = [&](int i, int j) {
@@ -441,12 +442,12 @@ __global__ __launch_bounds__(WD *WH * 64) void conv3_rows_kernel(const bf16_t *_
                 float g0, g1, y0, y1;
                 unpack2_16<T16>(gw[t], g0, g1);
                 unpack2_16<T16>(yw[t], y0, y1);
-                const float a0 = __builtin_fmaf(gA[2 * t], y0, gB[2 * t]), a1 = __builtin_fmaf(gA[2 * t + 1], y1, gB[2 * t + 1]);
-                const float q0 = a0 > 0.f ? g0 : g0 * gst.slope, q1 = a1 > 0.f ? g1 : g1 * gst.slope;
-                gs1[2 * t] += q0;
-                gs1[2 * t + 1] += q1;
-                gs2[2 * t] = __builtin_fmaf(q0, y0, gs2[2 * t]);
-                gs2[2 * t + 1] = __builtin_fmaf(q1, y1, gs2[2 * t + 1]);
+                const f32x2_t g2 = {g0, g1}, y2 = {y0, y1};
+                const f32x2_t a2 = __builtin_elementwise_fma(gA[t], y2, gB[t]);
+                const f32x2_t gsl = g2 * gst.slope;
+                const f32x2_t q2 = {a2[0] > 0.f ? g2[0] : gsl[0], a2[1] > 0.f ? g2[1] : gsl[1]};
+                gs1[t] += q2;
+                gs2[t] = __builtin_elementwise_fma(q2, y2, gs2[t]);
               }
             }
             const int ow = cur.ow0 + 16 * vb + li;
@@ -475,7 +476,7 @@ __global__ __launch_bounds__(WD *WH * 64) void conv3_rows_kernel(const bf16_t *_
           // lane li == 0 adds the job's sums to this wave's accumulators (one writer per slot: fixed order)
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
-            float a = gs1[e], c2 = gs2[e];
+            float a = gs1[e >> 1][e & 1], c2 = gs2[e >> 1][e & 1];
             a += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(a), 0xB1, 0xf, 0xf, false));
             c2 += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(c2), 0xB1, 0xf, 0xf, false));
             a += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(a), 0x4E, 0xf, 0xf, false));

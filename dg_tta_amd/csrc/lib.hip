@@ -49,6 +49,7 @@ static const DgttaSwitches *read_switches() {
   s->warp_nt = env_char("DGTTA_WARP_NT");
   s->warp_xcd = env_char("DGTTA_WARP_XCD");
   s->in_gstats = env_char("DGTTA_IN_GSTATS");
+  s->softdice16 = env_char("DGTTA_SOFTDICE16");
   s->wgrad_abl = env_char("DGTTA_WGRAD_ABL");
   return s;
 }

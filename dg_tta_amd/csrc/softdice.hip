@@ -314,6 +314,132 @@ __global__ __launch_bounds__(256) void softdice_probs_bwd_kernel(const float *__
   }
 }
 
+// ---- 16 classes in rows of 16 (the TTA plan's C_opt at the bench shape), round 3: four lanes per voxel, one float4 of
+// either branch per lane - every load and store instruction covers 16 voxels x 64 contiguous bytes, the softmax lives in
+// registers (quad reductions by DPP), no LDS tile, no second pass.  Same formulas as the generic kernels above; the class
+// sums of a voxel are taken as a quad tree instead of sequentially (the results differ in the last bits only), the
+// per-class partial sums keep the layout the finalize kernel reads.  DGTTA_SOFTDICE16=0: the generic kernels.
+__device__ __forceinline__ float quad_sum(float v) {
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, false));
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xf, 0xf, false));
+  return v;
+}
+__device__ __forceinline__ float quad_max(float v) {
+  v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, false)));
+  v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xf, 0xf, false)));
+  return v;
+}
+
+// masked softmax of this lane's 4 classes of one voxel: p[j] = exp(x_j - max) / sum_exp; returns the mask part (sum x > 0)
+__device__ __forceinline__ float quad_softmax4(const float4 &x, float *p) {
+  const float s = quad_sum((x.x + x.y) + (x.z + x.w));
+  const float mx = quad_max(fmaxf(fmaxf(x.x, x.y), fmaxf(x.z, x.w)));
+  const float e0 = expf(x.x - mx), e1 = expf(x.y - mx), e2 = expf(x.z - mx), e3 = expf(x.w - mx);
+  const float se = quad_sum((e0 + e1) + (e2 + e3));
+  p[0] = e0 / se;
+  p[1] = e1 / se;
+  p[2] = e2 / se;
+  p[3] = e3 / se;
+  return s > 0.0f ? 1.0f : 0.0f;
+}
+
+constexpr int SD16_VPT = 8;        // voxels per thread and workgroup pass
+
+__global__ __launch_bounds__(256) void softdice_fwd16_kernel(const float *__restrict__ la, const float *__restrict__ lb,
+                                                             double *__restrict__ partial, int64_t V) {
+  __shared__ float red[4][4][8];      // [wave][class quarter][4 x (nom, den)]
+  const int b = blockIdx.y, q = threadIdx.x & 3;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const float4 *pa = reinterpret_cast<const float4 *>(la + (int64_t)b * V * 16);
+  const float4 *pb = reinterpret_cast<const float4 *>(lb + (int64_t)b * V * 16);
+  float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+  // a workgroup pass covers 64 voxels; passes are dealt to the workgroups round robin
+  for (int64_t v0 = (int64_t)blockIdx.x * 64; v0 < V; v0 += (int64_t)gridDim.x * 64) {
+    const int64_t v = v0 + (threadIdx.x >> 2);
+    if (v < V) {         // (whole quads are in or out)
+      const float4 xa = pa[v * 4 + q], xb = pb[v * 4 + q];
+      float a[4], bq[4];
+      const float m = quad_softmax4(xa, a) * quad_softmax4(xb, bq);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float aj = a[j] * m, bj = bq[j] * m;
+        s1[j] += (2.0f * aj) * bj;
+        const float tt = aj + bj;
+        s2[j] += tt * tt;
+      }
+    }
+  }
+  // lanes with the same class quarter (lane & 3) hold different voxels: butterfly over the other lane bits, fixed order
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+#pragma unroll
+    for (int o = 4; o < 64; o <<= 1) {
+      s1[j] += __shfl_xor(s1[j], o, 64);
+      s2[j] += __shfl_xor(s2[j], o, 64);
+    }
+  }
+  if (lane < 4) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      red[wv][lane][2 * j] = s1[j];
+      red[wv][lane][2 * j + 1] = s2[j];
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < 32) {       // (class c = 4 quarter + j, k): waves in index order, in double
+    const int c = threadIdx.x >> 1, k = threadIdx.x & 1;
+    double t = 0.0;
+    for (int w = 0; w < 4; ++w) t += (double)red[w][c >> 2][2 * (c & 3) + k];
+    partial[(((int64_t)b * 16 + c) * 2 + k) * gridDim.x + blockIdx.x] = t;
+  }
+}
+
+__global__ __launch_bounds__(256) void softdice_bwd16_kernel(const float *__restrict__ la, const float *__restrict__ lb,
+                                                             float *__restrict__ ga, float *__restrict__ gb,
+                                                             const float *__restrict__ coef, float scale_h,
+                                                             const float *__restrict__ scale_dev, int64_t V) {
+  const int b = blockIdx.y, q = threadIdx.x & 3;
+  const float scale = scale_dev ? scale_h * scale_dev[0] : scale_h;
+  float P[4], Q[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    P[j] = coef[((int64_t)b * 16 + 4 * q + j) * 2];
+    Q[j] = coef[((int64_t)b * 16 + 4 * q + j) * 2 + 1];
+  }
+  const float4 *pa = reinterpret_cast<const float4 *>(la + (int64_t)b * V * 16);
+  const float4 *pb = reinterpret_cast<const float4 *>(lb + (int64_t)b * V * 16);
+  float4 *oa = reinterpret_cast<float4 *>(ga + (int64_t)b * V * 16), *ob = reinterpret_cast<float4 *>(gb + (int64_t)b * V * 16);
+  for (int64_t v0 = (int64_t)blockIdx.x * 64; v0 < V; v0 += (int64_t)gridDim.x * 64) {
+    const int64_t v = v0 + (threadIdx.x >> 2);
+    if (v < V) {
+      const float4 xa = pa[v * 4 + q], xb = pb[v * 4 + q];
+      float a[4], bq[4], ta[4], tb[4];
+      const float m = quad_softmax4(xa, a) * quad_softmax4(xb, bq);
+      float da = 0.f, db = 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float aj = a[j] * m, bj = bq[j] * m;
+        const float tt = Q[j] * (aj + bj);
+        ta[j] = P[j] * bj + tt;
+        tb[j] = P[j] * aj + tt;
+        da += ta[j] * a[j];
+        db += tb[j] * bq[j];
+      }
+      da = quad_sum(da);
+      db = quad_sum(db);
+      const float sm = scale * m;
+      oa[v * 4 + q] = make_float4(sm * a[0] * (ta[0] - da), sm * a[1] * (ta[1] - da), sm * a[2] * (ta[2] - da), sm * a[3] * (ta[3] - da));
+      ob[v * 4 + q] = make_float4(sm * bq[0] * (tb[0] - db), sm * bq[1] * (tb[1] - db), sm * bq[2] * (tb[2] - db),
+                                  sm * bq[3] * (tb[3] - db));
+    }
+  }
+}
+
+bool use16(const void *a, const void *b, const void *c, const void *d, int C, int ldc) {
+  return C == 16 && ldc == 16 && (((uintptr_t)a | (uintptr_t)b | (uintptr_t)c | (uintptr_t)d) & 15) == 0 &&
+         dgtta_switches().softdice16 != '0';
+}
+
 int waves_for(int ldc) {
   size_t per_wave = (size_t)2 * 64 * tile_pitch(ldc) * sizeof(float);
   int nw = (int)(LDS_BUDGET / per_wave);
@@ -363,11 +489,16 @@ extern "C" int dgtta_softdice_fwd(const float *la, const float *lb, float *dice,
   const int nblk = nblocks_for(V);
   double *partial = (double *)ws;
   float *coef = (float *)((char *)ws + align_up((size_t)B * nblk * C * 2 * sizeof(double), 256));
-  DG_REQUIRE(allow_big_lds() == 0, DGTTA_ERR_LAUNCH, "softdice: cannot raise the dynamic LDS limit");
-  const int nw = waves_for(ldc);
-  hipLaunchKernelGGL(softdice_fwd_kernel, dim3(nblk, B), dim3(nw * 64), lds_for(ldc, nw), st, la, lb, partial, C, V, ldc,
-                     (int)vec_ok(la, lb, nullptr, nullptr, ldc));
-  DG_CHECK_LAUNCH("softdice_fwd_kernel");
+  if (use16(la, lb, nullptr, nullptr, C, ldc)) {
+    hipLaunchKernelGGL(softdice_fwd16_kernel, dim3(nblk, B), dim3(256), 0, st, la, lb, partial, V);
+    DG_CHECK_LAUNCH("softdice_fwd16_kernel");
+  } else {
+    DG_REQUIRE(allow_big_lds() == 0, DGTTA_ERR_LAUNCH, "softdice: cannot raise the dynamic LDS limit");
+    const int nw = waves_for(ldc);
+    hipLaunchKernelGGL(softdice_fwd_kernel, dim3(nblk, B), dim3(nw * 64), lds_for(ldc, nw), st, la, lb, partial, C, V, ldc,
+                       (int)vec_ok(la, lb, nullptr, nullptr, ldc));
+    DG_CHECK_LAUNCH("softdice_fwd_kernel");
+  }
   hipLaunchKernelGGL(softdice_finalize_kernel, dim3(1), dim3(1024), 0, st, partial, nblk, B, C, V, start_class, dice,
                      loss, coef, guard_items);
   DG_CHECK_LAUNCH("softdice_finalize_kernel");
@@ -383,6 +514,14 @@ extern "C" int dgtta_softdice_bwd(const float *la, const float *lb, float *grad_
   hipStream_t st = (hipStream_t)stream;
   const int nblk = nblocks_for(V);
   const float *coef = (const float *)((const char *)ws + align_up((size_t)B * nblk * C * 2 * sizeof(double), 256));
+  if (use16(la, lb, grad_la, grad_lb, C, ldc)) {
+    int64_t g16 = (V + 63) / 64;
+    if (g16 > 4096) g16 = 4096;
+    hipLaunchKernelGGL(softdice_bwd16_kernel, dim3((int)g16, B), dim3(256), 0, st, la, lb, grad_la, grad_lb, coef, grad_scale,
+                       grad_scale_dev, V);
+    DG_CHECK_LAUNCH("softdice_bwd16_kernel");
+    return DGTTA_OK;
+  }
   DG_REQUIRE(allow_big_lds() == 0, DGTTA_ERR_LAUNCH, "softdice: cannot raise the dynamic LDS limit");
   const int nw = waves_for(ldc);
   int64_t gb = (V + 255) / 256;

@@ -473,3 +473,48 @@ def test_cooperative_warp_backward_is_bit_identical_to_the_owner_kernel(shape, m
     x = torch.zeros(b, c, d, h, w, device=DEV).contiguous(memory_format=torch.channels_last_3d).requires_grad_(True)
     ops.affine_warp(x, thetas[0].to(DEV), padding_mode="zeros", tta_grid_algebra=True).backward(gy)
     _close(x.grad, xr.grad, atol=5e-5, what="coop warp bwd vs autograd")
+
+
+def test_consistency_loss_16_class_kernels_match_the_oracle_and_the_generic_kernels(monkeypatch):
+    """Round 3: softdice_fwd16 / bwd16 (four lanes per voxel, softmax in registers) for the plan's C_opt = 16 against the
+    CPU oracle (tta.py:263-269 restated) and against the generic LDS-tile kernels (DGTTA_SOFTDICE16=0): loss, per-class Dice
+    and both gradients; voxels whose logits are all zero (outside the warped field of view) and whose class sum is negative
+    are masked out in both; the pair form (one batched tensor) is covered as well."""
+    from conftest import reload_kernel_switches
+    from dg_tta_amd import ops
+    from oracle import tta as otta
+    torch.manual_seed(8)
+    a, b = torch.randn(4, 16, 9, 13, 22) * 3, torch.randn(4, 16, 9, 13, 22) * 3
+    a[:, :, :2] = 0.0                       # zero-padded border of the inverse warp
+    b[:, :, :, :3] = 0.0
+    a[1, :, 4] -= 5.0                        # negative class sums: masked
+    ta, tb = a.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    ref = otta.consistency_loss(ta, tb)
+    (ref * 3.0).backward()
+    outs = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("DGTTA_SOFTDICE16", flag)
+        reload_kernel_switches()
+        da = a.to(DEV).contiguous(memory_format=torch.channels_last_3d).requires_grad_(True)
+        db = b.to(DEV).contiguous(memory_format=torch.channels_last_3d).requires_grad_(True)
+        loss, dice = ops.consistency_loss(da, db)
+        (loss * 3.0).backward()
+        outs[flag] = (float(loss), dice.cpu(), da.grad.cpu(), db.grad.cpu())
+        assert abs(float(loss) - float(ref)) < 2e-6
+        _close(da.grad, ta.grad, atol=1e-9, rtol=1e-3, what=f"dloss/da ({flag})")
+        _close(db.grad, tb.grad, atol=1e-9, rtol=1e-3, what=f"dloss/db ({flag})")
+    l1, d1, ga1, gb1 = outs["1"]
+    l0, d0, ga0, gb0 = outs["0"]
+    assert abs(l1 - l0) < 5e-7 and float((d1 - d0).abs().max()) < 2e-6
+    scale = float(ga0.abs().max())
+    assert float((ga1 - ga0).abs().max()) < 2e-5 * scale and float((gb1 - gb0).abs().max()) < 2e-5 * scale
+    # pair form: one batched tensor [2B, 16, ...], first half = branch a
+    monkeypatch.setenv("DGTTA_SOFTDICE16", "1")
+    reload_kernel_switches()
+    both = torch.cat([a, b]).to(DEV).contiguous(memory_format=torch.channels_last_3d).requires_grad_(True)
+    pa, pb = both[:4], both[4:]
+    pa._dgtta_pair = pb._dgtta_pair = both
+    loss, _ = ops.consistency_loss(pa, pb)
+    (loss * 3.0).backward()
+    assert abs(float(loss) - l1) < 1e-7
+    assert torch.equal(both.grad[:4].cpu(), ga1) and torch.equal(both.grad[4:].cpu(), gb1)

@@ -60,6 +60,7 @@ SIGNATURES = {
     "dgtta_resample_axis_ws_bytes": (SZ, [I64, I, I64, I]),
     "dgtta_resample_axis": (I, [P, P, P, SZ, I64, I, I, I64, I, P]),
     "dgtta_window_accumulate": (I, [P, P, P, P, I, I, I, I, I, I, I, I, I, I, P]),
+    "dgtta_seghead_window_accumulate": (I, [P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, P]),
     "dgtta_logits_chunk_f64": (I, [P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, P]),
     "dgtta_argmax_merge_f64": (I, [P, I64, I, I, P, P, I, P]),
 }

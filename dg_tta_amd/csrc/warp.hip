@@ -884,6 +884,55 @@ bool host_map_ok(const float *th, int D, int H, int W) {
   return vol <= 256.0f;        // (the device test accepts up to 512: a margin for the differences in rounding)
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Segmentation head fused with the Gaussian window accumulation (round 3, BASELINE config 3): a window's logits over ALL
+// classes ([3P] nnU-Net predict_sliding_window_return_logits via dg_tta/tta/nnunet_utils.py:116-125) are 880 MB at
+// 128^3 x 105 fp32 - written by the head and read back by window_accumulate_kernel.  Here a workgroup takes 64 consecutive
+// voxels of a window row, evaluates all classes from the 64-byte feature rows (same FMA chain over the 32 channels and bias
+// add as head_fwd_lds_kernel: identical logits), scales them by the voxel's Gaussian weight into an LDS tile and adds the
+// tile to the accumulator as one contiguous run (the window row is contiguous in the volume along its last axis).
+constexpr int HA_MAXC = 112;
+template <typename T>
+__global__ __launch_bounds__(256) void head_accumulate_kernel(const T *__restrict__ z, const float *__restrict__ w,
+                                                              const float *__restrict__ bias, const float *__restrict__ gauss,
+                                                              float *__restrict__ acc, float *__restrict__ nsum, int C, int PD,
+                                                              int PH, int PW, int X, int Y, int Z, int x0, int y0, int z0) {
+  extern __shared__ float hsm[];
+  float *sw = hsm;                          // [C][32]
+  float *sb = sw + C * HW_CIN;              // [C]
+  float *tile = sb + HA_MAXC;               // [64][C]
+  for (int i = threadIdx.x; i < C * HW_CIN; i += 256) sw[i] = w[i];
+  for (int i = threadIdx.x; i < C; i += 256) sb[i] = bias[i];
+  const int runs = (PW + 63) >> 6, nblk = PD * PH * runs;
+  const int vox = threadIdx.x & 63, grp = threadIdx.x >> 6;       // 4 class groups per voxel
+  // persistent over runs of 64 voxels: the head's weights (13 KB at 105 classes) are staged once per workgroup
+  for (int blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+    const int row = blk / runs, pw0 = (blk % runs) * 64;
+    const int pd = row / PH, ph = row % PH;
+    const int nv = PW - pw0 < 64 ? PW - pw0 : 64;
+    const int64_t p = ((int64_t)pd * PH + ph) * PW + pw0 + vox;   // voxel inside the window
+    __syncthreads();                                              // weights staged / previous tile consumed
+    if (vox < nv) {
+      float xr[HW_CIN];
+      const uint4 *zr = reinterpret_cast<const uint4 *>(z + p * HW_CIN);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) unpack8_16<T>(zr[g], xr + 8 * g);
+      const float gq = gauss[p];
+      for (int k = grp; k < C; k += 4) {
+        float a = 0.f;
+#pragma unroll
+        for (int ci = 0; ci < HW_CIN; ++ci) a = __builtin_fmaf(xr[ci], sw[k * HW_CIN + ci], a);
+        tile[vox * C + k] = (a + sb[k]) * gq;
+      }
+    }
+    __syncthreads();
+    const int64_t vg = ((int64_t)(x0 + pd) * Y + (y0 + ph)) * Z + (z0 + pw0);
+    float *ap = acc + vg * C;
+    for (int i = threadIdx.x; i < nv * C; i += 256) ap[i] += tile[i];
+    if (nsum && (int)threadIdx.x < nv) nsum[vg + threadIdx.x] += gauss[((int64_t)pd * PH + ph) * PW + pw0 + threadIdx.x];
+  }
+}
+
 int check_common(const char *name, const void *a, const void *t, const void *o, int B, int C, int Ds, int Hs, int Ws,
                  int Dd, int Hd, int Wd, int ndhwc, int src_ldc, int dst_ldc) {
   DG_REQUIRE(a && t && o, DGTTA_ERR_BADARG, "%s: null pointer", name);
@@ -1089,6 +1138,34 @@ extern "C" int dgtta_seghead_warp_bwd(const void *z, const float *gout, const fl
                        accumulate);
     DG_CHECK_LAUNCH("head_warp_bias_finalize_kernel");
   }
+  return DGTTA_OK;
+}
+
+extern "C" int dgtta_seghead_window_accumulate(const void *z, const float *w, const float *bias, const float *gauss, float *acc,
+                                               float *nsum, int Cin, int C, int PD, int PH, int PW, int X, int Y, int Z, int x0,
+                                               int y0, int z0, int dtype, void *stream) {
+  DG_REQUIRE(z && w && bias && gauss && acc, DGTTA_ERR_BADARG, "seghead_window_accumulate: null pointer");
+  DG_REQUIRE(Cin == HW_CIN && C > 0 && C <= HA_MAXC && (dtype == DGTTA_BF16 || dtype == DGTTA_F16), DGTTA_ERR_UNSUPPORTED,
+             "seghead_window_accumulate: built for 32 input channels, up to %d classes, 16-bit storage", HA_MAXC);
+  DG_REQUIRE(PD > 0 && PH > 0 && PW > 0 && x0 >= 0 && y0 >= 0 && z0 >= 0 && x0 + PD <= X && y0 + PH <= Y && z0 + PW <= Z,
+             DGTTA_ERR_BADARG, "seghead_window_accumulate: window outside the volume");
+  DG_REQUIRE(((uintptr_t)z & 15) == 0, DGTTA_ERR_BADARG, "seghead_window_accumulate: unaligned feature map");
+  const int64_t nblk = (int64_t)PD * PH * cdiv(PW, 64);
+  DG_REQUIRE(nblk < (1ll << 31), DGTTA_ERR_UNSUPPORTED, "seghead_window_accumulate: too many rows");
+  const size_t lds = ((size_t)C * HW_CIN + HA_MAXC + (size_t)64 * C) * sizeof(float);
+  static DynLdsOnce once_bf, once_h;
+  if (dtype == DGTTA_BF16) {
+    DG_REQUIRE(ensure_dyn_lds(once_bf, (const void *)head_accumulate_kernel<bf16_t>, (int)lds) == hipSuccess, DGTTA_ERR_LAUNCH,
+               "seghead_window_accumulate: cannot raise the dynamic LDS limit");
+    hipLaunchKernelGGL(head_accumulate_kernel<bf16_t>, dim3((unsigned)(nblk < 2048 ? nblk : 2048)), dim3(256), lds, (hipStream_t)stream, (const bf16_t *)z,
+                       w, bias, gauss, acc, nsum, C, PD, PH, PW, X, Y, Z, x0, y0, z0);
+  } else {
+    DG_REQUIRE(ensure_dyn_lds(once_h, (const void *)head_accumulate_kernel<f16_t>, (int)lds) == hipSuccess, DGTTA_ERR_LAUNCH,
+               "seghead_window_accumulate: cannot raise the dynamic LDS limit");
+    hipLaunchKernelGGL(head_accumulate_kernel<f16_t>, dim3((unsigned)(nblk < 2048 ? nblk : 2048)), dim3(256), lds, (hipStream_t)stream, (const f16_t *)z, w,
+                       bias, gauss, acc, nsum, C, PD, PH, PW, X, Y, Z, x0, y0, z0);
+  }
+  DG_CHECK_LAUNCH("head_accumulate_kernel");
   return DGTTA_OK;
 }
 

@@ -69,7 +69,32 @@ def pad_to_patch(data, patch_size):
     return data, crop
 
 
-WINDOW_BATCH = 4
+import os as _os
+
+WINDOW_BATCH = max(1, int(_os.environ.get("DGTTA_WINDOW_BATCH", "4")))
+
+
+def _inner(model):
+    return getattr(model, "_orig_mod", model)
+
+
+def _num_classes(model):
+    return _inner(model).decoder.seg_layers[-1].out_channels
+
+
+def _can_fuse_head_accumulate(model):
+    """The head may write straight into the window accumulator when the network offers it and nothing stands between the
+    head and the accumulation: every forward hook is the plan's untouched model-output modifier (identity)."""
+    from .config_log_utils import is_template_modifier
+    m = _inner(model)
+    if not hasattr(m, "can_fuse_window_accumulate") or not m.can_fuse_window_accumulate():
+        return False
+    for h in m._forward_hooks.values():
+        cells = getattr(h, "__closure__", None) or ()
+        fns = [c.cell_contents for c in cells if callable(c.cell_contents)]
+        if len(fns) != 1 or not is_template_modifier(fns[0], "modfify_tta_model_output_fn"):
+            return False
+    return True
 
 
 @torch.no_grad()
@@ -96,6 +121,13 @@ def predict_sliding_window_return_logits(model, data, patch_size, acc=None, tile
                             for sx, sy, sz in group]).contiguous()
         # MIND's variance clamp uses the mean over the whole CALL's batch (mind.py:159-161) and nnU-Net predicts one
         # window per call: the batched pass keeps per-window statistics (groups = windows in the batch)
+        if _can_fuse_head_accumulate(model):
+            # the head evaluates straight into the accumulator (the windows' logits - 880 MB each at 128^3 x 105 - are not written)
+            if acc is None:
+                acc = torch.zeros((X, Y, Z, _num_classes(model)), dtype=torch.float32, device=dev)
+            with mind_groups(model, len(group)), _inner(model).fuse_window_accumulate(acc, nsum, gauss, group):
+                model(work)
+            continue
         with mind_groups(model, len(group)):
             out = model(work)
         if isinstance(out, tuple):

@@ -147,6 +147,7 @@ class HipPlainConvUNet(nn.Module):
         self._packed = {}        # id(weight) -> (version, wf, wb)
         self.selected_classes = None   # optional LongTensor: evaluate only these head rows (== map_label 'logits')
         self._fused_warp = None        # (theta on the device, theta on the host) while fuse_output_warp() is active
+        self._window_acc = None        # sliding-window target while fuse_window_accumulate() is active
 
     def __deepcopy__(self, memo):
         # get_model_from_network deep-copies the network per ensemble member: do not drag the packed-weight cache along
@@ -195,6 +196,26 @@ class HipPlainConvUNet(nn.Module):
 
             def __exit__(self_, *exc):
                 net._fused_warp = None
+        return _Ctx()
+
+    # -- head fused with the Gaussian window accumulation of the sliding-window inference (csrc/warp.hip)
+    def can_fuse_window_accumulate(self):
+        import os
+        return (os.environ.get("DGTTA_FUSE_HEAD_ACCUMULATE", "1") != "0" and self.selected_classes is None and
+                self.act_dtype in (torch.float16, torch.bfloat16) and self.decoder.seg_layers[-1].in_channels == 32 and
+                self.decoder.seg_layers[-1].out_channels <= 112 and not torch.is_grad_enabled())
+
+    def fuse_window_accumulate(self, acc, nsum, gauss, origins):
+        """Context (inference, no grad): the next forward adds gauss * logits of window k of the batch into
+        acc [X,Y,Z,ncls] / nsum [X,Y,Z] at origins[k] instead of returning the logits (it returns an empty placeholder)."""
+        net = self
+
+        class _Ctx:
+            def __enter__(self_):
+                net._window_acc = (acc, nsum, gauss, list(origins))
+
+            def __exit__(self_, *exc):
+                net._window_acc = None
         return _Ctx()
 
     def forward(self, x):
@@ -369,6 +390,16 @@ class _UNetFn(torch.autograd.Function):
         ncls = head.out_channels
         nsel = ncls if sel is None else int(sel.numel())
         V = D * H * W
+        wa = net._window_acc
+        if wa is not None:
+            assert not need_grad and sel is None and ldu == head.in_channels and len(wa[3]) == B, "fuse_window_accumulate: misuse"
+            acc, nsum, gauss, origins = wa
+            X, Y, Z = acc.shape[:3]
+            for k, (sx, sy, sz) in enumerate(origins):      # overlapping windows: accumulated one after the other
+                check(lib.dgtta_seghead_window_accumulate(u_ptr + k * V * ldu * esz, ptr(head.weight), ptr(head.bias), ptr(gauss),
+                                                          ptr(acc), ptr(nsum), head.in_channels, ncls, D, H, W, X, Y, Z, sx, sy,
+                                                          sz, dt, st), "dgtta_seghead_window_accumulate")
+            return torch.empty((B, 0, D, H, W), dtype=torch.float32, device=dev)
         out = torch.empty((B, D, H, W, nsel), dtype=torch.float32, device=dev)
         fw = net._fused_warp
         if fw is not None:

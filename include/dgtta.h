@@ -271,6 +271,13 @@ int dgtta_argmax_dice(const float *logits, int ldc, int C, const int64_t *labels
 int dgtta_window_accumulate(const float *patch, const float *gauss, float *acc, float *nsum, int C, int PD, int PH,
                             int PW, int X, int Y, int Z, int x0, int y0, int z0, void *stream);
 
+/* The same with the 1x1x1 segmentation head in front of it: acc += gauss * (W z + bias) for ALL C classes of one window,
+ * from the window's feature map z [PD][PH][PW][32] (16-bit storage) - the window's logits (880 MB at 128^3 x 105) are never
+ * written.  Logits are evaluated as dgtta_seghead_fwd does (identical values). */
+int dgtta_seghead_window_accumulate(const void *z, const float *w, const float *bias, const float *gauss, float *acc,
+                                    float *nsum, int Cin, int C, int PD, int PH, int PW, int X, int Y, int Z, int x0, int y0,
+                                    int z0, int dtype, void *stream);
+
 /* One-axis spline resampling (order 0 / 1 / 3) with the coordinate rule and boundary handling of
  * skimage.transform.resize(mode='edge', anti_aliasing=False) = scipy.ndimage.zoom(mode='nearest', grid_mode=True), which is
  * what nnU-Net's DefaultPreprocessor resamples with (third-party nnunetv2==2.2.1, reached from preprocess_fromfile,

@@ -103,3 +103,48 @@ def test_sliding_window_at_size_properties():
     one = vol[:, :128, :128, :128]
     acc1, nsum1, _ = predict_sliding_window_return_logits(net, one, patch)
     assert (acc1 / nsum1[..., None] - first.permute(1, 2, 3, 0)).abs().max() < 1e-4 * first.abs().max()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_head_fused_with_the_window_accumulation_is_bit_identical(dtype, monkeypatch):
+    """Round 3: dgtta_seghead_window_accumulate (the head evaluates straight into the Gaussian window accumulator; a
+    window's 105-class logits are never written) against head + dgtta_window_accumulate (DGTTA_FUSE_HEAD_ACCUMULATE=0) on
+    the full net, through the product's run_inference with the plan's model-output hook in place: same FMA chain, same
+    accumulation order -> torch.equal accumulators, weight maps and label maps (overlapping windows, ragged last step)."""
+    from types import SimpleNamespace
+    from dg_tta_amd.mind import mind_hook
+    from dg_tta_amd.synthetic import he_init_
+    from dg_tta_amd.tta.config_log_utils import ModifierFunctions
+    from dg_tta_amd.tta.inference import predict_sliding_window_return_logits, run_inference, _can_fuse_head_accumulate
+    from dg_tta_amd.tta.model_utils import get_model_from_network
+    from dg_tta_amd.unet import HipPlainConvUNet
+    net = he_init_(HipPlainConvUNet(act_dtype=dtype), seed=7)
+    net.decoder.seg_layers[-1].bias.data.normal_()
+    net.register_forward_pre_hook(mind_hook)
+    model = get_model_from_network(net, SimpleNamespace(ModifierFunctions=ModifierFunctions), None).to(DEV)
+    torch.manual_seed(2)
+    vol = torch.randn(1, 96, 64, 150)
+    patch = [64, 64, 64]
+    outs = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("DGTTA_FUSE_HEAD_ACCUMULATE", flag)
+        with torch.no_grad():
+            assert _can_fuse_head_accumulate(model) == (flag == "1")
+        torch.manual_seed(9)                               # MIND noise of the windows: same draws in both runs
+        acc, nsum, crop = predict_sliding_window_return_logits(model, vol, patch)
+        torch.manual_seed(9)
+        seg = run_inference(vol, model, [model.state_dict()], patch)
+        outs[flag] = (acc.clone(), nsum.clone(), seg)
+    assert tuple(outs["1"][0].shape) == (96, 64, 150, 105)
+    assert torch.equal(outs["1"][0], outs["0"][0]) and torch.equal(outs["1"][1], outs["0"][1])
+    assert torch.equal(outs["1"][2], outs["0"][2]) and len(outs["1"][2].unique()) > 10
+    # a user's model-output modifier in front of the accumulation switches the fusion off
+    class Mods(ModifierFunctions):
+        @staticmethod
+        def modfify_tta_model_output_fn(pred):
+            return pred * 2.0
+    other = get_model_from_network(net, SimpleNamespace(ModifierFunctions=Mods), None).to(DEV)
+    monkeypatch.setenv("DGTTA_FUSE_HEAD_ACCUMULATE", "1")
+    with torch.no_grad():
+        assert not _can_fuse_head_accumulate(other)

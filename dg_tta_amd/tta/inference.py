@@ -71,7 +71,7 @@ def pad_to_patch(data, patch_size):
 
 import os as _os
 
-WINDOW_BATCH = max(1, int(_os.environ.get("DGTTA_WINDOW_BATCH", "4")))
+WINDOW_BATCH = max(1, int(_os.environ.get("DGTTA_WINDOW_BATCH", "8")))      # measured at 512^3: 2 / 4 / 8 / 16 windows per pass = 3.26 / 3.14 / 3.07 / 3.03 ms per window
 
 
 def _inner(model):

@@ -526,7 +526,10 @@ def tta_main(run_name, config, tta_data_dir, save_base_path, label_mapping, modi
                 results.update(evaluate_run(save_path, config, modifier_fn_module, device))
     except BaseException:
         if world > 1:           # peers waiting in the filesystem barrier stop instead of running into its timeout
-            failed_marker(save_path, rank).write_text("failed\n")
+            try:
+                failed_marker(save_path, rank).write_text("failed\n")
+            except OSError:
+                pass            # (never mask the original error)
         raise
     return results
 

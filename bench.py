@@ -330,7 +330,12 @@ def run_rank(args):
             dist.init_process_group("gloo")
         else:
             torch.cuda.set_device(local)
-            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
+            try:
+                dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
+            except Exception as e:      # the collectives only carry the barrier and the timings: gloo serves as well
+                print(f"bench.py: RCCL rendezvous failed ({e}); falling back to gloo for the barrier", file=sys.stderr)
+                backend = "gloo"
+                dist.init_process_group("gloo")
     device = torch.device("cpu") if stub else torch.device(f"cuda:{local}")
     coll_device = device if (dist is not None and backend == "nccl") else torch.device("cpu")
 

@@ -81,3 +81,26 @@ def test_prepare_and_run_tta_cli_full_net_64(tmp_path, monkeypatch):
     assert np.array_equal(tgt2, np.where(lab2 == 3, 0, lab2))      # my_organ is not optimised: mapped to background
     m2 = [c for c in sj["metric_per_case"] if c["prediction_file"].endswith("mr02.nii.gz")][0]["metrics"]
     assert m2["1"]["n_ref"] == int((lab2 == 1).sum()) and m2["1"]["n_pred"] == int((seg2 == 1).sum())
+
+
+def test_bench_two_real_ranks_on_one_gpu():
+    """bench.py --gpus 2 end to end with the REAL runner: the launcher starts two fresh rank
+    processes, each adapts its own sample with the product's tta_epoch, they meet at the barrier (gloo here, because both share
+    this box's one GPU - `--share-gpu`; on an 8-GPU node the same code path runs one rank per GPU over RCCL), and rank 0 prints
+    one line for the whole job."""
+    import os
+    import subprocess
+    import sys
+    root = Path(__file__).resolve().parents[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    res = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "2", "--share-gpu", "--steps", "2", "--warmup", "1",
+                          "--size", "64", "--accum", "4"], env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and len(out["per_rank_epochs_per_s"]) == 2
+    assert out["value"] == pytest.approx(2 * out["value_per_gpu"], rel=1e-4)
+    assert out["value_per_gpu"] <= min(out["per_rank_epochs_per_s"]) * 1.0001
+    assert 0.0 < out["loss_last_epoch"] < 1.0 and out["roofline"] is not None
+    assert "fp32" not in out and "cpu_baseline" not in out          # the single-GPU legs are not run in a multi-rank job

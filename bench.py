@@ -337,6 +337,8 @@ def run_rank(args):
                 backend = "gloo"
                 dist.init_process_group("gloo")
     device = torch.device("cpu") if stub else torch.device(f"cuda:{local}")
+    if world > 1:       # N ranks share the node's host cores: no rank's CPU ops (draws, case set-up) fan out over all of them
+        torch.set_num_threads(max(1, len(os.sched_getaffinity(0)) // world))
     coll_device = device if (dist is not None and backend == "nccl") else torch.device("cpu")
 
     def barrier():

@@ -20,6 +20,11 @@
 int conv3_rows_launch(const void *x, const View &xv, const void *w, const Taps &taps, const float *bias, void *y, const View &yv,
                       int B, int Cin, int Cout, int CinP, int CoutP, double *stats, int ntaps_src, int is_f16, hipStream_t st);
 
+int conv3_ring_launch(const void *x, const View &xv, const void *w, const Taps &taps, const float *bias, void *y, const View &yv,
+                      int B, int Cin, int Cout, int CinP, int CoutP, double *stats, int64_t stats_cap_slots, int ntaps_src,
+                      int is_f16, hipStream_t st);      // conv_ring.hip
+int64_t conv3_mfma_max_tiles(int Do, int Ho, int Wo);
+
 namespace {
 
 // x: view xv;  y: view yv;  virtual tap t uses weight tap taps.wt[t].
@@ -415,6 +420,13 @@ int dispatch_conv_classes(const void *x, const View &xv, const void *w, const Co
                          yv.sd % 8 == 0 && yv.sb % 8 == 0;
     // enough (tile, channel block) jobs to fill the chip with one persistent workgroup per CU; below that the generic kernel wins
     const long long njobs = (long long)cdiv(yv.W, 32) * cdiv(yv.H, 8) * cdiv(yv.D, 4) * cdiv(CoutP, 32) * B;
+    // 32 input channels: the D-ring kernel (conv_ring.hip; DGTTA_CONV_RING=0: its predecessor below)
+    if (all_taps && vec_out && Cin == 32 && CinP == 32 && (njobs >= 512 || dgtta_switches().conv_ring == '1') &&
+        dgtta_switches().conv_ring != '0' && rows != '1') {
+      const int rc = conv3_ring_launch(x, xv, w, cs.taps[0], bias, y, yv, B, Cin, Cout, CinP, CoutP, stats,
+                                       conv3_mfma_max_tiles(yv.D, yv.H, yv.W), ntaps_src, (int)std::is_same<T, f16_t>::value, st);
+      if (rc != DGTTA_ERR_UNSUPPORTED) return rc;
+    }
     if (all_taps && vec_out && (njobs >= 256 || rows == '1') && rows != '0')
       return conv3_rows_launch(x, xv, w, cs.taps[0], bias, y, yv, B, Cin, Cout, CinP, CoutP, stats, ntaps_src,
                                (int)std::is_same<T, f16_t>::value, st);

@@ -1,0 +1,480 @@
+// D-ring 3x3x3 convolution kernel (16-bit storage, stride 1, 32 input channels) -- the large 32-channel layers of the
+// 128^3 level (PlainConvUNet stages enc.0 / dec.3, reference topology dg_tta/__resources__/dummy_results/*/plans.json:279-401;
+// forward of the 32 -> 32 blocks and the data gradients whose dy has 32 channels).
+//
+// Why another kernel (round 4).  The row-reuse kernel (conv_rows.hip) re-stages, for every 4 x 8 x 32 tile and 16-channel
+// chunk, a 6 x 10 x 34 halo (1.99x the tile) AND the chunk's 27 weight fragments, behind two workgroup barriers per chunk:
+// its MFMA loop is 59 % of the wave time and the matrix pipe is busy 46 % of a phase (profiles/r04_mfma_util.json).
+// Here nothing is staged twice along D and the weights are never staged at all:
+//   * a persistent workgroup owns a COLUMN of the volume (8 rows x 32 voxels, all of D or a segment of it) and marches
+//     along D two planes at a time.  The LDS holds a ring of 6 input planes (10 x 34 halo voxels x 32 channels = 21.8 KB
+//     each): 4 in use, 2 arriving by LDS-DMA for the next step.  Halo factor 1.33 instead of 1.99, 5-6 DMA pieces per wave
+//     and step instead of 40 for the same FLOPs, ONE barrier per step (6.9 k MFMA cycles) instead of four.
+//   * v_mfma_f32_16x16x32 with the WEIGHTS as the M operand: a wave owns 16 output channels, and the 27 taps x 32 input
+//     channels x 16 output channels it needs are 27 fragments = 108 registers, loaded once per workgroup.  K = 32 is the
+//     whole channel extent, so there are no K chunks, no weight buffer in LDS, no reload.  (The guide's clock effect of
+//     the 16x16x32 shape comes on top.)
+//   * 8 waves = 4 row pairs x 2 output-channel halves; a wave computes 2 planes x 2 rows x 32 voxels x 16 channels per step
+//     (8 accumulator tiles = 32 registers) from 4 x 4 input rows: 96 fragment reads feed 216 MFMAs.
+//   * the accumulator of D = W^T X has the output CHANNELS along the registers and the voxel on the lane: four packed
+//     converts, two v_permlane16_swap and one 16-byte store per output row and wave - no LDS transpose, no epilogue barrier.
+//   * the two waves of a SIMD (w, w + 4) run half a step apart: waves 4-7 convert and store step k - 1 at the beginning
+//     of step k, while their partners are already issuing MFMAs (guide: MI355X_MICROARCH.md, two waves per SIMD, item 9).
+// LDS image of a plane: voxel-major rows of 34 voxels x 64 B; inside a voxel the four 16-byte channel groups sit at
+// position g ^ 2*((u >> 2) & 1) (u = voxel index in the row): with that, the 16 lanes that ds_read_b128 serves per cycle
+// (4 voxels apart in two channel groups) fall on 16 different 16-byte bank slots for every tap shift.  The permutation
+// is applied on the SOURCE address of the DMA (the LDS side of an LDS-DMA is lane-linear).
+// Zero padding and ragged edges: the DMA and the stores are raw BUFFER operations; a lane outside the volume gets an
+// offset beyond the descriptor's range, which reads as zero and drops the store.
+#include "conv_common.h"
+#include <stdlib.h>
+#include <type_traits>
+
+namespace {
+
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+
+struct RingCfg {
+  static constexpr int TH = 8, TW = 32;                              // (two output planes per step)
+  static constexpr int IH = TH + 2, IW = TW + 2;
+  static constexpr int VB = 64;                                      // bytes per voxel: 32 channels x 2
+  static constexpr int ROWB = IW * VB;                               // 2176
+  static constexpr int PIECES = (IH * ROWB + 1023) / 1024;           // 22 DMA pieces of 1 KiB per plane (the last one partly pad)
+  static constexpr int PLANE = PIECES * 1024;
+  static constexpr int NVOX = IH * IW;                               // 340 voxels per plane
+  static constexpr int NSLOT = 6;
+  static constexpr int NW = 8, NT = NW * 64;
+  static constexpr int NPW = (2 * PIECES + NW - 1) / NW;             // pieces per wave and step (6)
+  static constexpr int RED_BYTES = NW * 16 * 2 * (int)sizeof(float);
+  static constexpr int LDS_BYTES = NSLOT * PLANE + RED_BYTES;
+};
+
+template <typename T16>
+__device__ __forceinline__ void mfma16(const uint4 &a, const uint4 &b, f32x4_t &acc);
+template <>
+__device__ __forceinline__ void mfma16<bf16_t>(const uint4 &a, const uint4 &b, f32x4_t &acc) {
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), acc, 0, 0, 0);
+}
+template <>
+__device__ __forceinline__ void mfma16<f16_t>(const uint4 &a, const uint4 &b, f32x4_t &acc) {
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), acc, 0, 0, 0);
+}
+
+// LDS-DMA through a buffer descriptor: lane i's 16 bytes land at lds_addr + 16 i; a lane whose offset is outside the
+// descriptor's range delivers zeros.  Inline asm for the reason given at dma16_to_lds (no compiler-side vmcnt bookkeeping).
+__device__ __forceinline__ void dma16_buf_to_lds(u32x4_t rsrc, unsigned voff, unsigned soff, unsigned lds_addr) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(voff), "s"(rsrc), "s"(soff), "s"(lds_addr)
+               : "memory");
+}
+template <bool NT_ST>
+__device__ __forceinline__ void store16_buf(u32x4_t rsrc, unsigned voff, unsigned soff, u32x4_t val) {
+  if (NT_ST) asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen nt" ::"v"(val), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+  else asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen" ::"v"(val), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+}
+__device__ __forceinline__ void vm_wait_all_but(int n) {      // the n youngest vector-memory operations may stay in flight
+  if (n > 20) n = 20;       // (fewer in flight than allowed: always safe)
+  switch (n) {
+    case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+    case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+    case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+    case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+    case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+    case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+    case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+    case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+    case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+    case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+    case 11: asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); break;
+    case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+    case 13: asm volatile("s_waitcnt vmcnt(13)" ::: "memory"); break;
+    case 14: asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); break;
+    case 15: asm volatile("s_waitcnt vmcnt(15)" ::: "memory"); break;
+    case 16: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
+    case 17: asm volatile("s_waitcnt vmcnt(17)" ::: "memory"); break;
+    case 18: asm volatile("s_waitcnt vmcnt(18)" ::: "memory"); break;
+    case 19: asm volatile("s_waitcnt vmcnt(19)" ::: "memory"); break;
+    case 20: asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+  }
+}
+__device__ __forceinline__ u32x4_t make_rsrc(const void *base, unsigned bytes) {
+  const unsigned long long a = (unsigned long long)base;
+  u32x4_t r;
+  r[0] = __builtin_amdgcn_readfirstlane((unsigned)a);
+  r[1] = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32) & 0xffffu);      // stride 0
+  r[2] = __builtin_amdgcn_readfirstlane(bytes);
+  r[3] = 0x00020000u;                                                         // raw 32-bit data format (gfx9 family)
+  return r;
+}
+constexpr unsigned OOB = 0x80000000u;      // beyond every descriptor this kernel builds (the launcher checks < 2^31 bytes)
+
+// ABL (diagnostic builds, DGTTA_RING_ABL; results are wrong for 1 and 2): 1 no DMA after a job's first four planes, 2 no stores,
+// 3 a step's DMA pieces issued in one burst behind the barrier instead of one per input row, 6 per-segment cycle stamps and
+// the in-kernel clock, written behind the statistics (profiles/tools/ring_stamps.py)
+template <typename T16, bool NT_ST, int ABL = 0>
+__global__ __launch_bounds__(RingCfg::NT) void conv3_ring_kernel(const bf16_t *__restrict__ x, View xv, const bf16_t *__restrict__ w,
+                                                                 Taps taps, const float *__restrict__ bias, bf16_t *__restrict__ y,
+                                                                 View yv, int Cout, int tilesW, int tilesH, int nblkN, int nseg,
+                                                                 int steps_per_seg, int njobs, double *__restrict__ stats,
+                                                                 int ntaps_src, unsigned x_bytes, unsigned y_bytes) {
+  typedef RingCfg C;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float *red = reinterpret_cast<float *>(smem + C::NSLOT * C::PLANE);
+  const unsigned lds0 = lds_addr_of(smem);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int v = lane & 15, q = lane >> 4;
+  const int chalf = wave & 1, ws = (wave >> 1) & 3;
+  const int D = xv.D, H = xv.H, W = xv.W;
+  const int steps_total = (D + 1) / 2;
+
+  // this lane's fragment read offsets for the three tap shifts along W (voxel v + kw of rows 2 ws .. 2 ws + 3)
+  int aoff[3];
+#pragma unroll
+  for (int kw = 0; kw < 3; ++kw) {
+    const int u = v + kw;
+    aoff[kw] = (2 * ws) * C::ROWB + u * C::VB + ((q ^ (((u >> 2) & 1) << 1)) << 4);
+  }
+
+  uint4 wreg[27];
+  int nb_loaded = -1;
+  // ABL 6 (diagnostic): cycle stamps per segment - 0 job prologue, 1 rows 0..6, 2 wait + barrier, 3 rows 7..15, 4 epilogue
+  unsigned long long tseg[5] = {0, 0, 0, 0, 0}, tprev = 0, t_begin = 0, rt_begin = 0;
+  auto stamp = [&](int i) {
+    if (ABL == 6) {
+      __builtin_amdgcn_sched_barrier(0);
+      const unsigned long long t = __builtin_amdgcn_s_memtime();
+      __builtin_amdgcn_sched_barrier(0);
+      tseg[i] += t - tprev;
+      tprev = t;
+    }
+  };
+  if (ABL == 6) {
+    t_begin = __builtin_amdgcn_s_memtime();
+    rt_begin = __builtin_amdgcn_s_memrealtime();
+  }
+  const int G = gridDim.x;
+  const bool xcd_order = (G % 8) == 0;
+  const int rounds = (njobs + G - 1) / G;
+  for (int rd = 0; rd < rounds; ++rd) {
+    // job order: the 32 workgroups of an XCD (blockIdx % 8) take 32 consecutive jobs = columns that are neighbours along H
+    // (then W) and march in step, so the halo rows they share are fetched from HBM once
+    int j = xcd_order ? (rd * 8 + (int)(blockIdx.x % 8)) * (G / 8) + (int)(blockIdx.x / 8) : rd * G + (int)blockIdx.x;
+    if (j >= njobs) continue;       // (uniform per workgroup; rounds are independent: no barrier is skipped by others)
+    const int nb = j % nblkN;
+    j /= nblkN;
+    const int th = j % tilesH;
+    j /= tilesH;
+    const int tw = j % tilesW;
+    j /= tilesW;
+    const int seg = j % nseg;
+    const int b = j / nseg;
+    const int oh0 = th * C::TH, ow0 = tw * C::TW, n0 = nb * 32;
+    const int s_beg = seg * steps_per_seg;
+    const int s_end = (s_beg + steps_per_seg < steps_total) ? s_beg + steps_per_seg : steps_total;
+    const int nsteps = s_end - s_beg;
+    const int d0 = 2 * s_beg;
+    const u32x4_t rx = make_rsrc(x + (long long)b * xv.sb, x_bytes), ry = make_rsrc(y + (long long)b * yv.sb, y_bytes);
+
+    // weights: fragment (tap) of this wave's 16 output channels x 32 input channels, from the image of the generic kernels
+    // [N/32][K/16][ntaps][2][32][8]: this lane holds W[n0 + 16 chalf + v][8 q .. 8 q + 7]
+    if (nb != nb_loaded) {
+#pragma unroll
+      for (int t = 0; t < 27; ++t) {
+        const int wt = taps.wt[t];
+        const long long idx = ((((long long)nb * 2 + (q >> 1)) * ntaps_src + wt) * 2 + (q & 1)) * 32 + chalf * 16 + v;
+        wreg[t] = *reinterpret_cast<const uint4 *>(w + idx * 8);
+      }
+      nb_loaded = nb;
+    }
+    float bv[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) bv[r] = bias ? bias[n0 + chalf * 16 + 4 * q + r] : 0.f;
+    // the compiler's wait for these loads belongs HERE: left to the first use inside the step loop it becomes a
+    // vmcnt(0) per step, which also waits for the epilogue's stores
+#pragma unroll
+    for (int t = 0; t < 27; ++t) asm volatile("" ::"v"(wreg[t].x), "v"(wreg[t].w));
+#pragma unroll
+    for (int r = 0; r < 4; ++r) asm volatile("" ::"v"(bv[r]));
+
+    // per-lane source offsets (bytes inside a plane) of this wave's DMA pieces: piece idx = wave + 8 i of the 44 that make
+    // up two planes; lane -> voxel e = 16 P + lane / 4 of the plane, position lane & 3 inside the voxel
+    unsigned poff[C::NPW];
+#pragma unroll
+    for (int i = 0; i < C::NPW; ++i) {
+      const int idx = wave + C::NW * i;
+      const int P = idx % C::PIECES;
+      const int e = P * 16 + (lane >> 2), row = e / C::IW, u = e - row * C::IW;
+      const int g = (lane & 3) ^ (((u >> 2) & 1) << 1);
+      const int gh = oh0 - 1 + row, gw = ow0 - 1 + u;
+      const bool ok = idx < 2 * C::PIECES && e < C::NVOX && (unsigned)gh < (unsigned)H && (unsigned)gw < (unsigned)W;
+      poff[i] = ok ? (unsigned)((gh * xv.sh + gw * xv.sw + g * 8) * 2) : OOB;
+    }
+    // output: lane (row rho = q, voxel v) stores 8 channels of voxel v + 16 (rho & 1) after the row swaps
+    const int ovox = v + 16 * (q & 1);
+    const unsigned ooff = (ow0 + ovox < W) ? (unsigned)((ovox * yv.sw + chalf * 16 + (q >> 1) * 8) * 2) : OOB;
+    const bool wv0 = ow0 + v < W, wv1 = ow0 + 16 + v < W;      // this lane's voxel of tile half 0 / 1 inside the volume
+    const bool full_w = ow0 + 32 <= W;
+
+    // DMA piece i of the plane pair whose first plane is input plane ip (global plane d0 - 1 + ip) into ring pair pr
+    auto issue_piece = [&](int i, int pr, int ip) -> int {
+      const int idx = wave + C::NW * i;
+      if (C::NW * i + C::NW - 1 < 2 * C::PIECES || idx < 2 * C::PIECES) {
+        const int gd = d0 - 1 + ip + idx / C::PIECES;
+        const bool dok = (unsigned)gd < (unsigned)D;
+        const unsigned soff = dok ? (unsigned)(gd * xv.sd * 2) : 0u;
+        const unsigned voff = poff[i] | (dok ? 0u : OOB);
+        dma16_buf_to_lds(rx, voff, soff, lds0 + pr * (2 * C::PLANE) + idx * 1024);
+        return 1;
+      }
+      return 0;
+    };
+
+    f32x4_t acc[2][2][2];
+    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+    int nst = 0;        // stores issued by the last epilogue of this wave
+
+    auto epilogue = [&](int k) {
+      nst = 0;
+#pragma unroll
+      for (int od = 0; od < 2; ++od)
+#pragma unroll
+        for (int oh = 0; oh < 2; ++oh) {
+          const int odg = d0 + 2 * k + od, ohg = oh0 + 2 * ws + oh;
+          if (odg < D && ohg < H) {       // wave-uniform
+            const f32x4_t a0 = acc[od][oh][0], a1 = acc[od][oh][1];
+            if (full_w) {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                s1[r] += a0[r] + a1[r];
+                s2[r] = __builtin_fmaf(a0[r], a0[r], __builtin_fmaf(a1[r], a1[r], s2[r]));
+              }
+            } else {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                const float m0 = wv0 ? a0[r] : 0.f, m1 = wv1 ? a1[r] : 0.f;
+                s1[r] += m0 + m1;
+                s2[r] = __builtin_fmaf(m0, m0, __builtin_fmaf(m1, m1, s2[r]));
+              }
+            }
+            const unsigned x0 = pack2_16<T16>(a0[0], a0[1]), x1 = pack2_16<T16>(a0[2], a0[3]);
+            const unsigned y0 = pack2_16<T16>(a1[0], a1[1]), y1 = pack2_16<T16>(a1[2], a1[3]);
+            // rows (16 lanes) 1 and 3 of the half-0 tile change places with rows 0 and 2 of the half-1 tile: afterwards a lane
+            // holds 8 consecutive channels of ONE voxel (rows 0, 2: voxel v; rows 1, 3: voxel 16 + v)
+            const auto p0 = __builtin_amdgcn_permlane16_swap(x0, y0, false, false);
+            const auto p1 = __builtin_amdgcn_permlane16_swap(x1, y1, false, false);
+            const u32x4_t val = {p0[0], p1[0], p0[1], p1[1]};
+            const unsigned soff = (unsigned)(((long long)odg * yv.sd + (long long)ohg * yv.sh + (long long)ow0 * yv.sw + n0) * 2);
+            if (ABL != 2) {
+              store16_buf<NT_ST>(ry, ooff, soff, val);
+              ++nst;
+            } else {
+              asm volatile("" ::"v"(val), "s"(soff));
+            }
+          }
+        }
+    };
+
+    // Synchronisation: ONE barrier per step, in its middle.  Step k reads planes 2k, 2k+1 (rows rs 0..7, ring pair k % 3) and
+    // 2k+2, 2k+3 (rs 8..15, pair (k+1) % 3).  Barrier M_k sits before the first read of rs 8: behind it every wave has (a)
+    // waited for its own pieces of planes 2k+2, 2k+3 - so they have all landed - and (b) finished rs 0..7, so pair k % 3 is
+    // free and takes planes 2k+6, 2k+7, which are needed behind M_{k+2}: the DMA has two whole steps to land.  A wave's
+    // vector-memory operations complete in issue order; `issued` counts them, the marks remember the count behind each DMA
+    // group, and the wait in front of M_k leaves exactly the younger operations (later groups, the epilogues' stores) in flight.
+    lds_barrier();      // every wave is done with the previous job's planes
+    if (ABL == 6) tprev = __builtin_amdgcn_s_memtime();
+    int issued = 0;
+    auto issue_group = [&](int pr, int ip) {
+#pragma unroll
+      for (int i = 0; i < C::NPW; ++i) issued += issue_piece(i, pr, ip);
+      return issued;
+    };
+    const int mark_p = issue_group(0, 0);
+    int mark_cur = issue_group(1, 2), mark_nxt = mark_cur;
+    if (nsteps > 1) mark_nxt = issue_group(2, 4);
+    vm_wait_all_but(issued - mark_p);
+    lds_barrier();      // planes 0, 1 are there
+    stamp(0);
+    int kk = 0;         // k mod 3: ring pair that holds the step's first two planes
+    for (int k = 0; k < nsteps; ++k) {
+      const bool more = k + 2 < nsteps && ABL != 1;
+      int mark_new = issued;
+#pragma unroll
+      for (int od = 0; od < 2; ++od)
+#pragma unroll
+        for (int oh = 0; oh < 2; ++oh)
+#pragma unroll
+          for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[od][oh][hf][r] = bv[r];
+      // input rows rs = (dz, hy) of the wave's 4 x 4 patch; the six fragments of row rs + 1 (3 tap shifts x 2 voxel halves)
+      // are read while the MFMAs of row rs issue
+      uint4 fr[2][6];
+      auto load_row = [&](int rs, uint4(&f)[6]) {
+        const int dz = rs >> 2, hy = rs & 3;
+        int slot = 2 * kk + dz;
+        slot = slot >= 6 ? slot - 6 : slot;
+        const int sb = slot * C::PLANE;
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+          for (int hf = 0; hf < 2; ++hf)
+            f[kw * 2 + hf] = *reinterpret_cast<const uint4 *>(smem + (aoff[kw] + sb) + hy * C::ROWB + hf * 1024);
+      };
+      load_row(0, fr[0]);
+#pragma unroll
+      for (int rs = 0; rs < 16; ++rs) {
+        const int dz = rs >> 2, hy = rs & 3;
+        if (rs == 7) {      // M_k (the MFMAs of row 7 cover the latency of row 8's reads behind it)
+          stamp(1);
+          vm_wait_all_but(issued - mark_cur);
+          lds_barrier();
+          stamp(2);
+        }
+        if (rs + 1 < 16) load_row(rs + 1, fr[(rs + 1) & 1]);
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) {
+          if (ABL == 3) {
+            if (rs == 8) mark_new = issue_group(kk, 2 * k + 6);
+          } else if (rs >= 8 && rs < 8 + C::NPW) {
+            issued += issue_piece(rs - 8, kk, 2 * k + 6);
+            if (rs == 8 + C::NPW - 1) mark_new = issued;
+          }
+        }
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+          for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+            for (int kd = 0; kd < 3; ++kd)
+#pragma unroll
+              for (int kh = 0; kh < 3; ++kh) {
+                const int od = dz - kd, oh = hy - kh;
+                if (od >= 0 && od < 2 && oh >= 0 && oh < 2)
+                  mfma16<T16>(wreg[(kd * 3 + kh) * 3 + kw], fr[rs & 1][kw * 2 + hf], acc[od][oh][hf]);
+              }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      stamp(3);
+      epilogue(k);
+      stamp(4);
+      issued += nst;
+      mark_cur = mark_nxt;
+      mark_nxt = mark_new;
+      kk = kk == 2 ? 0 : kk + 1;
+    }
+
+    if (stats) {
+      // per-channel sums of the job: over the 16 lanes (voxels) of a row, then over the four row-pair waves of a channel half
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+#pragma unroll
+        for (int m = 1; m < 16; m <<= 1) {
+          s1[r] += __shfl_xor(s1[r], m, 64);
+          s2[r] += __shfl_xor(s2[r], m, 64);
+        }
+        if (v == 0) {
+          red[(wave * 16 + 4 * q + r) * 2 + 0] = s1[r];
+          red[(wave * 16 + 4 * q + r) * 2 + 1] = s2[r];
+        }
+      }
+      lds_barrier();
+      const int nblk = tilesH * tilesW * nseg;
+      if (tid < 32 && n0 + tid < Cout) {
+        const int ch = tid >> 4, cc = tid & 15;
+        double s = 0.0, ss = 0.0;
+#pragma unroll
+        for (int wq = 0; wq < 4; ++wq) {
+          s += (double)red[((wq * 2 + ch) * 16 + cc) * 2 + 0];
+          ss += (double)red[((wq * 2 + ch) * 16 + cc) * 2 + 1];
+        }
+        const int slot = (seg * tilesW + tw) * tilesH + th;
+        double *pp = stats + 32 + (((int64_t)b * nblk + slot) * Cout + n0 + tid) * 2;
+        pp[0] = s;
+        pp[1] = ss;
+      }
+      if (blockIdx.x == 0 && tid == 0 && rd == 0) reinterpret_cast<long long *>(stats)[0] = nblk;
+    }
+  }
+  if (ABL == 6 && stats && lane == 0) {      // behind everything the finalize kernels read (profiles/tools/ring_stamps.py knows the place)
+    double *o = stats + (1 << 20) + ((size_t)blockIdx.x * C::NW + wave) * 8;
+    for (int i = 0; i < 5; ++i) o[i] = (double)tseg[i];
+    o[5] = (double)(__builtin_amdgcn_s_memtime() - t_begin);
+    o[6] = (double)(__builtin_amdgcn_s_memrealtime() - rt_begin);
+  }
+}
+
+}  // namespace
+
+// Entry point used by the dispatcher in conv_mfma.hip: DGTTA_ERR_UNSUPPORTED when the shape is not this kernel's.
+int conv3_ring_launch(const void *x, const View &xv, const void *w, const Taps &taps, const float *bias, void *y, const View &yv,
+                      int B, int Cin, int Cout, int CinP, int CoutP, double *stats, int64_t stats_cap_slots, int ntaps_src,
+                      int is_f16, hipStream_t st) {
+  typedef RingCfg C;
+  if (Cin != 32 || CinP != 32 || Cout % 32 != 0 || CoutP != Cout) return DGTTA_ERR_UNSUPPORTED;
+  if (xv.D != yv.D || xv.H != yv.H || xv.W != yv.W) return DGTTA_ERR_UNSUPPORTED;
+  // the buffer descriptors address one sample with 32-bit byte offsets
+  const long long xb = ((long long)(xv.D - 1) * xv.sd + (long long)(xv.H - 1) * xv.sh + (long long)(xv.W - 1) * xv.sw + 32) * 2;
+  const long long yb = ((long long)(yv.D - 1) * yv.sd + (long long)(yv.H - 1) * yv.sh + (long long)(yv.W - 1) * yv.sw + Cout) * 2;
+  if (xb >= (1ll << 31) || yb >= (1ll << 31)) return DGTTA_ERR_UNSUPPORTED;
+  if (xv.sw % 8 || xv.sh % 8 || xv.sd % 8 || xv.sb % 8 || yv.sw % 8 || yv.sh % 8 || yv.sd % 8 || yv.sb % 8 || ((uintptr_t)x & 15) ||
+      ((uintptr_t)y & 15))
+    return DGTTA_ERR_UNSUPPORTED;
+  static int ncu = [] {
+    int dev = 0, n = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+    return n > 0 ? n : 256;
+  }();
+  const int tW = cdiv(yv.W, C::TW), tH = cdiv(yv.H, C::TH), nblkN = Cout / 32;
+  const int steps_total = (yv.D + 1) / 2;
+  const long long ncol = (long long)B * nblkN * tW * tH;
+  // segments along D: as few as fill the chip evenly (a segment start costs about one and a half steps of exposed latency)
+  int nseg = 1;
+  {
+    double best = 1e300;
+    for (int s = 1; s <= 32 && s <= steps_total; s *= 2) {
+      const int sps = cdiv(steps_total, s);
+      const int ns = cdiv(steps_total, sps);
+      const double t = (double)cdiv64(ncol * ns, ncu) * (sps + 1.5);
+      if (t < best * 0.97) best = t, nseg = ns;
+    }
+  }
+  const int sps = cdiv(steps_total, nseg);
+  nseg = cdiv(steps_total, sps);
+  if (stats && (int64_t)tW * tH * nseg > stats_cap_slots) return DGTTA_ERR_UNSUPPORTED;
+  const long long njobs = ncol * nseg;
+  if (njobs >= (1ll << 31)) return DGTTA_ERR_UNSUPPORTED;
+  const int grid = (int)(njobs < ncu ? njobs : ncu);
+  const bool nt = dgtta_switches().ring_nt == '1';      // DGTTA_RING_NT=1: non-temporal output stores (measured 5 % slower: the two
+                                                          // 32-byte halves of a voxel come from two waves and merge in L2)
+#define RING_LAUNCH(T16, NTS, ...)                                                                                            \
+  do {                                                                                                                        \
+    auto kern = conv3_ring_kernel<T16, NTS, ##__VA_ARGS__>;                                                                   \
+    static DynLdsOnce once;                                                                                                   \
+    DG_REQUIRE(ensure_dyn_lds(once, reinterpret_cast<const void *>(kern), C::LDS_BYTES) == hipSuccess, DGTTA_ERR_LAUNCH,      \
+               "conv3_ring: cannot raise the dynamic LDS limit to %d", C::LDS_BYTES);                                         \
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(C::NT), C::LDS_BYTES, st, (const bf16_t *)x, xv, (const bf16_t *)w, taps, bias, \
+                       (bf16_t *)y, yv, Cout, tW, tH, nblkN, nseg, sps, (int)njobs, stats, ntaps_src, (unsigned)xb,           \
+                       (unsigned)yb);                                                                                         \
+  } while (0)
+  const int abl = dgtta_switches().ring_abl;
+  if (is_f16 && abl > '0') {      // diagnostic builds exist for the fp16 instantiation only
+    if (abl == '1') RING_LAUNCH(f16_t, false, 1);
+    else if (abl == '2') RING_LAUNCH(f16_t, false, 2);
+    else if (abl == '3') RING_LAUNCH(f16_t, false, 3);
+    else RING_LAUNCH(f16_t, false, 6);
+  } else if (is_f16) {
+    if (nt) RING_LAUNCH(f16_t, true);
+    else RING_LAUNCH(f16_t, false);
+  } else {
+    if (nt) RING_LAUNCH(bf16_t, true);
+    else RING_LAUNCH(bf16_t, false);
+  }
+#undef RING_LAUNCH
+  DG_CHECK_LAUNCH("conv3_ring_kernel");
+  return DGTTA_OK;
+}

@@ -51,6 +51,9 @@ static const DgttaSwitches *read_switches() {
   s->in_gstats = env_char("DGTTA_IN_GSTATS");
   s->softdice16 = env_char("DGTTA_SOFTDICE16");
   s->wgrad_abl = env_char("DGTTA_WGRAD_ABL");
+  s->conv_ring = env_char("DGTTA_CONV_RING");
+  s->ring_nt = env_char("DGTTA_RING_NT");
+  s->ring_abl = env_char("DGTTA_RING_ABL");
   return s;
 }
 

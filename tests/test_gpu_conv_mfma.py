@@ -145,6 +145,70 @@ def test_conv_rows_kernel_bf16(case, monkeypatch):
     assert (m2 - m1).abs().max() < 1e-5 and ((r2 - r1) / r1).abs().max() < 1e-5
 
 
+RING_CASES = [  # (B, cin, cout, D, H, W): 32 input channels in the forward, or 32 output channels (-> the data gradient's input)
+    (1, 32, 32, 9, 13, 45), (2, 32, 64, 6, 17, 32), (1, 32, 96, 8, 8, 70), (1, 64, 32, 7, 9, 33),
+    (2, 32, 32, 32, 32, 64), (1, 32, 32, 36, 40, 32), (8, 32, 32, 4, 64, 160),      # the last: 320 columns = two rounds of jobs
+]
+
+
+@pytest.mark.parametrize("dts", ["bf16", "fp16"])
+@pytest.mark.parametrize("case", RING_CASES)
+def test_conv_ring_kernel(case, dts, monkeypatch):
+    """The D-ring kernel (conv_ring.hip: plane ring in LDS, weights in registers, 16x16x32 MFMA), forced on at small sizes,
+    against its predecessors (DGTTA_CONV_RING=0: row-reuse / generic MFMA kernel) and the fp32 VALU kernel on the same
+    16-bit operands: forward with fused InstanceNorm statistics, data gradient, ragged edges, several channel blocks."""
+    from dg_tta_amd import _lib
+    from dg_tta_amd._lib import check, ptr, stream_of
+    lib = _lib.load()
+    B, cin, cout, D, H, W = case
+    dt, tdt = (1, torch.bfloat16) if dts == "bf16" else (2, torch.float16)
+    torch.manual_seed(sum(case) + 11)
+    xb = torch.randn(B, D, H, W, cin, device=DEV).to(tdt)
+    w = (torch.randn(cout, cin, 3, 3, 3, device=DEV) / (27 * cin) ** 0.5).to(tdt).float()
+    bias = torch.randn(cout, device=DEV)
+    cinp, coutp = (cin + 15) // 16 * 16, (cout + 15) // 16 * 16
+    y_ref, _ = _call_fwd(xb.float(), w, bias, 1, 0, 1, (cin + 7) // 8 * 8, (cout + 7) // 8 * 8)
+
+    def run(ring):
+        monkeypatch.setenv("DGTTA_CONV_RING", ring)
+        reload_kernel_switches()
+        wpack = torch.empty(lib.dgtta_conv3d_packed_bytes(cinp, coutp, dt) // 2, dtype=tdt, device=DEV)
+        check(lib.dgtta_conv3d_pack_weights(ptr(w), ptr(wpack), cin, cout, cinp, coutp, dt, stream_of()), "pack")
+        y = torch.full((B, D, H, W, cout), float("nan"), dtype=tdt, device=DEV)
+        nb = lib.dgtta_conv3d_stats_bytes(B, cout, D, H, W)
+        st = torch.zeros(nb, dtype=torch.uint8, device=DEV)
+        check(lib.dgtta_conv3d_k3_fwd(ptr(xb), cin, ptr(wpack), ptr(bias), ptr(y), cout, ptr(st), B, cin, cout, cinp, coutp,
+                                      D, H, W, 1, dt, 2, stream_of()), "fwd")
+        mr = torch.empty(B, cout, 2, device=DEV)
+        z = torch.empty_like(y)
+        gamma, beta = torch.ones(cout, device=DEV), torch.zeros(cout, device=DEV)
+        nws = lib.dgtta_instnorm_ws_bytes(B, cout, D * H * W)
+        ws = torch.empty(nws, dtype=torch.uint8, device=DEV)
+        check(lib.dgtta_instnorm_lrelu_fwd(ptr(y), cout, ptr(st), ptr(gamma), ptr(beta), ptr(mr), ptr(z), cout, ptr(ws), nws,
+                                           B, cout, D * H * W, 1e-5, 0.01, dt, stream_of()), "instnorm")
+        mean, rstd = mr[..., 0].reshape(-1).clone(), mr[..., 1].reshape(-1).clone()
+        dy = torch.randn(B, D, H, W, cout, device=DEV, generator=torch.Generator(DEV).manual_seed(3)).to(tdt)
+        dx = _call_dgrad(dy, wpack, cin, cinp, coutp, (D, H, W), 1, dt, 2)
+        torch.cuda.synchronize()
+        return y, mean, rstd, dx
+
+    y0, m0, r0, dx0 = run("0")
+    y1, m1, r1, dx1 = run("1")
+    scale = y_ref.abs().max()
+    tol = scale / (128 if dt == 1 else 1024) + 1e-3
+    assert torch.isfinite(y1.float()).all() and torch.isfinite(dx1.float()).all()
+    assert (y1.float() - y_ref).abs().max() < tol
+    assert (y1.float() - y0.float()).abs().max() < tol
+    ref_mean = y_ref.reshape(B, -1, cout).mean(1).reshape(-1)
+    ref_rstd = (y_ref.reshape(B, -1, cout).var(1, unbiased=False) + 1e-5).rsqrt().reshape(-1)
+    assert (m1 - ref_mean).abs().max() < 1e-4 and (m1 - m0).abs().max() < 1e-5
+    assert ((r1 - ref_rstd) / ref_rstd).abs().max() < 1e-4 and ((r1 - r0) / r0).abs().max() < 1e-5
+    assert (dx1.float() - dx0.float()).abs().max() < dx0.float().abs().max() / (128 if dt == 1 else 1024) + 1e-3
+    # run to run: the same bits (fixed job order, no atomics)
+    y2, m2, r2, dx2 = run("1")
+    assert torch.equal(y2, y1) and torch.equal(dx2, dx1) and torch.equal(m2, m1) and torch.equal(r2, r1)
+
+
 def test_conv_mfma_timing_report(capsys):
     """Not a pass/fail perf gate: prints achieved TFLOP/s of the main layer shapes (read in gpurun logs)."""
     from dg_tta_amd import _lib

@@ -40,6 +40,19 @@ static inline hipError_t ensure_dyn_lds(DynLdsOnce &o, const void *fn, int bytes
   return e;
 }
 
+// context of a data-gradient launch that also produces the InstanceNorm backward statistics of the previous block (set by
+// dgtta_conv3d_k3_dgrad_gstats around the dispatcher call, consumed by the launcher of conv_ring.hip or conv_rows.hip that
+// takes the launch: the generic kernels know nothing about it)
+struct RowsGstCtx {
+  const void *y;
+  long long ldy;
+  const float *mr, *gamma, *beta;
+  float slope;
+  double *out;
+  int produced;
+};
+extern thread_local RowsGstCtx *g_rows_gst;
+
 #define DG_REQUIRE(cond, code, ...)      \
   do {                                   \
     if (!(cond)) {                       \

@@ -32,6 +32,7 @@ struct ConvClasses {
 }  // namespace dgconv
 using namespace dgconv;
 
+
 namespace {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;

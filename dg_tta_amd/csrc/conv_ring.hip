@@ -17,9 +17,13 @@
 //   * 8 waves = 4 row pairs x 2 output-channel halves; a wave computes 2 planes x 2 rows x 32 voxels x 16 channels per step
 //     (8 accumulator tiles = 32 registers) from 4 x 4 input rows: 96 fragment reads feed 216 MFMAs.
 //   * the accumulator of D = W^T X has the output CHANNELS along the registers and the voxel on the lane: four packed
-//     converts, two v_permlane16_swap and one 16-byte store per output row and wave - no LDS transpose, no epilogue barrier.
-//   * the two waves of a SIMD (w, w + 4) run half a step apart: waves 4-7 convert and store step k - 1 at the beginning
-//     of step k, while their partners are already issuing MFMAs (guide: MI355X_MICROARCH.md, two waves per SIMD, item 9).
+//     converts, two v_permlane16_swap and one 16-byte store per output row and wave - no LDS transpose, no epilogue barrier;
+//     an output row is converted and stored as soon as its last input row is done, between the MFMAs of the rows that remain.
+//   * one barrier per step, in its middle; the DMA of a plane pair has more than a step to land (see "Synchronisation" below).
+// Measured (MI355X, fp16, 8 x 128^3 x 32 -> 32, 400 back-to-back launches): 0.75-0.79 ms = 1170-1240 TFLOP/s against 0.975 ms
+// of the row-reuse kernel; in-kernel clock 1.65-1.8 GHz: the launch is POWER bound - fewer cycles come back as a lower
+// clock (stamps: the streaming epilogue took 1600 -> 480 cycles off a step and the clock fell from 1.69 to 1.80 ... the wall
+// time stayed) - so what helps now is less energy per FLOP, not a tighter schedule (profiles/r04_ab.txt).
 // LDS image of a plane: voxel-major rows of 34 voxels x 64 B; inside a voxel the four 16-byte channel groups sit at
 // position g ^ 2*((u >> 2) & 1) (u = voxel index in the row): with that, the 16 lanes that ds_read_b128 serves per cycle
 // (4 voxels apart in two channel groups) fall on 16 different 16-byte bank slots for every tap shift.  The permutation
@@ -46,7 +50,7 @@ struct RingCfg {
   static constexpr int NSLOT = 6;
   static constexpr int NW = 8, NT = NW * 64;
   static constexpr int NPW = (2 * PIECES + NW - 1) / NW;             // pieces per wave and step (6)
-  static constexpr int RED_BYTES = NW * 16 * 2 * (int)sizeof(float);
+  static constexpr int RED_BYTES = NW * 16 * 2 * (int)sizeof(float) + 32 * 2 * (int)sizeof(float);      // + GST constants
   static constexpr int LDS_BYTES = NSLOT * PLANE + RED_BYTES;
 };
 
@@ -59,6 +63,21 @@ __device__ __forceinline__ void mfma16<bf16_t>(const uint4 &a, const uint4 &b, f
 template <>
 __device__ __forceinline__ void mfma16<f16_t>(const uint4 &a, const uint4 &b, f32x4_t &acc) {
   acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), acc, 0, 0, 0);
+}
+
+// two fp32 -> one packed 16-bit pair by ONE instruction (v_cvt_pk_f16_f32 / v_cvt_pk_bf16_f32: what a vector fptrunc selects on
+// gfx950, round to nearest even like the scalar conversions of common.h, which cost three instructions per pair)
+template <typename T16>
+__device__ __forceinline__ unsigned pack2_pk(float lo, float hi);
+template <>
+__device__ __forceinline__ unsigned pack2_pk<f16_t>(float lo, float hi) {
+  typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_t{lo, hi}, h2_t));
+}
+template <>
+__device__ __forceinline__ unsigned pack2_pk<bf16_t>(float lo, float hi) {
+  typedef __bf16 b2_t __attribute__((ext_vector_type(2)));
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_t{lo, hi}, b2_t));
 }
 
 // LDS-DMA through a buffer descriptor: lane i's 16 bytes land at lds_addr + 16 i; a lane whose offset is outside the
@@ -112,18 +131,30 @@ __device__ __forceinline__ u32x4_t make_rsrc(const void *base, unsigned bytes) {
 }
 constexpr unsigned OOB = 0x80000000u;      // beyond every descriptor this kernel builds (the launcher checks < 2^31 bytes)
 
+// GST: the launch is the DATA GRADIENT of a conv whose input was z = LeakyReLU(InstanceNorm(y_prev)); the epilogue also leaves the
+// sums the InstanceNorm backward of that previous block needs (conv_rows.hip, GST: same definition, same partial-sum layout,
+// same finalize kernel): sum g' and sum g' y_prev with g' = gz * lrelu'(A y_prev + B), from the ROUNDED gz it stores.
+struct RingGst {
+  const bf16_t *y;          // y_prev, same lattice as the output
+  View v;
+  const float *mr, *gamma, *beta;
+  float slope;
+  unsigned bytes;
+};
+
 // ABL (diagnostic builds, DGTTA_RING_ABL; results are wrong for 1 and 2): 1 no DMA after a job's first four planes, 2 no stores,
 // 3 a step's DMA pieces issued in one burst behind the barrier instead of one per input row, 6 per-segment cycle stamps and
 // the in-kernel clock, written behind the statistics (profiles/tools/ring_stamps.py)
-template <typename T16, bool NT_ST, int ABL = 0>
+template <typename T16, bool NT_ST, int ABL = 0, bool GST = false>
 __global__ __launch_bounds__(RingCfg::NT) void conv3_ring_kernel(const bf16_t *__restrict__ x, View xv, const bf16_t *__restrict__ w,
                                                                  Taps taps, const float *__restrict__ bias, bf16_t *__restrict__ y,
                                                                  View yv, int Cout, int tilesW, int tilesH, int nblkN, int nseg,
                                                                  int steps_per_seg, int njobs, double *__restrict__ stats,
-                                                                 int ntaps_src, unsigned x_bytes, unsigned y_bytes) {
+                                                                 int ntaps_src, unsigned x_bytes, unsigned y_bytes, RingGst gst) {
   typedef RingCfg C;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float *red = reinterpret_cast<float *>(smem + C::NSLOT * C::PLANE);
+  float *gcst = red + C::NW * 16 * 2;      // GST: (A, B) of the job's 32 channels
   const unsigned lds0 = lds_addr_of(smem);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -193,7 +224,18 @@ __global__ __launch_bounds__(RingCfg::NT) void conv3_ring_kernel(const bf16_t *_
     }
     float bv[4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) bv[r] = bias ? bias[n0 + chalf * 16 + 4 * q + r] : 0.f;
+    for (int r = 0; r < 4; ++r) bv[r] = (!GST && bias) ? bias[n0 + chalf * 16 + 4 * q + r] : 0.f;
+    const __amdgpu_buffer_rsrc_t rg =
+        __builtin_amdgcn_make_buffer_rsrc((void *)(gst.y + (long long)b * gst.v.sb), (short)0, (int)gst.bytes, 0x00020000);
+    if (GST) {      // the job's InstanceNorm constants (published by the barriers in front of the first epilogue)
+      if (tid < 32) {
+        const int c = n0 + tid;
+        const float mu = gst.mr[((long long)b * Cout + c) * 2], rs = gst.mr[((long long)b * Cout + c) * 2 + 1];
+        const float a = gst.gamma[c] * rs;
+        gcst[tid * 2] = a;
+        gcst[tid * 2 + 1] = gst.beta[c] - mu * a;
+      }
+    }
     // the compiler's wait for these loads belongs HERE: left to the first use inside the step loop it becomes a
     // vmcnt(0) per step, which also waits for the epilogue's stores
 #pragma unroll
@@ -217,6 +259,7 @@ __global__ __launch_bounds__(RingCfg::NT) void conv3_ring_kernel(const bf16_t *_
     // output: lane (row rho = q, voxel v) stores 8 channels of voxel v + 16 (rho & 1) after the row swaps
     const int ovox = v + 16 * (q & 1);
     const unsigned ooff = (ow0 + ovox < W) ? (unsigned)((ovox * yv.sw + chalf * 16 + (q >> 1) * 8) * 2) : OOB;
+    const unsigned goff = (GST && ow0 + ovox < W) ? (unsigned)((ovox * gst.v.sw + chalf * 16 + (q >> 1) * 8) * 2) : OOB;
     const bool wv0 = ow0 + v < W, wv1 = ow0 + 16 + v < W;      // this lane's voxel of tile half 0 / 1 inside the volume
     const bool full_w = ow0 + 32 <= W;
 
@@ -235,74 +278,107 @@ __global__ __launch_bounds__(RingCfg::NT) void conv3_ring_kernel(const bf16_t *_
     };
 
     f32x4_t acc[2][2][2];
-    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
-    int nst = 0;        // stores issued by the last epilogue of this wave
+    f32x2_t s1[2] = {{0.f, 0.f}, {0.f, 0.f}}, s2[2] = {{0.f, 0.f}, {0.f, 0.f}};      // forward sums of this lane's 4 channels
+    f32x2_t gs1[4], gs2[4];       // GST: sums of this lane's 8 channels (channel pairs: packed fp32 math)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) gs1[t] = gs2[t] = f32x2_t{0.f, 0.f};
+    u32x4_t gy[2];                // GST: y_prev of this lane's voxel and 8 channels, the two rows of the output plane in work
+    int issued = 0;     // ... and by this wave in this job
 
-    auto epilogue = [&](int k) {
-      nst = 0;
+    // GST: the y_prev values of output plane od of step k, fetched two input rows ahead of their use (compiler-visible loads:
+    // it waits for them itself - its count ignores the inline-asm operations, which only makes the wait stricter)
+    auto load_gy = [&](int k, int od) {
 #pragma unroll
-      for (int od = 0; od < 2; ++od)
+      for (int oh = 0; oh < 2; ++oh) {
+        const int odg = d0 + 2 * k + od, ohg = oh0 + 2 * ws + oh;
+        if (odg < D && ohg < H) {
+          const unsigned soff = (unsigned)(((long long)odg * gst.v.sd + (long long)ohg * gst.v.sh + (long long)ow0 * gst.v.sw + n0) * 2);
+          gy[oh] = __builtin_amdgcn_raw_buffer_load_b128(rg, goff, soff, 0);
+          ++issued;
+        }
+      }
+    };
+
+    // Output row (od, oh) of step k is complete once input row (dz, hy) = (od + 2, oh + 2) has been processed: it is converted
+    // and stored right then, between the MFMAs of the remaining input rows (3 of the 4 output rows of a step), not in a block at
+    // the end of the step - where all eight waves queued on the store path at once (stamps: 1600-1900 cycles per step).
+    auto epilogue_row = [&](int k, int od, int oh) {
+      const int odg = d0 + 2 * k + od, ohg = oh0 + 2 * ws + oh;
+      if (odg < D && ohg < H) {       // wave-uniform
+        const f32x4_t a0 = acc[od][oh][0], a1 = acc[od][oh][1];
+        if (!GST) {      // forward statistics of the unrounded values: channel pairs as packed fp32 (v_pk_add_f32 / v_pk_fma_f32)
+          auto sums = [&](const f32x2_t l0, const f32x2_t h0, const f32x2_t l1, const f32x2_t h1) {
+            s1[0] += l0 + l1;
+            s1[1] += h0 + h1;
+            s2[0] = __builtin_elementwise_fma(l0, l0, __builtin_elementwise_fma(l1, l1, s2[0]));
+            s2[1] = __builtin_elementwise_fma(h0, h0, __builtin_elementwise_fma(h1, h1, s2[1]));
+          };
+          const f32x2_t z2 = {0.f, 0.f};
+          if (full_w)      // (two code paths on purpose: merged, the compiler copies all eight values of the common case)
+            sums(__builtin_shufflevector(a0, a0, 0, 1), __builtin_shufflevector(a0, a0, 2, 3),
+                 __builtin_shufflevector(a1, a1, 0, 1), __builtin_shufflevector(a1, a1, 2, 3));
+          else             // a voxel beyond W contributes nothing
+            sums(wv0 ? __builtin_shufflevector(a0, a0, 0, 1) : z2, wv0 ? __builtin_shufflevector(a0, a0, 2, 3) : z2,
+                 wv1 ? __builtin_shufflevector(a1, a1, 0, 1) : z2, wv1 ? __builtin_shufflevector(a1, a1, 2, 3) : z2);
+        }
+        const unsigned x0 = pack2_pk<T16>(a0[0], a0[1]), x1 = pack2_pk<T16>(a0[2], a0[3]);
+        const unsigned y0 = pack2_pk<T16>(a1[0], a1[1]), y1 = pack2_pk<T16>(a1[2], a1[3]);
+        // rows (16 lanes) 1 and 3 of the half-0 tile change places with rows 0 and 2 of the half-1 tile: afterwards a lane
+        // holds 8 consecutive channels of ONE voxel (rows 0, 2: voxel v; rows 1, 3: voxel 16 + v)
+        const auto p0 = __builtin_amdgcn_permlane16_swap(x0, y0, false, false);
+        const auto p1 = __builtin_amdgcn_permlane16_swap(x1, y1, false, false);
+        const u32x4_t val = {p0[0], p1[0], p0[1], p1[1]};
+        const unsigned soff = (unsigned)(((long long)odg * yv.sd + (long long)ohg * yv.sh + (long long)ow0 * yv.sw + n0) * 2);
+        if (ABL != 2) {
+          store16_buf<NT_ST>(ry, ooff, soff, val);
+          ++issued;
+        } else {
+          asm volatile("" ::"v"(val), "s"(soff));
+        }
+        if (GST && goff != OOB) {       // (a voxel beyond W contributes nothing)
+          const u32x4_t yq = gy[oh];
 #pragma unroll
-        for (int oh = 0; oh < 2; ++oh) {
-          const int odg = d0 + 2 * k + od, ohg = oh0 + 2 * ws + oh;
-          if (odg < D && ohg < H) {       // wave-uniform
-            const f32x4_t a0 = acc[od][oh][0], a1 = acc[od][oh][1];
-            if (full_w) {
-#pragma unroll
-              for (int r = 0; r < 4; ++r) {
-                s1[r] += a0[r] + a1[r];
-                s2[r] = __builtin_fmaf(a0[r], a0[r], __builtin_fmaf(a1[r], a1[r], s2[r]));
-              }
-            } else {
-#pragma unroll
-              for (int r = 0; r < 4; ++r) {
-                const float m0 = wv0 ? a0[r] : 0.f, m1 = wv1 ? a1[r] : 0.f;
-                s1[r] += m0 + m1;
-                s2[r] = __builtin_fmaf(m0, m0, __builtin_fmaf(m1, m1, s2[r]));
-              }
-            }
-            const unsigned x0 = pack2_16<T16>(a0[0], a0[1]), x1 = pack2_16<T16>(a0[2], a0[3]);
-            const unsigned y0 = pack2_16<T16>(a1[0], a1[1]), y1 = pack2_16<T16>(a1[2], a1[3]);
-            // rows (16 lanes) 1 and 3 of the half-0 tile change places with rows 0 and 2 of the half-1 tile: afterwards a lane
-            // holds 8 consecutive channels of ONE voxel (rows 0, 2: voxel v; rows 1, 3: voxel 16 + v)
-            const auto p0 = __builtin_amdgcn_permlane16_swap(x0, y0, false, false);
-            const auto p1 = __builtin_amdgcn_permlane16_swap(x1, y1, false, false);
-            const u32x4_t val = {p0[0], p1[0], p0[1], p1[1]};
-            const unsigned soff = (unsigned)(((long long)odg * yv.sd + (long long)ohg * yv.sh + (long long)ow0 * yv.sw + n0) * 2);
-            if (ABL != 2) {
-              store16_buf<NT_ST>(ry, ooff, soff, val);
-              ++nst;
-            } else {
-              asm volatile("" ::"v"(val), "s"(soff));
-            }
+          for (int t = 0; t < 4; ++t) {
+            const float4 c4 = *reinterpret_cast<const float4 *>(gcst + (chalf * 16 + (q >> 1) * 8 + 2 * t) * 2);      // (A, B) of two channels
+            const f32x2_t gA = {c4.x, c4.z}, gB = {c4.y, c4.w};
+            float g0, g1, yy0, yy1;
+            unpack2_16<T16>(val[t], g0, g1);
+            unpack2_16<T16>(yq[t], yy0, yy1);
+            const f32x2_t g2 = {g0, g1}, y2 = {yy0, yy1};
+            const f32x2_t a2 = __builtin_elementwise_fma(gA, y2, gB);
+            const f32x2_t gsl = g2 * gst.slope;
+            const f32x2_t q2 = {a2[0] > 0.f ? g2[0] : gsl[0], a2[1] > 0.f ? g2[1] : gsl[1]};
+            gs1[t] += q2;
+            gs2[t] = __builtin_elementwise_fma(q2, y2, gs2[t]);
           }
         }
+      }
     };
 
-    // Synchronisation: ONE barrier per step, in its middle.  Step k reads planes 2k, 2k+1 (rows rs 0..7, ring pair k % 3) and
-    // 2k+2, 2k+3 (rs 8..15, pair (k+1) % 3).  Barrier M_k sits before the first read of rs 8: behind it every wave has (a)
-    // waited for its own pieces of planes 2k+2, 2k+3 - so they have all landed - and (b) finished rs 0..7, so pair k % 3 is
-    // free and takes planes 2k+6, 2k+7, which are needed behind M_{k+2}: the DMA has two whole steps to land.  A wave's
-    // vector-memory operations complete in issue order; `issued` counts them, the marks remember the count behind each DMA
-    // group, and the wait in front of M_k leaves exactly the younger operations (later groups, the epilogues' stores) in flight.
-    lds_barrier();      // every wave is done with the previous job's planes
-    if (ABL == 6) tprev = __builtin_amdgcn_s_memtime();
-    int issued = 0;
-    auto issue_group = [&](int pr, int ip) {
+    // Synchronisation: ONE barrier per step, in its middle.  Step k reads planes 2k, 2k+1 (input rows rs 0..7, ring pair k % 3)
+    // and 2k+2, 2k+3 (rs 8..15, pair (k+1) % 3).  Barrier M_k sits before the first read of rs 8: in front of it every wave has
+    // waited for its own DMA pieces of planes 2k+2, 2k+3, so behind it they have all landed; and every wave has finished rs 0..7
+    // of step k - 1... of every earlier step, so pair (k+2) % 3 (planes 2k-2, 2k-1, last read in front of M_{k-1}) is free: it takes
+    // planes 2k+4, 2k+5 during rs 0..5 of step k (one DMA piece per row), first read behind M_{k+1}: more than a step to land.
+    // A wave's vector-memory operations complete in issue order; `issued` counts them, a mark remembers the count behind each
+    // DMA group, and the wait in front of M_k leaves exactly the younger operations (the next group, the epilogue's stores, GST's
+    // y loads) in flight.  Tried and dropped (profiles/r04_ab.txt): the two waves of a SIMD on opposite sides of the barrier
+    // (waves 4-7 running whole steps between barriers, so that each wave's conversion / store phase falls into its partner's MFMA
+    // stream): 0.786 vs 0.774 ms (static wave priorities either way: no change) - the older wave of a pair wins the arbitration, finishes its interval early and waits ~2900
+    // cycles per step at the barrier while the younger one runs alone, at the ~60 % MFMA rate one wave's LDS latencies allow.
+    uint4 fr[2][6];
+    auto load_row = [&](int rs, int kkv, uint4(&f)[6]) {
+      const int dz = rs >> 2, hy = rs & 3;
+      int slot = 2 * kkv + dz;
+      slot = slot >= 6 ? slot - 6 : slot;
+      const int sb = slot * C::PLANE;
 #pragma unroll
-      for (int i = 0; i < C::NPW; ++i) issued += issue_piece(i, pr, ip);
-      return issued;
+      for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf)
+          f[kw * 2 + hf] = *reinterpret_cast<const uint4 *>(smem + (aoff[kw] + sb) + hy * C::ROWB + hf * 1024);
     };
-    const int mark_p = issue_group(0, 0);
-    int mark_cur = issue_group(1, 2), mark_nxt = mark_cur;
-    if (nsteps > 1) mark_nxt = issue_group(2, 4);
-    vm_wait_all_but(issued - mark_p);
-    lds_barrier();      // planes 0, 1 are there
-    stamp(0);
-    int kk = 0;         // k mod 3: ring pair that holds the step's first two planes
-    for (int k = 0; k < nsteps; ++k) {
-      const bool more = k + 2 < nsteps && ABL != 1;
-      int mark_new = issued;
+    auto init_acc = [&]() {
 #pragma unroll
       for (int od = 0; od < 2; ++od)
 #pragma unroll
@@ -311,40 +387,42 @@ __global__ __launch_bounds__(RingCfg::NT) void conv3_ring_kernel(const bf16_t *_
           for (int hf = 0; hf < 2; ++hf)
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc[od][oh][hf][r] = bv[r];
-      // input rows rs = (dz, hy) of the wave's 4 x 4 patch; the six fragments of row rs + 1 (3 tap shifts x 2 voxel halves)
-      // are read while the MFMAs of row rs issue
-      uint4 fr[2][6];
-      auto load_row = [&](int rs, uint4(&f)[6]) {
+    };
+    int mark_cur = 0, mark_nxt = 0;
+    auto issue_group = [&](int pr, int ip) {
+#pragma unroll
+      for (int i = 0; i < C::NPW; ++i) issued += issue_piece(i, pr, ip);
+      return issued;
+    };
+    // input rows [RS0, RS1) of step k (ring phase kkv): the six fragments of row rs + 1 (3 tap shifts x 2 voxel halves) are read
+    // while the MFMAs of row rs issue; fr[RS0 & 1] holds row RS0 on entry; on exit fr[RS1 & 1] holds row RS1 (RS1 < 16).
+    // BAR7: the barrier M_k sits between rs 7 and rs 8 (in front of the first read of rs 8: the MFMAs of row 7 cover the latency
+    // of those reads).  DMA0: the row at which this wave issues its first DMA piece of planes 2k+4, 2k+5 (-1: not in this block).
+    auto rows = [&](auto rs0c, auto rs1c, auto bar7c, auto dma0c, int k, int kkv, bool more) {
+      constexpr int RS0 = decltype(rs0c)::value, RS1 = decltype(rs1c)::value, DMA0 = decltype(dma0c)::value;
+      constexpr bool BAR7 = decltype(bar7c)::value;
+      const int prn = kkv == 0 ? 2 : kkv - 1;      // (k + 2) % 3
+#pragma unroll
+      for (int rs = RS0; rs < RS1; ++rs) {
         const int dz = rs >> 2, hy = rs & 3;
-        int slot = 2 * kk + dz;
-        slot = slot >= 6 ? slot - 6 : slot;
-        const int sb = slot * C::PLANE;
-#pragma unroll
-        for (int kw = 0; kw < 3; ++kw)
-#pragma unroll
-          for (int hf = 0; hf < 2; ++hf)
-            f[kw * 2 + hf] = *reinterpret_cast<const uint4 *>(smem + (aoff[kw] + sb) + hy * C::ROWB + hf * 1024);
-      };
-      load_row(0, fr[0]);
-#pragma unroll
-      for (int rs = 0; rs < 16; ++rs) {
-        const int dz = rs >> 2, hy = rs & 3;
-        if (rs == 7) {      // M_k (the MFMAs of row 7 cover the latency of row 8's reads behind it)
+        if (BAR7 && rs == 7) {
           stamp(1);
           vm_wait_all_but(issued - mark_cur);
           lds_barrier();
           stamp(2);
         }
-        if (rs + 1 < 16) load_row(rs + 1, fr[(rs + 1) & 1]);
+        if (rs + 1 < 16) load_row(rs + 1, kkv, fr[(rs + 1) & 1]);
         __builtin_amdgcn_sched_barrier(0);
-        if (more) {
+        if (DMA0 >= 0 && more) {
           if (ABL == 3) {
-            if (rs == 8) mark_new = issue_group(kk, 2 * k + 6);
-          } else if (rs >= 8 && rs < 8 + C::NPW) {
-            issued += issue_piece(rs - 8, kk, 2 * k + 6);
-            if (rs == 8 + C::NPW - 1) mark_new = issued;
+            if (rs == DMA0) mark_nxt = issue_group(prn, 2 * k + 4);
+          } else if (rs >= DMA0 && rs < DMA0 + C::NPW) {
+            issued += issue_piece(rs - DMA0, prn, 2 * k + 4);
+            if (rs == DMA0 + C::NPW - 1) mark_nxt = issued;
           }
         }
+        if (GST && rs == 8) load_gy(k, 0);
+        if (GST && rs == 12) load_gy(k, 1);
 #pragma unroll
         for (int kw = 0; kw < 3; ++kw)
 #pragma unroll
@@ -358,28 +436,65 @@ __global__ __launch_bounds__(RingCfg::NT) void conv3_ring_kernel(const bf16_t *_
                   mfma16<T16>(wreg[(kd * 3 + kh) * 3 + kw], fr[rs & 1][kw * 2 + hf], acc[od][oh][hf]);
               }
         __builtin_amdgcn_sched_barrier(0);
+        if (rs == 15) stamp(3);
+        if (rs == 10 || rs == 11 || rs == 14 || rs == 15) epilogue_row(k, (rs >> 2) - 2, (rs & 3) - 2);
       }
-      stamp(3);
-      epilogue(k);
-      stamp(4);
-      issued += nst;
-      mark_cur = mark_nxt;
-      mark_nxt = mark_new;
-      kk = kk == 2 ? 0 : kk + 1;
+    };
+    typedef std::integral_constant<int, 0> I0;
+    typedef std::integral_constant<int, 7> I7;
+    typedef std::integral_constant<int, 16> I16;
+    typedef std::integral_constant<int, -1> IM1;
+
+    lds_barrier();      // every wave is done with the previous job's planes
+    if (ABL == 6) tprev = __builtin_amdgcn_s_memtime();
+    const int mark_p = issue_group(0, 0);
+    mark_cur = issue_group(1, 2);      // planes 2, 3: needed behind M_0
+    vm_wait_all_but(issued - mark_p);
+    lds_barrier();      // planes 0, 1 are there
+    stamp(0);
+    int kk = 0;         // k mod 3: ring pair that holds the step's first two planes
+    {
+      for (int k = 0; k < nsteps; ++k) {
+        const bool more = k + 1 < nsteps && ABL != 1;
+        mark_nxt = issued;
+        init_acc();
+        load_row(0, kk, fr[0]);
+        rows(I0{}, I16{}, std::true_type{}, I0{}, k, kk, more);
+        stamp(4);
+        mark_cur = mark_nxt;
+        kk = kk == 2 ? 0 : kk + 1;
+      }
     }
 
+    if (stats && GST) {
+      // this lane's 8 channels are shared by the 32 lanes of rows {0, 1} or {2, 3}
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float a = gs1[e >> 1][e & 1], c2 = gs2[e >> 1][e & 1];
+#pragma unroll
+        for (int m = 1; m < 32; m <<= 1) {
+          a += __shfl_xor(a, m, 64);
+          c2 += __shfl_xor(c2, m, 64);
+        }
+        if ((lane & 31) == 0) {
+          red[(wave * 16 + (q >> 1) * 8 + e) * 2 + 0] = a;
+          red[(wave * 16 + (q >> 1) * 8 + e) * 2 + 1] = c2;
+        }
+      }
+    }
     if (stats) {
       // per-channel sums of the job: over the 16 lanes (voxels) of a row, then over the four row-pair waves of a channel half
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
+      for (int r = 0; r < 4 && !GST; ++r) {
+        float a = s1[r >> 1][r & 1], c2 = s2[r >> 1][r & 1];
 #pragma unroll
         for (int m = 1; m < 16; m <<= 1) {
-          s1[r] += __shfl_xor(s1[r], m, 64);
-          s2[r] += __shfl_xor(s2[r], m, 64);
+          a += __shfl_xor(a, m, 64);
+          c2 += __shfl_xor(c2, m, 64);
         }
         if (v == 0) {
-          red[(wave * 16 + 4 * q + r) * 2 + 0] = s1[r];
-          red[(wave * 16 + 4 * q + r) * 2 + 1] = s2[r];
+          red[(wave * 16 + 4 * q + r) * 2 + 0] = a;
+          red[(wave * 16 + 4 * q + r) * 2 + 1] = c2;
         }
       }
       lds_barrier();
@@ -448,6 +563,25 @@ int conv3_ring_launch(const void *x, const View &xv, const void *w, const Taps &
   if (stats && (int64_t)tW * tH * nseg > stats_cap_slots) return DGTTA_ERR_UNSUPPORTED;
   const long long njobs = ncol * nseg;
   if (njobs >= (1ll << 31)) return DGTTA_ERR_UNSUPPORTED;
+  // a data gradient that is asked to leave the InstanceNorm backward sums of the previous block (dgtta_conv3d_k3_dgrad_gstats)
+  RingGst ga{};
+  RowsGstCtx *gctx = g_rows_gst;
+  const long long gb = gctx ? ((long long)(yv.D - 1) * yv.H * yv.W * gctx->ldy + (long long)(yv.H - 1) * yv.W * gctx->ldy +
+                               (long long)(yv.W - 1) * gctx->ldy + Cout) * 2 : 0;
+  const bool gst_on = gctx && !stats && !bias && gctx->ldy % 8 == 0 && ((uintptr_t)gctx->y & 15) == 0 && gb < (1ll << 31) &&
+                      (int64_t)tW * tH * nseg <= stats_cap_slots && dgtta_switches().ring_abl < 0;
+  if (gst_on) {
+    g_rows_gst = nullptr;       // one launch per context
+    ga.y = (const bf16_t *)gctx->y;
+    ga.v = dense_view(B, yv.D, yv.H, yv.W, (int)gctx->ldy);
+    ga.mr = gctx->mr;
+    ga.gamma = gctx->gamma;
+    ga.beta = gctx->beta;
+    ga.slope = gctx->slope;
+    ga.bytes = (unsigned)gb;
+    stats = gctx->out;
+    gctx->produced = 1;
+  }
   const int grid = (int)(njobs < ncu ? njobs : ncu);
   const bool nt = dgtta_switches().ring_nt == '1';      // DGTTA_RING_NT=1: non-temporal output stores (measured 5 % slower: the two
                                                           // 32-byte halves of a voxel come from two waves and merge in L2)
@@ -459,7 +593,7 @@ int conv3_ring_launch(const void *x, const View &xv, const void *w, const Taps &
                "conv3_ring: cannot raise the dynamic LDS limit to %d", C::LDS_BYTES);                                         \
     hipLaunchKernelGGL(kern, dim3(grid), dim3(C::NT), C::LDS_BYTES, st, (const bf16_t *)x, xv, (const bf16_t *)w, taps, bias, \
                        (bf16_t *)y, yv, Cout, tW, tH, nblkN, nseg, sps, (int)njobs, stats, ntaps_src, (unsigned)xb,           \
-                       (unsigned)yb);                                                                                         \
+                       (unsigned)yb, ga);                                                                                     \
   } while (0)
   const int abl = dgtta_switches().ring_abl;
   if (is_f16 && abl > '0') {      // diagnostic builds exist for the fp16 instantiation only
@@ -467,6 +601,9 @@ int conv3_ring_launch(const void *x, const View &xv, const void *w, const Taps &
     else if (abl == '2') RING_LAUNCH(f16_t, false, 2);
     else if (abl == '3') RING_LAUNCH(f16_t, false, 3);
     else RING_LAUNCH(f16_t, false, 6);
+  } else if (gst_on) {
+    if (is_f16) RING_LAUNCH(f16_t, false, 0, true);
+    else RING_LAUNCH(bf16_t, false, 0, true);
   } else if (is_f16) {
     if (nt) RING_LAUNCH(f16_t, true);
     else RING_LAUNCH(f16_t, false);

@@ -586,16 +586,6 @@ __global__ __launch_bounds__(WD *WH * 64) void conv3_rows_kernel(const bf16_t *_
 
 }  // namespace
 
-// context of a data-gradient launch that also produces the InstanceNorm backward statistics (set by
-// dgtta_conv3d_k3_dgrad_gstats around the dispatcher call, consumed here: the generic kernels know nothing about it)
-struct RowsGstCtx {
-  const void *y;
-  long long ldy;
-  const float *mr, *gamma, *beta;
-  float slope;
-  double *out;
-  int produced;
-};
 thread_local RowsGstCtx *g_rows_gst = nullptr;
 
 namespace {

@@ -1097,16 +1097,7 @@ extern "C" int dgtta_conv3d_k3_dgrad(const void *dy, int lddy, const void *wpack
   return DGTTA_OK;
 }
 
-// conv_rows.hip: context of a data-gradient launch that also produces InstanceNorm backward statistics
-struct RowsGstCtx {
-  const void *y;
-  long long ldy;
-  const float *mr, *gamma, *beta;
-  float slope;
-  double *out;
-  int produced;
-};
-extern thread_local RowsGstCtx *g_rows_gst;
+
 
 extern "C" int dgtta_conv3d_k3_dgrad_gstats(const void *dy, int lddy, const void *wpack, void *dx, int lddx, int B, int Cin,
                                             int Cout, int CinP, int CoutP, int Di, int Hi, int Wi, const void *y_prev,

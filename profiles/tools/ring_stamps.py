@@ -28,5 +28,7 @@ tot = o[..., 5]
 print(f"launch {e0.elapsed_time(e1)*1e3:.1f} us (stamped build); cycles per wave: mean {float(tot.mean()):.0f} min {float(tot.min()):.0f} max {float(tot.max()):.0f}")
 for i, nm in enumerate(names):
     print(f"  {nm:14s} mean {float(o[..., i].mean()):10.0f}  ({100*float(o[..., i].mean()/tot.mean()):5.1f} %)  min {float(o[..., i].min()):10.0f} max {float(o[..., i].max()):10.0f}")
+wt = o[..., 2].mean(0) / 128
+print("wait+barrier per step by wave:", " ".join(f"{float(x):.0f}" for x in wt), "| epilogue:", " ".join(f"{float(x):.0f}" for x in o[..., 4].mean(0) / 128))
 clk = (o[..., 5] / o[..., 6] * 100e6).flatten()
 print(f"in-kernel clock: median {float(clk.median())/1e9:.3f} GHz (min {float(clk.min())/1e9:.3f}, max {float(clk.max())/1e9:.3f}); kernel span {float((o[..., 6].max())/100):.1f} us")

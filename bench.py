@@ -43,14 +43,22 @@ def parse_args(argv=None):
     ap.add_argument("--size", type=int, default=128)
     ap.add_argument("--accum", type=int, default=16)
     ap.add_argument("--copt", type=int, default=16)
-    ap.add_argument("--dtype", default="fp16", choices=list(DTYPES),
-                    help="activation storage; accumulation, statistics, loss, gradients of weights and AdamW are fp32")
+    ap.add_argument("--dtype", default="bf16", choices=list(DTYPES),
+                    help="activation storage of the headline run (BASELINE.json config 2 names bf16); accumulation, statistics, "
+                         "loss, gradients of weights and AdamW are fp32.  fp32 = the reference's precision (measured in every "
+                         "default run as the `fp32` leg), fp16 = config 5's mixed precision (guarded loss scale)")
     ap.add_argument("--impl", type=int, default=0)
     ap.add_argument("--cpu-size", type=int, default=128)
     ap.add_argument("--cpu-warmup", type=int, default=1)
-    ap.add_argument("--ab-epochs", type=int, default=4,
-                    help="epochs of the same-seed fp32 vs 16-bit comparison (dice_delta; the fp32 leg's timing: the first "
-                         "epoch is its warm-up); 0 = skip")
+    ap.add_argument("--ab-epochs", type=int, default=6,
+                    help="epochs of the same-seed fp32 vs 16-bit comparison (dice_delta) and of the fp32 leg's timing (the "
+                         "first epoch is its warm-up: default 1 + 5 timed); 0 = skip")
+    ap.add_argument("--no-parity", action="store_true",
+                    help="skip parity_at_size (the HIP path in fp32 / fp16 / bf16 against the CPU oracle's accumulation step "
+                         "that cpu_baseline runs anyway)")
+    ap.add_argument("--write-fp32-trajectory", type=int, default=0, metavar="EPOCHS",
+                    help="run EPOCHS fp32 epochs with the headline run's seed and write their losses / pseudo-Dice to "
+                         "profiles/fp32_trajectory.json (what an N > 1 run compares its rank 0 with), then exit")
     ap.add_argument("--no-fp32", action="store_true", help="skip the reference-precision (fp32) leg and dice_delta")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--inference-size", type=int, default=512,
@@ -189,36 +197,137 @@ class StubRunner:
         self.dices.append(0.0)
 
 
-def cpu_baseline(args):
-    """Times the CPU oracle (restatement of the reference, kind 'port') on a bounded sample of the same workload, as
-    BASELINE.md §4 prescribes: ONE warm-up + ONE measured accumulation step (2 branches fwd + loss + bwd) on a
-    `cpu_size`^3 patch (default: the full 128^3), scaled by the voxel count if smaller and by (accum + eval forward)
-    to one epoch."""
+def oracle_step(n, copt, accum, seed_a=101, seed_b=102, w_seed=7, threads=None):
+    """ONE accumulation step of the CPU oracle (restatement of the reference's calc_branch x 2 + masked soft-Dice + backward,
+    dg_tta/tta/tta.py:233-275, :480-579) on an n^3 patch with recorded draws: what cpu_baseline times and what
+    parity_at_size / tests/test_gpu_at_size.py check the HIP path against.  Returns (seconds, record)."""
     import torch
     from oracle import tta as otta, unet as ounet
-    n = args.cpu_size
-    cores = min(len(os.sched_getaffinity(0)), 16)     # a one-GPU box's CPU share is 16 cores (oversubscribing 256 hurts)
-    torch.set_num_threads(cores)
-    om = ounet.init_he(ounet.PlainConvUNetOracle(), 7)
-    sel = torch.arange(args.copt) * 3
+    if threads:
+        torch.set_num_threads(threads)
+    om = ounet.perturb_affine(ounet.init_he(ounet.PlainConvUNetOracle(), w_seed), w_seed + 1)
+    sel = torch.arange(copt) * 3
     torch.manual_seed(0)
     imgs = torch.randn(1, 1, n, n, n)
 
     def draws(seed):
         torch.manual_seed(seed)
         return otta.draw_branch(1, [n, n, n])
-    times = []
+    da, db = draws(seed_a), draws(seed_b)
+    om.zero_grad()
+    t0 = time.perf_counter()
+    ta = otta.calc_branch(om, imgs, sel, **da)
+    tb = otta.calc_branch(om, imgs, sel, **db)
+    mask = (ta.sum(1, keepdim=True) > 0.0).float() * (tb.sum(1, keepdim=True) > 0.0).float()
+    dice = otta.soft_dice_loss(ta.softmax(1) * mask, tb.softmax(1) * mask)
+    loss = 1 - dice[:, otta.START_CLASS:].mean()
+    (loss / accum).backward()
+    dt = time.perf_counter() - t0
+    rec = {"n": n, "sel": sel, "imgs": imgs, "draws": (da, db), "state": {k: v.detach().clone() for k, v in om.state_dict().items()},
+           "loss": float(loss.detach()), "dice": dice.detach()[0].clone(), "accum": accum,
+           "grads": {k: p.grad.detach().clone() for k, p in om.named_parameters() if p.grad is not None}}
+    for name, t in (("a", ta), ("b", tb)):
+        top2 = t.detach().topk(2, dim=1).values
+        rec[f"argmax_{name}"] = t.detach().argmax(1).to(torch.uint8)
+        rec[f"margin_{name}"] = (top2[:, 0] - top2[:, 1]).half()
+        rec[f"range_{name}"] = float(t.detach().abs().max())
+        rec[f"slice_{name}"] = t.detach()[:, :, ::8, ::8, ::8].clone()
+    return dt, rec
+
+
+def cpu_baseline(args):
+    """Times the CPU oracle (restatement of the reference, kind 'port') on a bounded sample of the same workload, as
+    BASELINE.md §4 prescribes: warm-up + ONE measured accumulation step (2 branches fwd + loss + bwd) on a `cpu_size`^3
+    patch (default: the full 128^3), scaled by the voxel count if smaller and by (accum + eval forward) to one epoch.
+    The measured step's loss, Dice, label maps and gradients are kept: parity_at_size compares the HIP path with them."""
+    n = args.cpu_size
+    cores = min(len(os.sched_getaffinity(0)), 16)     # a one-GPU box's CPU share is 16 cores (oversubscribing 256 hurts)
+    times, rec = [], None
     for rep in range(1 + max(args.cpu_warmup, 0)):
-        t0 = time.perf_counter()
-        otta.tta_step(om, imgs, sel, draws(1 + 2 * rep), draws(2 + 2 * rep), accum=args.accum, backward=True)
-        times.append(time.perf_counter() - t0)
+        dt, rec = oracle_step(n, args.copt, args.accum, seed_a=101 + 2 * rep, seed_b=102 + 2 * rep, threads=cores)
+        times.append(dt)
     dt = times[-1]
     scale = (args.size / n) ** 3
     epoch_s = dt * scale * (args.accum + 1.0 / 6.0)       # eval forward ~ 1/6 of a step (1 of 6 network passes)
     return {"value": 1.0 / epoch_s, "unit": "TTA-epochs/s", "cores": cores, "kind": "port",
             "sample": f"{args.cpu_warmup} warm-up + 1 measured accumulation step (2 branches fwd + loss + bwd) of the CPU "
                       f"oracle on a {n}^3 patch = {dt:.1f} s (warm-up {times[0]:.1f} s), scaled x{scale:.2f} (voxels) "
-                      f"x{args.accum + 1 / 6:.2f} (steps per epoch)"}
+                      f"x{args.accum + 1 / 6:.2f} (steps per epoch)"}, rec
+
+
+def hip_step_vs_oracle(rec, dtype, device, conv_impl=0):
+    """The HIP path (product kernels, storage `dtype`) on the oracle step's inputs, draws and weights: loss, soft Dice per
+    class, label maps of both branches and every parameter gradient, compared with the record of oracle_step."""
+    import torch
+    from dg_tta_amd import ops
+    from dg_tta_amd.mind import MIND3D
+    from dg_tta_amd.unet import HipPlainConvUNet
+    from oracle import tta as otta
+    adt = {"fp32": torch.float32, "bf16": torch.bfloat16, "fp16": torch.float16}[dtype]
+    hm = HipPlainConvUNet(act_dtype=adt, conv_impl=conv_impl)
+    hm.load_state_dict(rec["state"])
+    hm = hm.to(device)
+    hm.set_selected_classes(rec["sel"])
+    imgs = rec["imgs"].to(device)
+
+    def branch(d):
+        alpha, ks, kers, shifts = d["gin_draw"]
+        x = ops.gin_chain(imgs, alpha.to(device), ks, [k.to(device) for k in kers], [s.to(device) for s in shifts])
+        r, rinv = otta.rand_affine_from_draw(d["affine_draw"])
+        x = ops.affine_warp(x, r.to(device), padding_mode="border", tta_grid_algebra=True)
+        x = MIND3D()(x, d["mind_noise"].to(device), out_dtype=adt)
+        return ops.affine_warp(hm(x), rinv.to(device), padding_mode="zeros", tta_grid_algebra=True)
+    outs = {"a": branch(rec["draws"][0]), "b": branch(rec["draws"][1])}
+    loss, dice = ops.consistency_loss(outs["a"], outs["b"], 1)
+    scale = float(hm.loss_scale)
+    torch.autograd.backward(loss, grad_tensors=torch.full((), scale / rec["accum"], device=device))
+    res = {"loss": float(loss.detach()), "loss_delta": abs(float(loss.detach()) - rec["loss"]),
+           "soft_dice_per_class_delta_max": float((dice.detach().cpu().reshape(-1) - rec["dice"].reshape(-1)).abs().max())}
+    agree, agree_safe, nsafe, ntot, lerr = 0.0, 0.0, 0, 0, 0.0
+    for name in ("a", "b"):
+        o = outs[name].detach()
+        am = o.argmax(1).cpu().to(torch.uint8)
+        safe = rec[f"margin_{name}"].float() > 1e-3
+        same = am == rec[f"argmax_{name}"]
+        agree += float(same.sum())
+        agree_safe += float(same[safe].sum())
+        nsafe += int(safe.sum())
+        ntot += same.numel()
+        lerr = max(lerr, float((o[:, :, ::8, ::8, ::8].cpu() - rec[f"slice_{name}"]).abs().max()) / rec[f"range_{name}"])
+    res.update({"argmax_agreement": agree / ntot, "argmax_agreement_where_margin_gt_1e-3": agree_safe / max(nsafe, 1),
+                "voxels_with_margin_gt_1e-3": nsafe / ntot, "logit_err_over_range": lerr})
+    cos_min, sign_min, worst, coss = 2.0, 2.0, "", []
+    named = dict(hm.named_parameters())
+    for name, gref in rec["grads"].items():
+        if name.endswith("conv.bias") and ".convs." in name:
+            continue        # a conv bias in front of InstanceNorm: zero gradient in exact arithmetic, rounding noise in autograd
+        got = named[name].grad.detach().double().cpu().flatten() / scale
+        ref = gref.double().flatten()
+        if float(ref.abs().max()) == 0.0:
+            continue
+        cos = float(got @ ref / (got.norm() * ref.norm()).clamp_min(1e-300))
+        coss.append(cos)
+        if cos < cos_min:
+            cos_min, worst = cos, name
+        if ref.numel() >= 1024:
+            sign_min = min(sign_min, float((torch.sign(got) == torch.sign(ref)).float().mean()))
+    coss.sort()
+    res.update(grad_cosine_min=cos_min, grad_cosine_worst_tensor=worst, grad_cosine_median=coss[len(coss) // 2],
+               grad_sign_agreement_min=sign_min, tensors=len(coss), loss_scale=scale)
+    del hm, outs
+    torch.cuda.empty_cache()
+    return res
+
+
+def parity_at_size(rec, device):
+    """BASELINE-size parity against the ORACLE (not against this engine's own fp32): one accumulation step at 128^3."""
+    out = {"reference": "CPU oracle (oracle/tta.py restating dg_tta/tta/tta.py:233-275, :480-579 on torch CPU, pinned against "
+                        "the reference by tests/golden/make_golden*.py), the accumulation step cpu_baseline timed: same image, "
+                        "same GIN / affine / MIND draws, same weights",
+           "patch": rec["n"], "oracle_loss": rec["loss"]}
+    for dtype in ("fp32", "fp16", "bf16"):
+        out[dtype] = hip_step_vs_oracle(rec, dtype, device)
+    return out
 
 
 def inference_leg(args, device, dtype):
@@ -251,7 +360,7 @@ def inference_leg(args, device, dtype):
     nwin = (max(1, -(-(n - args.size) // (args.size // 2))) + 1) ** 3 if n > args.size else 1
     return {"volume": n, "windows": nwin, "ms_per_window": round(dt / nwin * 1e3, 3), "seconds": round(dt, 3),
             "accumulator_gib": round(acc.numel() * 4 / 2 ** 30, 2), "classes": int(acc.shape[-1]), "dtype": dtype,
-            "note": "one ensemble member; network forward (4 windows per pass) + Gaussian accumulate + final argmax"}
+            "note": "one ensemble member; network forward (8 windows per pass) + Gaussian accumulate fused with the head + final argmax"}
 
 
 def product_switches():
@@ -262,30 +371,36 @@ def product_switches():
             "env": {k: v for k, v in os.environ.items() if k.startswith("DGTTA_") and k != "DGTTA_BENCH_CHILD"}}
 
 
-def kernel_source_sha():
+DOMINANT = {"fp32": ("conv3_mfma_kernel", "conv_mfma.hip", "conv_fp32_32_32_128"),
+            "16bit": ("conv3_ring_kernel", "conv_ring.hip", "conv_32_32_128")}
+
+
+def kernel_source_sha(fname):
     """sha256 (16 hex) of the dominant kernel's source: a PMC summary taken from another version of it is stale."""
-    return hashlib.sha256((ROOT / "dg_tta_amd" / "csrc" / "conv_rows.hip").read_bytes()).hexdigest()[:16]
+    return hashlib.sha256((ROOT / "dg_tta_amd" / "csrc" / fname).read_bytes()).hexdigest()[:16]
 
 
 def pmc_traffic(args, dtype, nb):
     """HBM bytes per launch of the dominant kernel from the rocprofv3 PMC passes committed under profiles/ (a counter
-    cannot be read from inside this process).  The summary carries the hash of the kernel source it was measured on; a
-    mismatch (or no summary) reports null with the reason instead of a stale number."""
-    if dtype == "fp32" or args.size != 128:
-        return None, "no PMC pass for this dtype / size"
-    cands = sorted((ROOT / "profiles").glob("r*_pmc_summary.json"), reverse=True)
-    for pmc in cands:
+    cannot be read from inside this process): profiles/r*_mfma_util.json, written by profiles/tools/pmc_mfma.sh on the TIMED
+    launch shape (fp16 storage, 8 samples per launch; FETCH_SIZE x 2 on gfx950, WRITE_SIZE as reported).  The summary carries
+    the hash of the kernel source it was measured on; a mismatch (or no summary) reports null with the reason."""
+    if args.size != 128:
+        return None, "no PMC pass for this size"
+    kern, fname, job = DOMINANT["fp32" if dtype == "fp32" else "16bit"]
+    for pmc in sorted((ROOT / "profiles").glob("r*_mfma_util.json"), reverse=True):
         d = json.loads(pmc.read_text())
-        ent = d.get("conv_128cube_32to32", {})
-        if "fetch_bytes_corrected_median" not in ent:
+        ent = next((v for k, v in d.get(job, {}).items() if kern in k and "FETCH_SIZE" in v and "WRITE_SIZE" in v), None)
+        if ent is None:
             continue
-        sha = d.get("kernel_source_sha16")
-        if sha != kernel_source_sha():
-            return None, (f"stale: profiles/{pmc.name} was measured on conv_rows.hip {sha or 'of an unrecorded version'}, "
-                          f"the tree holds {kernel_source_sha()}")
-        traffic = (ent["fetch_bytes_corrected_median"] + ent["write_bytes_median"]) * nb
-        return traffic, (f"profiles/{pmc.name} (rocprofv3 --pmc passes of one sample of this layer x samples_per_launch; "
-                         f"same kernel source {sha})")
+        sha = d.get("kernel_source_sha16", {}).get(fname)
+        if sha != kernel_source_sha(fname):
+            return None, (f"stale: profiles/{pmc.name} was measured on {fname} {sha or 'of an unrecorded version'}, "
+                          f"the tree holds {kernel_source_sha(fname)}")
+        per_launch = ent["FETCH_SIZE"] * 1024 * 2 + ent["WRITE_SIZE"] * 1024
+        return per_launch * nb / d.get("samples_per_launch", 8), (
+            f"profiles/{pmc.name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this layer at "
+            f"{d.get('samples_per_launch', 8)} samples per launch; same kernel source {sha})")
     return None, "no PMC summary under profiles/"
 
 
@@ -304,7 +419,7 @@ def roofline_of(probe, args, dtype):
     traffic, src = pmc_traffic(args, dtype, nb)
     return {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
             "traffic": traffic, "traffic_source": src,
-            "kernel": "conv3_mfma_kernel" if dtype == "fp32" else "conv3_rows_kernel",
+            "kernel": DOMINANT["fp32" if dtype == "fp32" else "16bit"][0],
             "launches": len(times), "avg_ms": round(avg_ms, 4), "flop_per_launch": flop, "samples_per_launch": nb,
             "scope": "forward launches of block dec.3.1 (128^3 32->32, fused statistics) in the training passes "
                      "(samples_per_launch = 2 branches x k accumulation steps); the kernel name also runs the other "
@@ -386,8 +501,19 @@ def run_rank(args):
         return dt, per_rank, runner, roofline_of(probe, args, dtype)
 
     main_dtype = args.dtype
+    traj_file = ROOT / "profiles" / "fp32_trajectory.json"
+    if args.write_fp32_trajectory > 0:       # the reference-precision trajectory of the headline seed (rank 0's sample)
+        torch.manual_seed(1234)
+        np.random.seed(1234)
+        r = Runner(args, device, 0, "fp32")
+        for _ in range(args.write_fp32_trajectory):
+            r.epoch()
+        traj_file.write_text(json.dumps({"seed": 1234, "dtype": "fp32", "size": args.size, "accum": args.accum, "copt": args.copt,
+                                         "loss": list(r.losses), "pseudo_dice": list(r.dices)}, indent=1))
+        print(f"wrote {traj_file}")
+        return
     dt, per_rank, runner, roof = timed_run(main_dtype, args.steps, args.warmup, 1234)
-    losses, dice = list(runner.losses), runner.dice
+    losses, dice, all_dices = list(runner.losses), runner.dice, list(runner.dices)
     del runner
     if not stub:
         torch.cuda.empty_cache()
@@ -463,11 +589,24 @@ def run_rank(args):
                           "value_is": "whole-job aggregate over all GPUs (value_per_gpu = one instance)",
                           "launcher": ("bench.py --gpus N (own child processes)" if os.environ.get("DGTTA_BENCH_CHILD")
                                        else ("torch.distributed.run" if world > 1 else "single process")),
+                          "rendezvous": (backend if world > 1 else "none (one process)"),
+                          "world_size_seen": (dist.get_world_size() if world > 1 else 1),
                           "product_switches": None if stub else product_switches()},
                "per_rank_epochs_per_s": [round(args.steps / t, 5) for t in per_rank],
                "loss_last_epoch": losses[-1], "pseudo_dice": dice,
                "epoch_tflop": round(96.89 * (args.size / 128) ** 3 * (args.accum * 6 + 1) / 97.0, 2),
                "roofline": roof}
+        if dice_delta is None and not stub and traj_file.exists():
+            # N > 1 (or --no-fp32): rank 0's trajectory against the stored fp32 run of the same seed and sample
+            tj = json.loads(traj_file.read_text())
+            n = min(len(losses), len(tj["loss"]))
+            if n and (tj["size"], tj["accum"], tj["copt"]) == (args.size, args.accum, args.copt):
+                dl = max(abs(a - b) for a, b in zip(losses[:n], tj["loss"][:n]))
+                dd = max(abs(a - b) for a, b in zip(all_dices[:n], tj["pseudo_dice"][:n]))
+                dice_delta = {"reference": f"stored fp32 trajectory of this engine, same seed and sample (profiles/{traj_file.name}, "
+                                           f"written by bench.py --write-fp32-trajectory), rank 0, first {n} epochs",
+                              "tolerance": DICE_TOLERANCE, "dtype": main_dtype, "loss": dl, "pseudo_dice": dd,
+                              "within_tolerance": bool(dl <= DICE_TOLERANCE and dd <= DICE_TOLERANCE)}
         if dice_delta is not None:
             out["dice_delta"] = dice_delta
         if fp32_leg is not None:
@@ -475,7 +614,10 @@ def run_rank(args):
         if args.inference_size > 0 and world == 1 and not stub:
             out["inference"] = inference_leg(args, device, main_dtype)
         if not args.no_cpu_baseline and world == 1 and not stub:
-            out["cpu_baseline"] = cpu_baseline(args)
+            out["cpu_baseline"], rec = cpu_baseline(args)
+            if not args.no_parity and args.cpu_size == args.size:
+                out["parity_at_size"] = parity_at_size(rec, device)
+            del rec
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

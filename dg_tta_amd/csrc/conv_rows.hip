@@ -600,7 +600,8 @@ int launch_conv_rows(const void *x, const View &xv, const void *w, const Taps &t
   g_rows_gst = nullptr;       // one launch per context
   // eligible: no forward statistics asked for, every tile whole, whole 32-channel blocks
   const bool gst_on = gctx && !stats && !bias && yv.D % Cfg::TD == 0 && yv.H % Cfg::TH == 0 && yv.W % 32 == 0 && Cout % 32 == 0 &&
-                      CoutP == Cout && gctx->ldy % 8 == 0 && ((uintptr_t)gctx->y & 15) == 0 && dgtta_switches().rows_abl < 0;
+                      CoutP == Cout && gctx->ldy % 8 == 0 && ((uintptr_t)gctx->y & 15) == 0 && dgtta_switches().rows_abl < 0 &&
+                      dgtta_switches().rows_var != '7' && dgtta_switches().rows_var != '0';      // (those builds have no GST form)
   if (gst_on) {
     ga.y = (const bf16_t *)gctx->y;
     ga.v = dense_view(B, yv.D, yv.H, yv.W, (int)gctx->ldy);

@@ -13,8 +13,10 @@ class HipAdamW(torch.optim.Optimizer):
         divides it out on load, so state and parameters are those of the unscaled problem.  With grad_scale != 1 every
         step is guarded: when a gradient is inf / NaN the kernel leaves parameters and state untouched, and the next
         `resolve_overflow()` (called by tta_epoch at the start of an epoch, when the stream is drained anyway) halves the
-        scale and takes the skipped step out of the step counters."""
+        scale and takes the skipped step out of the step counters.  The guard belongs to the 16-bit path, not to the value
+        of the scale: it stays on when the scale has decayed to min_grad_scale = 1."""
         self.grad_scale = float(grad_scale)
+        self.guarded = float(grad_scale) != 1.0
         self.min_grad_scale = float(min_grad_scale)
         self.skipped_steps = 0
         self._flag = None               # int32 device scalar of the last guarded step
@@ -43,8 +45,12 @@ class HipAdamW(torch.optim.Optimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
-        self.resolve_overflow()          # an unread flag of the previous step: settle it before counting this one
-        guarded = self.grad_scale != 1.0
+        # the gradients of THIS step carry the scale that was in force when they were produced: settling an unread flag of
+        # the previous step may halve self.grad_scale, which then applies to the NEXT backward (a caller that reads
+        # `grad_scale` for its loss only after step(), e.g. tta_epoch, sees one consistent value)
+        scale_now = self.grad_scale
+        self.resolve_overflow()
+        guarded = self.guarded
         work = []                        # (group, step, params)
         for group in self.param_groups:
             by_step = {}
@@ -70,7 +76,7 @@ class HipAdamW(torch.optim.Optimizer):
         for group, step, ps in work:
             ops.adamw_step([p.data for p in ps], [p.grad for p in ps], [self.state[p]["exp_avg"] for p in ps],
                            [self.state[p]["exp_avg_sq"] for p in ps], step, group["lr"], group["betas"],
-                           group["eps"], group["weight_decay"], self.grad_scale, skip_flag=flag)
+                           group["eps"], group["weight_decay"], scale_now, skip_flag=flag)
             # the kernel wrote through raw pointers: tell autograd / weight caches that the tensors changed
             torch.autograd.graph.increment_version(ps)
             if guarded:

@@ -42,13 +42,30 @@ def wait_for_files(paths, timeout_s=6 * 3600.0, poll_s=0.5, abort_if=()):
         missing = [p for p in paths if not p.is_file()]
         if not missing:
             return
-        dead = [p for p in abort_if if p.is_file()]
+        dead = [p for p in abort_if if _marker_of_this_launch(p, "failed")]
         if dead:
             raise RuntimeError(f"filesystem barrier: a peer rank failed ({[p.name for p in dead]}); still missing "
                                f"{[str(p) for p in missing]}")
         if time.monotonic() - t0 > timeout_s:
             raise TimeoutError(f"filesystem barrier: still missing after {timeout_s:.0f} s: {[str(p) for p in missing]}")
         time.sleep(poll_s)
+
+
+def _marker_of_this_launch(path, word):
+    """True if `path` exists and was written by THIS launch (markers carry the launch id; one of an earlier launch in a
+    resumed run directory is ignored).  A marker that vanishes between the check and the read (its owner unlinks stale
+    ones at start-up) counts as absent."""
+    try:
+        return path.read_text() == f"{word} {launch_id()}\n"
+    except (FileNotFoundError, NotADirectoryError):
+        return False
+
+
+def mark_rank_failed(save_path, rank):
+    try:
+        failed_marker(save_path, rank).write_text(f"failed {launch_id()}\n")
+    except OSError:
+        pass            # (never mask the original error)
 
 
 def done_marker(save_path, rank):
@@ -78,12 +95,11 @@ def mark_rank_done(save_path, rank):
 def wait_for_done_markers(save_path, world, timeout_s, poll_s=0.5):
     """Barrier of the summary: every rank's marker exists AND belongs to this launch."""
     import time
-    want = f"done {launch_id()}\n"
     t0 = time.monotonic()
     while True:
         wait_for_files([done_marker(save_path, r) for r in range(world)], max(timeout_s - (time.monotonic() - t0), 0.0),
                        poll_s, abort_if=[failed_marker(save_path, r) for r in range(world)])
-        stale = [r for r in range(world) if done_marker(save_path, r).read_text() != want]
+        stale = [r for r in range(world) if not _marker_of_this_launch(done_marker(save_path, r), "done")]
         if not stale:
             return
         if time.monotonic() - t0 > timeout_s:

@@ -21,7 +21,7 @@ import torch
 from .. import ops
 from ..gin import gin_aug
 from ..optim import HipAdamW
-from ..sharding import (done_marker, failed_marker, mark_rank_done, summary_by_parent, unit_owner,
+from ..sharding import (done_marker, failed_marker, mark_rank_done, mark_rank_failed, summary_by_parent, unit_owner,
                         wait_for_done_markers, wait_for_files)
 from .._state import state_of
 from ..utils import disable_internal_augmentation, numpy_rng, upload_async
@@ -420,20 +420,30 @@ def tta_main(run_name, config, tta_data_dir, save_base_path, label_mapping, modi
     A rank only ever loads / preprocesses the cases it works on (some ensemble member to adapt, or the case's ensemble
     prediction), and a case's tensors are dropped as soon as it is predicted: the reference keeps a second iterator over
     all cases for the inference loop (tta.py:149-155, 379-384); here a case whose members were all adapted by this rank is
-    predicted right after its last member (no draws happen in between, so the results are those of the reference's
-    order), the others after the filesystem barrier on the members' parameter files."""
+    predicted right after its last member, the others after the filesystem barrier on the members' parameter files.  The
+    prediction draws MIND noise from the device generator for every window batch (mind.py:150 does so too): the states of
+    the CPU, device and numpy generators are saved around it and restored, so the TTA of the NEXT sample sees the draw
+    sequence of the reference's order (all TTA first, then inference) - an externally seeded run without config['seed']
+    follows the reference's stream."""
     from .nnunet_utils import load_network, load_tta_data
     device = torch.device(device)
     if device.type != "cuda":
         raise RuntimeError("dg_tta_amd runs on the MI355X only (device must be 'cuda' / 'cuda:N'); there is no CPU path")
+    rank, world = shard
+    save_path = Path(save_base_path) / run_name
     if network_bundle is None:
-        network_bundle = load_network(config["pretrained_weights_filepath"], device, act_dtype=act_dtype,
-                                      conv_impl=conv_impl)
+        try:
+            network_bundle = load_network(config["pretrained_weights_filepath"], device, act_dtype=act_dtype,
+                                          conv_impl=conv_impl)
+        except BaseException:       # (a rank that cannot load the network: its peers stop instead of waiting for it)
+            if world > 1 and save_path.parent.is_dir():
+                save_path.mkdir(exist_ok=True, parents=False)
+                mark_rank_failed(save_path, rank)
+            raise
     predictor, patch_size, network, parameters = network_bundle
     across = config["tta_across_all_samples"]
     ensemble_count = config["ensemble_count"]
     num_epochs = config["epochs"]
-    rank, world = shard
     do_inference = config.get("run_inference", True) and not across and not debug
 
     def members_of(smp_idx, n_samples):
@@ -442,22 +452,23 @@ def tta_main(run_name, config, tta_data_dir, save_base_path, label_mapping, modi
     def predicts(smp_idx, n_samples):
         return do_inference and unit_owner(smp_idx, 0, n_samples, ensemble_count, world) == rank
 
-    print("\n# Loading data")
-    if tta_data is None:
-        tta_data = load_tta_data(config, tta_data_dir, predictor, across,
-                                 wanted=None if across else (lambda i, n: bool(members_of(i, n)) or predicts(i, n)))
-    tta_data, num_samples = tta_data
-    save_path = Path(save_base_path) / run_name
-    save_path.mkdir(exist_ok=True, parents=False)
-    for stale in (done_marker(save_path, rank), failed_marker(save_path, rank)):
-        stale.unlink(missing_ok=True)       # a resumed run must not pass the barrier on the previous launch's markers
-    with open(save_path / "tta_plan.json", "w") as f:
-        json.dump({k: v for k, v in config.items()}, f, indent=4)
-    disable_internal_augmentation()
-    results = {}
-    n_units_samples = 1 if across else num_samples
     timeout = float(config.get("barrier_timeout_s", 6 * 3600))
+    results = {}
     try:
+        # (everything from here on runs under the failure marker: a rank that dies while loading the data or writing the plan
+        # must not leave its peers in the filesystem barrier until the timeout)
+        save_path.mkdir(exist_ok=True, parents=False)
+        for stale in (done_marker(save_path, rank), failed_marker(save_path, rank)):
+            stale.unlink(missing_ok=True)       # (markers carry the launch id as well: peers ignore an earlier launch's)
+        print("\n# Loading data")
+        if tta_data is None:
+            tta_data = load_tta_data(config, tta_data_dir, predictor, across,
+                                     wanted=None if across else (lambda i, n: bool(members_of(i, n)) or predicts(i, n)))
+        tta_data, num_samples = tta_data
+        with open(save_path / "tta_plan.json", "w") as f:
+            json.dump({k: v for k, v in config.items()}, f, indent=4)
+        disable_internal_augmentation()
+        n_units_samples = 1 if across else num_samples
         print("\n# Starting TTA")
         deferred = []
         for smp_idx in ([0] if across else range(num_samples)):
@@ -505,8 +516,11 @@ def tta_main(run_name, config, tta_data_dir, save_base_path, label_mapping, modi
             if predict_here:
                 case = (sample, sample_id, sub_dir_tta)
                 if len(mine) == ensemble_count:
-                    _predict_case(case, config, network, predictor, patch_size, label_mapping, modifier_fn_module, device,
-                                  save_path, tta_data_dir, results, world, timeout)
+                    np_state = np.random.get_state()
+                    with torch.random.fork_rng(devices=[device]):      # CPU + device generator states restored on exit
+                        _predict_case(case, config, network, predictor, patch_size, label_mapping, modifier_fn_module, device,
+                                      save_path, tta_data_dir, results, world, timeout)
+                    np.random.set_state(np_state)
                 else:
                     deferred.append(case)            # members adapted on other GPUs: predicted after this rank's units
         # ---- ensemble sliding-window inference with the TTA'd parameter sets (reference: tta.py:376-416)
@@ -526,10 +540,7 @@ def tta_main(run_name, config, tta_data_dir, save_base_path, label_mapping, modi
                 results.update(evaluate_run(save_path, config, modifier_fn_module, device))
     except BaseException:
         if world > 1:           # peers waiting in the filesystem barrier stop instead of running into its timeout
-            try:
-                failed_marker(save_path, rank).write_text("failed\n")
-            except OSError:
-                pass            # (never mask the original error)
+            mark_rank_failed(save_path, rank)
         raise
     return results
 

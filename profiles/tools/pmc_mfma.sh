@@ -14,10 +14,11 @@ groups=("SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAVES"
         "GRBM_GUI_ACTIVE"
         "FETCH_SIZE"
         "WRITE_SIZE")
-IFS=";" read -ra JOBS <<< "${PMC_JOBS:-conv fp16 32 32 128 6 8;dgrad fp16 32 32 128 6 8;conv fp16 64 32 128 6 8;wgrad fp16 32 32 128 6 8;conv fp16 128 128 32 10 8}"
+IFS=";" read -ra JOBS <<< "${PMC_JOBS:-conv fp16 32 32 128 6 8;dgrad fp16 32 32 128 6 8;conv fp16 64 32 128 6 8;wgrad fp16 32 32 128 6 8;conv fp16 128 128 32 10 8;conv fp32 32 32 128 3 8}"
 for job in "${JOBS[@]}"; do
   set -- $job
   name=$1_$3_$4_$5
+  [ "$2" != fp16 ] && name=$1_$2_$3_$4_$5
   i=0
   for grp in "${groups[@]}"; do
     i=$((i+1))

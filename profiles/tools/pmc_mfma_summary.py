@@ -5,9 +5,12 @@ out = {"note": "rocprofv3 --pmc, one counter group per run with --kernel-trace o
                "(KB_STATS=1: forward statistics fused); values are medians over the launches of the job's dominant kernel(s); SQ_*_CYCLES in the "
                "units the guide states (SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* in quad-cycles summed over waves, SQ_VALU_MFMA_BUSY_CYCLES "
                "and SQ_BUSY_CYCLES in cycles summed over SEs/XCDs as rocprofv3 reports them); FETCH_SIZE / WRITE_SIZE in KiB, FETCH x2 on gfx950"}
+import hashlib
+out["samples_per_launch"] = 8
+out["kernel_source_sha16"] = {f: hashlib.sha256(open("dg_tta_amd/csrc/" + f, "rb").read()).hexdigest()[:16] for f in ("conv_ring.hip", "conv_rows.hip", "conv_mfma.hip", "conv_wgrad.hip")}
 jobs = collections.defaultdict(lambda: collections.defaultdict(lambda: collections.defaultdict(list)))
 for f in glob.glob(f"gpurun_out/{tag}_pmc_*/**/*counter_collection.csv", recursive=True):
-    job = re.search(rf"{tag}_pmc_(.+?)_\d+/", f).group(1)
+    job = re.search(rf"{tag}_pmc_(.+)_\d+/", f).group(1)
     for r in csv.DictReader(open(f)):
         k = r.get("Kernel_Name", "")
         if not any(s in k for s in ("conv3_", "wgrad", "conv_ring")):
@@ -15,7 +18,7 @@ for f in glob.glob(f"gpurun_out/{tag}_pmc_*/**/*counter_collection.csv", recursi
         kn = k.replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0][:70]
         jobs[job][kn][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for f in glob.glob(f"gpurun_out/{tag}_pmc_*/**/*kernel_trace.csv", recursive=True):
-    job = re.search(rf"{tag}_pmc_(.+?)_\d+/", f).group(1)
+    job = re.search(rf"{tag}_pmc_(.+)_\d+/", f).group(1)
     for r in csv.DictReader(open(f)):
         k = r.get("Kernel_Name", "")
         if not any(s in k for s in ("conv3_", "wgrad", "conv_ring")):

@@ -157,6 +157,7 @@ def test_bench_launches_its_own_ranks(tmp_path):
     assert len(lines) == 1                                   # ONE line, printed by rank 0
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["steps"] == 3 and out["warmup"] == 1 and out["scaling"] == "weak"
+    assert out["config"]["rendezvous"] == "gloo" and out["config"]["world_size_seen"] == 2      # which backend really ran
     assert len(out["per_rank_epochs_per_s"]) == 2
     assert out["value"] == pytest.approx(2 * out["value_per_gpu"], rel=1e-4)
     assert out["value_per_gpu"] <= min(out["per_rank_epochs_per_s"]) * 1.0001      # quoted on the slowest rank
@@ -180,12 +181,27 @@ def test_bench_launcher_reports_a_failed_rank():
 
 
 def test_barrier_aborts_on_a_failed_peer_and_stale_markers_are_cleared(tmp_path):
-    from dg_tta_amd.sharding import done_marker, failed_marker, mark_rank_done, wait_for_files
-    failed_marker(tmp_path, 1).write_text("failed\n")
+    from dg_tta_amd.sharding import done_marker, failed_marker, mark_rank_done, mark_rank_failed, wait_for_files
+    mark_rank_failed(tmp_path, 1)
     with pytest.raises(RuntimeError, match="peer rank failed"):
         wait_for_files([tmp_path / "x.pt"], timeout_s=30, poll_s=0.05, abort_if=[failed_marker(tmp_path, r) for r in range(2)])
     mark_rank_done(tmp_path, 0)
     assert done_marker(tmp_path, 0).is_file()
+
+
+def test_failed_marker_of_an_earlier_launch_does_not_abort_a_resumed_run(tmp_path, monkeypatch):
+    """a `.rank_k.failed` left by a previous launch is removed only by rank k itself; a faster peer of the resumed
+    launch must not abort on it (markers carry the launch id), and a marker that vanishes while it is read counts as absent."""
+    from dg_tta_amd.sharding import _marker_of_this_launch, failed_marker, mark_rank_failed, wait_for_files
+    monkeypatch.setenv("DGTTA_LAUNCH_ID", "first")
+    mark_rank_failed(tmp_path, 1)
+    monkeypatch.setenv("DGTTA_LAUNCH_ID", "second")
+    with pytest.raises(TimeoutError):        # not RuntimeError: the stale marker is ignored, the file just never comes
+        wait_for_files([tmp_path / "x.pt"], timeout_s=0.3, poll_s=0.05, abort_if=[failed_marker(tmp_path, r) for r in range(2)])
+    assert not _marker_of_this_launch(tmp_path / "gone" / ".rank_0.failed", "failed")
+    mark_rank_failed(tmp_path, 0)
+    with pytest.raises(RuntimeError, match="peer rank failed"):
+        wait_for_files([tmp_path / "x.pt"], timeout_s=30, poll_s=0.05, abort_if=[failed_marker(tmp_path, r) for r in range(2)])
 
 
 def test_done_markers_of_an_earlier_launch_do_not_pass_the_barrier(tmp_path, monkeypatch):

@@ -8,7 +8,7 @@ from pathlib import Path
 CSRC = Path(__file__).resolve().parent / "csrc"
 LIB = Path(__file__).resolve().parent / "libdgtta_hip.so"
 SOURCES = ["lib.hip", "mind3d.hip", "gin.hip", "warp.hip", "softdice.hip", "adamw.hip", "resample.hip", "unet_ref.hip", "conv_mfma.hip", "conv_rows.hip", "conv_ring.hip",
-           "conv_wgrad.hip", "convt_gemm.hip", "conv_s2.hip"]
+           "conv_wgrad.hip", "conv_wgrad_ring.hip", "convt_gemm.hip", "conv_s2.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
 
 

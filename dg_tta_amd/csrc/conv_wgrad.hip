@@ -2,6 +2,9 @@
 #include "conv_common.h"
 #include <stdlib.h>
 
+int conv3_wgrad_ring_launch(const void *x, const View &xv, const void *dy, const View &yv, float *slabs, size_t ws_bytes, int B,
+                            int Cin, int Cout, int is_f16, hipStream_t st, int *rc);      // conv_wgrad_ring.hip
+
 namespace {
 
 // =====================================================================================================================
@@ -1041,6 +1044,16 @@ static int wgrad_launch_classes(const void *x, const View &xv, const void *dy, c
     const DgttaSwitches &sw = dgtta_switches();
     if (sw.wgrad_tr != '0') {        // DGTTA_WGRAD_TR=0 (tests): the register-transpose predecessor
       const bool plain = wc.n == 1 && wc.mask[0] == 0x7ffffffu && wc.xoff[0] == 0 && wc.yoff[0] == 0;
+      if (plain && sw.wgrad_ring != '0') {      // the persistent ring sweep (conv_wgrad_ring.hip; DGTTA_WGRAD_RING=0: its predecessors)
+        int rc = DGTTA_OK;
+        const int g = conv3_wgrad_ring_launch(x, xv, dy, yv, (float *)ws, ws_bytes, B, Cin, Cout, (int)std::is_same<T16, f16_t>::value,
+                                              st, &rc);
+        if (rc != DGTTA_OK) return rc;
+        if (g > 0) {
+          nslab = g;
+          goto reduce;
+        }
+      }
       auto ktr = plain ? conv3_wgrad_tr_kernel<0, false, T16> : conv3_wgrad_tr_kernel<0, true, T16>;
       static DynLdsOnce tr_once[2];
       DG_REQUIRE(ensure_dyn_lds(tr_once[plain], reinterpret_cast<const void *>(ktr), (int)WT::LDS_BYTES) == hipSuccess,

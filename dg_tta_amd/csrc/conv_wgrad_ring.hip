@@ -1,0 +1,414 @@
+// Weight gradient of the stride-1 3x3x3 conv, 16-bit storage, as a persistent D-sweep with a deep LDS ring (round 4):
+//   dW[tap][ci][co] = sum_v x[v + tap - 1][ci] * dy[v][co]      (reference: autograd of the Conv3d blocks of the PlainConvUNet,
+//   dg_tta/tta/tta.py:275 `loss_accum.backward()`; topology dg_tta/__resources__/dummy_results/*/plans.json:279-401)
+// Same arithmetic, operand reads (ds_read_b64_tr_b16 out of voxel-major LDS slices filled by LDS-DMA), MFMA shape
+// (32x32x16: M = ci, N = co, K = 16 voxels along W), tap split (7 taps per wave) and slab output as conv3_wgrad_tr_kernel
+// (conv_wgrad.hip).  What differs is the schedule that kernel was bound by - its DMA of slice d + 2 was issued during slice
+// d and waited for at the END of slice d (under one slice = ~0.9 us to land, with a workgroup-wide drain and barrier):
+//   * ONE 8-wave workgroup per CU, persistent over (column, D-segment) jobs, column = 8 rows x 32 voxels (halo 1.33x instead
+//     of 1.59x); waves 2r and 2r + 1 ... wave w owns row half (w & 1) and taps (w >> 1) + 4 i: 56 MFMAs per wave and slice;
+//   * x ring of 5 slices, dy ring of 3: the DMA of x(d + 3), dy(d + 2) is issued during slice d and first read in slice d + 2;
+//     the wait in front of the (single) barrier of a slice is a counted vmcnt that leaves the youngest group in flight;
+//   * buffer-addressed DMA with per-lane offsets precomputed per job (zero fill = out-of-range offset), as conv_ring.hip;
+//   * v_mfma_f32_16x16x32 (K = the row's 32 voxels, four 16x16 accumulators per tap) - measured equal to the 32x32x16 form;
+//   * the accumulators live across all jobs of the workgroup: one slab per workgroup (<= 256 per channel-block pair), the two
+//     row halves of a tap are added through LDS once, at the very end.
+// Measured (MI355X, fp16, 8 x 128^3, 200 back-to-back launches, same box): 32 -> 32 0.948 -> 0.933 ms, 64 -> 32 1.96 -> 1.81 ms
+// (one dy stream per channel-block pair less halo).  Stamps (profiles/tools/wring_clock.py): in-kernel clock 1.87-1.98 GHz, MFMA
+// busy 60 % of the wave time, 19 % at the barrier (the older wave of a SIMD pair 30 %, the younger 8 %).  Timing models (wrong
+// results): without the DMA inside the sweep the cycles fall 8 % and the CLOCK rises from 1.98 to 2.39 GHz (0.82 -> 0.64 ms);
+// without the LDS operand reads -16 % cycles at 2.21 GHz: the sweep is power bound, and what it spends on moving its two
+// streamed operands (1.7x the DMA bytes per FLOP of the forward ring kernel) sets the clock.
+#include "conv_common.h"
+#include <stdlib.h>
+#include <type_traits>
+
+namespace {
+
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+
+struct WR {
+  static constexpr int TH = 8, XR = TH + 2, XW = 34;
+  static constexpr int X_ROW_B = XW * 64, XP = (XR * X_ROW_B + 1023) / 1024, X_SLICE_B = XP * 1024;      // 22 pieces
+  static constexpr int Y_ROW_B = 32 * 64, YP = TH * 2, Y_SLICE_B = TH * Y_ROW_B;                          // 16 pieces
+  static constexpr int NXS = 5, NYS = 3;
+  static constexpr int NP = XP + YP, NW = 8, NPW = (NP + NW - 1) / NW;                                    // 38 pieces, 5 per wave
+  static constexpr int LDS_BYTES = NXS * X_SLICE_B + NYS * Y_SLICE_B;                                     // 161,792
+  static constexpr int NVOX = XR * XW;
+};
+static_assert(WR::LDS_BYTES <= 160 * 1024, "wgrad ring does not fit the LDS");
+static_assert(4 * 7 * 16 * 64 * 4 <= WR::LDS_BYTES, "final combine buffer");
+
+__device__ __forceinline__ void wr_dma16(u32x4_t rsrc, unsigned voff, unsigned soff, unsigned lds_addr) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(voff), "s"(rsrc), "s"(soff), "s"(lds_addr)
+               : "memory");
+}
+__device__ __forceinline__ void wr_wait_all_but(int n) {      // the n youngest vector-memory operations may stay in flight
+  switch (n) {
+    case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+    case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+    case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+    case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+    case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+    case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+    case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+    case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+    case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+    case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;      // (n > 10 never happens; 0 is always safe)
+  }
+}
+__device__ __forceinline__ u32x4_t wr_rsrc(const void *base, unsigned bytes) {
+  const unsigned long long a = (unsigned long long)base;
+  u32x4_t r;
+  r[0] = __builtin_amdgcn_readfirstlane((unsigned)a);
+  r[1] = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32) & 0xffffu);
+  r[2] = __builtin_amdgcn_readfirstlane(bytes);
+  r[3] = 0x00020000u;
+  return r;
+}
+constexpr unsigned WR_OOB = 0x80000000u;
+
+typedef __attribute__((ext_vector_type(8))) short wr_s16x8_t;
+__device__ __forceinline__ bf16x8_t wr_operand(const unsigned char *p) {      // 8 consecutive voxels (k) of this lane's channel
+  const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t *)p);
+  const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t *)(p + 4 * 64));
+  const wr_s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(bf16x8_t, v);
+}
+template <typename T16>
+__device__ __forceinline__ f32x16_t wr_mfma(const bf16x8_t &a, const bf16x8_t &b, const f32x16_t &acc);
+template <>
+__device__ __forceinline__ f32x16_t wr_mfma<bf16_t>(const bf16x8_t &a, const bf16x8_t &b, const f32x16_t &acc) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+}
+template <>
+__device__ __forceinline__ f32x16_t wr_mfma<f16_t>(const bf16x8_t &a, const bf16x8_t &b, const f32x16_t &acc) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), acc, 0, 0, 0);
+}
+
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+template <typename T16>
+__device__ __forceinline__ f32x4_t wr_mfma16(const bf16x8_t &a, const bf16x8_t &b, const f32x4_t &acc);
+template <>
+__device__ __forceinline__ f32x4_t wr_mfma16<bf16_t>(const bf16x8_t &a, const bf16x8_t &b, const f32x4_t &acc) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc, 0, 0, 0);
+}
+template <>
+__device__ __forceinline__ f32x4_t wr_mfma16<f16_t>(const bf16x8_t &a, const bf16x8_t &b, const f32x4_t &acc) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), acc, 0, 0, 0);
+}
+
+// grid: (G workgroups, channel-block pairs); jobs (b, d-segment, tw, th) dealt so that the 32 workgroups of an XCD hold
+// columns that are neighbours along H (their halo rows meet in one L2); slabs[(pair * G + blockIdx.x)][27][32 ci][32 co]
+template <typename T16, bool MF16, bool CLK = false>      // MF16: v_mfma_f32_16x16x32 (K = the row's 32 voxels) instead of 32x32x16;
+                                                          // CLK (diagnostic): cycle / real-time stamps behind the slabs
+__global__ __launch_bounds__(WR::NW * 64) void conv3_wgrad_ring_kernel(const bf16_t *__restrict__ x, View xv, const bf16_t *__restrict__ dy,
+                                                                       View yv, float *__restrict__ slabs, int Cin, int Cout, int tilesW,
+                                                                       int tilesH, int nseg, int DR, int cobs, int njobs, unsigned x_bytes,
+                                                                       unsigned y_bytes) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char *sX = smem, *sY = smem + WR::NXS * WR::X_SLICE_B;
+  const unsigned lds0 = lds_addr_of(smem);
+  unsigned long long t_begin = 0, rt_begin = 0, t_wait = 0;
+  if (CLK) {
+    t_begin = __builtin_amdgcn_s_memtime();
+    rt_begin = __builtin_amdgcn_s_memrealtime();
+  }
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int rh = wave & 1, wq = wave >> 1;      // row half, tap residue
+  const int D = yv.D, H = yv.H, W = yv.W;
+  const int cib = blockIdx.y / cobs, cob = blockIdx.y % cobs;
+  const int cin_lim = (Cin + 7) / 8 * 8;
+
+  int tap_kd[7], tap_off[7];
+#pragma unroll
+  for (int i = 0; i < 7; ++i) {
+    const int tc = wq + 4 * i < 27 ? wq + 4 * i : 26;      // (the fourth residue class has 6 taps: its seventh slot repeats tap 26 into a discarded accumulator)
+    tap_kd[i] = tc / 9;
+    tap_off[i] = ((tc / 3) % 3) * WR::X_ROW_B + (tc % 3) * 64;
+  }
+  // transposed-read lane address inside a 16-voxel x 32-channel block (64-byte voxel rows), as conv3_wgrad_tr_kernel
+  // (MF16: 16-lane group g = lane >> 4 takes voxels 8 g .. 8 g + 7 of 16 channels; the channel half is an immediate offset)
+  const int lane_off = MF16 ? ((lane >> 4) * 8 + ((lane & 15) >> 2)) * 64 + (lane & 3) * 8
+                            : ((lane >> 5) * 8 + ((lane & 15) >> 2)) * 64 + ((lane >> 4) & 1) * 32 + (lane & 3) * 8;
+
+  // 7 taps x (32 ci x 32 co): one 32x32 accumulator per tap, or four 16x16 ones [ci half][co half] - 112 registers either way
+  float accf[7][16];
+#pragma unroll
+  for (int i = 0; i < 7; ++i)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) accf[i][q] = 0.f;
+
+  const int G = gridDim.x;
+  const bool xcd_order = (G % 8) == 0;
+  const int rounds = (njobs + G - 1) / G;
+  for (int rd = 0; rd < rounds; ++rd) {
+    int j = xcd_order ? (rd * 8 + (int)(blockIdx.x % 8)) * (G / 8) + (int)(blockIdx.x / 8) : rd * G + (int)blockIdx.x;
+    if (j >= njobs) continue;
+    const int th = j % tilesH;
+    j /= tilesH;
+    const int tw = j % tilesW;
+    j /= tilesW;
+    const int seg = j % nseg;
+    const int b = j / nseg;
+    const int h0 = th * WR::TH, w0 = tw * 32;
+    const int d_begin = seg * DR, d_end = (d_begin + DR < D) ? d_begin + DR : D;
+    const u32x4_t rx = wr_rsrc(x + (long long)b * xv.sb + cib * 32, x_bytes), ry = wr_rsrc(dy + (long long)b * yv.sb + cob * 32, y_bytes);
+
+    // per-lane source offsets of this wave's DMA pieces (piece idx = wave + 8 i of the 22 x + 16 dy pieces of a slice pair):
+    // lane -> voxel 16 P + lane / 4, 16-byte channel chunk lane & 3
+    unsigned poff[WR::NPW];
+#pragma unroll
+    for (int i = 0; i < WR::NPW; ++i) {
+      const int idx = wave + WR::NW * i;
+      const int chunk = lane & 3;
+      if (idx < WR::XP) {
+        const int e = idx * 16 + (lane >> 2), row = e / WR::XW, u = e - row * WR::XW;
+        const int gh = h0 - 1 + row, gw = w0 - 1 + u;
+        const bool ok = e < WR::NVOX && (unsigned)gh < (unsigned)H && (unsigned)gw < (unsigned)W && cib * 32 + chunk * 8 < cin_lim;
+        poff[i] = ok ? (unsigned)((gh * xv.sh + gw * xv.sw + chunk * 8) * 2) : WR_OOB;
+      } else {
+        const int p = idx - WR::XP, row = p >> 1, vox = 16 * (p & 1) + (lane >> 2);
+        const int gh = h0 + row, gw = w0 + vox;
+        const bool ok = idx < WR::NP && gh < H && gw < W && cob * 32 + chunk * 8 < Cout;
+        poff[i] = ok ? (unsigned)((gh * yv.sh + gw * yv.sw + chunk * 8) * 2) : WR_OOB;
+      }
+    }
+    // piece i of x slice xd / dy slice yd (either may be switched off)
+    auto issue_piece = [&](int i, int xd, bool do_x, int yd, bool do_y) -> int {
+      const int idx = wave + WR::NW * i;
+      if (idx < WR::XP) {
+        if (!do_x) return 0;
+        const bool dok = (unsigned)xd < (unsigned)D;
+        const int slot = (xd + 1 + WR::NXS) % WR::NXS;
+        wr_dma16(rx, poff[i] | (dok ? 0u : WR_OOB), dok ? (unsigned)(xd * xv.sd * 2) : 0u, lds0 + slot * WR::X_SLICE_B + idx * 1024);
+        return 1;
+      }
+      if (idx < WR::NP) {
+        if (!do_y) return 0;
+        const bool dok = (unsigned)yd < (unsigned)D;
+        const int slot = (yd + WR::NYS) % WR::NYS;
+        wr_dma16(ry, poff[i] | (dok ? 0u : WR_OOB), dok ? (unsigned)(yd * yv.sd * 2) : 0u,
+                 lds0 + WR::NXS * WR::X_SLICE_B + slot * WR::Y_SLICE_B + (idx - WR::XP) * 1024);
+        return 1;
+      }
+      return 0;
+    };
+    int issued = 0;
+    auto issue_group = [&](int xd, bool do_x, int yd, bool do_y) {
+#pragma unroll
+      for (int i = 0; i < WR::NPW; ++i) issued += issue_piece(i, xd, do_x, yd, do_y);
+      return issued;
+    };
+
+    lds_barrier();      // every wave is done with the previous job's slices
+    issue_group(d_begin - 1, true, 0, false);
+    issue_group(d_begin, true, d_begin, true);
+    int mark_cur = issue_group(d_begin + 1, true, 0, false);            // needed in slice d_begin
+    int mark_nxt = issue_group(d_begin + 2, true, d_begin + 1, true);   // needed in slice d_begin + 1
+    for (int d = d_begin; d < d_end; ++d) {
+      unsigned long long tw0 = 0;
+      if (CLK) tw0 = __builtin_amdgcn_s_memtime();
+      wr_wait_all_but(issued - mark_cur);      // this wave's pieces of x(d + 1), dy(d) have landed ...
+      lds_barrier();                           // ... and everyone's; every wave is done with slice d - 1
+      if (CLK) t_wait += __builtin_amdgcn_s_memtime() - tw0;
+      const bool more = d + 2 < d_end;         // x(d + 3), dy(d + 2): first read in slice d + 2
+      int mark_new = issued;
+      const unsigned char *ys = sY + ((d + WR::NYS) % WR::NYS) * WR::Y_SLICE_B + rh * 4 * WR::Y_ROW_B + lane_off;
+      int slice_off[3];
+#pragma unroll
+      for (int kd = 0; kd < 3; ++kd) slice_off[kd] = ((d + kd + WR::NXS) % WR::NXS) * WR::X_SLICE_B + rh * 4 * WR::X_ROW_B;
+      if (!MF16) {
+        // operands of (row, k-step) iteration it + 1 are read while the MFMAs of iteration it issue
+        bf16x8_t afr[2][7], bfr[2];
+        auto load_it = [&](int it, bf16x8_t(&a)[7], bf16x8_t &bb) {
+          const int oh = it >> 1, ks = it & 1;
+          bb = wr_operand(ys + oh * WR::Y_ROW_B + ks * 1024);
+#pragma unroll
+          for (int i = 0; i < 7; ++i) {
+            const int so = (tap_kd[i] == 0 ? slice_off[0] : (tap_kd[i] == 1 ? slice_off[1] : slice_off[2])) + tap_off[i];
+            a[i] = wr_operand(sX + lane_off + so + oh * WR::X_ROW_B + ks * 1024);
+          }
+        };
+        load_it(0, afr[0], bfr[0]);
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+          if (it + 1 < 8) load_it(it + 1, afr[(it + 1) & 1], bfr[(it + 1) & 1]);
+          __builtin_amdgcn_sched_barrier(0);
+          if (more && it < WR::NPW) {
+            issued += issue_piece(it, d + 3, true, d + 2, true);
+            if (it == WR::NPW - 1) mark_new = issued;
+          }
+#pragma unroll
+          for (int i = 0; i < 7; ++i) {
+            f32x16_t c;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) c[q] = accf[i][q];
+            c = wr_mfma<T16>(afr[it & 1][i], bfr[it & 1], c);
+#pragma unroll
+            for (int q = 0; q < 16; ++q) accf[i][q] = c[q];
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      } else {
+        // the row's 32 voxels are ONE k-step: per (row, tap) unit 2 x operands (ci halves) and 4 MFMAs against the row's 2 dy
+        // operands (co halves).  28 units per slice; the x operands of unit u + 2 and the dy operands of the next row are read
+        // while the MFMAs of unit u issue (a whole row of operands in flight would not fit the registers)
+        bf16x8_t fb[3][2], bb[2][2];
+        auto load_x = [&](int u, bf16x8_t(&a)[2]) {
+          const int oh = u / 7, i = u % 7;
+          const int so = (tap_kd[i] == 0 ? slice_off[0] : (tap_kd[i] == 1 ? slice_off[1] : slice_off[2])) + tap_off[i];
+#pragma unroll
+          for (int h = 0; h < 2; ++h) a[h] = wr_operand(sX + lane_off + so + oh * WR::X_ROW_B + h * 32);
+        };
+        auto load_y = [&](int oh, bf16x8_t(&y2)[2]) {
+#pragma unroll
+          for (int h = 0; h < 2; ++h) y2[h] = wr_operand(ys + oh * WR::Y_ROW_B + h * 32);
+        };
+        load_y(0, bb[0]);
+        load_x(0, fb[0]);
+        load_x(1, fb[1]);
+#pragma unroll
+        for (int u = 0; u < 28; ++u) {
+          const int oh = u / 7, i = u % 7;
+          if (u + 2 < 28) load_x(u + 2, fb[(u + 2) % 3]);
+          if (i == 3 && oh + 1 < 4) load_y(oh + 1, bb[(oh + 1) & 1]);
+          __builtin_amdgcn_sched_barrier(0);
+          if (more && i == 0) {      // the slice's DMA pieces: two after the first row's first unit, then one per row
+#pragma unroll
+            for (int pi = 0; pi < WR::NPW; ++pi)
+              if ((pi == 0 ? 0 : pi - 1) == oh) {
+                issued += issue_piece(pi, d + 3, true, d + 2, true);
+                if (pi == WR::NPW - 1) mark_new = issued;
+              }
+          }
+#pragma unroll
+          for (int ca = 0; ca < 2; ++ca)
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb) {
+              f32x4_t c = {accf[i][(ca * 2 + cb) * 4 + 0], accf[i][(ca * 2 + cb) * 4 + 1], accf[i][(ca * 2 + cb) * 4 + 2],
+                           accf[i][(ca * 2 + cb) * 4 + 3]};
+              c = wr_mfma16<T16>(fb[u % 3][ca], bb[oh & 1][cb], c);
+#pragma unroll
+              for (int r = 0; r < 4; ++r) accf[i][(ca * 2 + cb) * 4 + r] = c[r];
+            }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      mark_cur = mark_nxt;
+      mark_nxt = mark_new;
+    }
+  }
+
+  if (CLK && lane == 0) {
+    float *o = slabs + (int64_t)gridDim.y * gridDim.x * (27 * 1024) + ((int64_t)(blockIdx.y * gridDim.x + blockIdx.x) * WR::NW + wave) * 4;
+    o[0] = (float)(__builtin_amdgcn_s_memtime() - t_begin);
+    o[1] = (float)(__builtin_amdgcn_s_memrealtime() - rt_begin);
+    o[2] = (float)t_wait;
+  }
+  // the two row halves of a tap: waves with rh = 1 hand their accumulators over through LDS (all DMA has been waited for)
+  lds_barrier();
+  float *xch = reinterpret_cast<float *>(smem);
+  if (rh == 1) {
+#pragma unroll
+    for (int i = 0; i < 7; ++i)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) xch[((wq * 7 + i) * 16 + q) * 64 + lane] = accf[i][q];
+  }
+  lds_barrier();
+  if (rh == 0) {
+    // partial slab [27][32 ci][32 co].  C/D map of the 32x32 MFMA: col = lane & 31 (co), row = (q & 3) + 8 (q >> 2) + 4 (lane >> 5)
+    // (ci); of the 16x16 one [ci half ca][co half cb]: col = lane & 15, row = 4 (lane >> 4) + r
+    float *slab = slabs + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * (27 * 1024);
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+      const int tap = wq + 4 * i;
+      if (tap < 27) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          const int ci = MF16 ? (q >> 3) * 16 + 4 * (lane >> 4) + (q & 3) : (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
+          const int co = MF16 ? ((q >> 2) & 1) * 16 + (lane & 15) : (lane & 31);
+          slab[(tap * 32 + ci) * 32 + co] = accf[i][q] + xch[((wq * 7 + i) * 16 + q) * 64 + lane];
+        }
+      }
+    }
+  }
+}
+
+}  // namespace
+
+// Entry point used by wgrad_launch_classes (conv_wgrad.hip): plain stride-1 launches with 16-bit storage.  Returns the number
+// of slabs per channel-block pair it wrote (> 0), or 0 if the shape is not this kernel's (then nothing was launched).
+int conv3_wgrad_ring_launch(const void *x, const View &xv, const void *dy, const View &yv, float *slabs, size_t ws_bytes, int B,
+                            int Cin, int Cout, int is_f16, hipStream_t st, int *rc) {
+  *rc = DGTTA_OK;
+  if (Cout % 32 != 0 || xv.D != yv.D || xv.H != yv.H || xv.W != yv.W) return 0;
+  const int cibs = cdiv(Cin, 32), cobs = Cout / 32;
+  const long long xb = ((long long)(xv.D - 1) * xv.sd + (long long)(xv.H - 1) * xv.sh + (long long)(xv.W - 1) * xv.sw + 32) * 2;
+  const long long yb = ((long long)(yv.D - 1) * yv.sd + (long long)(yv.H - 1) * yv.sh + (long long)(yv.W - 1) * yv.sw + 32) * 2;
+  if (xb >= (1ll << 31) || yb >= (1ll << 31)) return 0;
+  if (xv.sw % 8 || xv.sh % 8 || xv.sd % 8 || xv.sb % 8 || yv.sw % 8 || yv.sh % 8 || yv.sd % 8 || yv.sb % 8) return 0;
+  static int ncu = [] {
+    int dev = 0, n = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+    return n > 0 ? n : 256;
+  }();
+  const int pairs = cibs * cobs;
+  if (pairs > 65535) return 0;
+  const int tW = cdiv(yv.W, 32), tH = cdiv(yv.H, WR::TH);
+  const long long ncol = (long long)B * tW * tH;
+  // workgroups per pair: a whole number of XCD groups (8) that fills the chip once over all pairs
+  int G = (ncu / pairs) / 8 * 8;
+  if (G < 8) G = 8;
+  // D segments: enough jobs to give every workgroup the same number (a segment start costs about three slices of exposed latency)
+  int nseg = 1;
+  {
+    double best = 1e300;
+    for (int s = 1; s <= 64 && s <= yv.D; s *= 2) {
+      const int dr = cdiv(yv.D, s), ns = cdiv(yv.D, dr);
+      const double t = (double)cdiv64(ncol * ns, G) * (dr + 3.0);
+      if (t < best * 0.97) best = t, nseg = ns;
+    }
+  }
+  const int DR = cdiv(yv.D, nseg);
+  nseg = cdiv(yv.D, DR);
+  const long long njobs = ncol * nseg;
+  if (njobs >= (1ll << 31)) return 0;
+  if (njobs < G) G = (int)njobs;
+  if (ws_bytes < (size_t)pairs * G * 27 * 1024 * sizeof(float)) return 0;
+  // small problems stay with the many-small-workgroups kernels: a persistent sweep needs a few slices per job to amortise its prologue
+  if (ncol * yv.D < 4ll * ncu * 8 / pairs && dgtta_switches().wgrad_ring != '1') return 0;      // (=1: forced, for the tests)
+#define WR_LAUNCH(T16, MF, CK)                                                                                                       \
+  do {                                                                                                                         \
+    auto kern = conv3_wgrad_ring_kernel<T16, MF, CK>;                                                                          \
+    static DynLdsOnce once;                                                                                                    \
+    if (ensure_dyn_lds(once, reinterpret_cast<const void *>(kern), WR::LDS_BYTES) != hipSuccess) {                             \
+      dgtta_set_error("wgrad_ring: cannot raise the dynamic LDS limit to %d", WR::LDS_BYTES);                                  \
+      *rc = DGTTA_ERR_LAUNCH;                                                                                                  \
+      return 0;                                                                                                                \
+    }                                                                                                                          \
+    hipLaunchKernelGGL(kern, dim3((unsigned)G, (unsigned)pairs), dim3(WR::NW * 64), WR::LDS_BYTES, st, (const bf16_t *)x, xv,  \
+                       (const bf16_t *)dy, yv, slabs, Cin, Cout, tW, tH, nseg, DR, cobs, (int)njobs, (unsigned)xb, (unsigned)yb); \
+  } while (0)
+  const bool mf16 = dgtta_switches().wgrad_ring != '3';      // DGTTA_WGRAD_RING=3: the 32x32x16 form
+  if (is_f16 && dgtta_switches().wgrad_ring == '6') {      // diagnostic: stamps (profiles/tools/wring_clock.py)
+    WR_LAUNCH(f16_t, true, true);
+  } else if (is_f16) {
+    if (mf16) WR_LAUNCH(f16_t, true, false);
+    else WR_LAUNCH(f16_t, false, false);
+  } else {
+    if (mf16) WR_LAUNCH(bf16_t, true, false);
+    else WR_LAUNCH(bf16_t, false, false);
+  }
+#undef WR_LAUNCH
+  if (hipGetLastError() != hipSuccess) {
+    dgtta_set_error("conv3_wgrad_ring_kernel: launch failed");
+    *rc = DGTTA_ERR_LAUNCH;
+    return 0;
+  }
+  return G;
+}

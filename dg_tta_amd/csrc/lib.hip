@@ -54,6 +54,7 @@ static const DgttaSwitches *read_switches() {
   s->conv_ring = env_char("DGTTA_CONV_RING");
   s->ring_nt = env_char("DGTTA_RING_NT");
   s->ring_abl = env_char("DGTTA_RING_ABL");
+  s->wgrad_ring = env_char("DGTTA_WGRAD_RING");
   return s;
 }
 

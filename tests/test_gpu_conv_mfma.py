@@ -667,6 +667,40 @@ def test_conv_stride2_register_operand_kernel(case, dt, monkeypatch):
     assert float(((r1.cpu() - ref_rstd) / ref_rstd).abs().max()) < 1e-4 and float(((r1 - r0) / r0).abs().max()) < 1e-5
 
 
+WRING_CASES = [(1, 32, 32, 9, 13, 45), (2, 12, 32, 6, 17, 32), (1, 64, 96, 7, 8, 70), (2, 32, 32, 32, 32, 64),
+               (1, 32, 64, 36, 40, 32), (8, 32, 32, 4, 64, 160)]      # ragged edges, ragged Cin, channel-block pairs, > 256 columns
+
+
+@pytest.mark.parametrize("dts", ["bf16", "fp16"])
+@pytest.mark.parametrize("case", WRING_CASES)
+def test_wgrad_ring_kernel(case, dts, monkeypatch):
+    """The persistent weight-gradient sweep (conv_wgrad_ring.hip: 8-wave workgroup per CU, x ring of 5 slices / dy ring of 3,
+    counted waits), forced on at small sizes, against its predecessors (DGTTA_WGRAD_RING=0) and torch on the same operands."""
+    B, cin, cout, D, H, W = case
+    dt, tdt = (1, torch.bfloat16) if dts == "bf16" else (2, torch.float16)
+    torch.manual_seed(sum(case) + 21)
+    ld = (cin + 7) // 8 * 8
+    x = torch.zeros(B, D, H, W, ld, device=DEV, dtype=tdt)
+    x[..., :cin] = torch.randn(B, D, H, W, cin, device=DEV).to(tdt)
+    dy = torch.randn(B, D, H, W, cout, device=DEV).to(tdt)
+
+    def run(ring):
+        monkeypatch.setenv("DGTTA_WGRAD_RING", ring)
+        reload_kernel_switches()
+        dw, db = _call_wgrad(x, dy, cin, cout, 1, dt, 2)
+        torch.cuda.synchronize()
+        return dw
+
+    old, new = run("0"), run("1")
+    ref = torch.nn.grad.conv3d_weight(x[..., :cin].float().permute(0, 4, 1, 2, 3).cpu().double(), (cout, cin, 3, 3, 3),
+                                      dy.float().permute(0, 4, 1, 2, 3).cpu().double(), stride=1, padding=1).float()
+    scale = float(ref.abs().max())
+    assert torch.isfinite(new).all()
+    assert float((new.cpu() - ref).abs().max()) < 2e-4 * scale + 1e-3
+    assert float((new - old).abs().max()) < 1e-4 * scale + 1e-3       # same products, another fp32 summation order
+    assert torch.equal(run("1"), new)                                  # run to run: the same bits
+
+
 @pytest.mark.parametrize("case", [(2, 32, 32, 8, 12, 40), (1, 32, 64, 6, 8, 64), (2, 64, 96, 5, 9, 33)])
 @pytest.mark.parametrize("upw", ["2", "3"])
 def test_wgrad_units_per_workgroup(case, upw, monkeypatch):

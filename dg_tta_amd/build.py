@@ -9,6 +9,9 @@ CSRC = Path(__file__).resolve().parent / "csrc"
 LIB = Path(__file__).resolve().parent / "libdgtta_hip.so"
 SOURCES = ["lib.hip", "mind3d.hip", "gin.hip", "warp.hip", "softdice.hip", "adamw.hip", "resample.hip", "unet_ref.hip", "conv_mfma.hip", "conv_rows.hip", "conv_ring.hip",
            "conv_wgrad.hip", "conv_wgrad_ring.hip", "convt_gemm.hip", "conv_s2.hip"]
+# conv_ring.hip: the 64-input-channel step body (432 MFMAs, 192 fragment reads, fully unrolled) is above hipcc's default
+# pragma-unroll threshold; partially unrolled its register arrays are indexed dynamically and land in scratch
+EXTRA_FLAGS = {"conv_ring.hip": ["-mllvm", "-pragma-unroll-threshold=262144"]}
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
 
 
@@ -24,7 +27,7 @@ def build(force=False, verbose=True):
         src, obj = CSRC / s, CSRC / (s + ".o")
         objs.append(obj)
         if force or _stale(obj, [src] + hdrs):
-            jobs.append([hipcc, *FLAGS, "-c", str(src), "-o", str(obj)])
+            jobs.append([hipcc, *FLAGS, *EXTRA_FLAGS.get(s, []), "-c", str(src), "-o", str(obj)])
 
     def run(cmd):
         if verbose:
@@ -57,7 +60,7 @@ def build_asan(verbose=False):
         src, obj = CSRC / s, ASAN_DIR / (s + ".o")
         objs.append(obj)
         if _stale(obj, [src] + hdrs):
-            jobs.append([hipcc, *ASAN_FLAGS, "-c", str(src), "-o", str(obj)])
+            jobs.append([hipcc, *ASAN_FLAGS, *EXTRA_FLAGS.get(s, []), "-c", str(src), "-o", str(obj)])
 
     def run(cmd):
         if verbose:

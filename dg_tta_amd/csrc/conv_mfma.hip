@@ -420,8 +420,8 @@ int dispatch_conv_classes(const void *x, const View &xv, const void *w, const Co
                          yv.sd % 8 == 0 && yv.sb % 8 == 0;
     // enough (tile, channel block) jobs to fill the chip with one persistent workgroup per CU; below that the generic kernel wins
     const long long njobs = (long long)cdiv(yv.W, 32) * cdiv(yv.H, 8) * cdiv(yv.D, 4) * cdiv(CoutP, 32) * B;
-    // 32 input channels: the D-ring kernel (conv_ring.hip; DGTTA_CONV_RING=0: its predecessor below)
-    if (all_taps && vec_out && Cin == 32 && CinP == 32 && (njobs >= 512 || dgtta_switches().conv_ring == '1') &&
+    // 32 or 64 input channels: the D-ring kernel (conv_ring.hip; DGTTA_CONV_RING=0: its predecessor below, =3: only 32 channels)
+    if (all_taps && vec_out && ((Cin == 32 && CinP == 32) || (Cin == 64 && CinP == 64)) && (njobs >= 512 || dgtta_switches().conv_ring == '1') &&
         dgtta_switches().conv_ring != '0' && rows != '1') {
       const int rc = conv3_ring_launch(x, xv, w, cs.taps[0], bias, y, yv, B, Cin, Cout, CinP, CoutP, stats,
                                        conv3_mfma_max_tiles(yv.D, yv.H, yv.W), ntaps_src, (int)std::is_same<T, f16_t>::value, st);

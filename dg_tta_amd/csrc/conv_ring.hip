@@ -39,20 +39,28 @@ namespace {
 typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 
-struct RingCfg {
-  static constexpr int TH = 8, TW = 32;                              // (two output planes per step)
+// KH = number of 32-channel K halves: 1 = 32 input channels (8 waves: 4 row pairs x 2 output-channel halves, 8-row tiles),
+// 2 = 64 input channels (round 4b).  With 64 input channels a wave's weights are 27 taps x 2 K halves = 216 registers, which
+// only fits ONE wave per SIMD: 4 waves of up to 512 registers (2 row pairs x 2 output-channel halves, 4-row tiles); a plane of
+// the ring is then two 32-channel sub-planes [K half][row][voxel][64 B], each with the bank layout described above.
+template <int KH>
+struct RingCfgT {
+  static constexpr int TH = 8 / KH, TW = 32;                         // (two output planes per step)
   static constexpr int IH = TH + 2, IW = TW + 2;
-  static constexpr int VB = 64;                                      // bytes per voxel: 32 channels x 2
+  static constexpr int VB = 64;                                      // bytes per voxel of a sub-plane: 32 channels x 2
   static constexpr int ROWB = IW * VB;                               // 2176
-  static constexpr int PIECES = (IH * ROWB + 1023) / 1024;           // 22 DMA pieces of 1 KiB per plane (the last one partly pad)
-  static constexpr int PLANE = PIECES * 1024;
-  static constexpr int NVOX = IH * IW;                               // 340 voxels per plane
+  static constexpr int SUB_PIECES = (IH * ROWB + 1023) / 1024;       // 1-KiB DMA pieces per sub-plane (the last one partly pad): 22 / 13
+  static constexpr int SUB = SUB_PIECES * 1024;
+  static constexpr int PIECES = KH * SUB_PIECES, PLANE = PIECES * 1024;
+  static constexpr int NVOX = IH * IW;                               // halo voxels per plane
   static constexpr int NSLOT = 6;
-  static constexpr int NW = 8, NT = NW * 64;
-  static constexpr int NPW = (2 * PIECES + NW - 1) / NW;             // pieces per wave and step (6)
+  static constexpr int NW = 8 / KH, NT = NW * 64;
+  static constexpr int NPW = (2 * PIECES + NW - 1) / NW;             // pieces per wave and step (6 / 13)
   static constexpr int RED_BYTES = NW * 16 * 2 * (int)sizeof(float) + 32 * 2 * (int)sizeof(float);      // + GST constants
   static constexpr int LDS_BYTES = NSLOT * PLANE + RED_BYTES;
 };
+typedef RingCfgT<1> RingCfg;
+static_assert(RingCfgT<2>::LDS_BYTES <= 160 * 1024 && RingCfgT<1>::LDS_BYTES <= 160 * 1024, "ring does not fit the LDS");
 
 template <typename T16>
 __device__ __forceinline__ void mfma16(const uint4 &a, const uint4 &b, f32x4_t &acc);
@@ -95,7 +103,7 @@ __device__ __forceinline__ void store16_buf(u32x4_t rsrc, unsigned voff, unsigne
   else asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen" ::"v"(val), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
 }
 __device__ __forceinline__ void vm_wait_all_but(int n) {      // the n youngest vector-memory operations may stay in flight
-  if (n > 20) n = 20;       // (fewer in flight than allowed: always safe)
+  if (n > 40) n = 40;       // (fewer in flight than allowed: always safe)
   switch (n) {
     case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
     case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
@@ -117,6 +125,26 @@ __device__ __forceinline__ void vm_wait_all_but(int n) {      // the n youngest 
     case 18: asm volatile("s_waitcnt vmcnt(18)" ::: "memory"); break;
     case 19: asm volatile("s_waitcnt vmcnt(19)" ::: "memory"); break;
     case 20: asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); break;
+    case 21: asm volatile("s_waitcnt vmcnt(21)" ::: "memory"); break;
+    case 22: asm volatile("s_waitcnt vmcnt(22)" ::: "memory"); break;
+    case 23: asm volatile("s_waitcnt vmcnt(23)" ::: "memory"); break;
+    case 24: asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); break;
+    case 25: asm volatile("s_waitcnt vmcnt(25)" ::: "memory"); break;
+    case 26: asm volatile("s_waitcnt vmcnt(26)" ::: "memory"); break;
+    case 27: asm volatile("s_waitcnt vmcnt(27)" ::: "memory"); break;
+    case 28: asm volatile("s_waitcnt vmcnt(28)" ::: "memory"); break;
+    case 29: asm volatile("s_waitcnt vmcnt(29)" ::: "memory"); break;
+    case 30: asm volatile("s_waitcnt vmcnt(30)" ::: "memory"); break;
+    case 31: asm volatile("s_waitcnt vmcnt(31)" ::: "memory"); break;
+    case 32: asm volatile("s_waitcnt vmcnt(32)" ::: "memory"); break;
+    case 33: asm volatile("s_waitcnt vmcnt(33)" ::: "memory"); break;
+    case 34: asm volatile("s_waitcnt vmcnt(34)" ::: "memory"); break;
+    case 35: asm volatile("s_waitcnt vmcnt(35)" ::: "memory"); break;
+    case 36: asm volatile("s_waitcnt vmcnt(36)" ::: "memory"); break;
+    case 37: asm volatile("s_waitcnt vmcnt(37)" ::: "memory"); break;
+    case 38: asm volatile("s_waitcnt vmcnt(38)" ::: "memory"); break;
+    case 39: asm volatile("s_waitcnt vmcnt(39)" ::: "memory"); break;
+    case 40: asm volatile("s_waitcnt vmcnt(40)" ::: "memory"); break;
     default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
   }
 }
@@ -145,13 +173,13 @@ struct RingGst {
 // ABL (diagnostic builds, DGTTA_RING_ABL; results are wrong for 1 and 2): 1 no DMA after a job's first four planes, 2 no stores,
 // 3 a step's DMA pieces issued in one burst behind the barrier instead of one per input row, 6 per-segment cycle stamps and
 // the in-kernel clock, written behind the statistics (profiles/tools/ring_stamps.py)
-template <typename T16, bool NT_ST, int ABL = 0, bool GST = false>
-__global__ __launch_bounds__(RingCfg::NT) void conv3_ring_kernel(const bf16_t *__restrict__ x, View xv, const bf16_t *__restrict__ w,
+template <typename T16, bool NT_ST, int ABL = 0, bool GST = false, int KH = 1>
+__global__ __launch_bounds__(RingCfgT<KH>::NT) void conv3_ring_kernel(const bf16_t *__restrict__ x, View xv, const bf16_t *__restrict__ w,
                                                                  Taps taps, const float *__restrict__ bias, bf16_t *__restrict__ y,
                                                                  View yv, int Cout, int tilesW, int tilesH, int nblkN, int nseg,
                                                                  int steps_per_seg, int njobs, double *__restrict__ stats,
                                                                  int ntaps_src, unsigned x_bytes, unsigned y_bytes, RingGst gst) {
-  typedef RingCfg C;
+  typedef RingCfgT<KH> C;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float *red = reinterpret_cast<float *>(smem + C::NSLOT * C::PLANE);
   float *gcst = red + C::NW * 16 * 2;      // GST: (A, B) of the job's 32 channels
@@ -159,7 +187,7 @@ __global__ __launch_bounds__(RingCfg::NT) void conv3_ring_kernel(const bf16_t *_
 
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int v = lane & 15, q = lane >> 4;
-  const int chalf = wave & 1, ws = (wave >> 1) & 3;
+  const int chalf = wave & 1, ws = wave >> 1;      // output-channel half, row pair
   const int D = xv.D, H = xv.H, W = xv.W;
   const int steps_total = (D + 1) / 2;
 
@@ -171,7 +199,7 @@ __global__ __launch_bounds__(RingCfg::NT) void conv3_ring_kernel(const bf16_t *_
     aoff[kw] = (2 * ws) * C::ROWB + u * C::VB + ((q ^ (((u >> 2) & 1) << 1)) << 4);
   }
 
-  uint4 wreg[27];
+  uint4 wreg[KH][27];
   int nb_loaded = -1;
   // ABL 6 (diagnostic): cycle stamps per segment - 0 job prologue, 1 rows 0..6, 2 wait + barrier, 3 rows 7..15, 4 epilogue
   unsigned long long tseg[5] = {0, 0, 0, 0, 0}, tprev = 0, t_begin = 0, rt_begin = 0;
@@ -217,8 +245,11 @@ __global__ __launch_bounds__(RingCfg::NT) void conv3_ring_kernel(const bf16_t *_
 #pragma unroll
       for (int t = 0; t < 27; ++t) {
         const int wt = taps.wt[t];
-        const long long idx = ((((long long)nb * 2 + (q >> 1)) * ntaps_src + wt) * 2 + (q & 1)) * 32 + chalf * 16 + v;
-        wreg[t] = *reinterpret_cast<const uint4 *>(w + idx * 8);
+#pragma unroll
+        for (int kh = 0; kh < KH; ++kh) {
+          const long long idx = ((((long long)nb * (2 * KH) + 2 * kh + (q >> 1)) * ntaps_src + wt) * 2 + (q & 1)) * 32 + chalf * 16 + v;
+          wreg[kh][t] = *reinterpret_cast<const uint4 *>(w + idx * 8);
+        }
       }
       nb_loaded = nb;
     }
@@ -239,22 +270,29 @@ __global__ __launch_bounds__(RingCfg::NT) void conv3_ring_kernel(const bf16_t *_
     // the compiler's wait for these loads belongs HERE: left to the first use inside the step loop it becomes a
     // vmcnt(0) per step, which also waits for the epilogue's stores
 #pragma unroll
-    for (int t = 0; t < 27; ++t) asm volatile("" ::"v"(wreg[t].x), "v"(wreg[t].w));
+    for (int t = 0; t < 27; ++t)
+#pragma unroll
+      for (int kh = 0; kh < KH; ++kh) asm volatile("" ::"v"(wreg[kh][t].x), "v"(wreg[kh][t].w));
 #pragma unroll
     for (int r = 0; r < 4; ++r) asm volatile("" ::"v"(bv[r]));
 
     // per-lane source offsets (bytes inside a plane) of this wave's DMA pieces: piece idx = wave + 8 i of the 44 that make
     // up two planes; lane -> voxel e = 16 P + lane / 4 of the plane, position lane & 3 inside the voxel
-    unsigned poff[C::NPW];
-#pragma unroll
-    for (int i = 0; i < C::NPW; ++i) {
+    // (KH = 2: computed at the issue instead - 13 more live registers would spill inside the step loop, and a scratch reload's
+    // wait also waits for the DMA in flight)
+    auto piece_off = [&](int i) -> unsigned {
       const int idx = wave + C::NW * i;
-      const int P = idx % C::PIECES;
+      const int P = idx % C::SUB_PIECES, kh = (idx / C::SUB_PIECES) % KH;      // piece of sub-plane kh of plane idx / PIECES
       const int e = P * 16 + (lane >> 2), row = e / C::IW, u = e - row * C::IW;
       const int g = (lane & 3) ^ (((u >> 2) & 1) << 1);
       const int gh = oh0 - 1 + row, gw = ow0 - 1 + u;
       const bool ok = idx < 2 * C::PIECES && e < C::NVOX && (unsigned)gh < (unsigned)H && (unsigned)gw < (unsigned)W;
-      poff[i] = ok ? (unsigned)((gh * xv.sh + gw * xv.sw + g * 8) * 2) : OOB;
+      return ok ? (unsigned)((gh * xv.sh + gw * xv.sw + kh * 32 + g * 8) * 2) : OOB;
+    };
+    unsigned poff[KH == 1 ? C::NPW : 1];
+    if (KH == 1) {
+#pragma unroll
+      for (int i = 0; i < C::NPW; ++i) poff[i] = piece_off(i);
     }
     // output: lane (row rho = q, voxel v) stores 8 channels of voxel v + 16 (rho & 1) after the row swaps
     const int ovox = v + 16 * (q & 1);
@@ -270,7 +308,7 @@ __global__ __launch_bounds__(RingCfg::NT) void conv3_ring_kernel(const bf16_t *_
         const int gd = d0 - 1 + ip + idx / C::PIECES;
         const bool dok = (unsigned)gd < (unsigned)D;
         const unsigned soff = dok ? (unsigned)(gd * xv.sd * 2) : 0u;
-        const unsigned voff = poff[i] | (dok ? 0u : OOB);
+        const unsigned voff = (KH == 1 ? poff[KH == 1 ? i : 0] : piece_off(i)) | (dok ? 0u : OOB);
         dma16_buf_to_lds(rx, voff, soff, lds0 + pr * (2 * C::PLANE) + idx * 1024);
         return 1;
       }
@@ -366,8 +404,8 @@ __global__ __launch_bounds__(RingCfg::NT) void conv3_ring_kernel(const bf16_t *_
     // (waves 4-7 running whole steps between barriers, so that each wave's conversion / store phase falls into its partner's MFMA
     // stream): 0.786 vs 0.774 ms (static wave priorities either way: no change) - the older wave of a pair wins the arbitration, finishes its interval early and waits ~2900
     // cycles per step at the barrier while the younger one runs alone, at the ~60 % MFMA rate one wave's LDS latencies allow.
-    uint4 fr[2][6];
-    auto load_row = [&](int rs, int kkv, uint4(&f)[6]) {
+    uint4 fr[2][6 * KH];
+    auto load_row = [&](int rs, int kkv, uint4(&f)[6 * KH]) {
       const int dz = rs >> 2, hy = rs & 3;
       int slot = 2 * kkv + dz;
       slot = slot >= 6 ? slot - 6 : slot;
@@ -376,7 +414,9 @@ __global__ __launch_bounds__(RingCfg::NT) void conv3_ring_kernel(const bf16_t *_
       for (int kw = 0; kw < 3; ++kw)
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf)
-          f[kw * 2 + hf] = *reinterpret_cast<const uint4 *>(smem + (aoff[kw] + sb) + hy * C::ROWB + hf * 1024);
+#pragma unroll
+          for (int kh = 0; kh < KH; ++kh)
+            f[(kw * 2 + hf) * KH + kh] = *reinterpret_cast<const uint4 *>(smem + (aoff[kw] + sb) + kh * C::SUB + hy * C::ROWB + hf * 1024);
     };
     auto init_acc = [&]() {
 #pragma unroll
@@ -432,8 +472,11 @@ __global__ __launch_bounds__(RingCfg::NT) void conv3_ring_kernel(const bf16_t *_
 #pragma unroll
               for (int kh = 0; kh < 3; ++kh) {
                 const int od = dz - kd, oh = hy - kh;
-                if (od >= 0 && od < 2 && oh >= 0 && oh < 2)
-                  mfma16<T16>(wreg[(kd * 3 + kh) * 3 + kw], fr[rs & 1][kw * 2 + hf], acc[od][oh][hf]);
+                if (od >= 0 && od < 2 && oh >= 0 && oh < 2) {
+#pragma unroll
+                  for (int kq = 0; kq < KH; ++kq)
+                    mfma16<T16>(wreg[kq][(kd * 3 + kh) * 3 + kw], fr[rs & 1][(kw * 2 + hf) * KH + kq], acc[od][oh][hf]);
+                }
               }
         __builtin_amdgcn_sched_barrier(0);
         if (rs == 15) stamp(3);
@@ -503,7 +546,7 @@ __global__ __launch_bounds__(RingCfg::NT) void conv3_ring_kernel(const bf16_t *_
         const int ch = tid >> 4, cc = tid & 15;
         double s = 0.0, ss = 0.0;
 #pragma unroll
-        for (int wq = 0; wq < 4; ++wq) {
+        for (int wq = 0; wq < C::NW / 2; ++wq) {
           s += (double)red[((wq * 2 + ch) * 16 + cc) * 2 + 0];
           ss += (double)red[((wq * 2 + ch) * 16 + cc) * 2 + 1];
         }
@@ -525,15 +568,14 @@ __global__ __launch_bounds__(RingCfg::NT) void conv3_ring_kernel(const bf16_t *_
 
 }  // namespace
 
-// Entry point used by the dispatcher in conv_mfma.hip: DGTTA_ERR_UNSUPPORTED when the shape is not this kernel's.
-int conv3_ring_launch(const void *x, const View &xv, const void *w, const Taps &taps, const float *bias, void *y, const View &yv,
-                      int B, int Cin, int Cout, int CinP, int CoutP, double *stats, int64_t stats_cap_slots, int ntaps_src,
-                      int is_f16, hipStream_t st) {
-  typedef RingCfg C;
-  if (Cin != 32 || CinP != 32 || Cout % 32 != 0 || CoutP != Cout) return DGTTA_ERR_UNSUPPORTED;
-  if (xv.D != yv.D || xv.H != yv.H || xv.W != yv.W) return DGTTA_ERR_UNSUPPORTED;
+namespace {
+
+template <int KH>
+int ring_launch_kh(const void *x, const View &xv, const void *w, const Taps &taps, const float *bias, void *y, const View &yv,
+                   int B, int Cout, double *stats, int64_t stats_cap_slots, int ntaps_src, int is_f16, hipStream_t st) {
+  typedef RingCfgT<KH> C;
   // the buffer descriptors address one sample with 32-bit byte offsets
-  const long long xb = ((long long)(xv.D - 1) * xv.sd + (long long)(xv.H - 1) * xv.sh + (long long)(xv.W - 1) * xv.sw + 32) * 2;
+  const long long xb = ((long long)(xv.D - 1) * xv.sd + (long long)(xv.H - 1) * xv.sh + (long long)(xv.W - 1) * xv.sw + 32 * KH) * 2;
   const long long yb = ((long long)(yv.D - 1) * yv.sd + (long long)(yv.H - 1) * yv.sh + (long long)(yv.W - 1) * yv.sw + Cout) * 2;
   if (xb >= (1ll << 31) || yb >= (1ll << 31)) return DGTTA_ERR_UNSUPPORTED;
   if (xv.sw % 8 || xv.sh % 8 || xv.sd % 8 || xv.sb % 8 || yv.sw % 8 || yv.sh % 8 || yv.sd % 8 || yv.sb % 8 || ((uintptr_t)x & 15) ||
@@ -585,9 +627,9 @@ int conv3_ring_launch(const void *x, const View &xv, const void *w, const Taps &
   const int grid = (int)(njobs < ncu ? njobs : ncu);
   const bool nt = dgtta_switches().ring_nt == '1';      // DGTTA_RING_NT=1: non-temporal output stores (measured 5 % slower: the two
                                                           // 32-byte halves of a voxel come from two waves and merge in L2)
-#define RING_LAUNCH(T16, NTS, ...)                                                                                            \
+#define RING_LAUNCH(T16, NTS, ABLV, GSTV)                                                                                     \
   do {                                                                                                                        \
-    auto kern = conv3_ring_kernel<T16, NTS, ##__VA_ARGS__>;                                                                   \
+    auto kern = conv3_ring_kernel<T16, NTS, ABLV, GSTV, KH>;                                                                  \
     static DynLdsOnce once;                                                                                                   \
     DG_REQUIRE(ensure_dyn_lds(once, reinterpret_cast<const void *>(kern), C::LDS_BYTES) == hipSuccess, DGTTA_ERR_LAUNCH,      \
                "conv3_ring: cannot raise the dynamic LDS limit to %d", C::LDS_BYTES);                                         \
@@ -596,22 +638,51 @@ int conv3_ring_launch(const void *x, const View &xv, const void *w, const Taps &
                        (unsigned)yb, ga);                                                                                     \
   } while (0)
   const int abl = dgtta_switches().ring_abl;
-  if (is_f16 && abl > '0') {      // diagnostic builds exist for the fp16 instantiation only
-    if (abl == '1') RING_LAUNCH(f16_t, false, 1);
-    else if (abl == '2') RING_LAUNCH(f16_t, false, 2);
-    else if (abl == '3') RING_LAUNCH(f16_t, false, 3);
-    else RING_LAUNCH(f16_t, false, 6);
+  bool diag = false;
+  if constexpr (KH == 1) {      // diagnostic builds exist for the fp16 / 32-channel instantiation only
+    if (is_f16 && abl > '0') {
+      diag = true;
+      if (abl == '1') RING_LAUNCH(f16_t, false, 1, false);
+      else if (abl == '2') RING_LAUNCH(f16_t, false, 2, false);
+      else if (abl == '3') RING_LAUNCH(f16_t, false, 3, false);
+      else RING_LAUNCH(f16_t, false, 6, false);
+    }
+  }
+  if (diag) {
   } else if (gst_on) {
     if (is_f16) RING_LAUNCH(f16_t, false, 0, true);
     else RING_LAUNCH(bf16_t, false, 0, true);
   } else if (is_f16) {
-    if (nt) RING_LAUNCH(f16_t, true);
-    else RING_LAUNCH(f16_t, false);
+    if constexpr (KH == 1) {
+      if (nt) RING_LAUNCH(f16_t, true, 0, false);
+      else RING_LAUNCH(f16_t, false, 0, false);
+    } else {
+      RING_LAUNCH(f16_t, false, 0, false);
+    }
   } else {
-    if (nt) RING_LAUNCH(bf16_t, true);
-    else RING_LAUNCH(bf16_t, false);
+    if constexpr (KH == 1) {
+      if (nt) RING_LAUNCH(bf16_t, true, 0, false);
+      else RING_LAUNCH(bf16_t, false, 0, false);
+    } else {
+      RING_LAUNCH(bf16_t, false, 0, false);
+    }
   }
 #undef RING_LAUNCH
   DG_CHECK_LAUNCH("conv3_ring_kernel");
   return DGTTA_OK;
+}
+
+}  // namespace
+
+// Entry point used by the dispatcher in conv_mfma.hip: DGTTA_ERR_UNSUPPORTED when the shape is not this kernel's.
+int conv3_ring_launch(const void *x, const View &xv, const void *w, const Taps &taps, const float *bias, void *y, const View &yv,
+                      int B, int Cin, int Cout, int CinP, int CoutP, double *stats, int64_t stats_cap_slots, int ntaps_src,
+                      int is_f16, hipStream_t st) {
+  if (Cin != CinP || (Cin != 32 && Cin != 64) || Cout % 32 != 0 || CoutP != Cout) return DGTTA_ERR_UNSUPPORTED;
+  if (xv.D != yv.D || xv.H != yv.H || xv.W != yv.W) return DGTTA_ERR_UNSUPPORTED;
+  if (Cin == 64) {
+    if (dgtta_switches().conv_ring == '3') return DGTTA_ERR_UNSUPPORTED;      // DGTTA_CONV_RING=3: the ring for 32 input channels only
+    return ring_launch_kh<2>(x, xv, w, taps, bias, y, yv, B, Cout, stats, stats_cap_slots, ntaps_src, is_f16, st);
+  }
+  return ring_launch_kh<1>(x, xv, w, taps, bias, y, yv, B, Cout, stats, stats_cap_slots, ntaps_src, is_f16, st);
 }

@@ -145,9 +145,10 @@ def test_conv_rows_kernel_bf16(case, monkeypatch):
     assert (m2 - m1).abs().max() < 1e-5 and ((r2 - r1) / r1).abs().max() < 1e-5
 
 
-RING_CASES = [  # (B, cin, cout, D, H, W): 32 input channels in the forward, or 32 output channels (-> the data gradient's input)
+RING_CASES = [  # (B, cin, cout, D, H, W): 32 / 64 input channels in the forward, 32 / 64 output channels (-> the data gradient's input)
     (1, 32, 32, 9, 13, 45), (2, 32, 64, 6, 17, 32), (1, 32, 96, 8, 8, 70), (1, 64, 32, 7, 9, 33),
     (2, 32, 32, 32, 32, 64), (1, 32, 32, 36, 40, 32), (8, 32, 32, 4, 64, 160),      # the last: 320 columns = two rounds of jobs
+    (1, 64, 64, 9, 13, 45), (2, 64, 96, 6, 7, 64), (2, 64, 64, 16, 32, 32), (4, 64, 32, 4, 64, 160),      # 64 channels both ways
 ]
 
 

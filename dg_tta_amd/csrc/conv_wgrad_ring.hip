@@ -10,7 +10,8 @@
 //   * x ring of 5 slices, dy ring of 3: the DMA of x(d + 3), dy(d + 2) is issued during slice d and first read in slice d + 2;
 //     the wait in front of the (single) barrier of a slice is a counted vmcnt that leaves the youngest group in flight;
 //   * buffer-addressed DMA with per-lane offsets precomputed per job (zero fill = out-of-range offset), as conv_ring.hip;
-//   * v_mfma_f32_16x16x32 (K = the row's 32 voxels, four 16x16 accumulators per tap) - measured equal to the 32x32x16 form;
+//   * also built: v_mfma_f32_16x16x32 (K = the row's 32 voxels, four 16x16 accumulators per tap, DGTTA_WGRAD_RING=4), with the
+//     half-swapped LDS image that makes its operand reads conflict free - measured within +-2 % of the 32x32x16 form;
 //   * the accumulators live across all jobs of the workgroup: one slab per workgroup (<= 256 per channel-block pair), the two
 //     row halves of a tap are added through LDS once, at the very end.
 // Measured (MI355X, fp16, 8 x 128^3, 200 back-to-back launches, same box): 32 -> 32 0.948 -> 0.933 ms, 64 -> 32 1.96 -> 1.81 ms
@@ -79,6 +80,12 @@ __device__ __forceinline__ bf16x8_t wr_operand(const unsigned char *p) {      //
   const wr_s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
   return __builtin_bit_cast(bf16x8_t, v);
 }
+__device__ __forceinline__ bf16x8_t wr_operand2(const unsigned char *p0, const unsigned char *p1) {      // the two reads at their own addresses
+  const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t *)p0);
+  const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t *)p1);
+  const wr_s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(bf16x8_t, v);
+}
 template <typename T16>
 __device__ __forceinline__ f32x16_t wr_mfma(const bf16x8_t &a, const bf16x8_t &b, const f32x16_t &acc);
 template <>
@@ -124,18 +131,43 @@ __global__ __launch_bounds__(WR::NW * 64) void conv3_wgrad_ring_kernel(const bf1
   const int cib = blockIdx.y / cobs, cob = blockIdx.y % cobs;
   const int cin_lim = (Cin + 7) / 8 * 8;
 
-  int tap_kd[7], tap_off[7];
+  int tap_kd[7], tap_off[7], tap_row[7], tap_kw[7];
 #pragma unroll
   for (int i = 0; i < 7; ++i) {
     const int tc = wq + 4 * i < 27 ? wq + 4 * i : 26;      // (the fourth residue class has 6 taps: its seventh slot repeats tap 26 into a discarded accumulator)
     tap_kd[i] = tc / 9;
     tap_off[i] = ((tc / 3) % 3) * WR::X_ROW_B + (tc % 3) * 64;
+    tap_row[i] = ((tc / 3) % 3) * WR::X_ROW_B;
+    tap_kw[i] = tc % 3;
   }
   // transposed-read lane address inside a 16-voxel x 32-channel block (64-byte voxel rows), as conv3_wgrad_tr_kernel
   // (MF16: 16-lane group g = lane >> 4 takes voxels 8 g .. 8 g + 7 of 16 channels; the channel half is an immediate offset)
   const int lane_off = MF16 ? ((lane >> 4) * 8 + ((lane & 15) >> 2)) * 64 + (lane & 3) * 8
                             : ((lane >> 5) * 8 + ((lane & 15) >> 2)) * 64 + ((lane >> 4) & 1) * 32 + (lane & 3) * 8;
 
+  // MF16 operand addresses.  A 16-lane group reads 4 voxels x 32 bytes (16 channels), and the two groups of a 32-lane half sit 8
+  // voxels = 512 bytes apart: on the plain image both hit the same banks (PMC, profiles/r04_mfma_util.json: SQ_LDS_BANK_CONFLICT =
+  // 50 % of the LDS cycles).  So voxels with bit 3 of their row index set store their channel halves swapped, and a lane reads
+  // half h of voxel u at byte (h ^ bit3(u)) * 32.  lane_y[s] = offset of half 0 for read s (voxels +0 / +4) without W shift; with
+  // the W shift kw of a tap the offset is (lane_y + 64 kw) ^ flip_kw, flip = 32 in the lanes where the shift carries into bit 3;
+  // half 1 is that ^ 32.  A tap's kw depends on the wave; it is selected with plain bit masks, because every form of
+  // `kw == 1 ? a : b` on these registers ends up as a table in scratch memory behind a pointer select (and a scratch load
+  // waits for the DMA in flight).
+  int lane_y[2], flip1[2], flip2[2], kw_off[7];
+  unsigned kw_m1[7], kw_m2[7];
+#pragma unroll
+  for (int sr = 0; sr < 2; ++sr) {
+    const int uy = (lane >> 4) * 8 + ((lane & 15) >> 2) + 4 * sr;
+    lane_y[sr] = uy * 64 + ((uy >> 3) & 1) * 32 + (lane & 3) * 8;
+    flip1[sr] = ((((uy + 1) >> 3) ^ (uy >> 3)) & 1) * 32;
+    flip2[sr] = ((((uy + 2) >> 3) ^ (uy >> 3)) & 1) * 32;
+  }
+#pragma unroll
+  for (int i = 0; i < 7; ++i) {
+    kw_off[i] = tap_kw[i] * 64;
+    kw_m1[i] = tap_kw[i] == 1 ? 0xffffffffu : 0u;
+    kw_m2[i] = tap_kw[i] == 2 ? 0xffffffffu : 0u;
+  }
   // 7 taps x (32 ci x 32 co): one 32x32 accumulator per tap, or four 16x16 ones [ci half][co half] - 112 registers either way
   float accf[7][16];
 #pragma unroll
@@ -165,14 +197,18 @@ __global__ __launch_bounds__(WR::NW * 64) void conv3_wgrad_ring_kernel(const bf1
 #pragma unroll
     for (int i = 0; i < WR::NPW; ++i) {
       const int idx = wave + WR::NW * i;
-      const int chunk = lane & 3;
+      // MF16: a voxel whose index in its LDS row has bit 3 set keeps its two 32-byte channel halves swapped (see lane_y below);
+      // the LDS side of an LDS-DMA is lane-linear, so the permutation is applied to the SOURCE chunk
+      int chunk = lane & 3;
       if (idx < WR::XP) {
         const int e = idx * 16 + (lane >> 2), row = e / WR::XW, u = e - row * WR::XW;
+        if (MF16) chunk ^= ((u >> 3) & 1) << 1;
         const int gh = h0 - 1 + row, gw = w0 - 1 + u;
         const bool ok = e < WR::NVOX && (unsigned)gh < (unsigned)H && (unsigned)gw < (unsigned)W && cib * 32 + chunk * 8 < cin_lim;
         poff[i] = ok ? (unsigned)((gh * xv.sh + gw * xv.sw + chunk * 8) * 2) : WR_OOB;
       } else {
         const int p = idx - WR::XP, row = p >> 1, vox = 16 * (p & 1) + (lane >> 2);
+        if (MF16) chunk ^= ((vox >> 3) & 1) << 1;
         const int gh = h0 + row, gw = w0 + vox;
         const bool ok = idx < WR::NP && gh < H && gw < W && cob * 32 + chunk * 8 < Cout;
         poff[i] = ok ? (unsigned)((gh * yv.sh + gw * yv.sw + chunk * 8) * 2) : WR_OOB;
@@ -218,7 +254,8 @@ __global__ __launch_bounds__(WR::NW * 64) void conv3_wgrad_ring_kernel(const bf1
       if (CLK) t_wait += __builtin_amdgcn_s_memtime() - tw0;
       const bool more = d + 2 < d_end;         // x(d + 3), dy(d + 2): first read in slice d + 2
       int mark_new = issued;
-      const unsigned char *ys = sY + ((d + WR::NYS) % WR::NYS) * WR::Y_SLICE_B + rh * 4 * WR::Y_ROW_B + lane_off;
+      const unsigned char *ys0 = sY + ((d + WR::NYS) % WR::NYS) * WR::Y_SLICE_B + rh * 4 * WR::Y_ROW_B;
+      const unsigned char *ys = ys0 + lane_off;
       int slice_off[3];
 #pragma unroll
       for (int kd = 0; kd < 3; ++kd) slice_off[kd] = ((d + kd + WR::NXS) % WR::NXS) * WR::X_SLICE_B + rh * 4 * WR::X_ROW_B;
@@ -256,26 +293,32 @@ __global__ __launch_bounds__(WR::NW * 64) void conv3_wgrad_ring_kernel(const bf1
         }
       } else {
         // the row's 32 voxels are ONE k-step: per (row, tap) unit 2 x operands (ci halves) and 4 MFMAs against the row's 2 dy
-        // operands (co halves).  28 units per slice; the x operands of unit u + 2 and the dy operands of the next row are read
+        // operands (co halves).  28 units per slice; the x operands of unit u + 1 and the dy operands of the next row are read
         // while the MFMAs of unit u issue (a whole row of operands in flight would not fit the registers)
-        bf16x8_t fb[3][2], bb[2][2];
+        bf16x8_t fb[2][2], bb[2][2];
         auto load_x = [&](int u, bf16x8_t(&a)[2]) {
           const int oh = u / 7, i = u % 7;
-          const int so = (tap_kd[i] == 0 ? slice_off[0] : (tap_kd[i] == 1 ? slice_off[1] : slice_off[2])) + tap_off[i];
+          const int so = (tap_kd[i] == 0 ? slice_off[0] : (tap_kd[i] == 1 ? slice_off[1] : slice_off[2])) + tap_row[i];
+          // (laundered: otherwise the 28 addresses of the 7 taps are hoisted out of the unit loop and spill)
+          int ly0 = lane_y[0], ly1 = lane_y[1];
+          asm volatile("" : "+v"(ly0), "+v"(ly1));
+          const int l0 = (ly0 + kw_off[i]) ^ (int)((flip1[0] & kw_m1[i]) | (flip2[0] & kw_m2[i]));
+          const int l1 = (ly1 + kw_off[i]) ^ (int)((flip1[1] & kw_m1[i]) | (flip2[1] & kw_m2[i]));
 #pragma unroll
-          for (int h = 0; h < 2; ++h) a[h] = wr_operand(sX + lane_off + so + oh * WR::X_ROW_B + h * 32);
+          for (int h = 0; h < 2; ++h)
+            a[h] = wr_operand2(sX + so + oh * WR::X_ROW_B + (l0 ^ (h * 32)), sX + so + oh * WR::X_ROW_B + (l1 ^ (h * 32)));
         };
         auto load_y = [&](int oh, bf16x8_t(&y2)[2]) {
 #pragma unroll
-          for (int h = 0; h < 2; ++h) y2[h] = wr_operand(ys + oh * WR::Y_ROW_B + h * 32);
+          for (int h = 0; h < 2; ++h)
+            y2[h] = wr_operand2(ys0 + oh * WR::Y_ROW_B + (lane_y[0] ^ (h * 32)), ys0 + oh * WR::Y_ROW_B + (lane_y[1] ^ (h * 32)));
         };
         load_y(0, bb[0]);
         load_x(0, fb[0]);
-        load_x(1, fb[1]);
 #pragma unroll
         for (int u = 0; u < 28; ++u) {
           const int oh = u / 7, i = u % 7;
-          if (u + 2 < 28) load_x(u + 2, fb[(u + 2) % 3]);
+          if (u + 1 < 28) load_x(u + 1, fb[(u + 1) & 1]);
           if (i == 3 && oh + 1 < 4) load_y(oh + 1, bb[(oh + 1) & 1]);
           __builtin_amdgcn_sched_barrier(0);
           if (more && i == 0) {      // the slice's DMA pieces: two after the first row's first unit, then one per row
@@ -292,7 +335,7 @@ __global__ __launch_bounds__(WR::NW * 64) void conv3_wgrad_ring_kernel(const bf1
             for (int cb = 0; cb < 2; ++cb) {
               f32x4_t c = {accf[i][(ca * 2 + cb) * 4 + 0], accf[i][(ca * 2 + cb) * 4 + 1], accf[i][(ca * 2 + cb) * 4 + 2],
                            accf[i][(ca * 2 + cb) * 4 + 3]};
-              c = wr_mfma16<T16>(fb[u % 3][ca], bb[oh & 1][cb], c);
+              c = wr_mfma16<T16>(fb[u & 1][ca], bb[oh & 1][cb], c);
 #pragma unroll
               for (int r = 0; r < 4; ++r) accf[i][(ca * 2 + cb) * 4 + r] = c[r];
             }
@@ -394,7 +437,9 @@ int conv3_wgrad_ring_launch(const void *x, const View &xv, const void *dy, const
     hipLaunchKernelGGL(kern, dim3((unsigned)G, (unsigned)pairs), dim3(WR::NW * 64), WR::LDS_BYTES, st, (const bf16_t *)x, xv,  \
                        (const bf16_t *)dy, yv, slabs, Cin, Cout, tW, tH, nseg, DR, cobs, (int)njobs, (unsigned)xb, (unsigned)yb); \
   } while (0)
-  const bool mf16 = dgtta_switches().wgrad_ring != '3';      // DGTTA_WGRAD_RING=3: the 32x32x16 form
+  // DGTTA_WGRAD_RING=4: the v_mfma_f32_16x16x32 form (conflict-free after the half swap above; measured within +-2 % of the
+  // 32x32x16 form on three boxes, which is the default: 36 registers less and no swizzle)
+  const bool mf16 = dgtta_switches().wgrad_ring == '4';
   if (is_f16 && dgtta_switches().wgrad_ring == '6') {      // diagnostic: stamps (profiles/tools/wring_clock.py)
     WR_LAUNCH(f16_t, true, true);
   } else if (is_f16) {

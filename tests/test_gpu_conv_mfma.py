@@ -692,13 +692,14 @@ def test_wgrad_ring_kernel(case, dts, monkeypatch):
         torch.cuda.synchronize()
         return dw
 
-    old, new = run("0"), run("1")
+    old, new, new16 = run("0"), run("1"), run("4")       # "4": the 16x16x32 MFMA form with the half-swapped LDS image
     ref = torch.nn.grad.conv3d_weight(x[..., :cin].float().permute(0, 4, 1, 2, 3).cpu().double(), (cout, cin, 3, 3, 3),
                                       dy.float().permute(0, 4, 1, 2, 3).cpu().double(), stride=1, padding=1).float()
     scale = float(ref.abs().max())
     assert torch.isfinite(new).all()
     assert float((new.cpu() - ref).abs().max()) < 2e-4 * scale + 1e-3
     assert float((new - old).abs().max()) < 1e-4 * scale + 1e-3       # same products, another fp32 summation order
+    assert float((new16 - old).abs().max()) < 1e-4 * scale + 1e-3
     assert torch.equal(run("1"), new)                                  # run to run: the same bits
 
 

@@ -256,20 +256,29 @@ __global__ __launch_bounds__(WR::NW * 64) void conv3_wgrad_ring_kernel(const bf1
       int mark_new = issued;
       const unsigned char *ys0 = sY + ((d + WR::NYS) % WR::NYS) * WR::Y_SLICE_B + rh * 4 * WR::Y_ROW_B;
       const unsigned char *ys = ys0 + lane_off;
+      const int xr0 = (d + WR::NXS) % WR::NXS;      // ring slot of x(d - 1)
       int slice_off[3];
 #pragma unroll
       for (int kd = 0; kd < 3; ++kd) slice_off[kd] = ((d + kd + WR::NXS) % WR::NXS) * WR::X_SLICE_B + rh * 4 * WR::X_ROW_B;
       if (!MF16) {
         // operands of (row, k-step) iteration it + 1 are read while the MFMAs of iteration it issue
+        // One address register per tap and slice (lane offset + ring slot of the tap's kd + its (kh, kw) offset, the slot picked
+        // without a branch): every operand read of the slice is then that register plus an immediate.  Before, each read carried
+        // a scalar compare / branch chain for the slot and its own address arithmetic - with two transposed reads per MFMA the
+        // sweep was bound by instruction issue, not by the matrix pipe (profiles/r04_ab.txt).
+        int xa[7];
+#pragma unroll
+        for (int i = 0; i < 7; ++i) {
+          int sl = xr0 + tap_kd[i];
+          sl = sl >= WR::NXS ? sl - WR::NXS : sl;
+          xa[i] = lane_off + sl * WR::X_SLICE_B + rh * 4 * WR::X_ROW_B + tap_off[i];
+        }
         bf16x8_t afr[2][7], bfr[2];
         auto load_it = [&](int it, bf16x8_t(&a)[7], bf16x8_t &bb) {
           const int oh = it >> 1, ks = it & 1;
           bb = wr_operand(ys + oh * WR::Y_ROW_B + ks * 1024);
 #pragma unroll
-          for (int i = 0; i < 7; ++i) {
-            const int so = (tap_kd[i] == 0 ? slice_off[0] : (tap_kd[i] == 1 ? slice_off[1] : slice_off[2])) + tap_off[i];
-            a[i] = wr_operand(sX + lane_off + so + oh * WR::X_ROW_B + ks * 1024);
-          }
+          for (int i = 0; i < 7; ++i) a[i] = wr_operand(sX + xa[i] + oh * WR::X_ROW_B + ks * 1024);
         };
         load_it(0, afr[0], bfr[0]);
 #pragma unroll
@@ -441,7 +450,7 @@ int conv3_wgrad_ring_launch(const void *x, const View &xv, const void *dy, const
   // 32x32x16 form on three boxes, which is the default: 36 registers less and no swizzle)
   const bool mf16 = dgtta_switches().wgrad_ring == '4';
   if (is_f16 && dgtta_switches().wgrad_ring == '6') {      // diagnostic: stamps (profiles/tools/wring_clock.py)
-    WR_LAUNCH(f16_t, true, true);
+    WR_LAUNCH(f16_t, false, true);
   } else if (is_f16) {
     if (mf16) WR_LAUNCH(f16_t, true, false);
     else WR_LAUNCH(f16_t, false, false);

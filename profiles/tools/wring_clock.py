@@ -26,7 +26,7 @@ start = int(cand[0]) if len(cand) else G * 27 * 1024
 o = f[start: start + G * 8 * 4].reshape(G, 8, 4).cpu()
 cyc, rt, wait = o[..., 0], o[..., 1], o[..., 2]
 clk = (cyc / rt * 100e6).flatten()
-mfma_cycles = 2 * 128 * 2 * 28 * 4 * 16          # per SIMD: 2 waves x (2 jobs x 128 slices) x 28 units x 4 MFMAs x 16 cycles
+mfma_cycles = 2 * 128 * 2 * 56 * 32          # per SIMD: 2 waves x (2 jobs x 128 slices) x 56 MFMAs (32x32x16) x 32 cycles
 print(f"launch {e0.elapsed_time(e1)*1e3:.1f} us incl. reduce; cycles per wave mean {float(cyc.mean()):.0f}; clock median {float(clk.median())/1e9:.3f} GHz")
 print(f"barrier + DMA wait per wave: mean {100*float((wait/cyc).mean()):.1f} % (by wave: " + " ".join(f"{100*float(v):.0f}" for v in (wait/cyc).mean(0)) + ")")
 print(f"MFMA-busy share of the wave time: {100*mfma_cycles/float(cyc.mean()):.1f} %")

@@ -462,6 +462,11 @@ __global__ __launch_bounds__(256, 2) void conv3_wgrad_tr_kernel(const bf16_t *__
     int slice_off[3];
 #pragma unroll
     for (int kd = 0; kd < 3; ++kd) slice_off[kd] = ((d + kd - 1) & 3) * WT::X_SLICE_B;
+    // the tap's ring slot is selected once per slice (round 4: inside the unrolled row loop every operand read carried its own
+    // compare / select chain - two transposed reads per MFMA made the sweep issue bound)
+    int so_t[7];
+#pragma unroll
+    for (int i = 0; i < 7; ++i) so_t[i] = (tap_kd[i] == 0 ? slice_off[0] : (tap_kd[i] == 1 ? slice_off[1] : slice_off[2])) + tap_off[i];
 #pragma unroll
     for (int oh = 0; oh < WT::TH; ++oh) {
 #pragma unroll
@@ -476,8 +481,7 @@ __global__ __launch_bounds__(256, 2) void conv3_wgrad_tr_kernel(const bf16_t *__
 #pragma unroll
         for (int i = 0; i < 7; ++i) {
           if (CLS && i >= ntap_w) continue;      // wave-uniform
-          const int so = (tap_kd[i] == 0 ? slice_off[0] : (tap_kd[i] == 1 ? slice_off[1] : slice_off[2])) + tap_off[i];
-          afr[i] = tr_operand(sX + lane_off + so + oh * WT::X_ROW_B + ks * 1024);
+          afr[i] = tr_operand(sX + lane_off + so_t[i] + oh * WT::X_ROW_B + ks * 1024);
         }
 #pragma unroll
         for (int i = 0; i < 7; ++i) {
@@ -612,6 +616,9 @@ __global__ __launch_bounds__(512, 1) void conv3_wgrad_tr8_kernel(const bf16_t *_
     int slice_off[3];
 #pragma unroll
     for (int kd = 0; kd < 3; ++kd) slice_off[kd] = ((d + kd - 1) & 3) * WT::X_SLICE_B;
+    int so_t[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) so_t[i] = (tap_kd[i] == 0 ? slice_off[0] : (tap_kd[i] == 1 ? slice_off[1] : slice_off[2])) + tap_off[i];
 #pragma unroll
     for (int oh = 0; oh < WT::TH; ++oh) {
 #pragma unroll
@@ -629,8 +636,7 @@ __global__ __launch_bounds__(512, 1) void conv3_wgrad_tr8_kernel(const bf16_t *_
         bf16x8_t afr[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          const int so = (tap_kd[i] == 0 ? slice_off[0] : (tap_kd[i] == 1 ? slice_off[1] : slice_off[2])) + tap_off[i];
-          afr[i] = tr_operand(sX + lane_off_x + so + oh * WT::X_ROW_B + ks * 1024);
+          afr[i] = tr_operand(sX + lane_off_x + so_t[i] + oh * WT::X_ROW_B + ks * 1024);
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -764,6 +770,9 @@ __global__ __launch_bounds__(256, 2) void conv3_wgrad_tr_s2_kernel(const bf16_t 
     int slice_off[3];
 #pragma unroll
     for (int kd = 0; kd < 3; ++kd) slice_off[kd] = xslot(2 * d + kd - 1) * WT2::X_SLICE_B;
+    int so_t[7];
+#pragma unroll
+    for (int i = 0; i < 7; ++i) so_t[i] = (tap_kd[i] == 0 ? slice_off[0] : (tap_kd[i] == 1 ? slice_off[1] : slice_off[2])) + tap_off[i];
 #pragma unroll
     for (int oh = 0; oh < WT2::TH; ++oh) {
       // K-step = the 16 output voxels of the row
@@ -775,8 +784,7 @@ __global__ __launch_bounds__(256, 2) void conv3_wgrad_tr_s2_kernel(const bf16_t 
       bf16x8_t afr[7];
 #pragma unroll
       for (int i = 0; i < 7; ++i) {
-        const int so = (tap_kd[i] == 0 ? slice_off[0] : (tap_kd[i] == 1 ? slice_off[1] : slice_off[2])) + tap_off[i];
-        const unsigned char *pa = sX + lane_off_x + so + 2 * oh * WT2::X_ROW_B;
+        const unsigned char *pa = sX + lane_off_x + so_t[i] + 2 * oh * WT2::X_ROW_B;
         const s16x4_t alo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t *)pa);
         const s16x4_t ahi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t *)(pa + 4 * 128));
         const s16x8_t av = {alo[0], alo[1], alo[2], alo[3], ahi[0], ahi[1], ahi[2], ahi[3]};

@@ -348,19 +348,58 @@ def inference_leg(args, device, dtype):
     vol = torch.randn(1, n, n, n, generator=torch.Generator().manual_seed(3)).to(device)
     patch = [args.size] * 3
     predict_sliding_window_return_logits(net, vol[:, :args.size, :args.size, :args.size], patch)      # warm-up: one window
-    # the 105-class accumulator (52.5 GiB at 512^3) is allocated and zeroed before the clock starts: how long the driver
-    # takes to hand out that much fresh memory varies by seconds between processes and is not what this leg measures
-    acc0 = torch.zeros((n, n, n, net.decoder.seg_layers[-1].out_channels), dtype=torch.float32, device=device)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    acc, nsum, _ = predict_sliding_window_return_logits(net, vol, patch, acc=acc0)
-    seg, _ = ops.argmax_dice(acc.permute(3, 0, 1, 2)[None])
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
     nwin = (max(1, -(-(n - args.size) // (args.size // 2))) + 1) ** 3 if n > args.size else 1
-    return {"volume": n, "windows": nwin, "ms_per_window": round(dt / nwin * 1e3, 3), "seconds": round(dt, 3),
-            "accumulator_gib": round(acc.numel() * 4 / 2 ** 30, 2), "classes": int(acc.shape[-1]), "dtype": dtype,
-            "note": "one ensemble member; network forward (8 windows per pass) + Gaussian accumulate fused with the head + final argmax"}
+    ncls = net.decoder.seg_layers[-1].out_channels
+    # forward FLOPs of one window (all conv layers + the head): the inference leg's own roofline figure
+    win_tflop = forward_tflop_per_sample(args.size, ncls)
+
+    def one(acc_dtype):
+        # the 105-class accumulator (52.5 GiB at 512^3 in fp32) is allocated and zeroed before the clock starts: how long
+        # the driver takes to hand out that much fresh memory varies by seconds between processes and is not what this leg measures
+        acc0 = torch.zeros((n, n, n, ncls), dtype=acc_dtype, device=device)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        acc, nsum, _ = predict_sliding_window_return_logits(net, vol, patch, acc=acc0)
+        seg = ops.argmax_rows(acc)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        rec = {"ms_per_window": round(dt / nwin * 1e3, 3), "seconds": round(dt, 3),
+               "accumulator_gib": round(acc.numel() * acc.element_size() / 2 ** 30, 2),
+               "tflops": round(win_tflop * nwin / dt, 1), "frac_of_mfma_peak": round(win_tflop * nwin / dt / 2500.0, 4)}
+        return rec, seg
+
+    torch.manual_seed(11)                    # MIND's noise draws: the same in both runs
+    r32, seg32 = one(torch.float32)
+    out = {"volume": n, "windows": nwin, **r32, "classes": int(ncls), "dtype": dtype, "accumulator": "fp32",
+           "window_tflop": round(win_tflop, 4),
+           "note": "one ensemble member; network forward (8 windows per pass) + Gaussian accumulate fused with the head + final argmax"}
+    del r32
+    torch.manual_seed(11)
+    r16, seg16 = one(torch.float16)
+    r16["label_agreement_with_fp32_accumulator"] = round(float((seg16 == seg32).float().mean()), 6)
+    out["fp16_accumulator"] = r16
+    return out
+
+
+def forward_tflop_per_sample(size, ncls):
+    """2 x MACs of one forward pass of the nnUNet 3d_fullres PlainConvUNet (6 stages, 32..320 features, 2 convs per stage,
+    transposed-conv upsampling, 1x1x1 head) on a size^3 patch with the 12-channel MIND input, in TFLOP."""
+    feats = [32, 64, 128, 256, 320, 320]
+    strides = [1, 2, 2, 2, 2, 2]
+    fl, cin, s = 0.0, 12, size
+    sizes = []
+    for f, st in zip(feats, strides):
+        s = s // st
+        fl += 2.0 * 27 * cin * f * s ** 3 + 2.0 * 27 * f * f * s ** 3
+        cin = f
+        sizes.append(s)
+    for lvl in range(len(feats) - 2, -1, -1):
+        f, s = feats[lvl], sizes[lvl]
+        fl += 2.0 * 8 * cin * f * (s // 2) ** 3            # 2x2x2 stride-2 transposed conv: 8 taps, each input voxel once per tap
+        fl += 2.0 * 27 * (2 * f) * f * s ** 3 + 2.0 * 27 * f * f * s ** 3
+        cin = f
+    fl += 2.0 * cin * ncls * size ** 3
+    return fl / 1e12
 
 
 def product_switches():

@@ -62,6 +62,10 @@ SIGNATURES = {
     "dgtta_window_accumulate": (I, [P, P, P, P, I, I, I, I, I, I, I, I, I, I, P]),
     "dgtta_seghead_window_accumulate": (I, [P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, P]),
     "dgtta_logits_chunk_f64": (I, [P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, P]),
+    "dgtta_window_accumulate_t": (I, [P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, P]),
+    "dgtta_seghead_window_accumulate_t": (I, [P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, I, P]),
+    "dgtta_argmax_rows": (I, [P, I, I, I64, P, P]),
+    "dgtta_logits_chunk_f64_t": (I, [P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, I, P]),
     "dgtta_argmax_merge_f64": (I, [P, I64, I, I, P, P, I, P]),
 }
 

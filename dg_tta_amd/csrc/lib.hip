@@ -55,6 +55,8 @@ static const DgttaSwitches *read_switches() {
   s->ring_nt = env_char("DGTTA_RING_NT");
   s->ring_abl = env_char("DGTTA_RING_ABL");
   s->wgrad_ring = env_char("DGTTA_WGRAD_RING");
+  s->ha_abl = env_char("DGTTA_HA_ABL");
+  s->ha_mfma = env_char("DGTTA_HA_MFMA");
   return s;
 }
 

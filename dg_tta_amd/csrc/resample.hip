@@ -102,7 +102,8 @@ __global__ void resample_axis_kernel(const double *__restrict__ src, double *__r
 // convert_predicted_logits_to_segmentation_with_correct_shape, reached from dg_tta/tta/nnunet_utils.py:208-230): the
 // accumulated window logits are normalised, resampled class group by class group (the passes above) and reduced to a label
 // map by a running argmax, so that the 105-class volume never exists twice.
-__global__ void logits_chunk_kernel(const float *__restrict__ acc, const float *__restrict__ nsum, double *__restrict__ dst,
+template <typename ACC>
+__global__ void logits_chunk_kernel(const ACC *__restrict__ acc, const float *__restrict__ nsum, double *__restrict__ dst,
                                     int C, int Y, int Z, int x0, int y0, int z0, int ys, int zs, int c0, int cg,
                                     int64_t total) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -112,7 +113,7 @@ __global__ void logits_chunk_kernel(const float *__restrict__ acc, const float *
   const int z = (int)(v % zs), y = (int)((v / zs) % ys);
   const int64_t x = v / ((int64_t)zs * ys);
   const int64_t sv = ((x + x0) * Y + (y + y0)) * Z + (z + z0);
-  dst[i] = (double)(acc[sv * C + c0 + j] / nsum[sv]);
+  dst[i] = (double)(ld_f<ACC>(acc + sv * C + c0 + j) / nsum[sv]);
 }
 
 __global__ void argmax_merge_kernel(const double *__restrict__ vals, int64_t V, int cg, int c0, double *__restrict__ best_val,
@@ -134,17 +135,27 @@ __global__ void argmax_merge_kernel(const double *__restrict__ vals, int64_t V, 
 
 }  // namespace
 
-extern "C" int dgtta_logits_chunk_f64(const float *acc, const float *nsum, double *dst, int C, int X, int Y, int Z, int x0,
-                                      int y0, int z0, int xs, int ys, int zs, int c0, int cg, void *stream) {
+extern "C" int dgtta_logits_chunk_f64_t(const void *acc, const float *nsum, double *dst, int C, int X, int Y, int Z, int x0,
+                                        int y0, int z0, int xs, int ys, int zs, int c0, int cg, int acc_dtype, void *stream) {
   DG_REQUIRE(acc && nsum && dst, DGTTA_ERR_BADARG, "logits_chunk: null pointer");
   DG_REQUIRE(C > 0 && cg > 0 && c0 >= 0 && c0 + cg <= C, DGTTA_ERR_BADARG, "logits_chunk: class range outside [0,%d)", C);
   DG_REQUIRE(x0 >= 0 && y0 >= 0 && z0 >= 0 && xs > 0 && ys > 0 && zs > 0 && x0 + xs <= X && y0 + ys <= Y && z0 + zs <= Z,
              DGTTA_ERR_BADARG, "logits_chunk: crop outside the volume");
+  DG_REQUIRE(acc_dtype == DGTTA_F32 || acc_dtype == DGTTA_F16, DGTTA_ERR_UNSUPPORTED, "logits_chunk: the accumulator is fp32 or fp16");
   const int64_t total = (int64_t)xs * ys * zs * cg;
-  hipLaunchKernelGGL(logits_chunk_kernel, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, (hipStream_t)stream, acc, nsum,
-                     dst, C, Y, Z, x0, y0, z0, ys, zs, c0, cg, total);
+  if (acc_dtype == DGTTA_F32)
+    hipLaunchKernelGGL(logits_chunk_kernel<float>, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const float *)acc, nsum, dst, C, Y, Z, x0, y0, z0, ys, zs, c0, cg, total);
+  else
+    hipLaunchKernelGGL(logits_chunk_kernel<f16_t>, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const f16_t *)acc, nsum, dst, C, Y, Z, x0, y0, z0, ys, zs, c0, cg, total);
   DG_CHECK_LAUNCH("logits_chunk_kernel");
   return DGTTA_OK;
+}
+
+extern "C" int dgtta_logits_chunk_f64(const float *acc, const float *nsum, double *dst, int C, int X, int Y, int Z, int x0,
+                                      int y0, int z0, int xs, int ys, int zs, int c0, int cg, void *stream) {
+  return dgtta_logits_chunk_f64_t(acc, nsum, dst, C, X, Y, Z, x0, y0, z0, xs, ys, zs, c0, cg, DGTTA_F32, stream);
 }
 
 extern "C" int dgtta_argmax_merge_f64(const double *vals, int64_t V, int cg, int c0, double *best_val, int *best_idx,

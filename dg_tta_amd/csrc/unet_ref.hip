@@ -921,6 +921,90 @@ __global__ void argmax_dice_kernel(const float *__restrict__ logits, int ldc, in
       if (scnt[i]) atomicAdd(&counts[i], (unsigned long long)scnt[i]);
 }
 
+// argmax over the classes of voxel-major rows that are stored back to back (ldc == C: the sliding-window accumulator,
+// 105 classes x 512^3 = 56 GB).  argmax_dice_kernel reads one row per thread - 64 lanes 420 bytes apart, 0.3 TB/s; here a
+// workgroup streams 64 rows (one contiguous run, all loads in flight at once) into LDS and scans them from there: four
+// threads per row take a quarter of the classes each (odd C: rows C words apart are conflict free), combined in class
+// order with the same strict comparison, so the first maximum wins as before.
+constexpr int AR_MAXC = 112;
+constexpr int AR_RUN = (64 * AR_MAXC + 255) / 256;
+template <typename ACC>
+__global__ __launch_bounds__(256) void argmax_rows_kernel(const ACC *__restrict__ logits, int C, int64_t *__restrict__ amax,
+                                                          int64_t total) {
+  extern __shared__ float ar_tile[];          // [64][C]
+  __shared__ float pv[4][64];
+  __shared__ int pi[4][64];
+  const int vox = threadIdx.x & 63, q = threadIdx.x >> 6;
+  const int cq = (C + 3) >> 2;
+  const int64_t ntile = (total + 63) >> 6;
+  for (int64_t t = blockIdx.x; t < ntile; t += gridDim.x) {
+    const int64_t v0 = t << 6;
+    const int nv = total - v0 < 64 ? (int)(total - v0) : 64;
+    const int n = nv * C;
+    const ACC *lp = logits + v0 * C;
+    if constexpr (sizeof(ACC) == 4) {
+      float r[AR_RUN];
+#pragma unroll
+      for (int j = 0; j < AR_RUN; ++j) {
+        const int i = (int)threadIdx.x + 256 * j;
+        r[j] = i < n ? ld_f<ACC>(lp + i) : 0.f;
+      }
+      __syncthreads();                        // previous tile scanned
+#pragma unroll
+      for (int j = 0; j < AR_RUN; ++j) {
+        const int i = (int)threadIdx.x + 256 * j;
+        if (i < n) ar_tile[i] = r[j];
+      }
+    } else {
+      // 16-bit rows: two classes per 32-bit load (a tile starts at voxel 64 t: 4-byte aligned for any C); the odd last
+      // half of the last tile is read on its own - the word would reach past the end of the buffer
+      constexpr int RUN2 = (AR_RUN + 1) / 2;
+      const unsigned short *hp = reinterpret_cast<const unsigned short *>(lp);
+      unsigned r[RUN2];
+#pragma unroll
+      for (int j = 0; j < RUN2; ++j) {
+        const int i = 2 * ((int)threadIdx.x + 256 * j);
+        r[j] = i + 1 < n ? *reinterpret_cast<const unsigned *>(hp + i) : (i < n ? (unsigned)hp[i] : 0u);
+      }
+      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < RUN2; ++j) {
+        const int i = 2 * ((int)threadIdx.x + 256 * j);
+        if (i < n) ar_tile[i] = f16_to_f32((unsigned short)(r[j] & 0xffffu));
+        if (i + 1 < n) ar_tile[i + 1] = f16_to_f32((unsigned short)(r[j] >> 16));
+      }
+    }
+    __syncthreads();
+    if (vox < nv) {
+      const float *row = ar_tile + vox * C;
+      const int c0 = q * cq, c1 = min(C, c0 + cq);
+      // quarter 0 starts from class 0 as the sequential scan does; the others from "nothing yet" (-inf, replaced by
+      // anything greater), so that a NaN inside a quarter is passed over exactly as in the sequential scan
+      float bv = q == 0 ? row[0] : -__builtin_inff();
+      int best = c0 < C ? c0 : C - 1;
+      for (int c = q == 0 ? 1 : c0; c < c1; ++c)
+        if (row[c] > bv) {
+          bv = row[c];
+          best = c;
+        }
+      pv[q][vox] = bv;
+      pi[q][vox] = best;
+    }
+    __syncthreads();
+    if (threadIdx.x < (unsigned)nv) {
+      float bv = pv[0][threadIdx.x];
+      int best = pi[0][threadIdx.x];
+#pragma unroll
+      for (int k = 1; k < 4; ++k)
+        if (pv[k][threadIdx.x] > bv) {
+          bv = pv[k][threadIdx.x];
+          best = pi[k][threadIdx.x];
+        }
+      amax[v0 + threadIdx.x] = best;
+    }
+  }
+}
+
 int gs_blocks(int64_t total, int cap = 16384) {
   int64_t b = (total + 255) / 256;
   return (int)(b < cap ? (b > 0 ? b : 1) : cap);
@@ -1509,12 +1593,32 @@ extern "C" int dgtta_ndhwc_to_ncdhw(const void *src, float *dst, int B, int C, i
   return DGTTA_OK;
 }
 
+extern "C" int dgtta_argmax_rows(const void *logits, int acc_dtype, int C, int64_t rows, int64_t *argmax_out, void *stream) {
+  DG_REQUIRE(logits && argmax_out && rows > 0, DGTTA_ERR_BADARG, "argmax_rows: bad args");
+  DG_REQUIRE(C > 0 && C <= AR_MAXC, DGTTA_ERR_UNSUPPORTED, "argmax_rows: built for up to %d classes (C %d)", AR_MAXC, C);
+  DG_REQUIRE(acc_dtype == DGTTA_F32 || acc_dtype == DGTTA_F16, DGTTA_ERR_UNSUPPORTED, "argmax_rows: rows are fp32 or fp16");
+  const int64_t ntile = cdiv64(rows, 64);
+  const dim3 grid((unsigned)(ntile < 4096 ? ntile : 4096));
+  const size_t lds = (size_t)64 * C * sizeof(float);
+  if (acc_dtype == DGTTA_F32)
+    hipLaunchKernelGGL(argmax_rows_kernel<float>, grid, dim3(256), lds, (hipStream_t)stream, (const float *)logits, C, argmax_out,
+                       rows);
+  else
+    hipLaunchKernelGGL(argmax_rows_kernel<f16_t>, grid, dim3(256), lds, (hipStream_t)stream, (const f16_t *)logits, C, argmax_out,
+                       rows);
+  DG_CHECK_LAUNCH("argmax_rows_kernel");
+  return DGTTA_OK;
+}
+
 extern "C" int dgtta_argmax_dice(const float *logits, int ldc, int C, const int64_t *labels, int64_t *argmax_out,
                                  int64_t *counts, int B, int64_t V, void *stream) {
   DG_REQUIRE((logits || argmax_out) && C > 0 && C <= 1024 && (!logits || ldc >= C) && B > 0 && V > 0, DGTTA_ERR_BADARG,
              "argmax_dice: bad args");
   DG_REQUIRE(!labels || counts, DGTTA_ERR_BADARG, "argmax_dice: labels without counts");
   const int64_t total = (int64_t)B * V;
+  // back-to-back rows, no Dice counts asked for (the sliding-window label map): the streaming kernel
+  if (logits && !labels && argmax_out && ldc == C && C <= AR_MAXC && total >= 4096)
+    return dgtta_argmax_rows(logits, DGTTA_F32, C, total, argmax_out, stream);
   hipLaunchKernelGGL(argmax_dice_kernel, dim3(gs_blocks(total, 2048)), dim3(256), 3 * C * sizeof(unsigned int),
                      (hipStream_t)stream, logits, ldc, C, labels, argmax_out, (unsigned long long *)counts, total);
   DG_CHECK_LAUNCH("argmax_dice_kernel");

@@ -891,28 +891,107 @@ bool host_map_ok(const float *th, int D, int H, int W) {
 // voxels of a window row, evaluates all classes from the 64-byte feature rows (same FMA chain over the 32 channels and bias
 // add as head_fwd_lds_kernel: identical logits), scales them by the voxel's Gaussian weight into an LDS tile and adds the
 // tile to the accumulator as one contiguous run (the window row is contiguous in the volume along its last axis).
+// Round 4: the run's accumulator values (27 per thread) are requested BEFORE the logits are evaluated and held in
+// registers - the round-3 kernel read them one dependent load at a time after the barrier (a workgroup then spends ~27
+// memory round trips per tile: 0.79 ms per window where the HBM traffic of 1.9 GB asks for 0.35 ms).  ACC: storage type of
+// the accumulator - float, or f16_t (what nnU-Net's predictor keeps, 2.2.1 `predicted_logits` dtype torch.half); the sum is
+// formed in fp32 either way and rounded once per window on the way back.
 constexpr int HA_MAXC = 112;
-template <typename T>
-__global__ __launch_bounds__(256) void head_accumulate_kernel(const T *__restrict__ z, const float *__restrict__ w,
+constexpr int HA_RUN = (64 * HA_MAXC + 255) / 256;      // accumulator values per thread and tile (fp32 storage)
+constexpr int HA_RUN2 = (64 * HA_MAXC / 2 + 1 + 255) / 256;   // 32-bit words per thread and tile (fp16 storage)
+
+// One tile's run of the accumulator (n values from ap) held in registers between the early loads and the late stores.
+// fp32 storage: thread t owns values t, t + 256, ...  fp16 storage: the run is addressed as 32-bit words from the aligned
+// address at or below ap (a run starts on an odd half when its voxel offset x 105 classes is odd); a word that straddles
+// the run's first or last half is accessed as that one half only - the other half belongs to the neighbouring run, which
+// another workgroup may be updating.
+template <typename ACC>
+struct AccRun;
+template <>
+struct AccRun<float> {
+  float r[HA_RUN];
+  __device__ __forceinline__ void load(const float *ap, int n) {
+#pragma unroll
+    for (int j = 0; j < HA_RUN; ++j) {
+      const int i = (int)threadIdx.x + 256 * j;
+      r[j] = i < n ? ap[i] : 0.f;
+    }
+  }
+  __device__ __forceinline__ void add_store(float *ap, int n, const float *tile) {
+#pragma unroll
+    for (int j = 0; j < HA_RUN; ++j) {
+      const int i = (int)threadIdx.x + 256 * j;
+      if (i < n) ap[i] = r[j] + tile[i];
+    }
+  }
+};
+template <>
+struct AccRun<f16_t> {
+  unsigned r[HA_RUN2];
+  __device__ __forceinline__ void load(const f16_t *ap, int n) {
+    const int h0 = (int)(((uintptr_t)ap >> 1) & 1);
+    const unsigned short *hp = reinterpret_cast<const unsigned short *>(ap);
+#pragma unroll
+    for (int j = 0; j < HA_RUN2; ++j) {
+      const int e0 = 2 * ((int)threadIdx.x + 256 * j) - h0;        // first half of the word, relative to ap
+      const bool v0 = e0 >= 0 && e0 < n, v1 = e0 + 1 < n;
+      unsigned v = 0;
+      if (v0 && v1) v = *reinterpret_cast<const unsigned *>(hp + e0);
+      else if (v0) v = hp[e0];
+      else if (v1) v = (unsigned)hp[e0 + 1] << 16;
+      r[j] = v;
+    }
+  }
+  __device__ __forceinline__ void add_store(f16_t *ap, int n, const float *tile) {
+    const int h0 = (int)(((uintptr_t)ap >> 1) & 1);
+    unsigned short *hp = reinterpret_cast<unsigned short *>(ap);
+#pragma unroll
+    for (int j = 0; j < HA_RUN2; ++j) {
+      const int e0 = 2 * ((int)threadIdx.x + 256 * j) - h0;
+      const bool v0 = e0 >= 0 && e0 < n, v1 = e0 + 1 < n;
+      const unsigned short lo = v0 ? f32_to_f16(f16_to_f32((unsigned short)(r[j] & 0xffffu)) + tile[e0]) : (unsigned short)0;
+      const unsigned short hi = v1 ? f32_to_f16(f16_to_f32((unsigned short)(r[j] >> 16)) + tile[e0 + 1]) : (unsigned short)0;
+      if (v0 && v1) *reinterpret_cast<unsigned *>(hp + e0) = (unsigned)lo | ((unsigned)hi << 16);
+      else if (v0) hp[e0] = lo;
+      else if (v1) hp[e0 + 1] = hi;
+    }
+  }
+};
+
+template <typename T, typename ACC>
+__global__ __launch_bounds__(256) void head_accumulate_fma_kernel(const T *__restrict__ z, const float *__restrict__ w,
                                                               const float *__restrict__ bias, const float *__restrict__ gauss,
-                                                              float *__restrict__ acc, float *__restrict__ nsum, int C, int PD,
-                                                              int PH, int PW, int X, int Y, int Z, int x0, int y0, int z0) {
+                                                              ACC *__restrict__ acc, float *__restrict__ nsum, int C, int PD,
+                                                              int PH, int PW, int X, int Y, int Z, int x0, int y0, int z0,
+                                                              int abl) {
   extern __shared__ float hsm[];
-  float *sw = hsm;                          // [C][32]
-  float *sb = sw + C * HW_CIN;              // [C]
-  float *tile = sb + HA_MAXC;               // [64][C]
-  for (int i = threadIdx.x; i < C * HW_CIN; i += 256) sw[i] = w[i];
-  for (int i = threadIdx.x; i < C; i += 256) sb[i] = bias[i];
+  float *tile = hsm;                        // [64][C]
+  // the head's weights are the same for every lane of a wave (a wave = 64 voxels x one class at a time): they are read
+  // through the scalar cache (13 KB at 105 classes; constant address space + a wave-uniform class index) and enter the
+  // FMAs as scalar operands.  Round 3 staged them in LDS: a 16-byte broadcast read still moves 1 KB per wave, and 216 of
+  // them per tile and wave kept the LDS pipe busier than HBM (0.42 of the 0.79 ms per window)
+  typedef const __attribute__((address_space(4))) float *cptr_t;
+  const cptr_t wc = (cptr_t)w, bc = (cptr_t)bias;
   const int runs = (PW + 63) >> 6, nblk = PD * PH * runs;
-  const int vox = threadIdx.x & 63, grp = threadIdx.x >> 6;       // 4 class groups per voxel
-  // persistent over runs of 64 voxels: the head's weights (13 KB at 105 classes) are staged once per workgroup
+  const int vox = threadIdx.x & 63;
+  const int grp = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));       // 4 class groups per voxel
   for (int blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
     const int row = blk / runs, pw0 = (blk % runs) * 64;
     const int pd = row / PH, ph = row % PH;
     const int nv = PW - pw0 < 64 ? PW - pw0 : 64;
     const int64_t p = ((int64_t)pd * PH + ph) * PW + pw0 + vox;   // voxel inside the window
-    __syncthreads();                                              // weights staged / previous tile consumed
-    if (vox < nv) {
+    const int64_t vg = ((int64_t)(x0 + pd) * Y + (y0 + ph)) * Z + (z0 + pw0);
+    ACC *ap = acc + vg * C;
+    const int n = nv * C;
+    AccRun<ACC> run;
+    if (abl != 2) run.load(ap, n);           // (abl: timing diagnostics, DGTTA_HA_ABL - 1: no logits, 2: no accumulator traffic)
+    float ns = 0.f, gs = 0.f;
+    if (nsum && (int)threadIdx.x < nv) {
+      ns = nsum[vg + threadIdx.x];
+      gs = gauss[((int64_t)pd * PH + ph) * PW + pw0 + threadIdx.x];
+    }
+    __syncthreads();                                              // previous tile consumed
+    if (vox < nv && abl != 1) {
       float xr[HW_CIN];
       const uint4 *zr = reinterpret_cast<const uint4 *>(z + p * HW_CIN);
 #pragma unroll
@@ -921,15 +1000,173 @@ __global__ __launch_bounds__(256) void head_accumulate_kernel(const T *__restric
       for (int k = grp; k < C; k += 4) {
         float a = 0.f;
 #pragma unroll
-        for (int ci = 0; ci < HW_CIN; ++ci) a = __builtin_fmaf(xr[ci], sw[k * HW_CIN + ci], a);
-        tile[vox * C + k] = (a + sb[k]) * gq;
+        for (int ci = 0; ci < HW_CIN; ++ci) a = __builtin_fmaf(xr[ci], wc[k * HW_CIN + ci], a);
+        tile[vox * C + k] = (a + bc[k]) * gq;
       }
     }
     __syncthreads();
-    const int64_t vg = ((int64_t)(x0 + pd) * Y + (y0 + ph)) * Z + (z0 + pw0);
-    float *ap = acc + vg * C;
-    for (int i = threadIdx.x; i < nv * C; i += 256) ap[i] += tile[i];
-    if (nsum && (int)threadIdx.x < nv) nsum[vg + threadIdx.x] += gauss[((int64_t)pd * PH + ph) * PW + pw0 + threadIdx.x];
+    if (abl != 2) run.add_store(ap, n, tile);
+    if (nsum && (int)threadIdx.x < nv) nsum[vg + threadIdx.x] = ns + gs;
+  }
+}
+
+// The same on the matrix cores (round 4, the default; DGTTA_HA_MFMA=0 selects the FMA chain above).  Timed alone on one
+// 128^3 x 105 window the FMA chain needs 0.31 ms for the logits and the accumulator traffic 0.35 ms (fp32) / 0.20 ms (fp16):
+// the vector ALU, not HBM, sets the pace.  Here a wave takes 16 voxels: their feature rows are the B operand of
+// v_mfma_f32_16x16x32 as they lie in memory (lane = voxel x 8-channel chunk, one 16-byte load), the head's weights are the A
+// operand, held in registers for the life of the workgroup, and D[class][voxel] leaves 4 consecutive classes of one voxel in
+// each lane.  The weights stay fp32-exact: every fp32 weight is split into three 16-bit terms (hi + mid + lo; 3 x 8 bits of
+// bf16 significand = the 24 of fp32, exact; fp16 terms carry 3 x 11 bits but stop at 2^-24 in magnitude), 16-bit activations
+// times 16-bit terms are exact in the fp32 accumulator, so the logits differ from the FMA chain by the order of the 32-term
+// sum only (tests: <= a few 1e-7 of the row's magnitude, same labels outside float ties).
+typedef __attribute__((ext_vector_type(8))) __bf16 hw_bf16x8_t;
+typedef __attribute__((ext_vector_type(8))) _Float16 hw_f16x8_t;
+typedef __attribute__((ext_vector_type(4))) float hw_f32x4_t;
+template <typename T>
+__device__ __forceinline__ hw_f32x4_t hw_mfma(const uint4 &a, const uint4 &b, hw_f32x4_t acc);
+template <>
+__device__ __forceinline__ hw_f32x4_t hw_mfma<bf16_t>(const uint4 &a, const uint4 &b, hw_f32x4_t acc) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(hw_bf16x8_t, a), __builtin_bit_cast(hw_bf16x8_t, b), acc, 0, 0, 0);
+}
+template <>
+__device__ __forceinline__ hw_f32x4_t hw_mfma<f16_t>(const uint4 &a, const uint4 &b, hw_f32x4_t acc) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(hw_f16x8_t, a), __builtin_bit_cast(hw_f16x8_t, b), acc, 0, 0, 0);
+}
+template <typename T>
+__device__ __forceinline__ float from16(unsigned short h);
+template <>
+__device__ __forceinline__ float from16<bf16_t>(unsigned short h) { return bf16_to_f32(h); }
+template <>
+__device__ __forceinline__ float from16<f16_t>(unsigned short h) { return f16_to_f32(h); }
+
+constexpr int HA_NCG = HA_MAXC / 16;        // class groups of 16
+template <typename T, typename ACC>
+__global__ __launch_bounds__(256) void head_accumulate_kernel(const T *__restrict__ z, const float *__restrict__ w,
+                                                              const float *__restrict__ bias, const float *__restrict__ gauss,
+                                                              ACC *__restrict__ acc, float *__restrict__ nsum, int C, int PD,
+                                                              int PH, int PW, int X, int Y, int Z, int x0, int y0, int z0,
+                                                              int abl) {
+  extern __shared__ float hsm[];
+  float *tile = hsm;                        // [64][C]
+  const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int ln = lane & 15, lq = lane >> 4;
+  // wave wv evaluates class groups wv and wv + 4 for all 64 voxels of a tile (a wave per voxel group would hold all 7
+  // groups x 3 terms = 84 registers of weights and run at 2 waves per SIMD; here it is 24, at 4 waves per SIMD - the
+  // accumulator loads in flight are what keeps HBM busy).  A operand: lane = (class ln of the group, channels 8 lq .. + 7)
+  uint4 wa[2][3];
+  float bq[2][4];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int cg = wv + 4 * j;
+    const int m = cg * 16 + ln;
+    unsigned short t[3][8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const float x = m < C ? w[m * HW_CIN + lq * 8 + i] : 0.f;
+      const unsigned short h = f32_to_16<T>(x);
+      const float r1 = x - from16<T>(h);
+      const unsigned short mid = f32_to_16<T>(r1);
+      const float r2 = r1 - from16<T>(mid);
+      t[0][i] = h;
+      t[1][i] = mid;
+      t[2][i] = f32_to_16<T>(r2);
+    }
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+      wa[j][q] = make_uint4((unsigned)t[q][0] | ((unsigned)t[q][1] << 16), (unsigned)t[q][2] | ((unsigned)t[q][3] << 16),
+                            (unsigned)t[q][4] | ((unsigned)t[q][5] << 16), (unsigned)t[q][6] | ((unsigned)t[q][7] << 16));
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int k = cg * 16 + lq * 4 + r;
+      bq[j][r] = k < C ? bias[k] : 0.f;
+    }
+  }
+  const int runs = (PW + 63) >> 6, nblk = PD * PH * runs;
+  // Software pipeline over the workgroup's tiles: the accumulator run and the feature rows of tile t + 1 are requested
+  // before tile t is evaluated, so that every workgroup keeps loads in flight while its waves are in the MFMA / LDS phase
+  // (loads return in order: a wave that asked for its 27 accumulator values first and its feature rows second cannot start
+  // on the logits before the whole run has arrived - without the pipeline the phases of a workgroup run strictly one after
+  // the other, and the fp32 accumulator, whose 27 registers per thread cost a wave of occupancy, ran at 2.6-3.2 TB/s)
+  struct TilePos {
+    int nv, n;
+    int64_t prow, vg;
+  };
+  auto tile_pos = [&](int blk) {
+    const int row = blk / runs, pw0 = (blk % runs) * 64;
+    const int pd = row / PH, ph = row % PH;
+    TilePos t;
+    t.nv = PW - pw0 < 64 ? PW - pw0 : 64;
+    t.n = t.nv * C;
+    t.prow = ((int64_t)pd * PH + ph) * PW + pw0;                  // first voxel of the run inside the window
+    t.vg = ((int64_t)(x0 + pd) * Y + (y0 + ph)) * Z + (z0 + pw0); // ... and inside the volume
+    return t;
+  };
+  AccRun<ACC> run, run_n;
+  uint4 zb[4], zb_n[4];                                           // B operand: lane = (voxel 16 vgp + ln, channels 8 lq .. + 7)
+  float gq[4], gq_n[4];
+  float ns = 0.f, gs = 0.f, ns_n = 0.f, gs_n = 0.f;
+  auto fetch = [&](const TilePos &t, AccRun<ACC> &rn, uint4 *zz, float *gg, float &nss, float &gss) {
+    if (abl != 2) rn.load(acc + t.vg * C, t.n);
+    nss = 0.f;
+    gss = 0.f;
+    if (nsum && (int)threadIdx.x < t.nv) {
+      nss = nsum[t.vg + threadIdx.x];
+      gss = gauss[t.prow + threadIdx.x];
+    }
+#pragma unroll
+    for (int vgp = 0; vgp < 4; ++vgp) {
+      const int vox = vgp * 16 + ln;
+      zz[vgp] = make_uint4(0u, 0u, 0u, 0u);
+      gg[vgp] = 0.f;
+      if (vox < t.nv) {
+        zz[vgp] = *reinterpret_cast<const uint4 *>(z + (t.prow + vox) * HW_CIN + lq * 8);
+        gg[vgp] = gauss[t.prow + vox];
+      }
+    }
+  };
+  int blk = blockIdx.x;
+  if (blk < nblk) fetch(tile_pos(blk), run, zb, gq, ns, gs);
+  for (; blk < nblk; blk += gridDim.x) {
+    const TilePos t = tile_pos(blk);
+    const bool more = blk + (int)gridDim.x < nblk;
+    if (more) fetch(tile_pos(blk + gridDim.x), run_n, zb_n, gq_n, ns_n, gs_n);
+    __syncthreads();                                              // previous tile consumed
+    if (abl != 1) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int cg = wv + 4 * j;
+        if (cg * 16 < C) {                                        // wave-uniform
+#pragma unroll
+          for (int vgp = 0; vgp < 4; ++vgp) {
+            hw_f32x4_t d = {0.f, 0.f, 0.f, 0.f};
+            d = hw_mfma<T>(wa[j][2], zb[vgp], d);
+            d = hw_mfma<T>(wa[j][1], zb[vgp], d);
+            d = hw_mfma<T>(wa[j][0], zb[vgp], d);
+            const int vox = vgp * 16 + ln;
+            if (vox < t.nv) {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                const int k = cg * 16 + lq * 4 + r;
+                if (k < C) tile[vox * C + k] = (d[r] + bq[j][r]) * gq[vgp];
+              }
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();
+    if (abl != 2) run.add_store(acc + t.vg * C, t.n, tile);
+    if (nsum && (int)threadIdx.x < t.nv) nsum[t.vg + threadIdx.x] = ns + gs;
+    if (more) {
+      run = run_n;
+#pragma unroll
+      for (int vgp = 0; vgp < 4; ++vgp) {
+        zb[vgp] = zb_n[vgp];
+        gq[vgp] = gq_n[vgp];
+      }
+      ns = ns_n;
+      gs = gs_n;
+    }
   }
 }
 
@@ -1141,32 +1378,51 @@ extern "C" int dgtta_seghead_warp_bwd(const void *z, const float *gout, const fl
   return DGTTA_OK;
 }
 
-extern "C" int dgtta_seghead_window_accumulate(const void *z, const float *w, const float *bias, const float *gauss, float *acc,
-                                               float *nsum, int Cin, int C, int PD, int PH, int PW, int X, int Y, int Z, int x0,
-                                               int y0, int z0, int dtype, void *stream) {
+extern "C" int dgtta_seghead_window_accumulate_t(const void *z, const float *w, const float *bias, const float *gauss, void *acc,
+                                                 float *nsum, int Cin, int C, int PD, int PH, int PW, int X, int Y, int Z, int x0,
+                                                 int y0, int z0, int dtype, int acc_dtype, void *stream) {
   DG_REQUIRE(z && w && bias && gauss && acc, DGTTA_ERR_BADARG, "seghead_window_accumulate: null pointer");
   DG_REQUIRE(Cin == HW_CIN && C > 0 && C <= HA_MAXC && (dtype == DGTTA_BF16 || dtype == DGTTA_F16), DGTTA_ERR_UNSUPPORTED,
              "seghead_window_accumulate: built for 32 input channels, up to %d classes, 16-bit storage", HA_MAXC);
+  DG_REQUIRE(acc_dtype == DGTTA_F32 || acc_dtype == DGTTA_F16, DGTTA_ERR_UNSUPPORTED,
+             "seghead_window_accumulate: the accumulator is fp32 or fp16 (acc_dtype %d)", acc_dtype);
   DG_REQUIRE(PD > 0 && PH > 0 && PW > 0 && x0 >= 0 && y0 >= 0 && z0 >= 0 && x0 + PD <= X && y0 + PH <= Y && z0 + PW <= Z,
              DGTTA_ERR_BADARG, "seghead_window_accumulate: window outside the volume");
   DG_REQUIRE(((uintptr_t)z & 15) == 0, DGTTA_ERR_BADARG, "seghead_window_accumulate: unaligned feature map");
   const int64_t nblk = (int64_t)PD * PH * cdiv(PW, 64);
   DG_REQUIRE(nblk < (1ll << 31), DGTTA_ERR_UNSUPPORTED, "seghead_window_accumulate: too many rows");
-  const size_t lds = ((size_t)C * HW_CIN + HA_MAXC + (size_t)64 * C) * sizeof(float);
-  static DynLdsOnce once_bf, once_h;
-  if (dtype == DGTTA_BF16) {
-    DG_REQUIRE(ensure_dyn_lds(once_bf, (const void *)head_accumulate_kernel<bf16_t>, (int)lds) == hipSuccess, DGTTA_ERR_LAUNCH,
-               "seghead_window_accumulate: cannot raise the dynamic LDS limit");
-    hipLaunchKernelGGL(head_accumulate_kernel<bf16_t>, dim3((unsigned)(nblk < 2048 ? nblk : 2048)), dim3(256), lds, (hipStream_t)stream, (const bf16_t *)z,
-                       w, bias, gauss, acc, nsum, C, PD, PH, PW, X, Y, Z, x0, y0, z0);
-  } else {
-    DG_REQUIRE(ensure_dyn_lds(once_h, (const void *)head_accumulate_kernel<f16_t>, (int)lds) == hipSuccess, DGTTA_ERR_LAUNCH,
-               "seghead_window_accumulate: cannot raise the dynamic LDS limit");
-    hipLaunchKernelGGL(head_accumulate_kernel<f16_t>, dim3((unsigned)(nblk < 2048 ? nblk : 2048)), dim3(256), lds, (hipStream_t)stream, (const f16_t *)z, w,
-                       bias, gauss, acc, nsum, C, PD, PH, PW, X, Y, Z, x0, y0, z0);
-  }
+  const size_t lds = (size_t)64 * C * sizeof(float);
+  static DynLdsOnce once[8];
+  const dim3 grid((unsigned)(nblk < 2048 ? nblk : 2048));
+  hipStream_t st = (hipStream_t)stream;
+  const int abl = dgtta_switches().ha_abl == '1' ? 1 : (dgtta_switches().ha_abl == '2' ? 2 : 0);
+  const bool fma = dgtta_switches().ha_mfma == '0';
+#define HA_LAUNCH(IDX, T, ACC)                                                                                               \
+  do {                                                                                                                       \
+    const void *fn = fma ? (const void *)head_accumulate_fma_kernel<T, ACC> : (const void *)head_accumulate_kernel<T, ACC>;  \
+    DG_REQUIRE(ensure_dyn_lds(once[IDX + (fma ? 4 : 0)], fn, (int)lds) == hipSuccess, DGTTA_ERR_LAUNCH,                      \
+               "seghead_window_accumulate: cannot raise the dynamic LDS limit");                                             \
+    if (fma)                                                                                                                 \
+      hipLaunchKernelGGL((head_accumulate_fma_kernel<T, ACC>), grid, dim3(256), lds, st, (const T *)z, w, bias, gauss,       \
+                         (ACC *)acc, nsum, C, PD, PH, PW, X, Y, Z, x0, y0, z0, abl);                                         \
+    else                                                                                                                     \
+      hipLaunchKernelGGL((head_accumulate_kernel<T, ACC>), grid, dim3(256), lds, st, (const T *)z, w, bias, gauss,           \
+                         (ACC *)acc, nsum, C, PD, PH, PW, X, Y, Z, x0, y0, z0, abl);                                         \
+  } while (0)
+  if (dtype == DGTTA_BF16 && acc_dtype == DGTTA_F32) HA_LAUNCH(0, bf16_t, float);
+  else if (dtype == DGTTA_BF16) HA_LAUNCH(1, bf16_t, f16_t);
+  else if (acc_dtype == DGTTA_F32) HA_LAUNCH(2, f16_t, float);
+  else HA_LAUNCH(3, f16_t, f16_t);
+#undef HA_LAUNCH
   DG_CHECK_LAUNCH("head_accumulate_kernel");
   return DGTTA_OK;
+}
+
+extern "C" int dgtta_seghead_window_accumulate(const void *z, const float *w, const float *bias, const float *gauss, float *acc,
+                                               float *nsum, int Cin, int C, int PD, int PH, int PW, int X, int Y, int Z, int x0,
+                                               int y0, int z0, int dtype, void *stream) {
+  return dgtta_seghead_window_accumulate_t(z, w, bias, gauss, acc, nsum, Cin, C, PD, PH, PW, X, Y, Z, x0, y0, z0, dtype, DGTTA_F32,
+                                           stream);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -1175,8 +1431,9 @@ extern "C" int dgtta_seghead_window_accumulate(const void *z, const float *w, co
 //   acc[v0 + p][c] += patch[p][c] * gauss[p];   nsum[v0 + p] += gauss[p]        (voxel-major fp32 accumulators)
 // One lane per (patch voxel, channel): rows of C floats are contiguous, windows overlap only between launches.
 namespace {
+template <typename ACC>
 __global__ void window_accumulate_kernel(const float *__restrict__ patch, const float *__restrict__ gauss,
-                                         float *__restrict__ acc, float *__restrict__ nsum, int C, int PD, int PH, int PW,
+                                         ACC *__restrict__ acc, float *__restrict__ nsum, int C, int PD, int PH, int PW,
                                          int X, int Y, int Z, int x0, int y0, int z0, int64_t total) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int c = (int)(i % C);
@@ -1184,21 +1441,32 @@ __global__ void window_accumulate_kernel(const float *__restrict__ patch, const 
     const int pw = (int)(p % PW), ph = (int)((p / PW) % PH), pd = (int)(p / ((int64_t)PW * PH));
     const int64_t v = ((int64_t)(x0 + pd) * Y + (y0 + ph)) * Z + (z0 + pw);
     const float g = gauss[p];
-    acc[v * C + c] += patch[i] * g;
+    st_f<ACC>(acc + v * C + c, ld_f<ACC>(acc + v * C + c) + patch[i] * g);
     if (c == 0 && nsum) nsum[v] += g;
   }
 }
 }  // namespace
 
-extern "C" int dgtta_window_accumulate(const float *patch, const float *gauss, float *acc, float *nsum, int C, int PD, int PH,
-                                       int PW, int X, int Y, int Z, int x0, int y0, int z0, void *stream) {
+extern "C" int dgtta_window_accumulate_t(const float *patch, const float *gauss, void *acc, float *nsum, int C, int PD, int PH,
+                                         int PW, int X, int Y, int Z, int x0, int y0, int z0, int acc_dtype, void *stream) {
   DG_REQUIRE(patch && gauss && acc, DGTTA_ERR_BADARG, "window_accumulate: null pointer");
   DG_REQUIRE(C > 0 && PD > 0 && PH > 0 && PW > 0 && x0 >= 0 && y0 >= 0 && z0 >= 0 && x0 + PD <= X && y0 + PH <= Y &&
                  z0 + PW <= Z,
              DGTTA_ERR_BADARG, "window_accumulate: window outside the volume");
+  DG_REQUIRE(acc_dtype == DGTTA_F32 || acc_dtype == DGTTA_F16, DGTTA_ERR_UNSUPPORTED,
+             "window_accumulate: the accumulator is fp32 or fp16 (acc_dtype %d)", acc_dtype);
   const int64_t total = (int64_t)PD * PH * PW * C;
-  hipLaunchKernelGGL(window_accumulate_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, patch, gauss, acc,
-                     nsum, C, PD, PH, PW, X, Y, Z, x0, y0, z0, total);
+  if (acc_dtype == DGTTA_F32)
+    hipLaunchKernelGGL(window_accumulate_kernel<float>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, patch, gauss,
+                       (float *)acc, nsum, C, PD, PH, PW, X, Y, Z, x0, y0, z0, total);
+  else
+    hipLaunchKernelGGL(window_accumulate_kernel<f16_t>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, patch, gauss,
+                       (f16_t *)acc, nsum, C, PD, PH, PW, X, Y, Z, x0, y0, z0, total);
   DG_CHECK_LAUNCH("window_accumulate_kernel");
   return DGTTA_OK;
+}
+
+extern "C" int dgtta_window_accumulate(const float *patch, const float *gauss, float *acc, float *nsum, int C, int PD, int PH,
+                                       int PW, int X, int Y, int Z, int x0, int y0, int z0, void *stream) {
+  return dgtta_window_accumulate_t(patch, gauss, acc, nsum, C, PD, PH, PW, X, Y, Z, x0, y0, z0, DGTTA_F32, stream);
 }

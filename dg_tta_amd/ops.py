@@ -347,6 +347,18 @@ def argmax_dice(logits, labels=None):
     return am, counts
 
 
+def argmax_rows(acc):
+    """Label map of a voxel-major accumulator [..., C] (fp32 or fp16, contiguous): argmax over the last axis, int64."""
+    require_cuda(acc)
+    if acc.dtype not in (torch.float32, torch.float16) or not acc.is_contiguous():
+        raise ValueError("argmax_rows: contiguous fp32 / fp16 rows expected")
+    lib = _lib.load()
+    out = torch.empty(acc.shape[:-1], dtype=torch.int64, device=acc.device)
+    check(lib.dgtta_argmax_rows(ptr(acc), F32 if acc.dtype == torch.float32 else F16, acc.shape[-1], out.numel(), ptr(out),
+                                stream_of(acc.device)), "dgtta_argmax_rows")
+    return out
+
+
 def argmax_dice_from_labels(pred, labels, num_classes):
     """Per-label counts for two integer label maps (dice_coeff, torch_utils.py:107-117): counts [3,C] int64."""
     require_cuda(pred, labels)

@@ -6,9 +6,10 @@ inference_allowed_mirroring_axes=None, nnUNetTrainer_GIN_MIND.py:34-35).
 
 The window logic is a restatement of nnunetv2==2.2.1 (`compute_gaussian`, `compute_steps_for_sliding_window`,
 `predict_sliding_window_return_logits`) from its published behaviour: that package is not vendored with the reference, so
-this stage is "parity unpinned" (checked against the CPU restatement in oracle/inference.py only).  Accumulators are
-fp32 and live in HBM for the whole volume (105 classes x 512^3 = 56 GB fits the 288 GB of an MI355X), where nnU-Net
-uses fp16.  `export_segmentation` takes the logits back to the case's original geometry.
+this stage is "parity unpinned" (checked against the CPU restatement in oracle/inference.py only).  Accumulators live
+in HBM for the whole volume (105 classes x 512^3 = 56 GB in fp32 fits the 288 GB of an MI355X); they are fp32 by default
+and fp16 - nnU-Net's storage type for `predicted_logits` - with DGTTA_WINDOW_ACC=fp16 or `acc_dtype=torch.float16` (sums
+still formed in fp32, rounded once per window: half the read-modify-write traffic).  `export_segmentation` takes the logits back to the case's original geometry.
 """
 import numpy as np
 import torch
@@ -74,6 +75,20 @@ import os as _os
 WINDOW_BATCH = max(1, int(_os.environ.get("DGTTA_WINDOW_BATCH", "8")))      # measured at 512^3: 2 / 4 / 8 / 16 windows per pass = 3.26 / 3.14 / 3.07 / 3.03 ms per window
 
 
+def window_acc_dtype():
+    """Storage type of the window accumulator: DGTTA_WINDOW_ACC = fp32 (default) | fp16."""
+    v = _os.environ.get("DGTTA_WINDOW_ACC", "fp32").lower()
+    if v not in ("fp32", "fp16"):
+        raise ValueError(f"DGTTA_WINDOW_ACC={v!r}: fp32 or fp16")
+    return torch.float32 if v == "fp32" else torch.float16
+
+
+def _acc_code(acc):
+    if acc.dtype not in (torch.float32, torch.float16):
+        raise ValueError("the window accumulator is fp32 or fp16")
+    return ops.F32 if acc.dtype == torch.float32 else ops.F16
+
+
 def _inner(model):
     return getattr(model, "_orig_mod", model)
 
@@ -98,9 +113,12 @@ def _can_fuse_head_accumulate(model):
 
 
 @torch.no_grad()
-def predict_sliding_window_return_logits(model, data, patch_size, acc=None, tile_step_size=0.5):
-    """data [C,X,Y,Z] (CPU or GPU) -> accumulates gauss-weighted logits of `model` into acc [X,Y,Z,ncls] (fp32, GPU).
+def predict_sliding_window_return_logits(model, data, patch_size, acc=None, tile_step_size=0.5, acc_dtype=None):
+    """data [C,X,Y,Z] (CPU or GPU) -> accumulates gauss-weighted logits of `model` into acc [X,Y,Z,ncls] (GPU; fp32 or
+    fp16: the dtype of a given `acc`, else `acc_dtype`, else window_acc_dtype()).
     Returns (acc, nsum, crop) ; logits = acc / nsum[..., None] cropped by `crop`."""
+    if acc_dtype is None:
+        acc_dtype = acc.dtype if acc is not None else window_acc_dtype()
     lib = _lib.load()
     dev = next(model.parameters()).device
     data, crop = pad_to_patch(data.float(), patch_size)
@@ -124,7 +142,7 @@ def predict_sliding_window_return_logits(model, data, patch_size, acc=None, tile
         if _can_fuse_head_accumulate(model):
             # the head evaluates straight into the accumulator (the windows' logits - 880 MB each at 128^3 x 105 - are not written)
             if acc is None:
-                acc = torch.zeros((X, Y, Z, _num_classes(model)), dtype=torch.float32, device=dev)
+                acc = torch.zeros((X, Y, Z, _num_classes(model)), dtype=acc_dtype, device=dev)
             with mind_groups(model, len(group)), _inner(model).fuse_window_accumulate(acc, nsum, gauss, group):
                 model(work)
             continue
@@ -135,10 +153,10 @@ def predict_sliding_window_return_logits(model, data, patch_size, acc=None, tile
         out = out.float().contiguous(memory_format=torch.channels_last_3d)        # [n,C,P] stored voxel-major
         ncls = out.shape[1]
         if acc is None:
-            acc = torch.zeros((X, Y, Z, ncls), dtype=torch.float32, device=dev)
+            acc = torch.zeros((X, Y, Z, ncls), dtype=acc_dtype, device=dev)
         for k, (sx, sy, sz) in enumerate(group):       # overlapping windows: accumulated one after the other
-            check(lib.dgtta_window_accumulate(ptr(out[k]), ptr(gauss), ptr(acc), ptr(nsum), ncls, *patch_size, X, Y, Z, sx,
-                                              sy, sz, stream_of(dev)), "dgtta_window_accumulate")
+            check(lib.dgtta_window_accumulate_t(ptr(out[k]), ptr(gauss), ptr(acc), ptr(nsum), ncls, *patch_size, X, Y, Z, sx,
+                                                sy, sz, _acc_code(acc), stream_of(dev)), "dgtta_window_accumulate_t")
     model.train(was_training)
     return acc, nsum, crop
 
@@ -204,12 +222,10 @@ def export_segmentation(acc, nsum, crop, properties, plans, configuration):
     (x0, xs), (y0, ys), (z0, zs) = cs
     cur_shape = [xs, ys, zs]
     if properties is None:
-        seg, _ = ops.argmax_dice(acc.permute(3, 0, 1, 2)[None])
-        return seg[0][tuple(crop)].cpu().numpy()
+        return ops.argmax_rows(acc)[tuple(crop)].cpu().numpy()
     tgt_shape = [int(v) for v in properties["shape_after_cropping_and_before_resampling"]]
     if tgt_shape == cur_shape:
-        seg, _ = ops.argmax_dice(acc.permute(3, 0, 1, 2)[None])
-        seg = seg[0][tuple(crop)].cpu().numpy()
+        seg = ops.argmax_rows(acc)[tuple(crop)].cpu().numpy()
     else:
         conf = _resolved_configuration(plans, configuration)
         cur_spacing = list(conf["spacing"])
@@ -226,8 +242,8 @@ def export_segmentation(acc, nsum, crop, properties, plans, configuration):
         for c0 in range(0, C, EXPORT_CLASS_GROUP):
             cg = min(EXPORT_CLASS_GROUP, C - c0)
             cur = torch.empty((xs, ys, zs, cg), dtype=torch.float64, device=dev)
-            check(lib.dgtta_logits_chunk_f64(ptr(acc), ptr(nsum), ptr(cur), C, X, Y, Z, x0, y0, z0, xs, ys, zs, c0, cg, st),
-                  "dgtta_logits_chunk_f64")
+            check(lib.dgtta_logits_chunk_f64_t(ptr(acc), ptr(nsum), ptr(cur), C, X, Y, Z, x0, y0, z0, xs, ys, zs, c0, cg,
+                                               _acc_code(acc), st), "dgtta_logits_chunk_f64_t")
             for ax in range(3):          # channels-last: the class group rides in `inner` of every pass
                 n, m = cur.shape[ax], tgt_shape[ax]
                 if n == m:

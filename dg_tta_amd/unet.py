@@ -396,9 +396,10 @@ class _UNetFn(torch.autograd.Function):
             acc, nsum, gauss, origins = wa
             X, Y, Z = acc.shape[:3]
             for k, (sx, sy, sz) in enumerate(origins):      # overlapping windows: accumulated one after the other
-                check(lib.dgtta_seghead_window_accumulate(u_ptr + k * V * ldu * esz, ptr(head.weight), ptr(head.bias), ptr(gauss),
-                                                          ptr(acc), ptr(nsum), head.in_channels, ncls, D, H, W, X, Y, Z, sx, sy,
-                                                          sz, dt, st), "dgtta_seghead_window_accumulate")
+                check(lib.dgtta_seghead_window_accumulate_t(u_ptr + k * V * ldu * esz, ptr(head.weight), ptr(head.bias),
+                                                            ptr(gauss), ptr(acc), ptr(nsum), head.in_channels, ncls, D, H, W, X,
+                                                            Y, Z, sx, sy, sz, dt, F32 if acc.dtype == torch.float32 else F16, st),
+                      "dgtta_seghead_window_accumulate_t")
             return torch.empty((B, 0, D, H, W), dtype=torch.float32, device=dev)
         out = torch.empty((B, D, H, W, nsel), dtype=torch.float32, device=dev)
         fw = net._fused_warp

@@ -278,6 +278,20 @@ int dgtta_seghead_window_accumulate(const void *z, const float *w, const float *
                                     float *nsum, int Cin, int C, int PD, int PH, int PW, int X, int Y, int Z, int x0, int y0,
                                     int z0, int dtype, void *stream);
 
+/* The accumulator's storage type as a parameter (round 4): acc_dtype DGTTA_F32 or DGTTA_F16.  nnU-Net's predictor keeps
+ * `predicted_logits` in torch.half (nnunetv2==2.2.1 predict_sliding_window_return_logits); with DGTTA_F16 the sum is formed
+ * in fp32 and rounded to half once per window and voxel - half the HBM traffic of the read-modify-write and half the 52.5 GiB
+ * of a 105-class 512^3 volume.  nsum stays fp32.  The functions above are these with DGTTA_F32. */
+int dgtta_window_accumulate_t(const float *patch, const float *gauss, void *acc, float *nsum, int C, int PD, int PH, int PW,
+                              int X, int Y, int Z, int x0, int y0, int z0, int acc_dtype, void *stream);
+int dgtta_seghead_window_accumulate_t(const void *z, const float *w, const float *bias, const float *gauss, void *acc,
+                                      float *nsum, int Cin, int C, int PD, int PH, int PW, int X, int Y, int Z, int x0, int y0,
+                                      int z0, int dtype, int acc_dtype, void *stream);
+/* argmax over the C <= 112 classes of `rows` voxel-major rows stored back to back (fp32 or fp16): the label map of the
+ * window accumulator (nnU-Net's convert_predicted_logits_to_segmentation..., argmax over ALL pretrain classes,
+ * dg_tta/tta/tta.py:404-413).  First maximum wins (dgtta_argmax_dice routes here when it can). */
+int dgtta_argmax_rows(const void *logits, int acc_dtype, int C, int64_t rows, int64_t *argmax_out, void *stream);
+
 /* One-axis spline resampling (order 0 / 1 / 3) with the coordinate rule and boundary handling of
  * skimage.transform.resize(mode='edge', anti_aliasing=False) = scipy.ndimage.zoom(mode='nearest', grid_mode=True), which is
  * what nnU-Net's DefaultPreprocessor resamples with (third-party nnunetv2==2.2.1, reached from preprocess_fromfile,
@@ -298,6 +312,8 @@ int dgtta_logits_chunk_f64(const float *acc, const float *nsum, double *dst, int
                            int z0, int xs, int ys, int zs, int c0, int cg, void *stream);
 int dgtta_argmax_merge_f64(const double *vals, int64_t V, int cg, int c0, double *best_val, int *best_idx, int first,
                            void *stream);
+int dgtta_logits_chunk_f64_t(const void *acc, const float *nsum, double *dst, int C, int X, int Y, int Z, int x0, int y0,
+                             int z0, int xs, int ys, int zs, int c0, int cg, int acc_dtype, void *stream);
 
 #ifdef __cplusplus
 }

@@ -106,12 +106,83 @@ def test_sliding_window_at_size_properties():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("acc_dtype", [torch.float32, torch.float16])
+@pytest.mark.parametrize("C,rows", [(105, 64 * 40 + 17), (105, 4096), (16, 5000), (2, 4100), (112, 129), (7, 63)])
+def test_argmax_rows_first_maximum_wins(C, rows, acc_dtype):
+    """Round 4: the streaming label-map kernel (dgtta_argmax_rows; dgtta_argmax_dice routes to it for back-to-back rows)
+    against a sequential first-maximum scan: ties (duplicated maxima in different quarters of the class range), -inf rows,
+    NaNs anywhere but class 0 (passed over, as the strict comparison of the one-thread-per-row kernel does), ragged tail."""
+    from dg_tta_amd import ops
+    g = torch.Generator().manual_seed(C * 1000 + rows)
+    x = torch.randn(rows, C, generator=g)
+    x = (x * 4).round() / 4                                     # many exact ties
+    x[3] = float("-inf")
+    x[5, :] = 1.0
+    if C > 4:
+        x[7, C // 2] = float("nan")
+        x[8, C - 1] = float("nan")
+        x[9, (C + 3) // 4] = float("nan")                       # first class of the second quarter
+        x[9, (C + 3) // 4 + 1] = 100.0
+    x = x.to(acc_dtype)
+    ref = torch.zeros(rows, dtype=torch.int64)
+    xf = x.float()
+    bv = xf[:, 0].clone()
+    for c in range(1, C):
+        take = xf[:, c] > bv
+        bv = torch.where(take, xf[:, c], bv)
+        ref = torch.where(take, torch.full_like(ref, c), ref)
+    out = ops.argmax_rows(x.to(DEV))
+    assert out.dtype == torch.int64 and torch.equal(out.cpu(), ref)
+    if acc_dtype == torch.float32 and rows >= 4096:             # the routed entry point
+        am, _ = ops.argmax_dice(x.to(DEV).reshape(1, rows, 1, 1, C).permute(0, 4, 1, 2, 3))
+        assert torch.equal(am.reshape(-1).cpu(), ref)
+
+
+@pytest.mark.gpu
+def test_fp16_window_accumulator_against_fp32():
+    """Round 4: DGTTA_WINDOW_ACC=fp16 / acc_dtype=torch.float16 (nnU-Net's storage type for predicted_logits): the same
+    windows accumulated in half storage (sum in fp32, rounded once per window) stay within half rounding of the fp32
+    accumulator - at most 8 overlapping windows, each rounding <= 2^-11 relative to the running sum - and give the same labels
+    wherever the top-2 margin exceeds that bound; export_segmentation reads either storage type."""
+    from dg_tta_amd.mind import MIND3D
+    from dg_tta_amd.synthetic import he_init_
+    from dg_tta_amd.tta.inference import export_segmentation, predict_sliding_window_return_logits
+    from dg_tta_amd.unet import HipPlainConvUNet
+    net = he_init_(HipPlainConvUNet(act_dtype=torch.bfloat16), seed=7)
+    net.decoder.seg_layers[-1].bias.data.normal_()
+    net.register_forward_pre_hook(lambda mod, inp: MIND3D(randn_weighting=0.0).forward(*inp, out_dtype=torch.bfloat16))
+    net = net.to(DEV)
+    torch.manual_seed(4)
+    vol = torch.randn(1, 96, 64, 150)
+    patch = [64, 64, 64]
+    a32, n32, crop = predict_sliding_window_return_logits(net, vol, patch, acc_dtype=torch.float32)
+    a16, n16, _ = predict_sliding_window_return_logits(net, vol, patch, acc_dtype=torch.float16)
+    assert a16.dtype == torch.float16 and a32.dtype == torch.float32 and torch.equal(n16, n32)
+    err = (a16.float() - a32).abs()
+    # every partial sum of a voxel is at most nsum x (the largest |logit| of the volume): <= 8 roundings of 2^-11 of that
+    lmax = float((a32.abs() / n32[..., None]).max())
+    bound = (8 * 2.0 ** -11 * lmax * n32 + 1e-6)[..., None].expand_as(a32)
+    assert bool((err <= bound).all()), float((err / bound).max())
+    assert float(err.mean()) < 2.0 ** -11 * float(a32.abs().mean())        # and typically one rounding of the final value
+    s32 = export_segmentation(a32, n32, crop, None, None, None)
+    s16 = export_segmentation(a16, n16, crop, None, None, None)
+    top2 = a32.topk(2, dim=-1).values
+    safe = ((top2[..., 0] - top2[..., 1]) > 2 * bound.max(-1).values).cpu().numpy()
+    assert (s16[safe] == s32[safe]).all() and (s16 == s32).mean() > 0.995 and safe.mean() > 0.5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("acc_dtype", [torch.float32, torch.float16])
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
-def test_head_fused_with_the_window_accumulation_is_bit_identical(dtype, monkeypatch):
+def test_head_fused_with_the_window_accumulation_is_bit_identical(dtype, acc_dtype, monkeypatch):
     """Round 3: dgtta_seghead_window_accumulate (the head evaluates straight into the Gaussian window accumulator; a
     window's 105-class logits are never written) against head + dgtta_window_accumulate (DGTTA_FUSE_HEAD_ACCUMULATE=0) on
-    the full net, through the product's run_inference with the plan's model-output hook in place: same FMA chain, same
-    accumulation order -> torch.equal accumulators, weight maps and label maps (overlapping windows, ragged last step)."""
+    the full net, through the product's run_inference with the plan's model-output hook in place.  With the FMA-chain
+    kernel (DGTTA_HA_MFMA=0): same chain, same accumulation order -> torch.equal accumulators, weight maps and label maps
+    (overlapping windows, ragged last step).  The default kernel evaluates the head on the matrix cores with fp32-exact
+    three-term weights: the 32-term sums are associated differently - a few 1e-7 of the logits' magnitude, same labels
+    outside float ties (round 4)."""
+    from conftest import reload_kernel_switches
     from types import SimpleNamespace
     from dg_tta_amd.mind import mind_hook
     from dg_tta_amd.synthetic import he_init_
@@ -127,18 +198,32 @@ def test_head_fused_with_the_window_accumulation_is_bit_identical(dtype, monkeyp
     vol = torch.randn(1, 96, 64, 150)
     patch = [64, 64, 64]
     outs = {}
-    for flag in ("1", "0"):
-        monkeypatch.setenv("DGTTA_FUSE_HEAD_ACCUMULATE", flag)
+    monkeypatch.setenv("DGTTA_WINDOW_ACC", "fp16" if acc_dtype == torch.float16 else "fp32")
+    for flag in ("1", "0", "mfma"):
+        monkeypatch.setenv("DGTTA_FUSE_HEAD_ACCUMULATE", "0" if flag == "0" else "1")
+        monkeypatch.setenv("DGTTA_HA_MFMA", "1" if flag == "mfma" else "0")
+        reload_kernel_switches()
         with torch.no_grad():
-            assert _can_fuse_head_accumulate(model) == (flag == "1")
+            assert _can_fuse_head_accumulate(model) == (flag != "0")
         torch.manual_seed(9)                               # MIND noise of the windows: same draws in both runs
         acc, nsum, crop = predict_sliding_window_return_logits(model, vol, patch)
         torch.manual_seed(9)
         seg = run_inference(vol, model, [model.state_dict()], patch)
         outs[flag] = (acc.clone(), nsum.clone(), seg)
-    assert tuple(outs["1"][0].shape) == (96, 64, 150, 105)
+    assert tuple(outs["1"][0].shape) == (96, 64, 150, 105) and outs["1"][0].dtype == acc_dtype
     assert torch.equal(outs["1"][0], outs["0"][0]) and torch.equal(outs["1"][1], outs["0"][1])
     assert torch.equal(outs["1"][2], outs["0"][2]) and len(outs["1"][2].unique()) > 10
+    a_m, n_m, seg_m = outs["mfma"]
+    a_r = outs["0"][0].float()
+    assert torch.equal(n_m, outs["0"][1])
+    lmax = float((a_r.abs() / n_m[..., None]).max())
+    tol = (2e-6 if acc_dtype == torch.float32 else 8 * 2.0 ** -11) * lmax * n_m[..., None] + 1e-6      # fp16 storage: a rounding per window may flip; subnormal halves at the window rim
+    assert bool(((a_m.float() - a_r).abs() <= tol).all())
+    if acc_dtype == torch.float32:
+        assert float((a_m - a_r).abs().max()) > 0        # (it IS the other kernel)
+    top2 = a_r.topk(2, dim=-1).values
+    safe = ((top2[..., 0] - top2[..., 1]) > 2 * tol[..., 0]).cpu()
+    assert torch.equal(seg_m[safe], outs["0"][2][safe]) and (seg_m == outs["0"][2]).float().mean() > 0.999
     # a user's model-output modifier in front of the accumulation switches the fusion off
     class Mods(ModifierFunctions):
         @staticmethod

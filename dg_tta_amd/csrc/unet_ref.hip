@@ -261,12 +261,18 @@ __global__ __launch_bounds__(256) void chan_reduce_vec_kernel(const T *__restric
     const T *gb = (MODE == 1) ? gz + (int64_t)b * V * ldgz + cg * EPV : nullptr;
     for (int64_t r = (int64_t)blockIdx.x * (2 * rpi) + rg; r < r1; r += (int64_t)gridDim.x * (2 * rpi)) {
       const bool two = r + rpi < r1;
-      uint4 v0 = *reinterpret_cast<const uint4 *>(yb + r * ldy), v1 = make_uint4(0, 0, 0, 0);
+      // streaming loads, as in the apply passes (the tensors are far larger than the caches and are read once per pass)
+      typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+      auto ldnt = [](const T *p) {
+        const u32x4_t v = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t *>(p));
+        return make_uint4(v[0], v[1], v[2], v[3]);
+      };
+      uint4 v0 = ldnt(yb + r * ldy), v1 = make_uint4(0, 0, 0, 0);
       uint4 g0 = make_uint4(0, 0, 0, 0), g1 = g0;
-      if (two) v1 = *reinterpret_cast<const uint4 *>(yb + (r + rpi) * ldy);
+      if (two) v1 = ldnt(yb + (r + rpi) * ldy);
       if (MODE == 1) {
-        g0 = *reinterpret_cast<const uint4 *>(gb + r * ldgz);
-        if (two) g1 = *reinterpret_cast<const uint4 *>(gb + (r + rpi) * ldgz);
+        g0 = ldnt(gb + r * ldgz);
+        if (two) g1 = ldnt(gb + (r + rpi) * ldgz);
       }
 #pragma unroll
       for (int k = 0; k < 2; ++k) {

@@ -21,7 +21,7 @@ void dgtta_set_error(const char *fmt, ...);
 struct DgttaSwitches {
   int conv_rows, conv_variant, conv_s2, dgrad_s2_allcls, wgrad_tr, wgrad_tr8, wgrad_s2_onepass, convt_wgrad_onepass;
   int conv_abl, rows_abl, wgrad_abl;
-  int convt_gemm, rows_order, in_nt, wgrad_upw, wgrad_xcd, rows_var, warp_coop, warp_nt, warp_xcd, in_gstats, softdice16, conv_ring, ring_nt, ring_abl, wgrad_ring, ha_abl, ha_mfma;
+  int convt_gemm, rows_order, in_nt, wgrad_upw, wgrad_xcd, rows_var, warp_coop, warp_nt, warp_xcd, in_gstats, softdice16, conv_ring, ring_nt, ring_abl, wgrad_ring, ha_abl, ha_mfma, warp_abl;
 };
 const DgttaSwitches &dgtta_switches();
 

@@ -57,6 +57,7 @@ static const DgttaSwitches *read_switches() {
   s->wgrad_ring = env_char("DGTTA_WGRAD_RING");
   s->ha_abl = env_char("DGTTA_HA_ABL");
   s->ha_mfma = env_char("DGTTA_HA_MFMA");
+  s->warp_abl = env_char("DGTTA_WARP_ABL");
   return s;
 }
 

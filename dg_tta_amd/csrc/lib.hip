@@ -11,7 +11,7 @@ void dgtta_set_error(const char *fmt, ...) {
   va_end(ap);
 }
 
-extern "C" int dgtta_version(void) { return 30000; /* 3.0.0: adamw_step(skip_if_nonzero), grads_nonfinite, export kernels */ }
+extern "C" int dgtta_version(void) { return 40000; /* 4.0.0: accumulator storage type (window_accumulate_t, seghead_window_accumulate_t, logits_chunk_f64_t), argmax_rows */ }
 extern "C" const char *dgtta_last_error(void) { return g_err; }
 
 // ---------------------------------------------------------------- environment switches (snapshot, see common.h)

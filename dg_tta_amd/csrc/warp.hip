@@ -629,11 +629,11 @@ __device__ __forceinline__ void unpack8_16(const uint4 &v, float *f) {
   for (int i = 0; i < 4; ++i) unpack2_16<T>(w[i], f[2 * i], f[2 * i + 1]);
 }
 
-template <typename T>
+template <typename T, bool ABL = false>
 __global__ __launch_bounds__(256) void head_warp_fwd_kernel(const T *__restrict__ z, const float *__restrict__ theta,
                                                             const float *__restrict__ w, const float *__restrict__ bias,
                                                             const int *__restrict__ sel, int nsel, float *__restrict__ out,
-                                                            int D, int H, int W, int algebra, int gx, int gy, int abl) {
+                                                            int D, int H, int W, int algebra, int gx, int gy) {
   __shared__ float sw[HW_NS * HW_CIN];
   __shared__ float sb[HW_NS];
   for (int i = threadIdx.x; i < HW_NS * HW_CIN; i += 256) {
@@ -662,7 +662,7 @@ __global__ __launch_bounds__(256) void head_warp_fwd_kernel(const T *__restrict_
         const int xx = cr.x0 + (k & 1), yy = cr.y0 + ((k >> 1) & 1), zz = cr.z0 + (k >> 2);
         if ((unsigned)xx < (unsigned)W && (unsigned)yy < (unsigned)H && (unsigned)zz < (unsigned)D) {
           // (abl: timing diagnostic DGTTA_WARP_ABL=1 - every corner read lands in a 2 x 4 x 16-voxel block that stays in L1)
-          const int64_t sv = abl ? (((int64_t)(zz & 1) * H + (yy & 3)) * W + (xx & 15)) : (((int64_t)zz * H + yy) * W + xx);
+          const int64_t sv = ABL ? (((int64_t)(zz & 1) * H + (yy & 3)) * W + (xx & 15)) : (((int64_t)zz * H + yy) * W + xx);
           const uint4 t = *reinterpret_cast<const uint4 *>(zb + sv * HW_CIN + g * 8);
           float f[8];
           unpack8_16<T>(t, f);
@@ -714,12 +714,12 @@ __device__ __forceinline__ uint4 pack8_16(const float *f) {
 // backward: one thread owns one voxel of the feature-map lattice; candidate search and accumulation exactly as
 // warp_bwd_gather_kernel<16, true> (same order), then d16 = 16-bit copy of the gathered logit gradient (operand of the
 // head's MFMA weight gradient), gz = W^T acc in the network's storage type, and the block's partial sums for the bias gradient
-template <typename T>
+template <typename T, bool ABL = false>
 __global__ __launch_bounds__(256, 6) void head_warp_bwd_kernel(const float *__restrict__ gdst, const float *__restrict__ theta,
                                                             const float *__restrict__ w, const int *__restrict__ sel,
                                                             int nsel, T *__restrict__ gz, unsigned short *__restrict__ d16,
                                                             double *__restrict__ bias_partial, int D, int H, int W,
-                                                            int algebra, int gx, int gy, int abl) {
+                                                            int algebra, int gx, int gy) {
   __shared__ float sw[HW_NS * HW_CIN];
   __shared__ InvMap s_im;
   __shared__ float sred[4][HW_NS];
@@ -785,7 +785,7 @@ __global__ __launch_bounds__(256, 6) void head_warp_bwd_kernel(const float *__re
           const float wy = dy == 0.f ? (fy + 1.0f) - s.iy : s.iy - fy;
           const float wz = dz == 0.f ? (fz + 1.0f) - s.iz : s.iz - fz;
           const float wt = wx * wy * wz;
-          const float *gp = gdst + (abl ? (((int64_t)(d & 1) * H + (h & 3)) * W + (wq & 15)) * nsel
+          const float *gp = gdst + (ABL ? (((int64_t)(d & 1) * H + (h & 3)) * W + (wq & 15)) * nsel
                                         : ((int64_t)b * V + ((int64_t)d * H + h) * W + wq) * nsel);
 #pragma unroll
           for (int q = 0; q < HW_NS; q += 4) {
@@ -1330,12 +1330,18 @@ extern "C" int dgtta_seghead_warp_fwd(const void *z, const float *w, const float
   const int gx = cdiv(W * 4, 256), gy = cdiv(H, WARP_ROWS);
   const int64_t nblk = (int64_t)gx * gy * D * B;
   DG_REQUIRE(nblk < (1ll << 31), DGTTA_ERR_UNSUPPORTED, "seghead_warp_fwd: too many tiles");
-  if (dtype == DGTTA_BF16)
-    hipLaunchKernelGGL(head_warp_fwd_kernel<bf16_t>, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, (const bf16_t *)z,
-                       theta, w, bias, sel, nsel, out, D, H, W, tta_grid_algebra, gx, gy, dgtta_switches().warp_abl == '1');
-  else
-    hipLaunchKernelGGL(head_warp_fwd_kernel<f16_t>, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, (const f16_t *)z,
-                       theta, w, bias, sel, nsel, out, D, H, W, tta_grid_algebra, gx, gy, dgtta_switches().warp_abl == '1');
+  const bool abl = dgtta_switches().warp_abl == '1';          // timing diagnostic: results wrong by construction
+#define HWF_LAUNCH(T, A)                                                                                                   \
+  hipLaunchKernelGGL((head_warp_fwd_kernel<T, A>), dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, (const T *)z, \
+                     theta, w, bias, sel, nsel, out, D, H, W, tta_grid_algebra, gx, gy)
+  if (dtype == DGTTA_BF16) {
+    if (abl) HWF_LAUNCH(bf16_t, true);
+    else HWF_LAUNCH(bf16_t, false);
+  } else {
+    if (abl) HWF_LAUNCH(f16_t, true);
+    else HWF_LAUNCH(f16_t, false);
+  }
+#undef HWF_LAUNCH
   DG_CHECK_LAUNCH("head_warp_fwd_kernel");
   return DGTTA_OK;
 }
@@ -1362,12 +1368,18 @@ extern "C" int dgtta_seghead_warp_bwd(const void *z, const float *gout, const fl
   const int gx = cdiv(W, 16), gy = cdiv(H, 4);
   const int64_t nblk = (int64_t)gx * gy * cdiv(D, 4) * B;
   DG_REQUIRE(nblk < (1ll << 31), DGTTA_ERR_UNSUPPORTED, "seghead_warp_bwd: too many tiles");
-  if (dtype == DGTTA_BF16)
-    hipLaunchKernelGGL(head_warp_bwd_kernel<bf16_t>, dim3((unsigned)nblk), dim3(256), 0, st, gout, theta, w, sel, nsel,
-                       (bf16_t *)gz, d16, db_sel ? bias_partial : nullptr, D, H, W, tta_grid_algebra, gx, gy, dgtta_switches().warp_abl == '1');
-  else
-    hipLaunchKernelGGL(head_warp_bwd_kernel<f16_t>, dim3((unsigned)nblk), dim3(256), 0, st, gout, theta, w, sel, nsel,
-                       (f16_t *)gz, d16, db_sel ? bias_partial : nullptr, D, H, W, tta_grid_algebra, gx, gy, dgtta_switches().warp_abl == '1');
+  const bool abl = dgtta_switches().warp_abl == '1';          // timing diagnostic: results wrong by construction
+#define HWB_LAUNCH(T, A)                                                                                                  \
+  hipLaunchKernelGGL((head_warp_bwd_kernel<T, A>), dim3((unsigned)nblk), dim3(256), 0, st, gout, theta, w, sel, nsel,   \
+                     (T *)gz, d16, db_sel ? bias_partial : nullptr, D, H, W, tta_grid_algebra, gx, gy)
+  if (dtype == DGTTA_BF16) {
+    if (abl) HWB_LAUNCH(bf16_t, true);
+    else HWB_LAUNCH(bf16_t, false);
+  } else {
+    if (abl) HWB_LAUNCH(f16_t, true);
+    else HWB_LAUNCH(f16_t, false);
+  }
+#undef HWB_LAUNCH
   DG_CHECK_LAUNCH("head_warp_bwd_kernel");
   if (dw_sel) {
     const int rc = head_wgrad_mfma(z, Cin, nullptr, nsel, dw_sel, ws_main, main_bytes, Cin, nsel, rows, accumulate, dtype, st, true);

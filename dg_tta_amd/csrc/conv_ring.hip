@@ -484,9 +484,7 @@ __global__ __launch_bounds__(RingCfgT<KH>::NT) void conv3_ring_kernel(const bf16
       }
     };
     typedef std::integral_constant<int, 0> I0;
-    typedef std::integral_constant<int, 7> I7;
     typedef std::integral_constant<int, 16> I16;
-    typedef std::integral_constant<int, -1> IM1;
 
     lds_barrier();      // every wave is done with the previous job's planes
     if (ABL == 6) tprev = __builtin_amdgcn_s_memtime();

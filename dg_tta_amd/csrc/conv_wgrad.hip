@@ -152,7 +152,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void conv3_wgrad_mfm
   x += wc.xoff[cls];
   dy += wc.yoff[cls];
   const unsigned tapmask = wc.mask[cls];
-  const int D = yv.D, H = yv.H, W = yv.W;
+  const int D = yv.D;
   typedef WG<T> C;
   constexpr int EPV = C::EPV;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -680,7 +680,6 @@ struct WT2 {
   static constexpr int NXS = 5;                         // x ring slots
   static constexpr int LDS_BYTES = NXS * X_SLICE_B + 2 * Y_SLICE_B;
   static constexpr int NPX1 = XR * 3;                   // DMA pieces per x slice (16 + 16 + 1 voxels per row)
-  static constexpr int NP = 2 * NPX1 + TH;              // pieces per output slice: two x slices + one dy slice
 };
 
 template <typename T16 = bf16_t>

@@ -343,7 +343,6 @@ __device__ __forceinline__ float quad_softmax4(const float4 &x, float *p) {
   return s > 0.0f ? 1.0f : 0.0f;
 }
 
-constexpr int SD16_VPT = 8;        // voxels per thread and workgroup pass
 
 __global__ __launch_bounds__(256) void softdice_fwd16_kernel(const float *__restrict__ la, const float *__restrict__ lb,
                                                              double *__restrict__ partial, int64_t V) {

@@ -728,7 +728,7 @@ __global__ __launch_bounds__(256, 6) void head_warp_bwd_kernel(const float *__re
     sw[i] = k < nsel ? w[(int64_t)(sel ? sel[k] : k) * HW_CIN + i % HW_CIN] : 0.f;
   }
   const int64_t V = (int64_t)D * H * W;
-  const int tilesX = (W + 15) >> 4, tilesZ = (D + 3) >> 2;
+  const int tilesZ = (D + 3) >> 2;
   const int tile = (int)blockIdx.x;
   const int bx = tile % gx, by = (tile / gx) % gy, bz = tile / (gx * gy);
   const int b = bz / tilesZ;
@@ -1042,7 +1042,7 @@ __device__ __forceinline__ float from16<bf16_t>(unsigned short h) { return bf16_
 template <>
 __device__ __forceinline__ float from16<f16_t>(unsigned short h) { return f16_to_f32(h); }
 
-constexpr int HA_NCG = HA_MAXC / 16;        // class groups of 16
+static_assert(HA_MAXC <= 8 * 16, "a wave takes class groups wv and wv + 4: at most 8 groups of 16 classes");
 template <typename T, typename ACC>
 __global__ __launch_bounds__(256) void head_accumulate_kernel(const T *__restrict__ z, const float *__restrict__ w,
                                                               const float *__restrict__ bias, const float *__restrict__ gauss,

@@ -949,7 +949,16 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restri
   if (ok) {
     const int pair = (ci >> 5) * cobs + cb;
     const float *p = slabs + (int64_t)pair * nslab * (27 * 1024) + (tap * 32 + (ci & 31)) * 32 + lane;
-    for (int k = grp; k < nslab; k += G) s += p[(int64_t)k * (27 * 1024)];
+    // eight slabs are requested before the first is added (round 4): one dependent load per slab made the launch a chain
+    // of nslab / G memory round trips (32 us for 256 slabs).  The additions keep their order: same sums, bit for bit.
+    for (int k = grp; k < nslab; k += 8 * G) {
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = (k + j * G < nslab) ? p[(int64_t)(k + j * G) * (27 * 1024)] : 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        if (k + j * G < nslab) s += v[j];
+    }
   }
   if (G > 1) {
     part[sub][lane] = s;

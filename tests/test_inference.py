@@ -25,6 +25,24 @@ def test_window_steps_and_gaussian_cpu():
     assert float(padded.sum()) == float(x.sum())
 
 
+def test_window_accumulator_storage_switch(monkeypatch):
+    """DGTTA_WINDOW_ACC: fp32 (default) | fp16; anything else is refused before memory is allocated."""
+    from dg_tta_amd.tta.inference import window_acc_dtype, _acc_code
+    from dg_tta_amd import ops
+    monkeypatch.delenv("DGTTA_WINDOW_ACC", raising=False)
+    assert window_acc_dtype() is torch.float32
+    monkeypatch.setenv("DGTTA_WINDOW_ACC", "FP16")
+    assert window_acc_dtype() is torch.float16
+    monkeypatch.setenv("DGTTA_WINDOW_ACC", "bf16")
+    with pytest.raises(ValueError, match="fp32 or fp16"):
+        window_acc_dtype()
+    assert _acc_code(torch.empty(1, dtype=torch.float16)) == ops.F16 and _acc_code(torch.empty(1)) == ops.F32
+    with pytest.raises(ValueError):
+        _acc_code(torch.empty(1, dtype=torch.bfloat16))
+    with pytest.raises(Exception):          # no CPU fallback: the label-map kernel refuses host tensors
+        ops.argmax_rows(torch.zeros(4, 5))
+
+
 @pytest.mark.gpu
 def test_ensemble_sliding_window_matches_cpu_restatement(tmp_path):
     from conftest import SMALL_CFG

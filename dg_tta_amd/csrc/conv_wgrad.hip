@@ -809,28 +809,180 @@ __global__ __launch_bounds__(256, 2) void conv3_wgrad_tr_s2_kernel(const bf16_t 
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// The same for TWO output-channel blocks per workgroup (round 4): 8 waves, waves 0-3 / 4-7 take the 27 taps of block 0 / 1 and
+// share the x tile.  With one block per workgroup a 32 -> 64 layer read x - four times the bytes of dy, the whole traffic of this
+// HBM-bound kernel - once per block (2.8 GB at the 128^3 -> 64^3 transition where 1.3 GB are the operands; 853 us).  One
+// 512-thread workgroup per CU halves the loads in flight, so the ring is two output slices ahead instead of one (7 x slots,
+// 3 dy slots) and a step waits with a counted vmcnt for the slices of the NEXT step only; every wave issues the same five
+// pieces per step (a wave without a piece of its own repeats a neighbour's: same bytes to the same address).
+struct WT2X {
+  static constexpr int NCO = 2, LA = 2;
+  static constexpr int NXS = 3 + 2 * LA, NYS = LA + 1;
+  static constexpr int Y_STEP_B = NCO * WT2::Y_SLICE_B;
+  static constexpr int LDS_BYTES = NXS * WT2::X_SLICE_B + NYS * Y_STEP_B;
+};
+
+template <typename T16 = bf16_t>
+__global__ __launch_bounds__(512, 2) void conv3_wgrad_tr_s2x_kernel(const bf16_t *__restrict__ x, View xv,
+                                                                    const bf16_t *__restrict__ dy, View yv,
+                                                                    float *__restrict__ slabs, int Cin, int Cout, int tilesW,
+                                                                    int tilesH, int nsd, int DR, int cobs) {
+  const int D = yv.D, H = yv.H, W = yv.W;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char *sX = smem;
+  unsigned char *sY = smem + WT2X::NXS * WT2::X_SLICE_B;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tg = wave & 3, cb = wave >> 2;                 // tap group, output-channel block of the pair
+
+  int t = xcd_unit(1);
+  const int tw = t % tilesW;
+  t /= tilesW;
+  const int th = t % tilesH;
+  t /= tilesH;
+  const int ds = t % nsd;
+  const int b = t / nsd;
+  const int cogs = cobs / 2;
+  const int cib = blockIdx.y / cogs, cog = blockIdx.y % cogs;
+  const int h0 = th * WT2::TH, w0 = tw * WT2::TWO;
+  const int d_begin = ds * DR, d_end = (d_begin + DR < D) ? d_begin + DR : D;
+  const bf16_t *xb = x + b * xv.sb + cib * 32;
+  const bf16_t *yb = dy + b * yv.sb + cog * 64;
+  const int cin_lim = (Cin + 7) / 8 * 8;
+  const int l_vox = lane >> 2, l_chunk = lane & 3;
+
+  auto xslot = [&](int xd) { return (xd + WT2X::NXS) % WT2X::NXS; };
+  // 15 pieces per x slice over 8 waves: pieces wave and wave + 8 (the 16th repeats piece 14)
+  auto issue_x_slice = [&](int xd) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      int idx = wave + 8 * i;
+      idx = idx < WT2::NPX1 ? idx : WT2::NPX1 - 1;
+      const int r = idx / 3, pi = idx % 3;
+      const int gh = 2 * h0 - 1 + r, wx = 16 * pi + l_vox, gw = 2 * w0 - 1 + wx;
+      // the third piece of a row is one voxel (4 lanes): the other lanes write zeros into the unused tail of the LDS row
+      const bool ok = (unsigned)xd < (unsigned)xv.D && (unsigned)gh < (unsigned)xv.H && (unsigned)gw < (unsigned)xv.W &&
+                      cib * 32 + l_chunk * 8 < cin_lim && (pi < 2 || lane < 4);
+      const void *src = ok ? (const void *)(xb + xd * xv.sd + gh * xv.sh + gw * xv.sw + l_chunk * 8) : (const void *)&g_zero16;
+      if (pi < 2 || lane < 12)      // voxels 32 .. 34 of the 36-voxel LDS row
+        dma16_to_lds(src, lds_addr_of(sX + xslot(xd) * WT2::X_SLICE_B + r * WT2::X_ROW_B + pi * 1024));
+    }
+  };
+  // 4 pieces per dy slice (2 rows x 2 blocks): piece wave & 3
+  auto issue_y_slice = [&](int yd) __attribute__((always_inline)) {
+    const int row = wave & 1, blk = (wave >> 1) & 1;
+    const int gh = h0 + row, gw = w0 + l_vox;
+    const bool ok = (unsigned)yd < (unsigned)D && gh < H && gw < W && cog * 64 + blk * 32 + l_chunk * 8 < Cout;
+    const void *src = ok ? (const void *)(yb + yd * yv.sd + gh * yv.sh + gw * yv.sw + blk * 32 + l_chunk * 8)
+                         : (const void *)&g_zero16;
+    dma16_to_lds(src, lds_addr_of(sY + (yd % WT2X::NYS) * WT2X::Y_STEP_B + blk * WT2::Y_SLICE_B + row * WT2::Y_ROW_B));
+  };
+  auto issue_step = [&](int od) __attribute__((always_inline)) {      // x slices 2 od, 2 od + 1 and dy slice od: 5 pieces per wave
+    issue_x_slice(2 * od);
+    issue_x_slice(2 * od + 1);
+    issue_y_slice(od);
+  };
+
+  const int kq = (lane >> 5) * 8 + ((lane & 15) >> 2), cpart = ((lane >> 4) & 1) * 32 + (lane & 3) * 8;
+  const int lane_off_y = kq * 64 + cpart, lane_off_x = kq * 128 + cpart;
+
+  int tap_kd[7], tap_off[7];
+#pragma unroll
+  for (int i = 0; i < 7; ++i) {
+    const int tc = tg + 4 * i < 27 ? tg + 4 * i : 26;
+    tap_kd[i] = tc / 9;
+    tap_off[i] = ((tc / 3) % 3) * WT2::X_ROW_B + (tc % 3) * 64;
+  }
+  f32x16_t acc[7];
+#pragma unroll
+  for (int i = 0; i < 7; ++i)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[i][q] = 0.f;
+
+  // prologue: x slice 2 d_begin - 1, then the steps d_begin and d_begin + 1
+  issue_x_slice(2 * d_begin - 1);
+  issue_step(d_begin);
+  if (d_begin + 1 < d_end) issue_step(d_begin + 1);
+  dma_wait_all();
+  lds_barrier();
+
+  for (int d = d_begin; d < d_end; ++d) {
+    const bool ahead = d + WT2X::LA < d_end;
+    if (ahead) issue_step(d + WT2X::LA);      // lands during this step and the next
+    const unsigned char *ys = sY + (d % WT2X::NYS) * WT2X::Y_STEP_B + cb * WT2::Y_SLICE_B + lane_off_y;
+    int slice_off[3];
+#pragma unroll
+    for (int kd = 0; kd < 3; ++kd) slice_off[kd] = xslot(2 * d + kd - 1) * WT2::X_SLICE_B;
+    int so_t[7];
+#pragma unroll
+    for (int i = 0; i < 7; ++i) so_t[i] = (tap_kd[i] == 0 ? slice_off[0] : (tap_kd[i] == 1 ? slice_off[1] : slice_off[2])) + tap_off[i];
+#pragma unroll
+    for (int oh = 0; oh < WT2::TH; ++oh) {
+      const s16x4_t blo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t *)(ys + oh * WT2::Y_ROW_B));
+      const s16x4_t bhi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t *)(ys + oh * WT2::Y_ROW_B + 4 * 64));
+      typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+      const s16x8_t bv = {blo[0], blo[1], blo[2], blo[3], bhi[0], bhi[1], bhi[2], bhi[3]};
+      const bf16x8_t bfr = __builtin_bit_cast(bf16x8_t, bv);
+      bf16x8_t afr[7];
+#pragma unroll
+      for (int i = 0; i < 7; ++i) {
+        const unsigned char *pa = sX + lane_off_x + so_t[i] + 2 * oh * WT2::X_ROW_B;
+        const s16x4_t alo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t *)pa);
+        const s16x4_t ahi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t *)(pa + 4 * 128));
+        const s16x8_t av = {alo[0], alo[1], alo[2], alo[3], ahi[0], ahi[1], ahi[2], ahi[3]};
+        afr[i] = __builtin_bit_cast(bf16x8_t, av);
+      }
+#pragma unroll
+      for (int i = 0; i < 7; ++i) acc[i] = mfma32_tr<T16>(afr[i], bfr, acc[i]);
+    }
+    // the slices of step d + 1 were issued one step ago: everything but the five pieces issued above must have landed
+    if (ahead) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+    else dma_wait_all();
+    lds_barrier();
+  }
+
+  const int pair = cib * cobs + cog * 2 + cb;
+  float *slab = slabs + ((int64_t)pair * gridDim.x + blockIdx.x) * (27 * 1024);
+  const int co = lane & 31, hh = lane >> 5;
+#pragma unroll
+  for (int i = 0; i < 7; ++i) {
+    const int tap = tg + 4 * i;
+    if (tap < 27) {
+#pragma unroll
+      for (int q = 0; q < 16; ++q) slab[(tap * 32 + (q & 3) + 8 * (q >> 2) + 4 * hh) * 32 + co] = acc[i][q];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // bf16 weight gradient of ConvTranspose3d(k2,s2) in one pass:  dW[ci][co][o] = sum_v x[v][ci] * dout[2v + o][co].
 // Tile = 2 rows x 16 voxels of the INPUT lattice; the dout tile is kept at full resolution (4 rows x 32 voxels, slices 2d and
 // 2d+1) and read with a 2-voxel row stride, the x fragment of a row is shared by the 8 offsets (2 per wave).  x and dout are
 // read once, instead of 8 single-tap class launches that each re-read x and gathered a dout parity sub-lattice.
+template <int NCI>
 struct WT3 {
   static constexpr int TH = 2, TWI = 16;
-  static constexpr int X_ROW_B = TWI * 64, X_SLICE_B = TH * X_ROW_B;             // 2 KiB
+  static constexpr int X_ROW_B = TWI * 64, X_BLK_B = TH * X_ROW_B;               // one 32-channel block of an x slice: 2 KiB
+  static constexpr int X_SLICE_B = NCI * X_BLK_B;
   static constexpr int Y_ROW_B = 2 * TWI * 64, Y_SLICE_B = 2 * TH * Y_ROW_B;     // one dout slice: 4 rows x 2 KiB
   static constexpr int Y_PAIR_B = 2 * Y_SLICE_B;                                 // dout slices 2d, 2d+1
   static constexpr int LDS_BYTES = 2 * X_SLICE_B + 2 * Y_PAIR_B;
   static constexpr int NPY = 2 * 2 * TH * 2;                                     // dout pieces per x slice (16 KiB)
 };
 
-template <typename T16 = bf16_t>
+// NCI (round 4): input-channel blocks of 32 per workgroup.  With one block per workgroup a 64-channel layer read dout - four
+// times the bytes of x, the whole traffic of this HBM-bound kernel - once per block: 2.4 GB instead of 1.3 GB at the
+// 64^3 -> 128^3 stage (836 us at 2.9 TB/s).  NCI = 2 shares the dout tile between two blocks of x.
+template <typename T16 = bf16_t, int NCI = 1>
 __global__ __launch_bounds__(256, 2) void convT_wgrad_tr_kernel(const bf16_t *__restrict__ x, View xv,
                                                                 const bf16_t *__restrict__ dout, View yv,
                                                                 float *__restrict__ slabs, int Cin, int Cout, int tilesW,
-                                                                int tilesH, int nsd, int DR, int cobs) {
+                                                                int tilesH, int nsd, int DR, int cobs, int cibs) {
+  typedef WT3<NCI> WT;
   const int D = xv.D, H = xv.H, W = xv.W;                  // input lattice; yv = dense view of dout (2D x 2H x 2W)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char *sX = smem;                                // 2 slots
-  unsigned char *sY = smem + 2 * WT3::X_SLICE_B;           // 2 slots of a slice pair
+  unsigned char *sY = smem + 2 * WT::X_SLICE_B;            // 2 slots of a slice pair
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   int t = xcd_unit(1);
@@ -840,46 +992,51 @@ __global__ __launch_bounds__(256, 2) void convT_wgrad_tr_kernel(const bf16_t *__
   t /= tilesH;
   const int ds = t % nsd;
   const int b = t / nsd;
-  const int cib = blockIdx.y / cobs, cob = blockIdx.y % cobs;
-  const int h0 = th * WT3::TH, w0 = tw * WT3::TWI;
+  const int cig = blockIdx.y / cobs, cob = blockIdx.y % cobs;      // group of NCI input-channel blocks
+  const int h0 = th * WT::TH, w0 = tw * WT::TWI;
   const int d_begin = ds * DR, d_end = (d_begin + DR < D) ? d_begin + DR : D;
-  const bf16_t *xb = x + b * xv.sb + cib * 32;
+  const bf16_t *xb = x + b * xv.sb + cig * NCI * 32;
   const bf16_t *yb = dout + b * yv.sb + cob * 32;
   const int cin_lim = (Cin + 7) / 8 * 8;
   const int l_vox = lane >> 2, l_chunk = lane & 3;
 
-  // pieces of x slice d: 2 rows (waves 0,1); pieces of the dout pair: 2 slices x 4 rows x 2 halves = 16 (4 per wave)
+  // pieces of x slice d: NCI blocks x 2 rows (one per wave while they last); pieces of the dout pair: 2 slices x 4 rows x 2
+  // halves = 16 (4 per wave)
   auto issue = [&](int d) __attribute__((always_inline)) {
-    if (wave < WT3::TH) {
-      const int gh = h0 + wave, gw = w0 + l_vox;
-      const bool ok = (unsigned)d < (unsigned)D && gh < H && gw < W && cib * 32 + l_chunk * 8 < cin_lim;
-      const void *src = ok ? (const void *)(xb + d * xv.sd + gh * xv.sh + gw * xv.sw + l_chunk * 8) : (const void *)&g_zero16;
-      dma16_to_lds(src, lds_addr_of(sX + (d & 1) * WT3::X_SLICE_B + wave * WT3::X_ROW_B));
+    if (wave < WT::TH * NCI) {
+      const int row = wave % WT::TH, blk = wave / WT::TH;
+      const int gh = h0 + row, gw = w0 + l_vox;
+      const bool ok = (unsigned)d < (unsigned)D && gh < H && gw < W && (cig * NCI + blk) * 32 + l_chunk * 8 < cin_lim;
+      const void *src = ok ? (const void *)(xb + d * xv.sd + gh * xv.sh + gw * xv.sw + blk * 32 + l_chunk * 8)
+                           : (const void *)&g_zero16;
+      dma16_to_lds(src, lds_addr_of(sX + (d & 1) * WT::X_SLICE_B + blk * WT::X_BLK_B + row * WT::X_ROW_B));
     }
 #pragma unroll
-    for (int i = 0; i < WT3::NPY / 4; ++i) {
+    for (int i = 0; i < WT::NPY / 4; ++i) {
       const int idx = wave + 4 * i;                     // (slice s, row r, half pi)
       const int sl = idx >> 3, r = (idx >> 1) & 3, pi = idx & 1;
       const int gd = 2 * d + sl, gh = 2 * h0 + r, gw = 2 * w0 + 16 * pi + l_vox;
       const bool ok = (unsigned)d < (unsigned)D && gd < yv.D && gh < yv.H && gw < yv.W && cob * 32 + l_chunk * 8 < Cout;
       const void *src = ok ? (const void *)(yb + gd * yv.sd + gh * yv.sh + gw * yv.sw + l_chunk * 8) : (const void *)&g_zero16;
-      dma16_to_lds(src, lds_addr_of(sY + (d & 1) * WT3::Y_PAIR_B + sl * WT3::Y_SLICE_B + r * WT3::Y_ROW_B + pi * 1024));
+      dma16_to_lds(src, lds_addr_of(sY + (d & 1) * WT::Y_PAIR_B + sl * WT::Y_SLICE_B + r * WT::Y_ROW_B + pi * 1024));
     }
   };
 
   const int kq = (lane >> 5) * 8 + ((lane & 15) >> 2), cpart = ((lane >> 4) & 1) * 32 + (lane & 3) * 8;
   const int lane_off_x = kq * 64 + cpart, lane_off_y = kq * 128 + cpart;
-  // this wave's two output offsets o = 2 wave, 2 wave + 1  (o = od*4 + oh*2 + ow)
-  f32x16_t acc[2];
+  // this wave's two output offsets o = 2 wave, 2 wave + 1  (o = od*4 + oh*2 + ow), for every input-channel block
+  f32x16_t acc[NCI][2];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int c = 0; c < NCI; ++c)
 #pragma unroll
-    for (int q = 0; q < 16; ++q) acc[i][q] = 0.f;
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[c][i][q] = 0.f;
   int ooff[2];
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int o = 2 * wave + i;
-    ooff[i] = (o >> 2) * WT3::Y_SLICE_B + ((o >> 1) & 1) * WT3::Y_ROW_B + (o & 1) * 64;
+    ooff[i] = (o >> 2) * WT::Y_SLICE_B + ((o >> 1) & 1) * WT::Y_ROW_B + (o & 1) * 64;
   }
 
   issue(d_begin);
@@ -888,34 +1045,47 @@ __global__ __launch_bounds__(256, 2) void convT_wgrad_tr_kernel(const bf16_t *__
   typedef __attribute__((ext_vector_type(8))) short s16x8_t;
   for (int d = d_begin; d < d_end; ++d) {
     if (d + 1 < d_end) issue(d + 1);
-    const unsigned char *xs = sX + (d & 1) * WT3::X_SLICE_B + lane_off_x;
-    const unsigned char *ys = sY + (d & 1) * WT3::Y_PAIR_B + lane_off_y;
+    const unsigned char *xs = sX + (d & 1) * WT::X_SLICE_B + lane_off_x;
+    const unsigned char *ys = sY + (d & 1) * WT::Y_PAIR_B + lane_off_y;
 #pragma unroll
-    for (int r = 0; r < WT3::TH; ++r) {
-      const s16x4_t alo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t *)(xs + r * WT3::X_ROW_B));
-      const s16x4_t ahi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t *)(xs + r * WT3::X_ROW_B + 4 * 64));
-      const s16x8_t av = {alo[0], alo[1], alo[2], alo[3], ahi[0], ahi[1], ahi[2], ahi[3]};
-      const bf16x8_t afr = __builtin_bit_cast(bf16x8_t, av);
+    for (int r = 0; r < WT::TH; ++r) {
+      bf16x8_t bfr[2];
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
-        const unsigned char *pb = ys + ooff[i] + 2 * r * WT3::Y_ROW_B;
+        const unsigned char *pb = ys + ooff[i] + 2 * r * WT::Y_ROW_B;
         const s16x4_t blo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t *)pb);
         const s16x4_t bhi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t *)(pb + 4 * 128));
         const s16x8_t bv = {blo[0], blo[1], blo[2], blo[3], bhi[0], bhi[1], bhi[2], bhi[3]};
-        acc[i] = mfma32_tr<T16>(afr, __builtin_bit_cast(bf16x8_t, bv), acc[i]);
+        bfr[i] = __builtin_bit_cast(bf16x8_t, bv);
+      }
+#pragma unroll
+      for (int c = 0; c < NCI; ++c) {
+        const unsigned char *pa = xs + c * WT::X_BLK_B + r * WT::X_ROW_B;
+        const s16x4_t alo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t *)pa);
+        const s16x4_t ahi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t *)(pa + 4 * 64));
+        const s16x8_t av = {alo[0], alo[1], alo[2], alo[3], ahi[0], ahi[1], ahi[2], ahi[3]};
+        const bf16x8_t afr = __builtin_bit_cast(bf16x8_t, av);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) acc[c][i] = mfma32_tr<T16>(afr, bfr[i], acc[c][i]);
       }
     }
     dma_wait_all();
     lds_barrier();
   }
-  // slab "tap" slot = output offset o
-  float *slab = slabs + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * (27 * 1024);
+  // slab "tap" slot = output offset o; one slab per (input-channel block, output-channel block) pair and unit
   const int co = lane & 31, hh = lane >> 5;
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int o = 2 * wave + i;
+  for (int c = 0; c < NCI; ++c) {
+    const int cib = cig * NCI + c;
+    if (cib < cibs) {
+      float *slab = slabs + ((int64_t)(cib * cobs + cob) * gridDim.x + blockIdx.x) * (27 * 1024);
 #pragma unroll
-    for (int q = 0; q < 16; ++q) slab[(o * 32 + (q & 3) + 8 * (q >> 2) + 4 * hh) * 32 + co] = acc[i][q];
+      for (int i = 0; i < 2; ++i) {
+        const int o = 2 * wave + i;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) slab[(o * 32 + (q & 3) + 8 * (q >> 2) + 4 * hh) * 32 + co] = acc[c][i][q];
+      }
+    }
   }
 }
 
@@ -1156,12 +1326,20 @@ static int wgrad_conv(const void *x, int ldx, const void *dy, int lddy, float *d
     const bool ok = Cout % 8 == 0 && ldx % 8 == 0 && lddy % 8 == 0 && !((uintptr_t)x & 15) && !((uintptr_t)dy & 15) &&
                     ldx >= (Cin + 7) / 8 * 8 && ws_bytes >= need && p.units < (1ll << 31) && p.cibs * p.cobs <= 65535;
     if (ok && one != '0') {
-      static DynLdsOnce once;
-      DG_REQUIRE(ensure_dyn_lds(once, reinterpret_cast<const void *>(conv3_wgrad_tr_s2_kernel<T16>), (int)WT2::LDS_BYTES) ==
-                     hipSuccess, DGTTA_ERR_LAUNCH, "wgrad_tr_s2: cannot raise the dynamic LDS limit");
-      hipLaunchKernelGGL(conv3_wgrad_tr_s2_kernel<T16>, dim3((unsigned)p.units, (unsigned)(p.cibs * p.cobs)), dim3(256),
-                         WT2::LDS_BYTES, st, (const bf16_t *)x, xfull, (const bf16_t *)dy, yv, (float *)ws, Cin, Cout, p.tW,
-                         p.tH, p.nsd, p.DR, p.cobs);
+      static DynLdsOnce once, once_x;
+      if (p.cobs % 2 == 0 && Cout % 64 == 0 && one != '1') {      // two output-channel blocks share the x tile (DGTTA_WGRAD_S2_ONEPASS=1: one)
+        DG_REQUIRE(ensure_dyn_lds(once_x, reinterpret_cast<const void *>(conv3_wgrad_tr_s2x_kernel<T16>), (int)WT2X::LDS_BYTES) ==
+                       hipSuccess, DGTTA_ERR_LAUNCH, "wgrad_tr_s2x: cannot raise the dynamic LDS limit");
+        hipLaunchKernelGGL(conv3_wgrad_tr_s2x_kernel<T16>, dim3((unsigned)p.units, (unsigned)(p.cibs * (p.cobs / 2))), dim3(512),
+                           WT2X::LDS_BYTES, st, (const bf16_t *)x, xfull, (const bf16_t *)dy, yv, (float *)ws, Cin, Cout, p.tW,
+                           p.tH, p.nsd, p.DR, p.cobs);
+      } else {
+        DG_REQUIRE(ensure_dyn_lds(once, reinterpret_cast<const void *>(conv3_wgrad_tr_s2_kernel<T16>), (int)WT2::LDS_BYTES) ==
+                       hipSuccess, DGTTA_ERR_LAUNCH, "wgrad_tr_s2: cannot raise the dynamic LDS limit");
+        hipLaunchKernelGGL(conv3_wgrad_tr_s2_kernel<T16>, dim3((unsigned)p.units, (unsigned)(p.cibs * p.cobs)), dim3(256),
+                           WT2::LDS_BYTES, st, (const bf16_t *)x, xfull, (const bf16_t *)dy, yv, (float *)ws, Cin, Cout, p.tW,
+                           p.tH, p.nsd, p.DR, p.cobs);
+      }
       DG_CHECK_LAUNCH("conv3_wgrad_tr_s2_kernel");
       RealTaps ident;
       ident.t[0] = identity_taps(0);
@@ -1236,12 +1414,20 @@ static int convT_wgrad(const void *x, int ldx, const void *dout, int lddo, float
     const bool ok = Cout % 8 == 0 && ldx % 8 == 0 && lddo % 8 == 0 && !((uintptr_t)x & 15) && !((uintptr_t)dout & 15) &&
                     ldx >= (Cin + 7) / 8 * 8 && ws_bytes >= need && p.units < (1ll << 31) && p.cibs * p.cobs <= 65535;
     if (ok && one != '0') {
-      static DynLdsOnce once;
-      DG_REQUIRE(ensure_dyn_lds(once, reinterpret_cast<const void *>(convT_wgrad_tr_kernel<T16>), (int)WT3::LDS_BYTES) ==
-                     hipSuccess, DGTTA_ERR_LAUNCH, "convT_wgrad_tr: cannot raise the dynamic LDS limit");
-      hipLaunchKernelGGL(convT_wgrad_tr_kernel<T16>, dim3((unsigned)p.units, (unsigned)(p.cibs * p.cobs)), dim3(256),
-                         WT3::LDS_BYTES, st, (const bf16_t *)x, xv, (const bf16_t *)dout, yfull, (float *)ws, Cin, Cout, p.tW,
-                         p.tH, p.nsd, p.DR, p.cobs);
+      static DynLdsOnce once1, once2;
+      if (p.cibs >= 2) {      // two input-channel blocks share a dout tile
+        DG_REQUIRE(ensure_dyn_lds(once2, reinterpret_cast<const void *>(convT_wgrad_tr_kernel<T16, 2>), (int)WT3<2>::LDS_BYTES) ==
+                       hipSuccess, DGTTA_ERR_LAUNCH, "convT_wgrad_tr: cannot raise the dynamic LDS limit");
+        hipLaunchKernelGGL((convT_wgrad_tr_kernel<T16, 2>), dim3((unsigned)p.units, (unsigned)(cdiv(p.cibs, 2) * p.cobs)), dim3(256),
+                           WT3<2>::LDS_BYTES, st, (const bf16_t *)x, xv, (const bf16_t *)dout, yfull, (float *)ws, Cin, Cout, p.tW,
+                           p.tH, p.nsd, p.DR, p.cobs, p.cibs);
+      } else {
+        DG_REQUIRE(ensure_dyn_lds(once1, reinterpret_cast<const void *>(convT_wgrad_tr_kernel<T16, 1>), (int)WT3<1>::LDS_BYTES) ==
+                       hipSuccess, DGTTA_ERR_LAUNCH, "convT_wgrad_tr: cannot raise the dynamic LDS limit");
+        hipLaunchKernelGGL((convT_wgrad_tr_kernel<T16, 1>), dim3((unsigned)p.units, (unsigned)(p.cibs * p.cobs)), dim3(256),
+                           WT3<1>::LDS_BYTES, st, (const bf16_t *)x, xv, (const bf16_t *)dout, yfull, (float *)ws, Cin, Cout, p.tW,
+                           p.tH, p.nsd, p.DR, p.cobs, p.cibs);
+      }
       DG_CHECK_LAUNCH("convT_wgrad_tr_kernel");
       RealTaps rt;
       for (int t = 0; t < 27; ++t) rt.t[0].wt[t] = (signed char)(t < 8 ? t : -1);      // slab tap slot o -> dw_t[..][o]

@@ -1,5 +1,5 @@
 import sys, torch
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from dg_tta_amd import _lib
 from dg_tta_amd._lib import check, ptr, stream_of
 lib = _lib.load(); DEV = "cuda:0"; dt = 1; tdt = torch.bfloat16

@@ -1481,6 +1481,97 @@ __global__ void f32_to_16_rows_kernel(const float *__restrict__ src, int lds_, u
 }
 }  // namespace
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Weight gradient of a POINTWISE layer with 32 input channels (the 1x1x1 segmentation head: dW[k][c] = sum_v d[v][k] z[v][c])
+// as a stream (round 4).  head_wgrad_mfma used to view the rows as a D x 4 x 32 volume and run the 27-tap class kernel with the
+// centre tap only: one of its four waves multiplies, every 128-voxel step ends in a DMA drain and a barrier with 12 KB in
+// flight - 642 us for 1.6 GB at 8 x 128^3 (2.5 TB/s).  Here a persistent workgroup takes chunks of 128 rows, keeps two chunks in
+// flight behind the one it multiplies (LDS-DMA into a 4-deep ring, counted vmcnt), every wave multiplies its own 32 rows of the
+// chunk (two v_mfma_f32_32x32x16 with transposed LDS reads, as in conv3_wgrad_tr_kernel), the four waves' accumulators are
+// added in wave order at the end and the workgroups' 32 x 32 partials in workgroup order by the finalize kernel: deterministic.
+// d has nsel <= 32 columns (a multiple of 8); its rows are zero-extended to 32 columns on the way into LDS.
+struct PWG {
+  static constexpr int CHUNK = 128, NBUF = 4, LA = 2;
+  static constexpr int X_B = CHUNK * 64, BUF_B = 2 * X_B;
+  static constexpr int LDS_BYTES = NBUF * BUF_B;
+};
+
+template <typename T16>
+__global__ __launch_bounds__(256, 2) void pointwise_wgrad_kernel(const bf16_t *__restrict__ x, int ldx,
+                                                                 const unsigned short *__restrict__ d16, int nsel,
+                                                                 float *__restrict__ partial, int64_t nchunks) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l_vox = lane >> 2, l_chunk = lane & 3;
+  const int64_t G = gridDim.x;
+  const int64_t n = (nchunks - (int64_t)blockIdx.x + G - 1) / G;      // this workgroup's chunks: blockIdx.x, + G, ...
+  // every wave issues 4 pieces of 1 KiB per chunk: x pieces wave, wave + 4 (16 rows x 64 B each) and the same two of d
+  auto issue = [&](int64_t i) __attribute__((always_inline)) {
+    const int64_t row0 = (blockIdx.x + i * G) * PWG::CHUNK;
+    unsigned char *buf = smem + (int)(i % PWG::NBUF) * PWG::BUF_B;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int pc = wave + 4 * j;
+      const int64_t row = row0 + pc * 16 + l_vox;
+      dma16_to_lds(x + row * ldx + l_chunk * 8, lds_addr_of(buf + pc * 1024));
+      const void *src = l_chunk * 8 < nsel ? (const void *)(d16 + row * nsel + l_chunk * 8) : (const void *)&g_zero16;
+      dma16_to_lds(src, lds_addr_of(buf + PWG::X_B + pc * 1024));
+    }
+  };
+  const int lane_off = ((lane >> 5) * 8 + ((lane & 15) >> 2)) * 64 + ((lane >> 4) & 1) * 32 + (lane & 3) * 8;
+  f32x16_t acc;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+  if (n > 0) issue(0);
+  if (n > 1) issue(1);
+  for (int64_t i = 0; i < n; ++i) {
+    if (i + 2 < n) {
+      issue(i + 2);
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");        // all but the two newest chunks of this wave have landed
+    } else if (i + 1 < n) {
+      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    } else {
+      dma_wait_all();
+    }
+    lds_barrier();                                            // ... and everybody else's pieces of chunk i
+    const unsigned char *buf = smem + (int)(i % PWG::NBUF) * PWG::BUF_B + wave * 32 * 64 + lane_off;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const bf16x8_t a = tr_operand(buf + ks * 1024);
+      const bf16x8_t b = tr_operand(buf + PWG::X_B + ks * 1024);
+      acc = mfma32_tr<T16>(a, b, acc);
+    }
+  }
+  // waves in order through LDS (the ring is free after a barrier), then one 32 x 32 partial per workgroup: [c][k]
+  lds_barrier();
+  float *red = reinterpret_cast<float *>(smem);
+  const int co = lane & 31, hh = lane >> 5;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) red[wave * 1024 + ((q & 3) + 8 * (q >> 2) + 4 * hh) * 32 + co] = acc[q];
+  __syncthreads();
+  for (int e = tid; e < 1024; e += 256)
+    partial[(int64_t)blockIdx.x * 1024 + e] = ((red[e] + red[1024 + e]) + red[2048 + e]) + red[3072 + e];
+}
+
+__global__ __launch_bounds__(1024) void pointwise_wgrad_finalize_kernel(const float *__restrict__ partial, int G, float *__restrict__ dw,
+                                                                        int nsel, int Cin, int accumulate) {
+  const int c = threadIdx.x >> 5, k = threadIdx.x & 31;      // partial layout [c][k]
+  float s = 0.f;
+  for (int g = 0; g < G; g += 8) {      // eight loads in flight, added in workgroup order
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = g + j < G ? partial[(int64_t)(g + j) * 1024 + threadIdx.x] : 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      if (g + j < G) s += v[j];
+  }
+  if (k < nsel && c < Cin) {
+    float *o = dw + (int64_t)k * Cin + c;
+    *o = accumulate ? *o + s : s;
+  }
+}
+
 size_t head_wgrad_mfma_ws_bytes(int Cin, int nsel, int64_t rows) {
   if (rows <= 0 || rows % 128 || rows / 128 >= (1ll << 30)) return 0;      // the MFMA plan does not apply (as head_wgrad_mfma)
   const int D = (int)(rows / 128);
@@ -1511,6 +1602,31 @@ int head_wgrad_mfma(const void *x, int ldx, const float *dout, int lddo, float *
       else
         hipLaunchKernelGGL(f32_to_16_rows_kernel<f16_t>, dim3(2048), dim3(256), 0, st, dout, lddo, d16, nsel, rows);
       DG_CHECK_LAUNCH("f32_to_16_rows_kernel");
+    }
+    // the streaming kernel (DGTTA_WGRAD_TR=0, tests: the class kernel below)
+    const int G = 512;
+    if (Cin == 32 && ldx >= 32 && ldx % 8 == 0 && nsel % 8 == 0 && nsel <= 32 && !((uintptr_t)x & 15) &&
+        ws_bytes - cbytes >= (size_t)G * 1024 * sizeof(float) && dgtta_switches().wgrad_tr != '0') {
+      float *partial = reinterpret_cast<float *>((char *)ws + cbytes);
+      const int64_t nchunks = rows / PWG::CHUNK;
+      const int g = (int)(nchunks < G ? nchunks : G);
+      static DynLdsOnce once_b, once_h;
+      if (dtype == DGTTA_BF16) {
+        DG_REQUIRE(ensure_dyn_lds(once_b, reinterpret_cast<const void *>(pointwise_wgrad_kernel<bf16_t>), PWG::LDS_BYTES) == hipSuccess,
+                   DGTTA_ERR_LAUNCH, "pointwise_wgrad: cannot raise the dynamic LDS limit");
+        hipLaunchKernelGGL(pointwise_wgrad_kernel<bf16_t>, dim3((unsigned)g), dim3(256), PWG::LDS_BYTES, st, (const bf16_t *)x, ldx, d16,
+                           nsel, partial, nchunks);
+      } else {
+        DG_REQUIRE(ensure_dyn_lds(once_h, reinterpret_cast<const void *>(pointwise_wgrad_kernel<f16_t>), PWG::LDS_BYTES) == hipSuccess,
+                   DGTTA_ERR_LAUNCH, "pointwise_wgrad: cannot raise the dynamic LDS limit");
+        hipLaunchKernelGGL(pointwise_wgrad_kernel<f16_t>, dim3((unsigned)g), dim3(256), PWG::LDS_BYTES, st, (const bf16_t *)x, ldx, d16,
+                           nsel, partial, nchunks);
+      }
+      DG_CHECK_LAUNCH("pointwise_wgrad_kernel");
+      hipLaunchKernelGGL(pointwise_wgrad_finalize_kernel, dim3(1), dim3(1024), 0, st, (const float *)partial, g, dw_sel, nsel, Cin,
+                         accumulate);
+      DG_CHECK_LAUNCH("pointwise_wgrad_finalize_kernel");
+      return DGTTA_OK;
     }
     const View yv = dense_view(1, D, 4, 32, nsel);
     if (dtype == DGTTA_BF16)

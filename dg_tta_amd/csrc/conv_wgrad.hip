@@ -977,7 +977,8 @@ template <typename T16 = bf16_t, int NCI = 1>
 __global__ __launch_bounds__(256, 2) void convT_wgrad_tr_kernel(const bf16_t *__restrict__ x, View xv,
                                                                 const bf16_t *__restrict__ dout, View yv,
                                                                 float *__restrict__ slabs, int Cin, int Cout, int tilesW,
-                                                                int tilesH, int nsd, int DR, int cobs, int cibs) {
+                                                                int tilesH, int nsd, int DR, int cobs, int cibs,
+                                                                float *__restrict__ bias_part) {
   typedef WT3<NCI> WT;
   const int D = xv.D, H = xv.H, W = xv.W;                  // input lattice; yv = dense view of dout (2D x 2H x 2W)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1038,11 +1039,24 @@ __global__ __launch_bounds__(256, 2) void convT_wgrad_tr_kernel(const bf16_t *__
     const int o = 2 * wave + i;
     ooff[i] = (o >> 2) * WT::Y_SLICE_B + ((o >> 1) & 1) * WT::Y_ROW_B + (o & 1) * 64;
   }
+  // bias gradient sum_v dout[v][co] on the side (round 4; the first input-channel group's workgroups only): an x operand that is 1
+  // in row 0 and 0 elsewhere leaves the column sums of the dout fragments in row 0 of a third accumulator pair - the pass
+  // over dout that chan_reduce_vec_kernel<., 2> made for them (1.5 ms per epoch) is not needed
+  typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+  const bool do_bias = bias_part != nullptr && cig == 0;
+  const short one16 = sizeof(T16) == 2 && std::is_same<T16, f16_t>::value ? (short)0x3C00 : (short)0x3F80;
+  const short o1 = (lane & 31) == 0 ? one16 : (short)0;
+  const s16x8_t onesv = {o1, o1, o1, o1, o1, o1, o1, o1};
+  const bf16x8_t ones = __builtin_bit_cast(bf16x8_t, onesv);
+  f32x16_t bacc[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) bacc[i][q] = 0.f;
 
   issue(d_begin);
   dma_wait_all();
   lds_barrier();
-  typedef __attribute__((ext_vector_type(8))) short s16x8_t;
   for (int d = d_begin; d < d_end; ++d) {
     if (d + 1 < d_end) issue(d + 1);
     const unsigned char *xs = sX + (d & 1) * WT::X_SLICE_B + lane_off_x;
@@ -1057,6 +1071,10 @@ __global__ __launch_bounds__(256, 2) void convT_wgrad_tr_kernel(const bf16_t *__
         const s16x4_t bhi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t *)(pb + 4 * 128));
         const s16x8_t bv = {blo[0], blo[1], blo[2], blo[3], bhi[0], bhi[1], bhi[2], bhi[3]};
         bfr[i] = __builtin_bit_cast(bf16x8_t, bv);
+      }
+      if (do_bias) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) bacc[i] = mfma32_tr<T16>(ones, bfr[i], bacc[i]);
       }
 #pragma unroll
       for (int c = 0; c < NCI; ++c) {
@@ -1087,6 +1105,29 @@ __global__ __launch_bounds__(256, 2) void convT_wgrad_tr_kernel(const bf16_t *__
       }
     }
   }
+  if (do_bias) {      // row 0 of the accumulator = lanes 0..31, element 0; offsets, then waves, in order
+    float *red = reinterpret_cast<float *>(smem);
+    if (lane < 32) red[wave * 32 + lane] = bacc[0][0] + bacc[1][0];
+    __syncthreads();
+    if (tid < 32) bias_part[(int64_t)blockIdx.x * (cobs * 32) + cob * 32 + tid] = ((red[tid] + red[32 + tid]) + red[64 + tid]) + red[96 + tid];
+  }
+}
+
+// sums the per-unit bias partials of convT_wgrad_tr_kernel in unit order (double), one thread per output channel
+__global__ __launch_bounds__(256) void convT_bias_finalize_kernel(const float *__restrict__ part, int units, int ldp, int Cout,
+                                                                  float *__restrict__ db, int accumulate) {
+  const int co = blockIdx.x * 256 + threadIdx.x;
+  if (co >= Cout) return;
+  double s = 0.0;
+  for (int u = 0; u < units; u += 8) {
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = u + j < units ? part[(int64_t)(u + j) * ldp + co] : 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      if (u + j < units) s += (double)v[j];
+  }
+  db[co] = accumulate ? db[co] + (float)s : (float)s;
 }
 
 // dw[co*s_co + ci*s_ci + real_tap*s_tap] (+)= sum over slabs of virtual tap t (real_tap = real.wt[t], -1: skip).
@@ -1403,7 +1444,9 @@ int conv3_wgrad_mfma(const void *x, int ldx, const void *dy, int lddy, float *dw
 // ConvTranspose3d k2 s2 weight gradient: dw_t[ci][co][o] (+)= sum_v x[v][ci] * dout[2v+o][co]  (8 single-tap launches)
 template <typename T>
 static int convT_wgrad(const void *x, int ldx, const void *dout, int lddo, float *dw_t, void *ws, size_t ws_bytes, int B,
-                       int Cin, int Cout, int Di, int Hi, int Wi, int accumulate, hipStream_t st) {
+                       int Cin, int Cout, int Di, int Hi, int Wi, int accumulate, hipStream_t st, float *bias_part,
+                       size_t bias_part_bytes, int *bias_units) {
+  if (bias_units) *bias_units = 0;
   const View xv = dense_view(B, Di, Hi, Wi, ldx);
   if constexpr (sizeof(T) == 2) {
     typedef T T16;
@@ -1415,18 +1458,21 @@ static int convT_wgrad(const void *x, int ldx, const void *dout, int lddo, float
                     ldx >= (Cin + 7) / 8 * 8 && ws_bytes >= need && p.units < (1ll << 31) && p.cibs * p.cobs <= 65535;
     if (ok && one != '0') {
       static DynLdsOnce once1, once2;
+      // bias partials [unit][32 cobs] ride along when the caller offers room for them
+      float *bp = (bias_part && bias_units && bias_part_bytes >= (size_t)p.units * p.cobs * 32 * sizeof(float)) ? bias_part : nullptr;
+      if (bp) *bias_units = (int)p.units;
       if (p.cibs >= 2) {      // two input-channel blocks share a dout tile
         DG_REQUIRE(ensure_dyn_lds(once2, reinterpret_cast<const void *>(convT_wgrad_tr_kernel<T16, 2>), (int)WT3<2>::LDS_BYTES) ==
                        hipSuccess, DGTTA_ERR_LAUNCH, "convT_wgrad_tr: cannot raise the dynamic LDS limit");
         hipLaunchKernelGGL((convT_wgrad_tr_kernel<T16, 2>), dim3((unsigned)p.units, (unsigned)(cdiv(p.cibs, 2) * p.cobs)), dim3(256),
                            WT3<2>::LDS_BYTES, st, (const bf16_t *)x, xv, (const bf16_t *)dout, yfull, (float *)ws, Cin, Cout, p.tW,
-                           p.tH, p.nsd, p.DR, p.cobs, p.cibs);
+                           p.tH, p.nsd, p.DR, p.cobs, p.cibs, bp);
       } else {
         DG_REQUIRE(ensure_dyn_lds(once1, reinterpret_cast<const void *>(convT_wgrad_tr_kernel<T16, 1>), (int)WT3<1>::LDS_BYTES) ==
                        hipSuccess, DGTTA_ERR_LAUNCH, "convT_wgrad_tr: cannot raise the dynamic LDS limit");
         hipLaunchKernelGGL((convT_wgrad_tr_kernel<T16, 1>), dim3((unsigned)p.units, (unsigned)(p.cibs * p.cobs)), dim3(256),
                            WT3<1>::LDS_BYTES, st, (const bf16_t *)x, xv, (const bf16_t *)dout, yfull, (float *)ws, Cin, Cout, p.tW,
-                           p.tH, p.nsd, p.DR, p.cobs, p.cibs);
+                           p.tH, p.nsd, p.DR, p.cobs, p.cibs, bp);
       }
       DG_CHECK_LAUNCH("convT_wgrad_tr_kernel");
       RealTaps rt;
@@ -1461,12 +1507,27 @@ static int convT_wgrad(const void *x, int ldx, const void *dout, int lddo, float
                                  accumulate, st);
 }
 
+// bias_part / bias_units (optional): room for [units][ceil(Cout / 32) * 32] floats; *bias_units > 0 on return means the launch left
+// the per-unit sums of dout there (convT_bias_finalize adds them up), 0 means the caller runs its own pass over dout
 int convT_wgrad_mfma(const void *x, int ldx, const void *dout, int lddo, float *dw_t, void *ws, size_t ws_bytes, int B,
-                     int Cin, int Cout, int Di, int Hi, int Wi, int accumulate, int dtype, hipStream_t st) {
-  if (dtype == DGTTA_F32) return convT_wgrad<float>(x, ldx, dout, lddo, dw_t, ws, ws_bytes, B, Cin, Cout, Di, Hi, Wi, accumulate, st);
-  if (dtype == DGTTA_BF16) return convT_wgrad<bf16_t>(x, ldx, dout, lddo, dw_t, ws, ws_bytes, B, Cin, Cout, Di, Hi, Wi, accumulate, st);
-  if (dtype == DGTTA_F16) return convT_wgrad<f16_t>(x, ldx, dout, lddo, dw_t, ws, ws_bytes, B, Cin, Cout, Di, Hi, Wi, accumulate, st);
+                     int Cin, int Cout, int Di, int Hi, int Wi, int accumulate, int dtype, hipStream_t st, float *bias_part,
+                     size_t bias_part_bytes, int *bias_units) {
+  if (bias_units) *bias_units = 0;
+  if (dtype == DGTTA_F32)
+    return convT_wgrad<float>(x, ldx, dout, lddo, dw_t, ws, ws_bytes, B, Cin, Cout, Di, Hi, Wi, accumulate, st, nullptr, 0, nullptr);
+  if (dtype == DGTTA_BF16)
+    return convT_wgrad<bf16_t>(x, ldx, dout, lddo, dw_t, ws, ws_bytes, B, Cin, Cout, Di, Hi, Wi, accumulate, st, bias_part,
+                               bias_part_bytes, bias_units);
+  if (dtype == DGTTA_F16)
+    return convT_wgrad<f16_t>(x, ldx, dout, lddo, dw_t, ws, ws_bytes, B, Cin, Cout, Di, Hi, Wi, accumulate, st, bias_part,
+                              bias_part_bytes, bias_units);
   return DGTTA_ERR_UNSUPPORTED;
+}
+
+int convT_bias_finalize(const float *part, int units, int Cout, float *db, int accumulate, hipStream_t st) {
+  hipLaunchKernelGGL(convT_bias_finalize_kernel, dim3((unsigned)cdiv(Cout, 256)), dim3(256), 0, st, part, units, cdiv(Cout, 32) * 32,
+                     Cout, db, accumulate);
+  return hipGetLastError() == hipSuccess ? DGTTA_OK : DGTTA_ERR_LAUNCH;
 }
 
 // 1x1x1 head weight gradient dw[k][ci] = sum_rows dout[row][k] * x[row][ci] as a single-tap run of the wgrad kernel:

@@ -1066,7 +1066,9 @@ int convT_fwd_mfma(const void *x, int ldx, const float *w_t, const float *bias, 
 int convT_dgrad_mfma(const void *dout, int lddo, const float *w_t, void *dx, int lddx, void *ws, int B, int Cin, int Cout,
                      int Di, int Hi, int Wi, int dtype, hipStream_t st);
 int convT_wgrad_mfma(const void *x, int ldx, const void *dout, int lddo, float *dw_t, void *ws, size_t ws_bytes, int B,
-                     int Cin, int Cout, int Di, int Hi, int Wi, int accumulate, int dtype, hipStream_t st);
+                     int Cin, int Cout, int Di, int Hi, int Wi, int accumulate, int dtype, hipStream_t st, float *bias_part,
+                     size_t bias_part_bytes, int *bias_units);
+int convT_bias_finalize(const float *part, int units, int Cout, float *db, int accumulate, hipStream_t st);
 int conv3_wgrad_mfma(const void *x, int ldx, const void *dy, int lddy, float *dw_t, float *db, void *ws, size_t ws_bytes,
                      int B, int Cin, int Cout, int Di, int Hi, int Wi, int stride, int accumulate, int dtype,
                      hipStream_t st);
@@ -1431,6 +1433,7 @@ extern "C" int dgtta_convT3d_k2s2_bwd(const void *x, int ldx, const void *dout, 
   void *ws_pack = (char *)ws + convT_bias_region(B, Cout, Di, Hi, Wi);
   void *ws_main = (char *)ws_pack + convT_pack_region(Cin, Cout, DGTTA_F32);
   const size_t main_bytes = ws_bytes - ((char *)ws_main - (char *)ws);
+  int bias_units = 0;
   if (dx) {
     DG_REQUIRE(lddx >= Cin, DGTTA_ERR_BADARG, "convT3d_k2s2_bwd: lddx < Cin");
     int rc = DGTTA_ERR_UNSUPPORTED;
@@ -1447,8 +1450,9 @@ extern "C" int dgtta_convT3d_k2s2_bwd(const void *x, int ldx, const void *dout, 
   }
   if (dw_t) {
     int rc = DGTTA_ERR_UNSUPPORTED;
-    if (impl != 1)
-      rc = convT_wgrad_mfma(x, ldx, dout, lddo, dw_t, ws_main, main_bytes, B, Cin, Cout, Di, Hi, Wi, accumulate, dtype, st);
+    if (impl != 1)      // (the one-pass kernel also leaves the bias gradient's partial sums in the bias region when asked)
+      rc = convT_wgrad_mfma(x, ldx, dout, lddo, dw_t, ws_main, main_bytes, B, Cin, Cout, Di, Hi, Wi, accumulate, dtype, st,
+                            db ? (float *)ws_bias : nullptr, convT_bias_region(B, Cout, Di, Hi, Wi), &bias_units);
     if (rc == DGTTA_ERR_UNSUPPORTED) {
       DG_REQUIRE(impl != 2, DGTTA_ERR_UNSUPPORTED, "convT3d_k2s2_bwd: wgrad shape not covered by the MFMA kernel");
       const int nsplit = wgrad_splits(nvox);
@@ -1462,6 +1466,11 @@ extern "C" int dgtta_convT3d_k2s2_bwd(const void *x, int ldx, const void *dout, 
     } else if (rc != DGTTA_OK) {
       return rc;
     }
+  }
+  if (db && bias_units > 0) {
+    DG_REQUIRE(convT_bias_finalize((const float *)ws_bias, bias_units, Cout, db, accumulate, st) == DGTTA_OK, DGTTA_ERR_LAUNCH,
+               "convT3d_k2s2_bwd: bias finalize launch failed");
+    return DGTTA_OK;
   }
   if (db) return bias_grad(dout, lddo, db, ws_bias, B, Cout, (int64_t)Di * Hi * Wi * 8, accumulate, dtype, st);
   return DGTTA_OK;

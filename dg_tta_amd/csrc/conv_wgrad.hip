@@ -1113,21 +1113,29 @@ __global__ __launch_bounds__(256, 2) void convT_wgrad_tr_kernel(const bf16_t *__
   }
 }
 
-// sums the per-unit bias partials of convT_wgrad_tr_kernel in unit order (double), one thread per output channel
+// sums the per-unit bias partials of convT_wgrad_tr_kernel: one workgroup per 32 output channels, 8 unit groups (unit mod 8)
+// with eight loads in flight each, the groups added in order (double): a fixed summation order
 __global__ __launch_bounds__(256) void convT_bias_finalize_kernel(const float *__restrict__ part, int units, int ldp, int Cout,
                                                                   float *__restrict__ db, int accumulate) {
-  const int co = blockIdx.x * 256 + threadIdx.x;
-  if (co >= Cout) return;
+  __shared__ double red[8][32];
+  const int co = blockIdx.x * 32 + (threadIdx.x & 31), grp = threadIdx.x >> 5;
   double s = 0.0;
-  for (int u = 0; u < units; u += 8) {
+  for (int u = grp; u < units; u += 64) {
     float v[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = u + j < units ? part[(int64_t)(u + j) * ldp + co] : 0.f;
+    for (int j = 0; j < 8; ++j) v[j] = u + 8 * j < units ? part[(int64_t)(u + 8 * j) * ldp + co] : 0.f;
 #pragma unroll
     for (int j = 0; j < 8; ++j)
-      if (u + j < units) s += (double)v[j];
+      if (u + 8 * j < units) s += (double)v[j];
   }
-  db[co] = accumulate ? db[co] + (float)s : (float)s;
+  red[grp][threadIdx.x & 31] = s;
+  __syncthreads();
+  if (threadIdx.x < 32 && co < Cout) {
+    double t = 0.0;
+#pragma unroll
+    for (int g = 0; g < 8; ++g) t += red[g][threadIdx.x];
+    db[co] = accumulate ? db[co] + (float)t : (float)t;
+  }
 }
 
 // dw[co*s_co + ci*s_ci + real_tap*s_tap] (+)= sum over slabs of virtual tap t (real_tap = real.wt[t], -1: skip).
@@ -1525,7 +1533,7 @@ int convT_wgrad_mfma(const void *x, int ldx, const void *dout, int lddo, float *
 }
 
 int convT_bias_finalize(const float *part, int units, int Cout, float *db, int accumulate, hipStream_t st) {
-  hipLaunchKernelGGL(convT_bias_finalize_kernel, dim3((unsigned)cdiv(Cout, 256)), dim3(256), 0, st, part, units, cdiv(Cout, 32) * 32,
+  hipLaunchKernelGGL(convT_bias_finalize_kernel, dim3((unsigned)cdiv(Cout, 32)), dim3(256), 0, st, part, units, cdiv(Cout, 32) * 32,
                      Cout, db, accumulate);
   return hipGetLastError() == hipSuccess ? DGTTA_OK : DGTTA_ERR_LAUNCH;
 }

@@ -337,7 +337,8 @@ def test_wgrad_mfma_timing_report(capsys):
         print("\n" + "\n".join(rows))
 
 
-@pytest.mark.parametrize("case", [(1, 32, 64, 8, 8, 32), (1, 16, 24, 10, 12, 14), (2, 64, 128, 4, 8, 16)])
+@pytest.mark.parametrize("case", [(1, 32, 64, 8, 8, 32), (1, 16, 24, 10, 12, 14), (2, 64, 128, 4, 8, 16), (1, 32, 192, 4, 8, 8),
+                                  (1, 40, 64, 6, 4, 34)])      # (round 4: three pairs of output-channel blocks; ragged Cin and width)
 @pytest.mark.parametrize("dt", [0, 1])
 def test_wgrad_stride2_mfma(case, dt):
     B, cin, cout, D, H, W = case
@@ -354,7 +355,7 @@ def test_wgrad_stride2_mfma(case, dt):
         assert (dw2.cpu() - ref).abs().max() < 3e-5 * ref.abs().max()
 
 
-@pytest.mark.parametrize("case", [(1, 64, 32, 4, 8, 16), (2, 24, 16, 4, 4, 8), (1, 320, 256, 4, 4, 4)])
+@pytest.mark.parametrize("case", [(1, 64, 32, 4, 8, 16), (2, 24, 16, 4, 4, 8), (1, 320, 256, 4, 4, 4), (1, 96, 48, 4, 4, 8)])      # (round 4: an odd number of input-channel blocks)
 @pytest.mark.parametrize("dt", [0, 1])
 def test_convT_mfma(case, dt):
     """ConvTranspose3d k2 s2 forward / data gradient / weight gradient: MFMA composition vs VALU kernels vs torch."""

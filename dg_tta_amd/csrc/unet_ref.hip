@@ -1614,6 +1614,7 @@ extern "C" int dgtta_argmax_rows(const void *logits, int acc_dtype, int C, int64
   DG_REQUIRE(logits && argmax_out && rows > 0, DGTTA_ERR_BADARG, "argmax_rows: bad args");
   DG_REQUIRE(C > 0 && C <= AR_MAXC, DGTTA_ERR_UNSUPPORTED, "argmax_rows: built for up to %d classes (C %d)", AR_MAXC, C);
   DG_REQUIRE(acc_dtype == DGTTA_F32 || acc_dtype == DGTTA_F16, DGTTA_ERR_UNSUPPORTED, "argmax_rows: rows are fp32 or fp16");
+  DG_REQUIRE(((uintptr_t)logits & 3) == 0, DGTTA_ERR_BADARG, "argmax_rows: rows must start on a 4-byte boundary");
   const int64_t ntile = cdiv64(rows, 64);
   const dim3 grid((unsigned)(ntile < 4096 ? ntile : 4096));
   const size_t lds = (size_t)64 * C * sizeof(float);

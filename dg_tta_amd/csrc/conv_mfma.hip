@@ -240,6 +240,24 @@ __global__ __launch_bounds__(NW * 64) void conv3_mfma_kernel(const T *__restrict
       const int mb = wave * MPW + i;
       const int mbd = mb / MBH, mbh = mb % MBH;
       const int co = n0 + r;
+      // the skip-connection sum reads the old rows: all 16 of a tile's 16-byte pieces are requested before the first class is
+      // written back (round 4) - one load, one wait, one store per class made the epilogue a chain of 16 memory round trips
+      // per tile, about as long as the tile's MFMA loop
+      uint4 olds[8][2];
+      if constexpr (sizeof(T) == 2) {
+        if (vec && accumulate) {
+#pragma unroll
+          for (int c8 = 0; c8 < 8; ++c8)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+              const int m = t * 16 + (lane >> 2), cq = (lane & 3) * 8;
+              const int od = od0 + mbd, oh = oh0 + mbh * G::RPM + m / MBW, ow = ow0 + m % MBW;
+              olds[c8][t] = make_uint4(0u, 0u, 0u, 0u);
+              if (n0 + cq < Cout && od < Do && oh < Ho && ow < Wo)
+                olds[c8][t] = *reinterpret_cast<const uint4 *>(y + cs.yoff[c8] + b * yv.sb + od * yv.sd + oh * yv.sh + ow * yv.sw + n0 + cq);
+            }
+        }
+      }
 #pragma unroll
       for (int c8 = 0; c8 < 8; ++c8) {
         if (!vec) {
@@ -271,7 +289,7 @@ __global__ __launch_bounds__(NW * 64) void conv3_mfma_kernel(const T *__restrict
             if constexpr (sizeof(T) == 2) {
               uint4 *o4 = reinterpret_cast<uint4 *>(o);
               if (accumulate) {
-                const uint4 old = *o4;
+                const uint4 old = olds[c8][t];
                 const unsigned wv[4] = {old.x, old.y, old.z, old.w};
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {

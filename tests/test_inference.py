@@ -124,6 +124,56 @@ def test_sliding_window_at_size_properties():
 
 
 @pytest.mark.gpu
+def test_sliding_window_512_full_size_properties():
+    """BASELINE config 3 at FULL size (round 4): 512^3 volume, 128^3 windows at step 0.5 = 7^3 = 343 windows, 105 classes,
+    52.5 GiB fp32 accumulator.  Size-independent properties: the weight map equals the sum of the 343 window Gaussians
+    (separable: the product of three 1-D sums, formed on the host), every voxel is covered, the label map is the argmax of
+    the accumulator (streaming kernel against torch on a slab), and the fp16 accumulator gives the same labels wherever the
+    fp32 top-2 margin exceeds its rounding bound."""
+    from dg_tta_amd import ops
+    from dg_tta_amd.mind import MIND3D
+    from dg_tta_amd.synthetic import he_init_
+    from dg_tta_amd.tta.inference import compute_gaussian, compute_steps_for_sliding_window, predict_sliding_window_return_logits
+    from dg_tta_amd.unet import HipPlainConvUNet
+    net = he_init_(HipPlainConvUNet(act_dtype=torch.bfloat16), seed=7)
+    net.decoder.seg_layers[-1].bias.data.normal_()
+    net.register_forward_pre_hook(lambda mod, inp: MIND3D(randn_weighting=0.0).forward(*inp, out_dtype=torch.bfloat16))
+    net = net.to(DEV)
+    n, patch = 512, [128, 128, 128]
+    vol = torch.randn(1, n, n, n, generator=torch.Generator().manual_seed(5))
+    steps = compute_steps_for_sliding_window((n, n, n), patch)
+    assert steps == [[0, 64, 128, 192, 256, 320, 384]] * 3
+    acc, nsum, crop = predict_sliding_window_return_logits(net, vol, patch, acc_dtype=torch.float32)
+    assert tuple(acc.shape) == (n, n, n, 105) and acc.dtype == torch.float32
+    # the Gaussian is NOT separable after nnU-Net's rescaling / zero replacement, so the reference map is summed window by
+    # window - on the device, with torch (343 slice additions)
+    g = compute_gaussian(tuple(patch)).to(DEV)
+    ref_n = torch.zeros((n, n, n), device=DEV)
+    for sx in steps[0]:
+        for sy in steps[1]:
+            for sz in steps[2]:
+                ref_n[sx:sx + 128, sy:sy + 128, sz:sz + 128] += g
+    assert float(nsum.min()) > 0
+    assert float((nsum - ref_n).abs().max()) <= 1e-5 * float(ref_n.max())      # 8 fp32 additions per voxel, order aside
+    del ref_n
+    seg = ops.argmax_rows(acc)
+    sl = slice(200, 232)
+    assert torch.equal(seg[sl], acc[sl].argmax(-1))
+    assert len(seg[sl].unique()) > 10
+    top2 = acc[sl].topk(2, dim=-1).values
+    lmax = float((acc[sl].abs().amax(-1) / nsum[sl]).max())
+    # (a window's own logits may exceed the blended ones that lmax is taken from: factor 4 on the rounding bound of 8 windows)
+    safe = (top2[..., 0] - top2[..., 1]) > 2 * 4 * 8 * 2.0 ** -11 * lmax * nsum[sl]
+    seg32 = seg[sl].clone()
+    del acc, seg, top2
+    torch.cuda.empty_cache()
+    acc16, nsum16, _ = predict_sliding_window_return_logits(net, vol, patch, acc_dtype=torch.float16)
+    assert acc16.dtype == torch.float16 and torch.equal(nsum16, nsum)
+    seg16 = ops.argmax_rows(acc16)[sl]
+    assert torch.equal(seg16[safe], seg32[safe]) and float((seg16 == seg32).float().mean()) > 0.99 and float(safe.float().mean()) > 0.3
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("acc_dtype", [torch.float32, torch.float16])
 @pytest.mark.parametrize("C,rows", [(105, 64 * 40 + 17), (105, 4096), (16, 5000), (2, 4100), (112, 129), (7, 63)])
 def test_argmax_rows_first_maximum_wins(C, rows, acc_dtype):

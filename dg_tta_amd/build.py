@@ -74,9 +74,42 @@ def build_asan(verbose=False):
     return lib
 
 
+DIAG_DIR = CSRC.parents[1] / "build" / "diag"
+DIAG_LIB = CSRC.parents[1] / "profiles" / "tools" / "libdgtta_hip_diag.so"
+
+
+def build_diag(verbose=False):
+    """The LABORATORY build (-DDGTTA_DIAG): the same sources plus the timing-model / cycle-stamp instantiations and the
+    DGTTA_*_ABL, DGTTA_ROWS_VAR, DGTTA_RING_NT, DGTTA_WGRAD_RING_CLK switches that select them (results wrong by
+    construction, stamps written behind the caller's buffers).  It lands beside the scripts that use it
+    (profiles/tools/, loaded through DGTTA_LIB) and never in the package: the product library has none of this."""
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    DIAG_DIR.mkdir(parents=True, exist_ok=True)
+    hdrs = list(CSRC.glob("*.h")) + [CSRC.parents[1] / "include" / "dgtta.h"]
+    objs, jobs = [], []
+    for s in SOURCES:
+        src, obj = CSRC / s, DIAG_DIR / (s + ".o")
+        objs.append(obj)
+        if _stale(obj, [src] + hdrs):
+            jobs.append([hipcc, *FLAGS, "-DDGTTA_DIAG", *EXTRA_FLAGS.get(s, []), "-c", str(src), "-o", str(obj)])
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+
+    with ThreadPoolExecutor(max_workers=6) as ex:
+        list(ex.map(run, jobs))
+    if jobs or _stale(DIAG_LIB, objs):
+        run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(DIAG_LIB), *map(str, objs)])
+    return DIAG_LIB
+
+
 if __name__ == "__main__":
     if "--asan" in sys.argv:
         print(build_asan(verbose=True))
+    elif "--diag" in sys.argv:
+        print(build_diag(verbose=True))
     else:
         build(force="--force" in sys.argv)
         print(LIB)

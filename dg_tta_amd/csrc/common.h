@@ -15,15 +15,25 @@
 
 void dgtta_set_error(const char *fmt, ...);
 
-// Diagnostic / test switches (Switches): a snapshot of the DGTTA_* environment taken ONCE (std::call_once)
-// at first use and again only on dgtta_reload_env(); dispatch code reads the snapshot, never the environment.
+// Test switches (Switches): a snapshot of the DGTTA_* environment taken ONCE (std::call_once) at first use and
+// again only on dgtta_reload_env(); dispatch code reads the snapshot, never the environment.  Every one of them selects
+// between kernels that compute the SAME result (a fast kernel and the predecessor it replaced; tests run both).
 // -1 = variable not set; otherwise the first character ('0', '1', ...) of its value.
 struct DgttaSwitches {
   int conv_rows, conv_variant, conv_s2, dgrad_s2_allcls, wgrad_tr, wgrad_tr8, wgrad_s2_onepass, convt_wgrad_onepass;
-  int conv_abl, rows_abl, wgrad_abl;
-  int convt_gemm, rows_order, in_nt, wgrad_upw, wgrad_xcd, rows_var, warp_coop, warp_nt, warp_xcd, in_gstats, softdice16, conv_ring, ring_nt, ring_abl, wgrad_ring, ha_abl, ha_mfma, warp_abl;
+  int convt_gemm, rows_order, in_nt, wgrad_upw, wgrad_xcd, in_gstats, softdice16, conv_ring, wgrad_ring, ha_mfma;
+  // Laboratory switches: timing models whose results are WRONG BY CONSTRUCTION (*_abl), cycle stamps written past the
+  // caller's buffers, measured-no-gain variants.  They exist only in the diagnostic build (-DDGTTA_DIAG ->
+  // libdgtta_hip_diag.so, `python -m dg_tta_amd.build --diag`, loaded by profiles/tools/ through DGTTA_LIB); the product
+  // library neither reads these variables nor contains the kernel instantiations behind them.
+  int rows_abl, rows_var, ring_nt, ring_abl, wgrad_ring_lab, ha_abl, warp_abl, convt_gemm_abl;
 };
 const DgttaSwitches &dgtta_switches();
+#ifdef DGTTA_DIAG
+#define DG_LAB(field) (dgtta_switches().field)
+#else
+#define DG_LAB(field) (-1)
+#endif
 
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (kernel, device): lock-free and per device (a plain
 // `static bool` was neither).  One static DynLdsOnce per launch site.
@@ -40,9 +50,9 @@ static inline hipError_t ensure_dyn_lds(DynLdsOnce &o, const void *fn, int bytes
   return e;
 }
 
-// context of a data-gradient launch that also produces the InstanceNorm backward statistics of the previous block (set by
-// dgtta_conv3d_k3_dgrad_gstats around the dispatcher call, consumed by the launcher of conv_ring.hip or conv_rows.hip that
-// takes the launch: the generic kernels know nothing about it)
+// context of a data-gradient launch that also produces the InstanceNorm backward statistics of the previous block: built by
+// dgtta_conv3d_k3_dgrad_gstats and handed DOWN the dispatch chain as an argument (conv3_fwd_mfma -> dispatch_conv ->
+// conv3_ring_launch / conv3_rows_launch); the launcher that takes it sets `produced`, the generic kernels ignore it
 struct RowsGstCtx {
   const void *y;
   long long ldy;
@@ -51,7 +61,6 @@ struct RowsGstCtx {
   double *out;
   int produced;
 };
-extern thread_local RowsGstCtx *g_rows_gst;
 
 #define DG_REQUIRE(cond, code, ...)      \
   do {                                   \

@@ -570,7 +570,8 @@ namespace {
 
 template <int KH>
 int ring_launch_kh(const void *x, const View &xv, const void *w, const Taps &taps, const float *bias, void *y, const View &yv,
-                   int B, int Cout, double *stats, int64_t stats_cap_slots, int ntaps_src, int is_f16, hipStream_t st) {
+                   int B, int Cout, double *stats, int64_t stats_cap_slots, int ntaps_src, int is_f16, hipStream_t st,
+                   RowsGstCtx *gctx) {
   typedef RingCfgT<KH> C;
   // the buffer descriptors address one sample with 32-bit byte offsets
   const long long xb = ((long long)(xv.D - 1) * xv.sd + (long long)(xv.H - 1) * xv.sh + (long long)(xv.W - 1) * xv.sw + 32 * KH) * 2;
@@ -605,13 +606,12 @@ int ring_launch_kh(const void *x, const View &xv, const void *w, const Taps &tap
   if (njobs >= (1ll << 31)) return DGTTA_ERR_UNSUPPORTED;
   // a data gradient that is asked to leave the InstanceNorm backward sums of the previous block (dgtta_conv3d_k3_dgrad_gstats)
   RingGst ga{};
-  RowsGstCtx *gctx = g_rows_gst;
+  const int abl = DG_LAB(ring_abl);      // laboratory builds (libdgtta_hip_diag.so only): timing models and cycle stamps
   const long long gb = gctx ? ((long long)(yv.D - 1) * yv.H * yv.W * gctx->ldy + (long long)(yv.H - 1) * yv.W * gctx->ldy +
                                (long long)(yv.W - 1) * gctx->ldy + Cout) * 2 : 0;
   const bool gst_on = gctx && !stats && !bias && gctx->ldy % 8 == 0 && ((uintptr_t)gctx->y & 15) == 0 && gb < (1ll << 31) &&
-                      (int64_t)tW * tH * nseg <= stats_cap_slots && dgtta_switches().ring_abl < 0;
+                      (int64_t)tW * tH * nseg <= stats_cap_slots && abl < 0;
   if (gst_on) {
-    g_rows_gst = nullptr;       // one launch per context
     ga.y = (const bf16_t *)gctx->y;
     ga.v = dense_view(B, yv.D, yv.H, yv.W, (int)gctx->ldy);
     ga.mr = gctx->mr;
@@ -623,8 +623,9 @@ int ring_launch_kh(const void *x, const View &xv, const void *w, const Taps &tap
     gctx->produced = 1;
   }
   const int grid = (int)(njobs < ncu ? njobs : ncu);
-  const bool nt = dgtta_switches().ring_nt == '1';      // DGTTA_RING_NT=1: non-temporal output stores (measured 5 % slower: the two
-                                                          // 32-byte halves of a voxel come from two waves and merge in L2)
+  // DGTTA_RING_NT=1 (diagnostic build): non-temporal output stores (measured 5 % slower: the two 32-byte halves of a voxel come
+  // from two waves and merge in L2)
+  const bool nt = DG_LAB(ring_nt) == '1';
 #define RING_LAUNCH(T16, NTS, ABLV, GSTV)                                                                                     \
   do {                                                                                                                        \
     auto kern = conv3_ring_kernel<T16, NTS, ABLV, GSTV, KH>;                                                                  \
@@ -635,37 +636,38 @@ int ring_launch_kh(const void *x, const View &xv, const void *w, const Taps &tap
                        (bf16_t *)y, yv, Cout, tW, tH, nblkN, nseg, sps, (int)njobs, stats, ntaps_src, (unsigned)xb,           \
                        (unsigned)yb, ga);                                                                                     \
   } while (0)
-  const int abl = dgtta_switches().ring_abl;
   bool diag = false;
-  if constexpr (KH == 1) {      // diagnostic builds exist for the fp16 / 32-channel instantiation only
-    if (is_f16 && abl > '0') {
+#ifdef DGTTA_DIAG
+  if constexpr (KH == 1) {      // diagnostic builds exist for the fp16 / 32-channel instantiation only; exact values only
+    if (is_f16 && (abl == '1' || abl == '2' || abl == '3')) {
       diag = true;
       if (abl == '1') RING_LAUNCH(f16_t, false, 1, false);
       else if (abl == '2') RING_LAUNCH(f16_t, false, 2, false);
-      else if (abl == '3') RING_LAUNCH(f16_t, false, 3, false);
-      else RING_LAUNCH(f16_t, false, 6, false);
+      else RING_LAUNCH(f16_t, false, 3, false);
+    } else if (is_f16 && abl == '6') {
+      // cycle stamps go to stats + 2^20 doubles, past what dgtta_conv3d_stats_bytes covers: only profiles/tools/ring_stamps.py,
+      // which allocates that area itself, may ask for this build (it does not exist in the product library)
+      diag = true;
+      RING_LAUNCH(f16_t, false, 6, false);
+    }
+    if (!diag && nt) {
+      diag = true;
+      if (is_f16) RING_LAUNCH(f16_t, true, 0, false);
+      else RING_LAUNCH(bf16_t, true, 0, false);
     }
   }
+#endif
   if (diag) {
   } else if (gst_on) {
     if (is_f16) RING_LAUNCH(f16_t, false, 0, true);
     else RING_LAUNCH(bf16_t, false, 0, true);
   } else if (is_f16) {
-    if constexpr (KH == 1) {
-      if (nt) RING_LAUNCH(f16_t, true, 0, false);
-      else RING_LAUNCH(f16_t, false, 0, false);
-    } else {
-      RING_LAUNCH(f16_t, false, 0, false);
-    }
+    RING_LAUNCH(f16_t, false, 0, false);
   } else {
-    if constexpr (KH == 1) {
-      if (nt) RING_LAUNCH(bf16_t, true, 0, false);
-      else RING_LAUNCH(bf16_t, false, 0, false);
-    } else {
-      RING_LAUNCH(bf16_t, false, 0, false);
-    }
+    RING_LAUNCH(bf16_t, false, 0, false);
   }
 #undef RING_LAUNCH
+  (void)nt;
   DG_CHECK_LAUNCH("conv3_ring_kernel");
   return DGTTA_OK;
 }
@@ -675,12 +677,12 @@ int ring_launch_kh(const void *x, const View &xv, const void *w, const Taps &tap
 // Entry point used by the dispatcher in conv_mfma.hip: DGTTA_ERR_UNSUPPORTED when the shape is not this kernel's.
 int conv3_ring_launch(const void *x, const View &xv, const void *w, const Taps &taps, const float *bias, void *y, const View &yv,
                       int B, int Cin, int Cout, int CinP, int CoutP, double *stats, int64_t stats_cap_slots, int ntaps_src,
-                      int is_f16, hipStream_t st) {
+                      int is_f16, hipStream_t st, RowsGstCtx *gst) {
   if (Cin != CinP || (Cin != 32 && Cin != 64) || Cout % 32 != 0 || CoutP != Cout) return DGTTA_ERR_UNSUPPORTED;
   if (xv.D != yv.D || xv.H != yv.H || xv.W != yv.W) return DGTTA_ERR_UNSUPPORTED;
   if (Cin == 64) {
     if (dgtta_switches().conv_ring == '3') return DGTTA_ERR_UNSUPPORTED;      // DGTTA_CONV_RING=3: the ring for 32 input channels only
-    return ring_launch_kh<2>(x, xv, w, taps, bias, y, yv, B, Cout, stats, stats_cap_slots, ntaps_src, is_f16, st);
+    return ring_launch_kh<2>(x, xv, w, taps, bias, y, yv, B, Cout, stats, stats_cap_slots, ntaps_src, is_f16, st, gst);
   }
-  return ring_launch_kh<1>(x, xv, w, taps, bias, y, yv, B, Cout, stats, stats_cap_slots, ntaps_src, is_f16, st);
+  return ring_launch_kh<1>(x, xv, w, taps, bias, y, yv, B, Cout, stats, stats_cap_slots, ntaps_src, is_f16, st, gst);
 }

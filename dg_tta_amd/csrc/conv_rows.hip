@@ -586,22 +586,23 @@ __global__ __launch_bounds__(WD *WH * 64) void conv3_rows_kernel(const bf16_t *_
 
 }  // namespace
 
-thread_local RowsGstCtx *g_rows_gst = nullptr;
-
 namespace {
 
 template <int PD, int PH, int WD, int WH, typename T16>
 int launch_conv_rows(const void *x, const View &xv, const void *w, const Taps &taps, const float *bias, void *y,
                      const View &yv, int B, int Cin, int Cout, int CinP, int CoutP, double *stats, int ntaps_src,
-                     hipStream_t st) {
+                     hipStream_t st, RowsGstCtx *gctx) {
   typedef RowsCfg<PD, PH, WD, WH> Cfg;
   GstArgs ga{};
-  RowsGstCtx *gctx = g_rows_gst;
-  g_rows_gst = nullptr;       // one launch per context
+  // laboratory builds of the same kernel (libdgtta_hip_diag.so only).  DGTTA_ROWS_ABL: 1 no DMA, 3 no MFMA, 6 per-segment cycle
+  // stamps, 7 the voxel-major (ragged-tile) epilogue for every tile, 8 plain (temporal) output stores; DGTTA_ROWS_VAR: '0' =
+  // the round-2 kernel, default = feature mask 5
+  const int abl = DG_LAB(rows_abl);
+  const int var = DG_LAB(rows_var);
   // eligible: no forward statistics asked for, every tile whole, whole 32-channel blocks
   const bool gst_on = gctx && !stats && !bias && yv.D % Cfg::TD == 0 && yv.H % Cfg::TH == 0 && yv.W % 32 == 0 && Cout % 32 == 0 &&
-                      CoutP == Cout && gctx->ldy % 8 == 0 && ((uintptr_t)gctx->y & 15) == 0 && dgtta_switches().rows_abl < 0 &&
-                      dgtta_switches().rows_var != '7' && dgtta_switches().rows_var != '0';      // (those builds have no GST form)
+                      CoutP == Cout && gctx->ldy % 8 == 0 && ((uintptr_t)gctx->y & 15) == 0 && abl < 0 &&
+                      var != '7' && var != '0';      // (those builds have no GST form)
   if (gst_on) {
     ga.y = (const bf16_t *)gctx->y;
     ga.v = dense_view(B, yv.D, yv.H, yv.W, (int)gctx->ldy);
@@ -612,15 +613,12 @@ int launch_conv_rows(const void *x, const View &xv, const void *w, const Taps &t
     stats = gctx->out;
     gctx->produced = 1;
   }
-  // DGTTA_ROWS_ABL (diagnostic builds of the same kernel): 1 no DMA, 3 no MFMA, 6 per-segment cycle stamps, 7 the
-  // voxel-major (ragged-tile) epilogue for every tile, 8 plain (temporal) output stores
-  const int abl = dgtta_switches().rows_abl;
-  const int var = dgtta_switches().rows_var;       // DGTTA_ROWS_VAR: '0' = the round-2 kernel; default = feature mask 5
   auto kern = conv3_rows_kernel<PD, PH, WD, WH, 0, T16, 5>;
   static DynLdsOnce once[16];
   int slot = 0;
-  if (var == '0') kern = conv3_rows_kernel<PD, PH, WD, WH, 0, T16, 0>, slot = 6;
   if (gst_on) kern = conv3_rows_kernel<PD, PH, WD, WH, 0, T16, 5, true>, slot = 15;
+#ifdef DGTTA_DIAG
+  if (var == '0') kern = conv3_rows_kernel<PD, PH, WD, WH, 0, T16, 0>, slot = 6;
   if (std::is_same<T16, bf16_t>::value) {      // diagnostic builds exist for the bf16 instantiation only
     if (var == '7') kern = conv3_rows_kernel<PD, PH, WD, WH, 0, T16, 7>, slot = 7;
     if (abl == '1') kern = conv3_rows_kernel<PD, PH, WD, WH, 1, T16, 0>, slot = 1;
@@ -635,6 +633,7 @@ int launch_conv_rows(const void *x, const View &xv, const void *w, const Taps &t
     if (abl == '9') kern = conv3_rows_kernel<PD, PH, WD, WH, 9, T16, 0>, slot = 14;
     if (abl == '8') kern = conv3_rows_kernel<PD, PH, WD, WH, 8, T16, 0>, slot = 5;
   }
+#endif
   DG_REQUIRE(ensure_dyn_lds(once[slot], reinterpret_cast<const void *>(kern), (int)Cfg::LDS_BYTES) == hipSuccess,
              DGTTA_ERR_LAUNCH, "conv3_rows: cannot raise the dynamic LDS limit to %zu", (size_t)Cfg::LDS_BYTES);
   const int tW = cdiv(yv.W, 32), tH = cdiv(yv.H, Cfg::TH), tD = cdiv(yv.D, Cfg::TD), nblkN = cdiv(CoutP, 32);
@@ -658,8 +657,9 @@ int launch_conv_rows(const void *x, const View &xv, const void *w, const Taps &t
 
 // entry point used by the dispatcher in conv_mfma.hip
 int conv3_rows_launch(const void *x, const View &xv, const void *w, const Taps &taps, const float *bias, void *y, const View &yv,
-                      int B, int Cin, int Cout, int CinP, int CoutP, double *stats, int ntaps_src, int is_f16, hipStream_t st) {
+                      int B, int Cin, int Cout, int CinP, int CoutP, double *stats, int ntaps_src, int is_f16, hipStream_t st,
+                      RowsGstCtx *gst) {
   if (is_f16)
-    return launch_conv_rows<2, 2, 2, 4, f16_t>(x, xv, w, taps, bias, y, yv, B, Cin, Cout, CinP, CoutP, stats, ntaps_src, st);
-  return launch_conv_rows<2, 2, 2, 4, bf16_t>(x, xv, w, taps, bias, y, yv, B, Cin, Cout, CinP, CoutP, stats, ntaps_src, st);
+    return launch_conv_rows<2, 2, 2, 4, f16_t>(x, xv, w, taps, bias, y, yv, B, Cin, Cout, CinP, CoutP, stats, ntaps_src, st, gst);
+  return launch_conv_rows<2, 2, 2, 4, bf16_t>(x, xv, w, taps, bias, y, yv, B, Cin, Cout, CinP, CoutP, stats, ntaps_src, st, gst);
 }

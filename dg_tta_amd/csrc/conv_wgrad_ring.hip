@@ -362,7 +362,10 @@ __global__ __launch_bounds__(WR::NW * 64) void conv3_wgrad_ring_kernel(const bf1
     o[1] = (float)(__builtin_amdgcn_s_memrealtime() - rt_begin);
     o[2] = (float)t_wait;
   }
-  // the two row halves of a tap: waves with rh = 1 hand their accumulators over through LDS (all DMA has been waited for)
+  // the two row halves of a tap: waves with rh = 1 hand their accumulators over through LDS, which overlays the rings.  A
+  // workgroup whose LAST job has a single slice (DR == 1 or a one-slice tail segment) has only waited for the first three of
+  // its prologue's four DMA groups: drain them all before the overlay is written (free for every other job: already drained)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   lds_barrier();
   float *xch = reinterpret_cast<float *>(smem);
   if (rh == 1) {
@@ -449,8 +452,14 @@ int conv3_wgrad_ring_launch(const void *x, const View &xv, const void *dy, const
   // DGTTA_WGRAD_RING=4: the v_mfma_f32_16x16x32 form (conflict-free after the half swap above; measured within +-2 % of the
   // 32x32x16 form on three boxes, which is the default: 36 registers less and no swizzle)
   const bool mf16 = dgtta_switches().wgrad_ring == '4';
-  if (is_f16 && dgtta_switches().wgrad_ring == '6') {      // diagnostic: stamps (profiles/tools/wring_clock.py)
+  bool lab = false;
+#ifdef DGTTA_DIAG
+  if (is_f16 && DG_LAB(wgrad_ring_lab) == '6') {      // DGTTA_WGRAD_RING_CLK=6: cycle stamps BEHIND the slabs; only
+    lab = true;                                        // profiles/tools/wring_clock.py, which allocates that area, asks for it
     WR_LAUNCH(f16_t, false, true);
+  }
+#endif
+  if (lab) {
   } else if (is_f16) {
     if (mf16) WR_LAUNCH(f16_t, true, false);
     else WR_LAUNCH(f16_t, false, false);

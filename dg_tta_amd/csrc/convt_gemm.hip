@@ -151,7 +151,7 @@ int launch_gemm(const void *in, int ldin, const T *blob, const float *bias, void
   const long long want = cdiv64(nMB, 8), cap = (long long)cus * (LDS <= 64 * 1024 ? 2 : 1);
   hipLaunchKernelGGL(kern, dim3((unsigned)(want < cap ? want : cap)), dim3(512), LDS, st, (const T *)in, ldin, blob, bias,
                      (T *)out, ldout, Di, Hi, Wi, Cout, nWB, nMB,
-                     dgtta_switches().convt_gemm >= '2' ? dgtta_switches().convt_gemm - '0' : 0);
+                     DG_LAB(convt_gemm_abl) >= '2' ? DG_LAB(convt_gemm_abl) - '0' : 0);      // timing models: diagnostic build only
   DG_CHECK_LAUNCH("convT_gemm_kernel");
   return DGTTA_OK;
 }

@@ -21,9 +21,11 @@ extern "C" const char *dgtta_last_error(void) { return g_err; }
 static std::atomic<const DgttaSwitches *> g_switches{nullptr};
 static std::once_flag g_switches_once;
 
+
+// strict: a switch is the single character the documentation names; anything else ('off', 'no', '7x', ...) counts as unset
 static int env_char(const char *name) {
   const char *v = getenv(name);
-  return (v && v[0]) ? (int)(unsigned char)v[0] : -1;
+  return (v && v[0] && !v[1] && v[0] >= '0' && v[0] <= '9') ? (int)(unsigned char)v[0] : -1;
 }
 
 static const DgttaSwitches *read_switches() {
@@ -42,22 +44,26 @@ static const DgttaSwitches *read_switches() {
   s->wgrad_tr8 = env_char("DGTTA_WGRAD_TR8");
   s->wgrad_s2_onepass = env_char("DGTTA_WGRAD_S2_ONEPASS");
   s->convt_wgrad_onepass = env_char("DGTTA_CONVT_WGRAD_ONEPASS");
-  s->conv_abl = env_char("DGTTA_CONV_ABL");
-  s->rows_abl = env_char("DGTTA_ROWS_ABL");
-  s->rows_var = env_char("DGTTA_ROWS_VAR");
-  s->warp_coop = env_char("DGTTA_WARP_COOP");
-  s->warp_nt = env_char("DGTTA_WARP_NT");
-  s->warp_xcd = env_char("DGTTA_WARP_XCD");
   s->in_gstats = env_char("DGTTA_IN_GSTATS");
   s->softdice16 = env_char("DGTTA_SOFTDICE16");
-  s->wgrad_abl = env_char("DGTTA_WGRAD_ABL");
   s->conv_ring = env_char("DGTTA_CONV_RING");
+  s->wgrad_ring = env_char("DGTTA_WGRAD_RING");
+  s->ha_mfma = env_char("DGTTA_HA_MFMA");
+  // product switches select between kernels of equal results only: values outside a switch's documented set are ignored
+  if (s->conv_ring != '0' && s->conv_ring != '1' && s->conv_ring != '3') s->conv_ring = -1;
+  if (s->wgrad_ring != '0' && s->wgrad_ring != '1' && s->wgrad_ring != '4') s->wgrad_ring = -1;
+  if (s->convt_gemm != '0' && s->convt_gemm != '1') s->convt_gemm = -1;
+  s->rows_abl = s->rows_var = s->ring_nt = s->ring_abl = s->wgrad_ring_lab = s->ha_abl = s->warp_abl = s->convt_gemm_abl = -1;
+#ifdef DGTTA_DIAG
+  s->rows_abl = env_char("DGTTA_ROWS_ABL");
+  s->convt_gemm_abl = env_char("DGTTA_CONVT_GEMM_ABL");      // '2' / '3': the transposed-conv GEMM without stores / without MFMAs
+  s->rows_var = env_char("DGTTA_ROWS_VAR");
   s->ring_nt = env_char("DGTTA_RING_NT");
   s->ring_abl = env_char("DGTTA_RING_ABL");
-  s->wgrad_ring = env_char("DGTTA_WGRAD_RING");
+  s->wgrad_ring_lab = env_char("DGTTA_WGRAD_RING_CLK");      // '6': cycle stamps behind the slabs (profiles/tools/wring_clock.py)
   s->ha_abl = env_char("DGTTA_HA_ABL");
-  s->ha_mfma = env_char("DGTTA_HA_MFMA");
   s->warp_abl = env_char("DGTTA_WARP_ABL");
+#endif
   return s;
 }
 

@@ -1013,6 +1013,34 @@ __global__ __launch_bounds__(256) void argmax_rows_kernel(const ACC *__restrict_
   }
 }
 
+// More classes than the LDS tile of argmax_rows_kernel holds (e.g. the 118 classes of TotalSegmentator v2 weights): one WAVE
+// per row, lane l scans classes l, l + 64, ...; the partial maxima are combined so that the FIRST class that reaches the
+// maximum wins and NaNs are passed over, exactly as the sequential scan does (row[0] = NaN keeps class 0).
+template <typename ACC>
+__global__ __launch_bounds__(256) void argmax_rows_wide_kernel(const ACC *__restrict__ logits, int C, int64_t *__restrict__ amax,
+                                                               int64_t total) {
+  const int lane = threadIdx.x & 63;
+  const int64_t w0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nw = (int64_t)gridDim.x * 4;
+  for (int64_t v = w0; v < total; v += nw) {
+    const ACC *row = logits + v * C;
+    float bv = -__builtin_inff();
+    int best = lane < C ? lane : C - 1;
+    if (lane == 0) bv = ld_f<ACC>(row);
+    for (int c = lane == 0 ? 64 : lane; c < C; c += 64) {
+      const float x = ld_f<ACC>(row + c);
+      if (x > bv) bv = x, best = c;
+    }
+    const bool first_nan = __shfl(bv != bv ? 1 : 0, 0, 64) != 0;
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+      const float ov = __shfl_xor(bv, m, 64);
+      const int ob = __shfl_xor(best, m, 64);
+      if (ov > bv || (ov == bv && ob < best)) bv = ov, best = ob;
+    }
+    if (lane == 0) amax[v] = first_nan ? 0 : best;
+  }
+}
+
 int gs_blocks(int64_t total, int cap = 16384) {
   int64_t b = (total + 255) / 256;
   return (int)(b < cap ? (b > 0 ? b : 1) : cap);
@@ -1056,7 +1084,7 @@ int wgrad_splits(int64_t nvox) {
 // MFMA implementations (conv_mfma.hip); return DGTTA_ERR_UNSUPPORTED when the shape is not covered.
 int conv3_fwd_mfma(const void *x, int ldx, const void *w_kmajor, int mirror, const float *bias, void *y, int ldy, int B,
                    int Cin, int Cout, int CinP, int CoutP, int Di, int Hi, int Wi, int stride, int dtype,
-                   hipStream_t st, double *stats);
+                   hipStream_t st, double *stats, RowsGstCtx *gst = nullptr);
 int64_t conv3_mfma_max_tiles(int Do, int Ho, int Wo);
 int conv3_dgrad_s2_mfma(const void *dy, int lddy, const void *w_kmajor, void *dx, int lddx, int B, int Cin, int Cout,
                         int CinP, int CoutP, int Di, int Hi, int Wi, int accumulate, int dtype, hipStream_t st);
@@ -1158,9 +1186,10 @@ extern "C" int dgtta_conv3d_k3_fwd(const void *x, int ldx, const void *wpack, co
   return DGTTA_OK;
 }
 
-extern "C" int dgtta_conv3d_k3_dgrad(const void *dy, int lddy, const void *wpack, void *dx, int lddx, int B, int Cin,
-                                     int Cout, int CinP, int CoutP, int Di, int Hi, int Wi, int stride, int accumulate,
-                                     int dtype, int impl, void *stream) {
+// gst: the InstanceNorm-backward context of dgtta_conv3d_k3_dgrad_gstats (null for the plain data gradient); it travels down
+// the dispatch chain as an argument and only the ring / row-reuse launchers act on it
+static int k3_dgrad(const void *dy, int lddy, const void *wpack, void *dx, int lddx, int B, int Cin, int Cout, int CinP, int CoutP,
+                    int Di, int Hi, int Wi, int stride, int accumulate, int dtype, int impl, void *stream, RowsGstCtx *gst) {
   DG_REQUIRE(dy && wpack && dx, DGTTA_ERR_BADARG, "conv3d_k3_dgrad: null pointer");
   const void *wb = wb_of(wpack, CinP, CoutP, dtype);
   DG_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && CinP >= Cin && CoutP >= Cout && Di > 0 && Hi > 0 && Wi > 0,
@@ -1172,7 +1201,7 @@ extern "C" int dgtta_conv3d_k3_dgrad(const void *dy, int lddy, const void *wpack
     // stride-1 data gradient == forward conv of dy with the mirrored, transposed weights (wb)
     // (imgB: N = ci, K = co; taps mirrored)
     int rc = conv3_fwd_mfma(dy, lddy, imgB_of(wpack, CinP, CoutP, dtype), 1, nullptr, dx, lddx, B, Cout, Cin, CoutP, CinP, Di,
-                            Hi, Wi, 1, dtype, st, nullptr);
+                            Hi, Wi, 1, dtype, st, nullptr, gst);
     if (rc != DGTTA_ERR_UNSUPPORTED) return rc;
     DG_REQUIRE(impl == 0, DGTTA_ERR_UNSUPPORTED, "conv3d_k3_dgrad: shape not covered by the MFMA kernel");
   }
@@ -1191,6 +1220,11 @@ extern "C" int dgtta_conv3d_k3_dgrad(const void *dy, int lddy, const void *wpack
   return DGTTA_OK;
 }
 
+extern "C" int dgtta_conv3d_k3_dgrad(const void *dy, int lddy, const void *wpack, void *dx, int lddx, int B, int Cin,
+                                     int Cout, int CinP, int CoutP, int Di, int Hi, int Wi, int stride, int accumulate,
+                                     int dtype, int impl, void *stream) {
+  return k3_dgrad(dy, lddy, wpack, dx, lddx, B, Cin, Cout, CinP, CoutP, Di, Hi, Wi, stride, accumulate, dtype, impl, stream, nullptr);
+}
 
 
 extern "C" int dgtta_conv3d_k3_dgrad_gstats(const void *dy, int lddy, const void *wpack, void *dx, int lddx, int B, int Cin,
@@ -1206,9 +1240,9 @@ extern "C" int dgtta_conv3d_k3_dgrad_gstats(const void *dy, int lddy, const void
   RowsGstCtx ctx{y_prev, ldy_prev, mean_rstd_prev, gamma_prev, beta_prev, slope, (double *)gstats, 0};
   // only the row-reuse kernel (16-bit storage, large whole-tile volumes) knows the fused form; any other dispatch ignores
   // the context and *h_produced stays 0: the caller then runs the plain dgtta_instnorm_lrelu_bwd
-  if (dtype != DGTTA_F32 && impl != 1 && dgtta_switches().in_gstats != '0') g_rows_gst = &ctx;
-  const int rc = dgtta_conv3d_k3_dgrad(dy, lddy, wpack, dx, lddx, B, Cin, Cout, CinP, CoutP, Di, Hi, Wi, 1, 0, dtype, impl, stream);
-  g_rows_gst = nullptr;
+  const bool fuse = dtype != DGTTA_F32 && impl != 1 && dgtta_switches().in_gstats != '0';
+  const int rc = k3_dgrad(dy, lddy, wpack, dx, lddx, B, Cin, Cout, CinP, CoutP, Di, Hi, Wi, 1, 0, dtype, impl, stream,
+                          fuse ? &ctx : nullptr);
   *h_produced = rc == DGTTA_OK ? ctx.produced : 0;
   return rc;
 }
@@ -1612,9 +1646,18 @@ extern "C" int dgtta_ndhwc_to_ncdhw(const void *src, float *dst, int B, int C, i
 
 extern "C" int dgtta_argmax_rows(const void *logits, int acc_dtype, int C, int64_t rows, int64_t *argmax_out, void *stream) {
   DG_REQUIRE(logits && argmax_out && rows > 0, DGTTA_ERR_BADARG, "argmax_rows: bad args");
-  DG_REQUIRE(C > 0 && C <= AR_MAXC, DGTTA_ERR_UNSUPPORTED, "argmax_rows: built for up to %d classes (C %d)", AR_MAXC, C);
+  DG_REQUIRE(C > 0 && C <= 65536, DGTTA_ERR_UNSUPPORTED, "argmax_rows: C %d", C);
   DG_REQUIRE(acc_dtype == DGTTA_F32 || acc_dtype == DGTTA_F16, DGTTA_ERR_UNSUPPORTED, "argmax_rows: rows are fp32 or fp16");
   DG_REQUIRE(((uintptr_t)logits & 3) == 0, DGTTA_ERR_BADARG, "argmax_rows: rows must start on a 4-byte boundary");
+  if (C > AR_MAXC) {      // wider than the LDS tile: one wave per row
+    const dim3 gridw((unsigned)(cdiv64(rows, 4) < 16384 ? cdiv64(rows, 4) : 16384));
+    if (acc_dtype == DGTTA_F32)
+      hipLaunchKernelGGL(argmax_rows_wide_kernel<float>, gridw, dim3(256), 0, (hipStream_t)stream, (const float *)logits, C, argmax_out, rows);
+    else
+      hipLaunchKernelGGL(argmax_rows_wide_kernel<f16_t>, gridw, dim3(256), 0, (hipStream_t)stream, (const f16_t *)logits, C, argmax_out, rows);
+    DG_CHECK_LAUNCH("argmax_rows_wide_kernel");
+    return DGTTA_OK;
+  }
   const int64_t ntile = cdiv64(rows, 64);
   const dim3 grid((unsigned)(ntile < 4096 ? ntile : 4096));
   const size_t lds = (size_t)64 * C * sizeof(float);

@@ -16,16 +16,9 @@ __device__ __forceinline__ float base_coord(int j, int n) {
   return (v * (float)(n - 1)) / (float)n;
 }
 
-// Workgroups are handed to the 8 XCDs (each with its own L2) round robin in launch order, and neighbouring tiles of these
-// kernels share the rows / slices their trilinear footprints overlap in.  With the launch order as the tile order every
-// XCD fetched its own copy of those rows from HBM; this maps launch index L to a tile index such that each XCD walks a
-// CONTIGUOUS eighth of the tiles.  Measured (round 3, 8 x 128^3 x 16): no gain forward, 20 % SLOWER backward - the
-// counters show both kernels waiting on L1 misses that hit in L2 (L2 hit rate 93 %), not on HBM - so it is opt-in
-// (DGTTA_WARP_XCD=1) and the launch order stays the tile order.
-__device__ __forceinline__ int xcd_contiguous_tile(int L, int n, int enable) {
-  const int n8 = n & ~7;
-  return (enable && L < n8) ? (L & 7) * (n8 >> 3) + (L >> 3) : L;
-}
+// (Round 3 measured an XCD-contiguous tile order for these kernels - no gain forward, 20 % slower backward: both wait on L1
+// misses that hit in L2, not on HBM - and a cooperative owner / loader backward, bit-identical and no faster; both prototypes
+// were removed in round 5, the numbers are in DESIGN.md.)
 
 struct Sample {
   float ix, iy, iz;
@@ -264,14 +257,13 @@ template <int CH, bool VEC>
 __global__ __launch_bounds__(256) void warp_bwd_gather_kernel(const float *__restrict__ gdst,
                                                               const float *__restrict__ theta, float *__restrict__ gsrc,
                                                               int C, int Ds, int Hs, int Ws, int Dd, int Hd, int Wd,
-                                                              int src_ldc, int dst_ldc, int algebra, int gx, int gy,
-                                                              int xcd) {
+                                                              int src_ldc, int dst_ldc, int algebra, int gx, int gy) {
   const int64_t Vd = (int64_t)Dd * Hd * Wd, Vs = (int64_t)Ds * Hs * Ws;
   // workgroup = compact 16 x 4 x 4 tile of source voxels (small grad_dst footprint -> L1/L2 reuse of the 8x overlap).
   // (4 lanes per voxel with 4 channels each would make the row loads 4x denser per instruction, but repeats the
   // candidate search 4x and measured slower: 374 vs 206 us at 128^3 x 16.)
   const int tilesX = (Ws + 15) >> 4, tilesZ = (Ds + 3) >> 2;
-  const int tile = xcd_contiguous_tile((int)blockIdx.x, (int)gridDim.x, xcd);
+  const int tile = (int)blockIdx.x;
   const int bx = tile % gx, by = (tile / gx) % gy, bz = tile / (gx * gy);
   const int c0 = (bx / tilesX) * CH;
   const int b = bz / tilesZ;
@@ -368,178 +360,6 @@ __global__ __launch_bounds__(256) void warp_bwd_gather_kernel(const float *__res
   }
 }
 
-// Cooperative form of warp_bwd_gather_kernel<16, true> (round 3).  The owner-computes kernel above gives a lane ONE
-// grad_src voxel with 16 channels: each of its grad_dst loads is four 16-byte pieces per lane at a 64-byte lane stride, so a
-// wave instruction touches 64 cache lines for 1 KiB of data - the texture path, not HBM, set its 1.4 TB/s.  Here the wave
-// splits the two jobs: (1) as OWNER, lane o still searches the candidate dst voxels of its source voxel (same arithmetic, same
-// order) but only writes (dst voxel index, weight) pairs into a per-wave LDS list; (2) as LOADER, lane l takes channel
-// slot l & 3 of the four owners 16 q + (l >> 2), q = 0..3 (one row of the 16 x 4 tile each), reads their list entries
-// (broadcast reads) and accumulates 4 channels per owner: a wave load covers 16 voxels x 64 contiguous bytes, and the final
-// stores are whole coalesced rows.  Per (voxel, channel) the terms and their order are those of the kernel above: the
-// results are bit-identical (tests/test_gpu_ops.py).  Lists hold WB_KMAX entries; an owner with more candidates (strongly
-// minifying maps) resumes its search in further rounds.
-constexpr int WB_KMAX = 12;
-__global__ __launch_bounds__(256) void warp_bwd_gather_coop_kernel(const float *__restrict__ gdst,
-                                                                   const float *__restrict__ theta,
-                                                                   float *__restrict__ gsrc, int C, int Ds, int Hs, int Ws,
-                                                                   int Dd, int Hd, int Wd, int src_ldc, int dst_ldc,
-                                                                   int algebra, int nt, int gx, int gy, int xcd) {
-  const int64_t Vd = (int64_t)Dd * Hd * Wd, Vs = (int64_t)Ds * Hs * Ws;
-  const int tilesX = (Ws + 15) >> 4, tilesZ = (Ds + 3) >> 2;
-  const int tile = xcd_contiguous_tile((int)blockIdx.x, (int)gridDim.x, xcd);
-  const int bx = tile % gx, by = (tile / gx) % gy, bz = tile / (gx * gy);
-  const int c0 = (bx / tilesX) * 16;
-  const int b = bz / tilesZ;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int x0 = (bx % tilesX) * 16, y0 = by * 4, z = (bz % tilesZ) * 4 + wave;
-  const int x = x0 + (lane & 15), y = y0 + (lane >> 4);
-  __shared__ InvMap s_im;
-  __shared__ int2 s_list[4][WB_KMAX][64];
-  __shared__ int s_cnt[4][64];
-  // normalised base coordinates of the dst lattice (two IEEE divisions each): evaluated once per workgroup instead of once
-  // per candidate; same function, same bits
-  constexpr int BC_MAX = 512;
-  __shared__ float s_bc[3][BC_MAX];
-  const bool bc_tab = Wd <= BC_MAX && Hd <= BC_MAX && Dd <= BC_MAX;
-  if (bc_tab) {
-    for (int i = threadIdx.x; i < Wd; i += 256) s_bc[0][i] = base_coord(i, Wd);
-    for (int i = threadIdx.x; i < Hd; i += 256) s_bc[1][i] = base_coord(i, Hd);
-    for (int i = threadIdx.x; i < Dd; i += 256) s_bc[2][i] = base_coord(i, Dd);
-  }
-  const float *th = theta + b * 12;
-  if (threadIdx.x == 0) s_im = inverse_map(th, Ds, Hs, Ws, Dd, Hd, Wd, algebra);
-  __syncthreads();
-  const InvMap im = s_im;
-  if (!im.ok) return;   // the scatter kernels (launched next) take over (uniform per batch item)
-  // ---- owner role: candidate search state
-  bool done = !(x < Ws && y < Hs && z < Ds);
-  const float rel[3] = {(float)x - im.s0[0], (float)y - im.s0[1], (float)z - im.s0[2]};
-  int lo[3], hi[3];
-  {
-    const int dims[3] = {Wd, Hd, Dd};
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-      const float c = im.inv[a][0] * rel[0] + im.inv[a][1] * rel[1] + im.inv[a][2] * rel[2];
-      const float slack = im.e[a] + 0.02f;
-      lo[a] = max(0, (int)fmaxf(ceilf(c - slack), -1.0f));
-      hi[a] = min(dims[a] - 1, (int)fminf(floorf(c + slack), (float)dims[a]));
-    }
-  }
-  float rcp0[3];
-  bool bounds_w[3];
-#pragma unroll
-  for (int j = 0; j < 3; ++j) {
-    bounds_w[j] = fabsf(im.m[j][0]) > 1e-6f;
-    rcp0[j] = bounds_w[j] ? 1.0f / im.m[j][0] : 0.f;
-  }
-  int d = lo[2], h = lo[1], wres = INT_MIN;      // next (d, h) line and, inside a line cut short by a full list, the next w
-  if (lo[1] > hi[1] || lo[2] > hi[2]) done = true;
-  // ---- loader role
-  const int slot = lane & 3, oq = lane >> 2;
-  const bool ch_ok = c0 + slot * 4 < C;
-  float acc[4][4];
-#pragma unroll
-  for (int q = 0; q < 4; ++q)
-#pragma unroll
-    for (int e = 0; e < 4; ++e) acc[q][e] = 0.f;
-  const float *gb = gdst + (int64_t)b * Vd * dst_ldc + c0 + slot * 4;
-  for (;;) {
-    int n = 0;
-    while (!done && n < WB_KMAX) {
-      const float zc = bc_tab ? s_bc[2][d] : base_coord(d, Dd), yc = bc_tab ? s_bc[1][h] : base_coord(h, Hd);
-      float wl = (float)lo[0], wh = (float)hi[0];
-#pragma unroll
-      for (int j = 0; j < 3; ++j) {
-        const float r = -rel[j] + im.m[j][1] * (float)h + im.m[j][2] * (float)d;
-        if (bounds_w[j]) {
-          const float a = (-1.02f - r) * rcp0[j], bq = (1.02f - r) * rcp0[j];
-          wl = fmaxf(wl, fminf(a, bq));
-          wh = fminf(wh, fmaxf(a, bq));
-        } else if (fabsf(r) > 1.02f) {
-          wh = wl - 1.0f;
-        }
-      }
-      const int w1 = (int)floorf(wh);
-      int w = max((int)ceilf(wl), wres);
-      for (; w <= w1; ++w) {
-        const Sample sp = sample_from_base(th, bc_tab ? s_bc[0][w] : base_coord(w, Wd), yc, zc, Ds, Hs, Ws, algebra,
-                                           DGTTA_PAD_ZEROS);
-        const float fx = floorf(sp.ix), fy = floorf(sp.iy), fz = floorf(sp.iz);
-        const float dx = (float)x - fx, dy = (float)y - fy, dz = (float)z - fz;
-        if (!((dx == 0.f || dx == 1.f) && (dy == 0.f || dy == 1.f) && (dz == 0.f || dz == 1.f))) continue;
-        if (n == WB_KMAX) break;      // list full: this candidate opens the next round
-        const float wx = dx == 0.f ? (fx + 1.0f) - sp.ix : sp.ix - fx;
-        const float wy = dy == 0.f ? (fy + 1.0f) - sp.iy : sp.iy - fy;
-        const float wz = dz == 0.f ? (fz + 1.0f) - sp.iz : sp.iz - fz;
-        s_list[wave][n][lane] = make_int2((d * Hd + h) * Wd + w, __float_as_int(wx * wy * wz));
-        ++n;
-      }
-      if (w <= w1) {
-        wres = w;
-        break;
-      }
-      wres = INT_MIN;
-      if (++h > hi[1]) {
-        h = lo[1];
-        if (++d > hi[2]) done = true;
-      }
-    }
-    s_cnt[wave][lane] = n;
-    int maxn = n;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) maxn = max(maxn, __shfl_xor(maxn, o, 64));
-    // the list is written and read by the same wave: its LDS operations complete in order; the compiler must not move them
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    if (ch_ok) {
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int owner = 16 * q + oq;
-        const int nq = s_cnt[wave][owner];
-        // four list entries per step: their loads are in flight together (a load per step left the kernel waiting on
-        // one L2 round trip per candidate); entries past the owner's count read a valid address with weight 0 * skipped
-        for (int k0 = 0; k0 < maxn; k0 += 4) {
-          int2 e[4];
-          float4 g[4];
-#pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            e[u] = (k0 + u < nq) ? s_list[wave][k0 + u][owner] : make_int2(-1, 0);
-            if (e[u].x >= 0) g[u] = *reinterpret_cast<const float4 *>(gb + (int64_t)e[u].x * dst_ldc);
-          }
-#pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            if (e[u].x >= 0) {
-              const float wt = __int_as_float(e[u].y);
-              acc[q][0] += g[u].x * wt;
-              acc[q][1] += g[u].y * wt;
-              acc[q][2] += g[u].z * wt;
-              acc[q][3] += g[u].w * wt;
-            }
-          }
-        }
-      }
-    }
-    if (__all(done)) break;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  }
-  if (ch_ok && z < Ds) {
-    typedef float f32x4_t __attribute__((ext_vector_type(4)));
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int ox = x0 + oq, oy = y0 + q;
-      if (ox < Ws && oy < Hs) {
-        float *o = gsrc + ((int64_t)b * Vs + ((int64_t)z * Hs + oy) * Ws + ox) * src_ldc + c0 + slot * 4;
-        const f32x4_t v = {acc[q][0], acc[q][1], acc[q][2], acc[q][3]};
-        if (nt) __builtin_nontemporal_store(v, reinterpret_cast<f32x4_t *>(o));
-        else *reinterpret_cast<f32x4_t *>(o) = v;
-      }
-    }
-  }
-}
-
 // Fallback for maps the gather kernel declines (singular / extreme minification): zero, then scatter with atomics.
 __global__ void warp_bwd_zero_if_declined_kernel(const float *__restrict__ theta, float *__restrict__ gsrc, int B, int Ds,
                                                  int Hs, int Ws, int Dd, int Hd, int Wd, int algebra, int64_t per_batch) {
@@ -560,11 +380,10 @@ constexpr int WARP_ROWS = 8;
 __global__ __launch_bounds__(256) void warp_fwd_rows4_kernel(const float *__restrict__ src, const float *__restrict__ theta,
                                                              float *__restrict__ dst, int C, int Ds, int Hs, int Ws, int Dd,
                                                              int Hd, int Wd, int src_ldc, int dst_ldc, int pad_mode,
-                                                             int algebra, const float *__restrict__ sub_const, int nt,
-                                                             int gx, int gy, int xcd) {
+                                                             int algebra, const float *__restrict__ sub_const, int gx, int gy) {
   const int cg = C >> 2;
   const float sub = sub_const ? sub_const[0] : 0.f;
-  const int tile = xcd_contiguous_tile((int)blockIdx.x, (int)gridDim.x, xcd);
+  const int tile = (int)blockIdx.x;
   const int bx = tile % gx, by = (tile / gx) % gy, bz = tile / (gx * gy);
   const int d = bz % Dd, b = bz / Dd;
   const int64_t Vd = (int64_t)Dd * Hd * Wd, Vs = (int64_t)Ds * Hs * Ws;
@@ -594,10 +413,8 @@ __global__ __launch_bounds__(256) void warp_fwd_rows4_kernel(const float *__rest
     float *drow = dst + ((int64_t)b * Vd + ((int64_t)d * Hd + h) * Wd) * dst_ldc;
     typedef float f32x4_t __attribute__((ext_vector_type(4)));
     const f32x4_t ov = {acc[0] + sub, acc[1] + sub, acc[2] + sub, acc[3] + sub};
-    // the output is consumed by another kernel after ~1 GB has gone by: a non-temporal store keeps it from displacing
-    // the source rows the neighbouring output rows are about to read (DGTTA_WARP_NT=0: plain stores)
-    if (nt) __builtin_nontemporal_store(ov, reinterpret_cast<f32x4_t *>(drow + (int64_t)w * dst_ldc + g * 4));
-    else *reinterpret_cast<f32x4_t *>(drow + (int64_t)w * dst_ldc + g * 4) = ov;
+    // (non-temporal stores measured no different here, round 3)
+    *reinterpret_cast<f32x4_t *>(drow + (int64_t)w * dst_ldc + g * 4) = ov;
   }
 }
 
@@ -1208,8 +1025,7 @@ extern "C" int dgtta_affine_warp3d_fwd(const float *src, const float *theta, flo
     if (v4 && interp_mode == DGTTA_INTERP_LINEAR && nblk < (1ll << 31)) {
       const int gx = cdiv(items, 256), gy = cdiv(Hd, WARP_ROWS);
       hipLaunchKernelGGL(warp_fwd_rows4_kernel, dim3((unsigned)nblk), dim3(256), 0, st, src, theta, dst, C, Ds, Hs, Ws, Dd, Hd, Wd,
-                         src_ldc, dst_ldc, pad_mode, tta_grid_algebra, sub_const_dev,
-                         (dgtta_switches().warp_nt == '1' && C >= 8) ? 1 : 0, gx, gy, dgtta_switches().warp_xcd == '1');
+                         src_ldc, dst_ldc, pad_mode, tta_grid_algebra, sub_const_dev, gx, gy);
     } else if (v4) {
       int64_t total = (int64_t)B * Vd * (C / 4);
       hipLaunchKernelGGL((warp_fwd_kernel<4, true>), dim3(grid_for(total)), dim3(256), 0, st, src, theta, dst, C, Ds, Hs,
@@ -1246,17 +1062,12 @@ extern "C" int dgtta_affine_warp3d_bwd(const float *grad_dst, const float *theta
     const int64_t nblk = (int64_t)gx * gy * cdiv(Ds, 4) * B;
     DG_REQUIRE(B <= 16 && nblk < (1ll << 31), DGTTA_ERR_UNSUPPORTED, "warp_bwd: need B <= 16 and fewer than 2^31 tiles");
     dim3 grid((unsigned)nblk);
-    const int xcd = dgtta_switches().warp_xcd == '1';
-    // DGTTA_WARP_COOP=1: the cooperative owner / loader kernel (bit-identical results; measured slower)
-    if (vec && dgtta_switches().warp_coop == '1')
-      hipLaunchKernelGGL(warp_bwd_gather_coop_kernel, grid, dim3(256), 0, st, grad_dst, theta, grad_src, C, Ds, Hs, Ws, Dd,
-                         Hd, Wd, src_ldc, dst_ldc, tta_grid_algebra, dgtta_switches().warp_nt == '1', gx, gy, xcd);
-    else if (vec)
+    if (vec)
       hipLaunchKernelGGL((warp_bwd_gather_kernel<16, true>), grid, dim3(256), 0, st, grad_dst, theta, grad_src, C, Ds, Hs,
-                         Ws, Dd, Hd, Wd, src_ldc, dst_ldc, tta_grid_algebra, gx, gy, xcd);
+                         Ws, Dd, Hd, Wd, src_ldc, dst_ldc, tta_grid_algebra, gx, gy);
     else
       hipLaunchKernelGGL((warp_bwd_gather_kernel<16, false>), grid, dim3(256), 0, st, grad_dst, theta, grad_src, C, Ds,
-                         Hs, Ws, Dd, Hd, Wd, src_ldc, dst_ldc, tta_grid_algebra, gx, gy, xcd);
+                         Hs, Ws, Dd, Hd, Wd, src_ldc, dst_ldc, tta_grid_algebra, gx, gy);
     DG_CHECK_LAUNCH("warp_bwd_gather_kernel");
     hipLaunchKernelGGL(warp_bwd_zero_if_declined_kernel, dim3(256), dim3(256), 0, st, theta, grad_src, B, Ds, Hs, Ws, Dd,
                        Hd, Wd, tta_grid_algebra, Vs * src_ldc);
@@ -1330,16 +1141,22 @@ extern "C" int dgtta_seghead_warp_fwd(const void *z, const float *w, const float
   const int gx = cdiv(W * 4, 256), gy = cdiv(H, WARP_ROWS);
   const int64_t nblk = (int64_t)gx * gy * D * B;
   DG_REQUIRE(nblk < (1ll << 31), DGTTA_ERR_UNSUPPORTED, "seghead_warp_fwd: too many tiles");
-  const bool abl = dgtta_switches().warp_abl == '1';          // timing diagnostic: results wrong by construction
 #define HWF_LAUNCH(T, A)                                                                                                   \
   hipLaunchKernelGGL((head_warp_fwd_kernel<T, A>), dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, (const T *)z, \
                      theta, w, bias, sel, nsel, out, D, H, W, tta_grid_algebra, gx, gy)
-  if (dtype == DGTTA_BF16) {
-    if (abl) HWF_LAUNCH(bf16_t, true);
-    else HWF_LAUNCH(bf16_t, false);
+  bool lab = false;
+#ifdef DGTTA_DIAG
+  if (DG_LAB(warp_abl) == '1') {      // timing model (every gather read L1-resident): results wrong by construction
+    lab = true;
+    if (dtype == DGTTA_BF16) HWF_LAUNCH(bf16_t, true);
+    else HWF_LAUNCH(f16_t, true);
+  }
+#endif
+  if (lab) {
+  } else if (dtype == DGTTA_BF16) {
+    HWF_LAUNCH(bf16_t, false);
   } else {
-    if (abl) HWF_LAUNCH(f16_t, true);
-    else HWF_LAUNCH(f16_t, false);
+    HWF_LAUNCH(f16_t, false);
   }
 #undef HWF_LAUNCH
   DG_CHECK_LAUNCH("head_warp_fwd_kernel");
@@ -1368,16 +1185,22 @@ extern "C" int dgtta_seghead_warp_bwd(const void *z, const float *gout, const fl
   const int gx = cdiv(W, 16), gy = cdiv(H, 4);
   const int64_t nblk = (int64_t)gx * gy * cdiv(D, 4) * B;
   DG_REQUIRE(nblk < (1ll << 31), DGTTA_ERR_UNSUPPORTED, "seghead_warp_bwd: too many tiles");
-  const bool abl = dgtta_switches().warp_abl == '1';          // timing diagnostic: results wrong by construction
 #define HWB_LAUNCH(T, A)                                                                                                  \
   hipLaunchKernelGGL((head_warp_bwd_kernel<T, A>), dim3((unsigned)nblk), dim3(256), 0, st, gout, theta, w, sel, nsel,   \
                      (T *)gz, d16, db_sel ? bias_partial : nullptr, D, H, W, tta_grid_algebra, gx, gy)
-  if (dtype == DGTTA_BF16) {
-    if (abl) HWB_LAUNCH(bf16_t, true);
-    else HWB_LAUNCH(bf16_t, false);
+  bool lab = false;
+#ifdef DGTTA_DIAG
+  if (DG_LAB(warp_abl) == '1') {      // timing model: results wrong by construction
+    lab = true;
+    if (dtype == DGTTA_BF16) HWB_LAUNCH(bf16_t, true);
+    else HWB_LAUNCH(f16_t, true);
+  }
+#endif
+  if (lab) {
+  } else if (dtype == DGTTA_BF16) {
+    HWB_LAUNCH(bf16_t, false);
   } else {
-    if (abl) HWB_LAUNCH(f16_t, true);
-    else HWB_LAUNCH(f16_t, false);
+    HWB_LAUNCH(f16_t, false);
   }
 #undef HWB_LAUNCH
   DG_CHECK_LAUNCH("head_warp_bwd_kernel");
@@ -1410,7 +1233,7 @@ extern "C" int dgtta_seghead_window_accumulate_t(const void *z, const float *w, 
   static DynLdsOnce once[8];
   const dim3 grid((unsigned)(nblk < 2048 ? nblk : 2048));
   hipStream_t st = (hipStream_t)stream;
-  const int abl = dgtta_switches().ha_abl == '1' ? 1 : (dgtta_switches().ha_abl == '2' ? 2 : 0);
+  const int abl = DG_LAB(ha_abl) == '1' ? 1 : (DG_LAB(ha_abl) == '2' ? 2 : 0);      // timing models: diagnostic build only
   const bool fma = dgtta_switches().ha_mfma == '0';
 #define HA_LAUNCH(IDX, T, ACC)                                                                                               \
   do {                                                                                                                       \

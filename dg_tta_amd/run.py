@@ -117,6 +117,12 @@ class DGTTAProgram:
         if run_name is None and int(os.environ.get("WORLD_SIZE", 1)) > 1:
             # every rank would invent its own timestamp + random name and then wait for the others in a directory of its own
             raise SystemExit("run_tta: WORLD_SIZE > 1 needs --run_name (the same on every rank); `--gpus N` sets it itself")
+        if int(os.environ.get("WORLD_SIZE", 1)) > 1:
+            from .sharding import launch_id
+            if not launch_id():
+                # the done / failed markers of two launches into one run directory could not be told apart
+                raise SystemExit("run_tta: WORLD_SIZE > 1 under a launcher other than torch.distributed.run needs DGTTA_LAUNCH_ID "
+                                 "(any string that is the same on every rank and new for every launch)")
         if run_name is None:
             now_str = datetime.now().strftime("%Y%m%d__%H_%M_%S")
             results_dir.mkdir(exist_ok=True, parents=True)

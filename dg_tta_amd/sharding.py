@@ -78,11 +78,31 @@ def failed_marker(save_path, rank):
     return Path(save_path) / f".rank_{rank}.failed"
 
 
+def _parent_identity():
+    """(pid, start time in clock ticks since boot) of the parent process: the same for every rank torch.distributed.run's
+    agent spawned, different for every launch (a recycled pid cannot have the same start tick)."""
+    ppid = os.getppid()
+    try:
+        with open(f"/proc/{ppid}/stat") as f:
+            start = f.read().rsplit(")", 1)[1].split()[19]          # field 22 (starttime); the comm field may hold spaces
+    except (OSError, IndexError):
+        start = "?"
+    return f"{ppid}.{start}"
+
+
 def launch_id():
-    """Identifies ONE launch of a multi-rank run: set by `dgtta run_tta --gpus N` for its children (DGTTA_LAUNCH_ID) and by
-    torch.distributed.run (TORCHELASTIC_RUN_ID); empty otherwise.  Written into the done markers, so that a resumed run in
-    the same directory does not pass the barrier on a previous launch's markers."""
-    return os.environ.get("DGTTA_LAUNCH_ID") or os.environ.get("TORCHELASTIC_RUN_ID") or ""
+    """Identifies ONE launch of a multi-rank run; written into the done / failed markers so that a resumed run in the same
+    directory neither passes the barrier nor aborts on a previous launch's markers.  `dgtta run_tta --gpus N` hands its
+    children a fresh DGTTA_LAUNCH_ID.  Under torch.distributed.run the id is TORCHELASTIC_RUN_ID (the constant 'none'
+    unless --rdzv-id is given) PLUS the identity of the elastic agent, the common parent of all ranks of one
+    launch.  Any other external launcher has to export DGTTA_LAUNCH_ID itself (`dgtta run_tta` refuses WORLD_SIZE > 1
+    without one); empty only for in-process use (tests that run the ranks one after the other)."""
+    lid = os.environ.get("DGTTA_LAUNCH_ID")
+    if lid:
+        return lid
+    if "TORCHELASTIC_RUN_ID" in os.environ:
+        return f"{os.environ['TORCHELASTIC_RUN_ID']}@{_parent_identity()}"
+    return ""
 
 
 def mark_rank_done(save_path, rank):

@@ -119,6 +119,12 @@ def predict_sliding_window_return_logits(model, data, patch_size, acc=None, tile
     Returns (acc, nsum, crop) ; logits = acc / nsum[..., None] cropped by `crop`."""
     if acc_dtype is None:
         acc_dtype = acc.dtype if acc is not None else window_acc_dtype()
+    if acc_dtype not in (torch.float32, torch.float16):
+        raise ValueError(f"the window accumulator is fp32 or fp16, not {acc_dtype}")
+    if acc is not None and acc.dtype != acc_dtype:
+        raise ValueError(f"acc is {acc.dtype} but acc_dtype = {acc_dtype}")
+    if acc is not None and not (acc.is_cuda and acc.is_contiguous()):
+        raise ValueError("acc must be a contiguous GPU tensor [X,Y,Z,classes]")
     lib = _lib.load()
     dev = next(model.parameters()).device
     data, crop = pad_to_patch(data.float(), patch_size)

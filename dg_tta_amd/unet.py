@@ -210,6 +210,11 @@ class HipPlainConvUNet(nn.Module):
         acc [X,Y,Z,ncls] / nsum [X,Y,Z] at origins[k] instead of returning the logits (it returns an empty placeholder)."""
         net = self
 
+        if acc.dtype not in (torch.float32, torch.float16):      # the kernel knows these two accumulator storage types
+            raise ValueError(f"fuse_window_accumulate: the accumulator is fp32 or fp16, not {acc.dtype}")
+        if not (acc.is_contiguous() and nsum.dtype == torch.float32 and gauss.dtype == torch.float32):
+            raise ValueError("fuse_window_accumulate: contiguous accumulator, fp32 weight sum and fp32 Gaussian expected")
+
         class _Ctx:
             def __enter__(self_):
                 net._window_acc = (acc, nsum, gauss, list(origins))

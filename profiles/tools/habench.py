@@ -2,6 +2,7 @@
 One 128^3 window of a 320^3 x 105 accumulator (origins cycle so that the lines are not cache resident), bf16 features."""
 import sys, pathlib, time
 sys.path.insert(0, str(pathlib.Path(__file__).resolve().parents[2]))
+os.environ.setdefault("DGTTA_LIB", os.path.join(os.path.dirname(os.path.abspath(__file__)), "libdgtta_hip_diag.so"))      # laboratory build: python -m dg_tta_amd.build --diag
 import torch
 from dg_tta_amd import _lib, ops
 from dg_tta_amd._lib import check, ptr, stream_of

@@ -1,4 +1,5 @@
 #!/bin/bash
+export DGTTA_LIB="$(dirname "$(readlink -f "$0")")/libdgtta_hip_diag.so"      # laboratory build (python -m dg_tta_amd.build --diag): the product library has no *_ABL / ROWS_VAR switches
 # FETCH_SIZE / WRITE_SIZE of the row-reuse conv at 128^3 32->32 for the cache-policy experiments (DGTTA_ROWS_ABL 0 / 8 / 9)
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp

@@ -40,7 +40,7 @@ else
     done
     echo "# fused head + inverse logit warp, 8 x 128^3 (profiles/tools/headwarpbench.py); second block: every gather read L1 resident (DGTTA_WARP_ABL=1)"
     HW_DT=bf16 python3 profiles/tools/headwarpbench.py
-    DGTTA_WARP_ABL=1 HW_DT=bf16 python3 profiles/tools/headwarpbench.py
+    DGTTA_LIB=profiles/tools/libdgtta_hip_diag.so DGTTA_WARP_ABL=1 HW_DT=bf16 python3 profiles/tools/headwarpbench.py
     echo "# InstanceNorm backward of one layer (profiles/tools/inbench.py)"
     python3 profiles/tools/inbench.py 32 128 8
     python3 profiles/tools/inbench.py 64 64 8

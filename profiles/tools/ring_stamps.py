@@ -2,6 +2,7 @@
 usage: ring_stamps.py [batch]"""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+os.environ.setdefault("DGTTA_LIB", os.path.join(os.path.dirname(os.path.abspath(__file__)), "libdgtta_hip_diag.so"))      # laboratory build: python -m dg_tta_amd.build --diag
 os.environ["DGTTA_RING_ABL"] = "6"
 from dg_tta_amd import _lib
 from dg_tta_amd._lib import check, ptr, stream_of

@@ -2,6 +2,7 @@
 import os, sys, torch
 os.environ["DGTTA_ROWS_ABL"] = "6"
 sys.path.insert(0, '.')
+os.environ.setdefault("DGTTA_LIB", os.path.join(os.path.dirname(os.path.abspath(__file__)), "libdgtta_hip_diag.so"))      # laboratory build: python -m dg_tta_amd.build --diag
 from dg_tta_amd import _lib
 from dg_tta_amd._lib import check, ptr, stream_of
 lib = _lib.load()

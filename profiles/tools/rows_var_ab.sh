@@ -1,4 +1,5 @@
 #!/bin/bash
+export DGTTA_LIB="$(dirname "$(readlink -f "$0")")/libdgtta_hip_diag.so"      # laboratory build (python -m dg_tta_amd.build --diag): the product library has no *_ABL / ROWS_VAR switches
 # same-box A/B of the row-reuse kernel's feature masks (DGTTA_ROWS_VAR): single-layer timings + cycle stamps
 out=gpurun_out/rows_var_ab.txt
 : > $out

@@ -25,4 +25,4 @@ for _ in range(10):
     y.backward(gy); e[2].record(); torch.cuda.synchronize(); x.grad = None
     t["fwd"] += e[0].elapsed_time(e[1]) / 10; t["bwd"] += e[1].elapsed_time(e[2]) / 10
 gb = 2 * B * N ** 3 * C * 4 / 1e9
-print(f"COOP={os.environ.get('DGTTA_WARP_COOP','-')} NT={os.environ.get('DGTTA_WARP_NT','-')}: fwd {t['fwd']:.3f} ms ({gb / t['fwd']:.2f} TB/s), bwd {t['bwd']:.3f} ms ({gb / t['bwd']:.2f} TB/s)")
+print(f"fwd {t['fwd']:.3f} ms ({gb / t['fwd']:.2f} TB/s), bwd {t['bwd']:.3f} ms ({gb / t['bwd']:.2f} TB/s)")

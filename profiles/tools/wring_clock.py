@@ -1,7 +1,8 @@
-"""In-kernel clock, barrier wait and MFMA-busy share of the weight-gradient ring kernel (DGTTA_WGRAD_RING=6, fp16, 8 x 128^3 x 32 -> 32)."""
+"""In-kernel clock, barrier wait and MFMA-busy share of the weight-gradient ring kernel (DGTTA_WGRAD_RING_CLK=6, diagnostic build, fp16, 8 x 128^3 x 32 -> 32)."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
-os.environ["DGTTA_WGRAD_RING"] = sys.argv[1] if len(sys.argv) > 1 else "6"
+os.environ.setdefault("DGTTA_LIB", os.path.join(os.path.dirname(os.path.abspath(__file__)), "libdgtta_hip_diag.so"))      # laboratory build: python -m dg_tta_amd.build --diag
+os.environ["DGTTA_WGRAD_RING_CLK"] = sys.argv[1] if len(sys.argv) > 1 else "6"
 from dg_tta_amd import _lib
 from dg_tta_amd._lib import check, ptr, stream_of
 lib = _lib.load()

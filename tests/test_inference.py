@@ -41,6 +41,19 @@ def test_window_accumulator_storage_switch(monkeypatch):
         _acc_code(torch.empty(1, dtype=torch.bfloat16))
     with pytest.raises(Exception):          # no CPU fallback: the label-map kernel refuses host tensors
         ops.argmax_rows(torch.zeros(4, 5))
+    # the fused head + accumulate path validates the accumulator's storage type as the plain path does
+    from dg_tta_amd.tta.inference import predict_sliding_window_return_logits
+    from dg_tta_amd.unet import HipPlainConvUNet
+    from conftest import SMALL_CFG
+    net = HipPlainConvUNet(SMALL_CFG)
+    for bad in (torch.bfloat16, torch.float64):
+        with pytest.raises(ValueError, match="fp32 or fp16"):
+            predict_sliding_window_return_logits(net, torch.zeros(1, 16, 16, 16), [16, 16, 16], acc_dtype=bad)
+        with pytest.raises(ValueError, match="fp32 or fp16"):
+            net.fuse_window_accumulate(torch.zeros(2, 2, 2, 9, dtype=bad), torch.zeros(2, 2, 2), torch.zeros(2, 2, 2), [])
+    with pytest.raises(ValueError, match="acc_dtype"):
+        predict_sliding_window_return_logits(net, torch.zeros(1, 16, 16, 16), [16, 16, 16], acc=torch.zeros(16, 16, 16, 9),
+                                             acc_dtype=torch.float16)
 
 
 @pytest.mark.gpu
@@ -175,7 +188,8 @@ def test_sliding_window_512_full_size_properties():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("acc_dtype", [torch.float32, torch.float16])
-@pytest.mark.parametrize("C,rows", [(105, 64 * 40 + 17), (105, 4096), (16, 5000), (2, 4100), (112, 129), (7, 63)])
+@pytest.mark.parametrize("C,rows", [(105, 64 * 40 + 17), (105, 4096), (16, 5000), (2, 4100), (112, 129), (7, 63),
+                                    (118, 4097), (113, 50), (300, 70)])        # > 112 classes: the one-wave-per-row kernel
 def test_argmax_rows_first_maximum_wins(C, rows, acc_dtype):
     """Round 4: the streaming label-map kernel (dgtta_argmax_rows; dgtta_argmax_dice routes to it for back-to-back rows)
     against a sequential first-maximum scan: ties (duplicated maxima in different quarters of the class range), -inf rows,

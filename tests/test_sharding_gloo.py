@@ -216,3 +216,31 @@ def test_done_markers_of_an_earlier_launch_do_not_pass_the_barrier(tmp_path, mon
         wait_for_done_markers(tmp_path, 2, timeout_s=0.3, poll_s=0.05)
     mark_rank_done(tmp_path, 1)
     wait_for_done_markers(tmp_path, 2, timeout_s=5, poll_s=0.05)
+
+
+def test_launch_id_is_unique_per_launch_under_torchrun(monkeypatch):
+    """torch.distributed.run sets TORCHELASTIC_RUN_ID to the constant 'none' unless --rdzv-id is given; the launch
+    id therefore carries the identity (pid, start tick) of the elastic agent, the common parent of one launch's ranks.
+    Children of ONE parent agree; children of two different parents differ; an explicit DGTTA_LAUNCH_ID wins; in-process use
+    without any launcher keeps the empty id (the sequential-rank tests rely on it)."""
+    import subprocess
+    import sys
+    from dg_tta_amd import sharding
+    monkeypatch.delenv("DGTTA_LAUNCH_ID", raising=False)
+    monkeypatch.delenv("TORCHELASTIC_RUN_ID", raising=False)
+    assert sharding.launch_id() == ""
+    monkeypatch.setenv("TORCHELASTIC_RUN_ID", "none")
+    here = sharding.launch_id()
+    assert here.startswith("none@") and here == sharding.launch_id()
+    code = "import sys; sys.path.insert(0, %r); from dg_tta_amd import sharding; print(sharding.launch_id())" % str(__import__("pathlib").Path(__file__).resolve().parents[1])
+    env = dict(os.environ, TORCHELASTIC_RUN_ID="none")
+    env.pop("DGTTA_LAUNCH_ID", None)
+    kids = [subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, check=True).stdout.strip()
+            for _ in range(2)]
+    assert kids[0] == kids[1] and kids[0].startswith("none@")          # two ranks of this "agent" (this process)
+    # another launch = another agent process: a shell in between plays the second agent
+    other = subprocess.run(["sh", "-c", f"{sys.executable} -c {code!r}; true"], env=env, capture_output=True, text=True,
+                           check=True).stdout.strip()
+    assert other.startswith("none@") and other != kids[0]
+    monkeypatch.setenv("DGTTA_LAUNCH_ID", "explicit")
+    assert sharding.launch_id() == "explicit"

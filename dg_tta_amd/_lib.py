@@ -28,6 +28,9 @@ SIGNATURES = {
     "dgtta_softdice_bwd": (I, [P, P, P, P, P, F, P, I, I, I64, I, I, P]),
     "dgtta_softdice_probs_fwd": (I, [P, P, P, P, SZ, I, I, I64, I64, I64, I64, P]),
     "dgtta_softdice_probs_bwd": (I, [P, P, P, P, P, P, I, I, I64, I64, I64, I64, P]),
+    "dgtta_dice_ce_ws_bytes": (SZ, [I, I, I64]),
+    "dgtta_dice_ce_fwd": (I, [P, I, P, P, P, P, SZ, I, I, I64, F, I, P]),
+    "dgtta_dice_ce_bwd": (I, [P, I, P, P, F, P, P, I, I, I, I64, P]),
     "dgtta_adamw_step": (I, [C.POINTER(P), C.POINTER(P), C.POINTER(P), C.POINTER(P), C.POINTER(I64), I, F, F, F, F, F,
                              I, F, P, P]),
     "dgtta_grads_nonfinite": (I, [C.POINTER(P), C.POINTER(I64), I, P, P]),

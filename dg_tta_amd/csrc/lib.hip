@@ -11,7 +11,7 @@ void dgtta_set_error(const char *fmt, ...) {
   va_end(ap);
 }
 
-extern "C" int dgtta_version(void) { return 40000; /* 4.0.0: accumulator storage type (window_accumulate_t, seghead_window_accumulate_t, logits_chunk_f64_t), argmax_rows */ }
+extern "C" int dgtta_version(void) { return 50000; /* 5.0.0: dice_ce_fwd / bwd (pre-training loss), argmax_rows for > 112 classes, laboratory switches out of the product build */ }
 extern "C" const char *dgtta_last_error(void) { return g_err; }
 
 // ---------------------------------------------------------------- environment switches (snapshot, see common.h)
@@ -31,7 +31,6 @@ static int env_char(const char *name) {
 static const DgttaSwitches *read_switches() {
   DgttaSwitches *s = new DgttaSwitches;       // snapshots are immutable and never freed (a handful of bytes per reload)
   s->conv_rows = env_char("DGTTA_CONV_ROWS");
-  s->conv_variant = env_char("DGTTA_CONV_VARIANT");
   s->conv_s2 = env_char("DGTTA_CONV_S2");
   s->convt_gemm = env_char("DGTTA_CONVT_GEMM");
   s->rows_order = env_char("DGTTA_ROWS_ORDER");

@@ -254,6 +254,47 @@ def consistency_loss(target_a, target_b, start_class=1):
                                   int(getattr(target_a, "_dgtta_guard_items", 0)))
 
 
+class _DiceCE(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, labels, smooth, do_bg):
+        lib = _lib.load()
+        b, c = logits.shape[:2]
+        v = logits[0, 0].numel()
+        logits = logits.contiguous(memory_format=torch.channels_last_3d)
+        labels = labels.reshape(b, v).contiguous()
+        loss3 = torch.empty(3, dtype=torch.float32, device=logits.device)
+        dice = torch.empty((b, c), dtype=torch.float32, device=logits.device)
+        nbytes = lib.dgtta_dice_ce_ws_bytes(b, c, v)
+        ws = _ws(nbytes, logits.device)
+        check(lib.dgtta_dice_ce_fwd(ptr(logits), c, ptr(labels), ptr(loss3), ptr(dice), ptr(ws), nbytes, b, c, v, float(smooth),
+                                    int(do_bg), stream_of(logits.device)), "dgtta_dice_ce_fwd")
+        ctx.save_for_backward(logits, labels, ws)
+        ctx.meta = (b, c, v)
+        ctx.mark_non_differentiable(dice)
+        return loss3[0], dice, loss3[1:].detach()
+
+    @staticmethod
+    def backward(ctx, gloss, _gdice, _gparts):
+        logits, labels, ws = ctx.saved_tensors
+        b, c, v = ctx.meta
+        lib = _lib.load()
+        g = torch.empty_like(logits, memory_format=torch.preserve_format)
+        gs = gloss.reshape(1).float().contiguous()
+        check(lib.dgtta_dice_ce_bwd(ptr(logits), c, ptr(labels), ptr(ws), 1.0, ptr(gs), ptr(g), c, b, c, v,
+                                    stream_of(logits.device)), "dgtta_dice_ce_bwd")
+        return g, None, None, None
+
+
+def dice_ce_loss(logits, labels, smooth=1e-5, do_bg=False):
+    """nnU-Net's pre-training loss DC_and_CE_loss [3P] (soft Dice per sample without background + cross-entropy) of logits
+    [B,C,D,H,W] (fp32) against an integer label map [B,1,D,H,W] / [B,D,H,W] (labels outside [0, C) are ignored).
+    Returns (loss, dice [B,C], (ce, -mean dice)); differentiable w.r.t. the logits."""
+    require_cuda(logits, labels)
+    if labels.dtype != torch.int64:
+        labels = labels.long()
+    return _DiceCE.apply(logits.float(), labels, smooth, do_bg)
+
+
 class _SoftDice(torch.autograd.Function):
     @staticmethod
     def forward(ctx, a, b):

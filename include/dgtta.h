@@ -127,6 +127,20 @@ int dgtta_softdice_probs_bwd(const float *a, const float *b, const float *grad_d
                              const void *ws, int B, int C, int64_t V, int64_t stride_b, int64_t stride_c,
                              int64_t stride_v, void *stream);
 
+/* Supervised loss of the PRE-TRAINING side: soft Dice + cross-entropy against an integer label map -
+ * nnU-Net's DC_and_CE_loss [3P nnunetv2==2.2.1], the loss of the nnUNetTrainer the reference's trainers inherit
+ * (dg_tta/pretraining/nnUNetTrainer_GIN.py:38-59, nnUNetTrainer_MIND.py:37-57, nnUNetTrainer_GIN_MIND.py:38-59):
+ *   p = softmax_c(logits);  voxels whose label is outside [0, C) are ignored
+ *   loss3[0] = loss3[1] + loss3[2];  loss3[1] = -mean_v log p[v][y_v];  loss3[2] = -mean_{b, c >= (do_bg ? 0 : 1)} dice[b][c]
+ *   dice[b][c] = (2 sum_v p y + smooth) / (sum_v p + sum_v y + smooth)          (per sample: batch_dice = False)
+ * logits / grad_logits: voxel-major fp32 [B][V][ld], labels int64 [B][V].  bwd: grad_logits = grad_scale * (*grad_scale_dev
+ * if given) * d loss3[0] / d logits.  ws: dgtta_dice_ce_ws_bytes(B, C, V), kept between fwd and bwd.  1 <= B <= 8, C <= 128. */
+size_t dgtta_dice_ce_ws_bytes(int B, int C, int64_t V);
+int dgtta_dice_ce_fwd(const float *logits, int ldc, const int64_t *labels, float *loss3, float *dice, void *ws,
+                      size_t ws_bytes, int B, int C, int64_t V, float smooth, int do_bg, void *stream);
+int dgtta_dice_ce_bwd(const float *logits, int ldc, const int64_t *labels, const void *ws, float grad_scale,
+                      const float *grad_scale_dev, float *grad_logits, int ldg, int B, int C, int64_t V, void *stream);
+
 /* ---------------------------------------------------------------------------------------------
  * AdamW (decoupled weight decay, bias-corrected, no amsgrad) over a list of tensors.  Replaces
  * torch.optim.AdamW(model.parameters(), lr).step() at dg_tta/tta/tta.py:185,278 (betas 0.9/0.999,

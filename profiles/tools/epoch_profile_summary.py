@@ -1,0 +1,66 @@
+"""Summary of profiles/tools/epoch_profile.sh: HBM bytes and per-kernel-name time of ONE steady-state TTA epoch =
+(3-epoch run - 1-epoch run) / 2 of the same bench.py command.  FETCH_SIZE / WRITE_SIZE in KiB as rocprofv3 reports them,
+FETCH x 2 on gfx950 (MI355X_MICROARCH.md, HBM: 128-byte requests tallied at 64 bytes)."""
+import collections, csv, glob, json, sys
+tag, dts = sys.argv[1], sys.argv[2:]
+# weight gradients that the ring sweep takes (conv_wgrad_ring.hip): the 13 plain stride-1 3x3x3 layers at >= 16^3, forward GFLOP
+# per 128^3 sample from SURVEY.md 8d (a weight gradient costs what the forward costs), x 32 sample passes per epoch
+WRING_GFLOP = [43.49, 115.96, 57.98, 28.99, 14.50, 28.99, 14.50, 57.98, 28.99, 115.96, 57.98, 231.93, 115.96]
+
+
+def short(k):
+    return k.replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0]
+
+
+def pmc_sum(d, counter):
+    tot, n = 0.0, 0
+    for f in glob.glob(f"{d}/**/*counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] == counter:
+                tot += float(r["Counter_Value"])
+                n += 1
+    return tot, n
+
+
+def by_name(d):
+    t, c = collections.Counter(), collections.Counter()
+    for f in glob.glob(f"{d}/**/*kernel_trace.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            k = short(r["Kernel_Name"])
+            t[k] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6
+            c[k] += 1
+    return t, c
+
+
+out = {}
+for dt in dts:
+    f1, n1 = pmc_sum(f"gpurun_out/{tag}_ep_{dt}_fetch_1", "FETCH_SIZE")
+    f3, n3 = pmc_sum(f"gpurun_out/{tag}_ep_{dt}_fetch_3", "FETCH_SIZE")
+    w1, _ = pmc_sum(f"gpurun_out/{tag}_ep_{dt}_write_1", "WRITE_SIZE")
+    w3, _ = pmc_sum(f"gpurun_out/{tag}_ep_{dt}_write_3", "WRITE_SIZE")
+    t1, c1 = by_name(f"gpurun_out/{tag}_ep_{dt}_stats_1")
+    t3, c3 = by_name(f"gpurun_out/{tag}_ep_{dt}_stats_3")
+    per = {k: (t3[k] - t1[k]) / 2 for k in t3}
+    cnt = {k: (c3[k] - c1[k]) / 2 for k in c3}
+    total = sum(per.values())
+    top = sorted(per.items(), key=lambda kv: -kv[1])[:12]
+    fetch_b, write_b = (f3 - f1) / 2 * 1024 * 2, (w3 - w1) / 2 * 1024
+    ent = {"size": 128, "accum": 16, "storage": dt,
+           "how": "(3-epoch run - 1-epoch run) / 2 of `bench.py --dtype %s --warmup 0 --weights he --no-fp32 --no-cpu-baseline "
+                  "--inference-size 0` under rocprofv3: --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes with --kernel-trace "
+                  "only (FETCH x 2 on gfx950), --kernel-trace --stats for the per-name time" % dt,
+           "dispatches_per_epoch": (n3 - n1) / 2,
+           "fetch_bytes_per_epoch": fetch_b, "write_bytes_per_epoch": write_b, "hbm_bytes_per_epoch": fetch_b + write_b,
+           "kernel_ms_per_epoch": round(total, 2),
+           "top_kernels_ms_per_epoch": [{"kernel": k, "ms": round(v, 3), "launches": cnt[k], "share": round(v / total, 4)} for k, v in top]}
+    if top:
+        k, v = top[0]
+        lc = {"kernel": k, "ms_per_epoch": round(v, 2), "share_of_kernel_time": round(v / total, 4), "launches_per_epoch": cnt[k]}
+        if "wgrad_ring" in k:
+            tf = sum(WRING_GFLOP) * 32 / 1e3
+            lc.update(tflop_per_epoch=round(tf, 2), achieved_tflops=round(tf / (v * 1e-3), 1),
+                      frac_of_peak=round(tf / (v * 1e-3) / (157.3 if dt == "fp32" else 2500.0), 4),
+                      flop_basis="13 plain stride-1 3x3x3 layers at >= 16^3 (SURVEY.md 8d per-layer GFLOP) x 32 sample passes")
+        ent["largest_consumer"] = lc
+    out["fp32" if dt == "fp32" else "16bit"] = ent
+print(json.dumps(out, indent=1))

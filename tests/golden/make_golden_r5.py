@@ -1,0 +1,225 @@
+#!/usr/bin/env python3
+"""Round-5 golden vectors: TTA runs that MEAN something, produced by the REFERENCE.
+
+`tta_unit_trained.npz` (GIN + MIND pre-training, the TS104_GIN_MIND recipe; mild target shift) and
+`tta_unit_trained_mind.npz` (MIND-only pre-training, nnUNetTrainer_MIND.py:53-55; low-SNR target, where adaptation has
+something to win back: hard Dice vs ground truth 0.69 -> 0.71):
+ 1. the small 9-class net (tests/conftest.SMALL_CFG) is PRE-TRAINED on the source domain of the synthetic atlas task
+    (dg_tta_amd/synthetic.atlas_case: structures at anatomical positions with per-case jitter, CT-like appearance) the way
+    dg_tta/pretraining/nnUNetTrainer_GIN_MIND.py:55-57 trains: the reference's `gin_hook` + `mind_hook` registered as forward
+    pre-hooks with DG_TTA_INTERNAL_AUGMENTATION on, random 16^3 patches (the reference's get_batch), cross-entropy + soft
+    Dice, torch Adam, a few hundred CPU steps; the weights are committed in the fixture (~100 kB);
+ 2. the reference's OWN loop (tta.py:189-340 around its real get_batch / calc_branch / soft_dice_loss / dice_coeff /
+    map_label, torch AdamW, exactly as make_golden_r2.gold_unit does) adapts that model to a case of the TARGET domain
+    (inverted + gamma-remapped contrast, bias field, thick slices, more noise): per-epoch consistency loss, pseudo-Dice of
+    the evaluation patch, hard Dice vs ground truth per class before / after, the final label map on the FIRST MIND
+    noise draw after the run (no search for a convenient draw), the adapted parameters;
+ 3. in the same pass the CPU oracle (oracle/tta.py) is checked bit for bit against the reference run.
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden_r5.py
+"""
+import os
+import sys
+import time
+from pathlib import Path
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+
+HERE = Path(__file__).resolve().parent
+sys.path.insert(0, str(HERE))
+import make_golden as mg                                                      # noqa: E402,F401  (mocks + reference imports)
+from make_golden import (check, save, gin_aug, gin_hook, mind_hook, ref_calc_branch, TEMPLATE_PLAN,      # noqa: E402
+                         ModifierFunctions, otta, omind, ounet)
+from make_golden import SMALL_CFG                                             # noqa: E402
+
+from dg_tta_amd.synthetic import atlas_case                                    # noqa: E402
+
+TR = dict(
+    # ---- pre-training (source domain)
+    w_seed=7, train_seed=2025, train_cases=6, train_steps=400, train_batch=4, train_lr=3e-3, train_gin=True,
+    # ---- the unit (target domain)
+    seed=5151, case_seed=31, epochs=12, accum=8, lr=3e-4, patch=[16, 16, 16], vol=24, k=4, noise_seed=999,
+    target_noise=None, target_thick=2,
+    label_mapping={"background": (0, 0), "a": (2, 3), "b": (3, 1), "c": (5, 4), "d": (8, 2)},
+    optimized=["background", "a", "b", "c", "d"])
+VARIANTS = {"tta_unit_trained": {},
+            "tta_unit_trained_mind": dict(train_gin=False, target_noise=0.5)}
+
+
+def pretrain_ids():
+    """TTA-dataset label id (= atlas structure index, 1..K) -> pretrain class id of the same structure."""
+    lm = TR["label_mapping"]
+    t = torch.zeros(TR["k"] + 1, dtype=torch.int64)
+    for name, (pre, tta) in lm.items():
+        t[tta] = pre
+    return t
+
+
+def pretrain():
+    """Source-domain training of the small net with the reference's hooks in their pre-training role."""
+    import dg_tta.utils as rutils
+    from dg_tta.tta.torch_utils import get_batch
+    net = ounet.init_he(ounet.PlainConvUNetOracle(SMALL_CFG), TR["w_seed"])
+    net.register_forward_pre_hook(gin_hook)
+    net.register_forward_pre_hook(mind_hook)
+    cases = [atlas_case(TR["vol"], TR["k"], s, "source") for s in range(TR["train_cases"])]
+    to_pre = pretrain_ids()
+    opt = torch.optim.Adam(net.parameters(), lr=TR["train_lr"])
+    ncls = SMALL_CFG["num_classes"]
+    torch.manual_seed(TR["train_seed"])
+    np.random.seed(TR["train_seed"])
+    if TR["train_gin"]:
+        rutils.enable_internal_augmentation()       # the GIN trainers' setting: gin_hook augments (gin.py:244-247)
+    t0 = time.time()
+    try:
+        net.train()
+        for step in range(TR["train_steps"]):
+            idxs = np.random.choice(range(len(cases)), TR["train_batch"]).tolist()
+            with torch.no_grad():
+                imgs, labels = get_batch(cases, idxs, TR["patch"], fixed_patch_idx=None, device="cpu")
+            imgs, labels = torch.cat(imgs, 0), to_pre[torch.cat(labels, 0)[:, 0]]
+            logits = net(imgs)
+            ce = torch.nn.functional.cross_entropy(logits, labels)
+            p = logits.softmax(1)
+            oh = torch.nn.functional.one_hot(labels, ncls).permute(0, 4, 1, 2, 3).float()
+            inter, den = (p * oh).sum((2, 3, 4)), (p + oh).sum((2, 3, 4))
+            dice = ((2 * inter + 1e-5) / (den + 1e-5))[:, 1:]
+            present = oh.sum((2, 3, 4))[:, 1:] > 0
+            loss = ce + 1 - dice[present].mean()
+            opt.zero_grad()
+            loss.backward()
+            opt.step()
+            if step % 50 == 0 or step == TR["train_steps"] - 1:
+                print(f"  pretrain step {step:4d}: loss {loss.item():.4f} (ce {ce.item():.4f}), {time.time() - t0:.0f} s")
+    finally:
+        rutils.disable_internal_augmentation()
+    return {k: v.detach().clone() for k, v in net.state_dict().items()}
+
+
+def hard_dice_vs_gt(model, data, map_pre, map_tta, noise):
+    """Per-class hard Dice (dice_coeff, torch_utils.py:107-117) of the centre patch against the case's own labels."""
+    with torch.no_grad():
+        imgs, labels = otta.get_batch_item(data, TR["patch"], None)
+        out = otta.map_label(model(omind.mind3d(imgs, noise)), map_pre, "logits")
+        gt = otta.map_label(labels, map_tta, "argmaxed").long()
+        return otta.dice_coeff(out.argmax(1), gt, len(map_pre)), out
+
+
+def gold_unit_trained(name):
+    from dg_tta.tta.model_utils import get_model_from_network
+    from dg_tta.tta.torch_utils import fix_all, release_all, soft_dice_loss, dice_coeff, map_label, get_map_idxs, get_batch
+    U = TR
+    P, B = U["patch"], 1
+    lm, opt_labels = U["label_mapping"], U["optimized"]
+    weights = pretrain()
+    cfg = dict(TEMPLATE_PLAN)
+    cfg.update(do_intensity_aug_in="both", do_spatial_aug_in="both", patches_to_be_accumulated=U["accum"], lr=U["lr"],
+               epochs=U["epochs"])
+    modmod = SimpleNamespace(ModifierFunctions=ModifierFunctions)
+
+    def fresh(hooks):
+        n = ounet.PlainConvUNetOracle(SMALL_CFG)
+        n.load_state_dict(weights)
+        if hooks:
+            n.register_forward_pre_hook(gin_hook)
+            n.register_forward_pre_hook(mind_hook)
+        return n
+    net = fresh(True)
+    model = get_model_from_network(net, modmod, [net.state_dict()])
+    omodel = fresh(False)
+    data = atlas_case(U["vol"], U["k"], U["case_seed"], "target", noise=U["target_noise"], thick=U["target_thick"])
+    map_pre = otta.get_map_idxs(lm, opt_labels, "pretrain_labels")
+    map_tta = otta.get_map_idxs(lm, opt_labels, "tta_labels")
+    torch.manual_seed(U["noise_seed"])
+    noise = torch.randn(B, 12, *P)                       # the FIRST draw of this seed: no search
+    dice_before, logits_before = hard_dice_vs_gt(omodel, data, map_pre, map_tta, noise)
+    src_dice, _ = hard_dice_vs_gt(omodel, atlas_case(U["vol"], U["k"], 77, "source"), map_pre, map_tta, noise)
+    print(f"  pre-trained model: hard Dice {src_dice.nanmean():.4f} on an unseen SOURCE case, {dice_before.nanmean():.4f} on the "
+          f"target case before TTA")
+    identity_grid = torch.nn.functional.affine_grid(torch.eye(4).repeat(B, 1, 1)[:, :3], [B, 1] + P, align_corners=False)
+    optimizer = torch.optim.AdamW(model.parameters(), lr=cfg["lr"])
+    E, accum, start = U["epochs"], U["accum"], cfg["start_tta_at_epoch"]
+    tta_losses, eval_dices, steps = torch.zeros(E), torch.zeros(E), []
+    torch.manual_seed(U["seed"])
+    np.random.seed(U["seed"])
+    model.apply(fix_all)
+    t0 = time.time()
+    for epoch in range(E):
+        model.train()
+        step_losses = []
+        if epoch == start:
+            model.apply(fix_all)
+            model.apply(release_all)
+        for _ in range(accum):
+            with torch.no_grad():
+                imgs, _ = get_batch([data], np.random.choice(range(1), B).tolist(), P, fixed_patch_idx=None, device="cpu")
+            imgs = torch.cat(imgs, dim=0)
+            a = (cfg, model, gin_aug, identity_grid, P, B, lm, opt_labels, modmod, imgs, "cpu")
+            ta = ref_calc_branch("branch_a", *a)
+            tb = ref_calc_branch("branch_b", *a)
+            mask = (ta.sum(1, keepdim=True) > 0.0).float() * (tb.sum(1, keepdim=True) > 0.0).float()
+            loss = 1 - soft_dice_loss(ta.softmax(1) * mask, tb.softmax(1) * mask)[:, 1:].mean()
+            step_losses.append(loss.detach().cpu())
+            if epoch >= start:
+                (loss / accum).backward()
+        if epoch >= start:
+            optimizer.step()
+            optimizer.zero_grad()
+        tta_losses[epoch] = torch.stack(step_losses).mean().item()
+        steps += step_losses
+        with torch.inference_mode():
+            model.eval()
+            for _ in range(cfg["tta_eval_patches"]):
+                imgs, labels = get_batch([data], np.random.choice(range(1), B).tolist(), P, fixed_patch_idx="center",
+                                         device="cpu")
+                imgs = torch.cat(imgs, dim=0)
+                labels = torch.cat(labels, dim=0)
+                out = model(imgs)
+                out = map_label(out, get_map_idxs(lm, opt_labels, "pretrain_labels"), "logits")
+                labels = map_label(labels, get_map_idxs(lm, opt_labels, "tta_labels"), "argmaxed").long()
+                d = dice_coeff(out.argmax(1), labels, len(opt_labels))
+                eval_dices[epoch] += 1 / cfg["tta_eval_patches"] * d.nanmean().item()
+    print(f"  reference TTA run: {time.time() - t0:.1f} s; loss {tta_losses.tolist()}")
+    print(f"  pseudo-Dice of the eval patch per epoch {eval_dices.tolist()}")
+    # oracle twin on the same draw stream
+    oopt = torch.optim.AdamW(omodel.parameters(), lr=cfg["lr"])
+    torch.manual_seed(U["seed"])
+    np.random.seed(U["seed"])
+    ol, od, osteps = otta.tta_unit(omodel, oopt, [data], P, map_pre, map_tta, E, start, accum, cfg["tta_eval_patches"])
+    check(osteps, torch.stack(steps), "trained unit: step losses")
+    check(ol, tta_losses, "trained unit: epoch losses")
+    check(od, eval_dices, "trained unit: eval dices")
+    for (k, p), (_, q) in zip(omodel.state_dict().items(), model.state_dict().items()):
+        assert torch.equal(p, q), k
+    print("  oracle == reference: post-TTA parameters")
+    omodel.eval()
+    dice_after, final = hard_dice_vs_gt(omodel, data, map_pre, map_tta, noise)
+    top2 = final.topk(2, dim=1).values
+    margin = top2[:, 0] - top2[:, 1]
+    print(f"  hard Dice vs GT: before {dice_before.tolist()} (mean {dice_before.nanmean():.4f}) -> after {dice_after.tolist()} "
+          f"(mean {dice_after.nanmean():.4f}); labels changed by TTA: "
+          f"{float((final.argmax(1) != logits_before.argmax(1)).float().mean()):.4f}")
+    print(f"  final label map on the first noise draw: min top-2 margin {margin.min().item():.3e}, "
+          f"{int((margin < 1e-3).sum())} of {margin.numel()} voxels below 1e-3")
+    keep = lambda sd: {k: v for k, v in sd.items() if ".all_modules." not in k and not k.startswith("decoder.encoder.")}   # noqa: E731
+    sd = {f"w::{k}": v.clone() for k, v in keep(weights).items()}
+    post = {f"p::{k}": v for k, v in keep(omodel.state_dict()).items()}
+    save(name, data=data, seed=np.array(U["seed"]), lr=np.array(U["lr"]), epochs=np.array(E),
+         accum=np.array(accum), tta_losses=tta_losses, eval_dices=eval_dices, step_losses=torch.stack(steps), eval_noise=noise,
+         eval_logits=final, eval_argmax=final.argmax(1), eval_margin=margin, argmax_before=logits_before.argmax(1).to(torch.uint8),
+         dice_before=dice_before, dice_after=dice_after, source_dice=src_dice, **sd, **post)
+
+
+if __name__ == "__main__":
+    torch.set_num_threads(8)
+    base = dict(TR)
+    for name, over in VARIANTS.items():
+        if sys.argv[1:] and name not in sys.argv[1:]:
+            continue
+        TR.clear()
+        TR.update(base, **over)
+        print(f"{name}: {over or 'defaults'}")
+        gold_unit_trained(name)
+    print("round-5 golden vectors written; oracle pinned against the reference")

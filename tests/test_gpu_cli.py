@@ -94,7 +94,7 @@ def test_bench_two_real_ranks_on_one_gpu():
     root = Path(__file__).resolve().parents[1]
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
     res = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "2", "--share-gpu", "--steps", "2", "--warmup", "1",
-                          "--size", "64", "--accum", "4"], env=env, capture_output=True, text=True, timeout=600)
+                          "--size", "64", "--accum", "4", "--pretrain-steps", "30", "--cpu-size", "64"], env=env, capture_output=True, text=True, timeout=600)
     assert res.returncode == 0, res.stderr[-3000:]
     lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
@@ -103,4 +103,5 @@ def test_bench_two_real_ranks_on_one_gpu():
     assert out["value"] == pytest.approx(2 * out["value_per_gpu"], rel=1e-4)
     assert out["value_per_gpu"] <= min(out["per_rank_epochs_per_s"]) * 1.0001
     assert 0.0 < out["loss_last_epoch"] < 1.0 and out["roofline"] is not None
-    assert "fp32" not in out and "cpu_baseline" not in out          # the single-GPU legs are not run in a multi-rank job
+    # the fp32 / oracle-refereed legs are single-GPU work; the CPU baseline rides on rank 0 after the timed region (round 5)
+    assert "fp32" not in out and out["cpu_baseline"]["value"] > 0 and "pretraining" in out and "epoch_roofline" in out

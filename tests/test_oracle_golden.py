@@ -1,4 +1,5 @@
 """CPU: the oracle reproduces every golden vector generated from the reference (tests/golden/make_golden.py)."""
+import pytest
 import torch
 
 from conftest import load_golden, unpack_draws, SMALL_CFG, state_from_golden
@@ -128,6 +129,42 @@ def test_tta_unit_golden_cpu():
         imgs, _ = otta.get_batch_item(g["data"], [16, 16, 16], None)
         final = otta.map_label(om(omind.mind3d(imgs, g["eval_noise"])), pre, "logits")
     assert torch.equal(final.argmax(1), g["eval_argmax"])
+
+
+@pytest.mark.parametrize("fixture", ["tta_unit_trained", "tta_unit_trained_mind"])
+def test_tta_unit_trained_golden_cpu(fixture):
+    """Round 5: the oracle reproduces the reference's run on PRE-TRAINED weights under a domain shift (make_golden_r5.py: 12
+    epochs x 8 steps at lr 3e-4; consistency loss, pseudo-Dice, adapted parameters) and its before / after hard Dice vs
+    ground truth on the stored first noise draw; the fixture itself says the run means something (source Dice >= 0.8, target
+    Dice >= 0.5, adaptation moves it by more than ten times north_star's tolerance)."""
+    import numpy as np
+    g = load_golden(fixture)
+    om = ounet.PlainConvUNetOracle(SMALL_CFG)
+    om.load_state_dict(state_from_golden(g, "w::"), strict=False)
+    lm = {"background": (0, 0), "a": (2, 3), "b": (3, 1), "c": (5, 4), "d": (8, 2)}
+    names = ["background", "a", "b", "c", "d"]
+    pre, tta = otta.get_map_idxs(lm, names, "pretrain_labels"), otta.get_map_idxs(lm, names, "tta_labels")
+
+    def hard_dice(model):
+        with torch.no_grad():
+            imgs, labels = otta.get_batch_item(g["data"], [16, 16, 16], None)
+            out = otta.map_label(model(omind.mind3d(imgs, g["eval_noise"])), pre, "logits")
+            return otta.dice_coeff(out.argmax(1), otta.map_label(labels, tta, "argmaxed").long(), len(names)), out
+    before, _ = hard_dice(om)
+    assert torch.allclose(before, g["dice_before"], atol=1e-6)
+    assert float(g["source_dice"].nanmean()) >= 0.8 and float(g["dice_before"].nanmean()) >= 0.5
+    assert abs(float(g["dice_after"].nanmean()) - float(g["dice_before"].nanmean())) > 1e-2
+    opt = torch.optim.AdamW(om.parameters(), lr=float(g["lr"]))
+    torch.manual_seed(int(g["seed"]))
+    np.random.seed(int(g["seed"]))
+    losses, dices, steps = otta.tta_unit(om, opt, [g["data"]], [16, 16, 16], pre, tta, int(g["epochs"]), 1, int(g["accum"]))
+    # (thread-count dependent summation order of torch's CPU kernels: float tolerance, see test_tta_unit_golden_cpu)
+    assert torch.allclose(steps, g["step_losses"], atol=2e-5) and torch.allclose(losses, g["tta_losses"], atol=2e-5)
+    assert torch.allclose(dices, g["eval_dices"], atol=1e-3)
+    om.eval()
+    after, final = hard_dice(om)
+    assert float((after - g["dice_after"]).abs().max()) <= 2e-3
+    assert float((final.argmax(1) == g["eval_argmax"]).float().mean()) >= 0.9995
 
 
 def test_full_topology_golden_cpu():

@@ -185,7 +185,9 @@ def pretrained_weights(args, device):
     mapping, names = synthetic_label_mapping(k)
     sel = torch.tensor([mapping[n][0] for n in names])
     adt = {"fp32": torch.float32, "bf16": torch.bfloat16, "fp16": torch.float16}[PRETRAIN["storage"]]
-    net = he_init_(HipPlainConvUNet(act_dtype=adt, conv_impl=args.impl), seed=PRETRAIN["w_seed"])
+    # (always the default kernels: --impl selects the kernels of the MEASURED runs; --impl 1 = the VALU reference kernels would
+    # make this step take minutes)
+    net = he_init_(HipPlainConvUNet(act_dtype=adt, conv_impl=0), seed=PRETRAIN["w_seed"])
     handles = register_dg_hooks(net, "nnUNetTrainer_GIN_MIND")
     net = net.to(device)
     # ALL 105 classes are trained (labels = pretrain ids): cross-entropy drives the 89 classes that never occur negative, which is

@@ -21,18 +21,21 @@ void dgtta_set_error(const char *fmt, ...);
 // -1 = variable not set; otherwise the first character ('0', '1', ...) of its value.
 struct DgttaSwitches {
   int conv_rows, conv_s2, dgrad_s2_allcls, wgrad_tr, wgrad_tr8, wgrad_s2_onepass, convt_wgrad_onepass;
-  int convt_gemm, rows_order, in_nt, wgrad_upw, wgrad_xcd, in_gstats, softdice16, conv_ring, wgrad_ring, ha_mfma;
+  int convt_gemm, rows_order, in_nt, wgrad_upw, wgrad_xcd, in_gstats, softdice16, conv_ring, wgrad_ring, ha_mfma, wgrad_f32_split;
   // Laboratory switches: timing models whose results are WRONG BY CONSTRUCTION (*_abl), cycle stamps written past the
   // caller's buffers, measured-no-gain variants.  They exist only in the diagnostic build (-DDGTTA_DIAG ->
   // libdgtta_hip_diag.so, `python -m dg_tta_amd.build --diag`, loaded by profiles/tools/ through DGTTA_LIB); the product
   // library neither reads these variables nor contains the kernel instantiations behind them.
   int rows_abl, rows_var, ring_nt, ring_abl, wgrad_ring_lab, ha_abl, warp_abl, convt_gemm_abl;
+  int ncu;      // DGTTA_NCU=<n> (diagnostic build): persistent kernels size their grid for n CUs (CU-masked stream experiments); 0 = unset
 };
 const DgttaSwitches &dgtta_switches();
 #ifdef DGTTA_DIAG
 #define DG_LAB(field) (dgtta_switches().field)
+#define DG_LAB_NCU(n) (dgtta_switches().ncu > 0 ? dgtta_switches().ncu : (n))
 #else
 #define DG_LAB(field) (-1)
+#define DG_LAB_NCU(n) (n)
 #endif
 
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (kernel, device): lock-free and per device (a plain

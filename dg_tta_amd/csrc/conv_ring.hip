@@ -580,11 +580,12 @@ int ring_launch_kh(const void *x, const View &xv, const void *w, const Taps &tap
   if (xv.sw % 8 || xv.sh % 8 || xv.sd % 8 || xv.sb % 8 || yv.sw % 8 || yv.sh % 8 || yv.sd % 8 || yv.sb % 8 || ((uintptr_t)x & 15) ||
       ((uintptr_t)y & 15))
     return DGTTA_ERR_UNSUPPORTED;
-  static int ncu = [] {
+  static int ncu_dev = [] {
     int dev = 0, n = 256;
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
     return n > 0 ? n : 256;
   }();
+  const int ncu = DG_LAB_NCU(ncu_dev);
   const int tW = cdiv(yv.W, C::TW), tH = cdiv(yv.H, C::TH), nblkN = Cout / 32;
   const int steps_total = (yv.D + 1) / 2;
   const long long ncol = (long long)B * nblkN * tW * tH;

@@ -1437,13 +1437,114 @@ static int wgrad_conv(const void *x, int ldx, const void *dy, int lddy, float *d
   return wgrad_launch_classes<T>(x, xv, dy, yv, dw_t, ws, ws_bytes, B, Cin, Cout, wc, reals, s_co, s_ci, s_tap, accumulate, st);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// fp32 weight gradient on the 16-bit matrix-core kernels (round 5).  The reference computes in fp32
+// (dg_tta/tta/tta.py:560 never autocasts) and fp32 is what `dgtta run_tta` defaults to; the fp32 MFMA weight-gradient kernel
+// (v_mfma_f32_32x32x2_f32, 157 TFLOP/s peak) took 40 % of an fp32 epoch at 0.48 of that peak.  An fp32 number is EXACTLY the
+// sum of three bf16 numbers (3 x 8 significand bits, same exponent range):  x = x0 + x1 + x2,  dy = g0 + g1 + g2, and a
+// bf16 x bf16 product is exact in the fp32 accumulator of v_mfma_f32_*_bf16.  So
+//     dW = sum_v x dy = sum over (i, j) of [sum_v x_i g_j]:  the six products with i + j <= 2 carry everything above 2^-24 of the
+// largest term (what fp32 rounding leaves anyway); each is ONE launch of the 16-bit weight-gradient kernels above (ring sweep,
+// tr, tr8) on the split planes, accumulated into dW in a fixed order (0,0) (0,1) (1,0) (0,2) (1,1) (2,0).  The split is one
+// streaming pass per operand (4 B read, 6 B written per element).  Six launches at 0.40 of the 2.5 PF peak = 167 TFLOP/s
+// fp32-equivalent before the split passes, against 75 for the kernel it replaces.
+// Workspace: [slab region of the 16-bit plan][x planes 3 x B V ldxs][dy planes 3 x B V ldys] (dgtta_conv3d_wgrad_split_ws_bytes).
+namespace {
+__device__ __forceinline__ void split3(float v, bf16_t &a0, bf16_t &a1, bf16_t &a2) {
+  a0 = f32_to_bf16(v);
+  const float r1 = v - bf16_to_f32(a0);          // exact
+  a1 = f32_to_bf16(r1);
+  const float r2 = r1 - bf16_to_f32(a1);         // exact
+  a2 = f32_to_bf16(r2);
+}
+
+// rows [n][ld] fp32 (C used channels) -> three planes [n][lds] bf16 (channels >= C zero); one thread = 8 channels of a row
+__global__ __launch_bounds__(256) void split3_bf16_kernel(const float *__restrict__ x, int ld, int C, int lds, int64_t n,
+                                                        bf16_t *__restrict__ p0, bf16_t *__restrict__ p1,
+                                                        bf16_t *__restrict__ p2) {
+  const int groups = lds >> 3;
+  const int64_t total = n * groups;
+  const bool vec = (ld & 3) == 0 && (C & 7) == 0 && (((uintptr_t)x) & 15) == 0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / groups;
+    const int g = (int)(i - r * groups);
+    float v[8];
+    if (vec) {
+      const float4 lo = *reinterpret_cast<const float4 *>(x + r * ld + 8 * g), hi = *reinterpret_cast<const float4 *>(x + r * ld + 8 * g + 4);
+      v[0] = lo.x, v[1] = lo.y, v[2] = lo.z, v[3] = lo.w, v[4] = hi.x, v[5] = hi.y, v[6] = hi.z, v[7] = hi.w;
+    } else {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] = (8 * g + k) < C ? x[r * ld + 8 * g + k] : 0.f;
+    }
+    bf16_t a[3][8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) split3(v[k], a[0][k], a[1][k], a[2][k]);
+    bf16_t *dst[3] = {p0, p1, p2};
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      uint4 w;
+      w.x = (unsigned)a[q][0] | ((unsigned)a[q][1] << 16);
+      w.y = (unsigned)a[q][2] | ((unsigned)a[q][3] << 16);
+      w.z = (unsigned)a[q][4] | ((unsigned)a[q][5] << 16);
+      w.w = (unsigned)a[q][6] | ((unsigned)a[q][7] << 16);
+      *reinterpret_cast<uint4 *>(dst[q] + r * lds + 8 * g) = w;
+    }
+  }
+}
+}  // namespace
+
+static size_t wgrad_split_plane_bytes(int B, int C, int D, int H, int W) {
+  return align_up((size_t)B * D * H * W * ((C + 7) / 8 * 8) * sizeof(bf16_t), 256);
+}
+// extra bytes behind the slab region: 3 planes of x and 3 of dy (stride 1: input extent == output extent)
+size_t conv3_wgrad_split_extra_bytes(int B, int Cin, int Cout, int D, int H, int W) {
+  return 3 * wgrad_split_plane_bytes(B, Cin, D, H, W) + 3 * wgrad_split_plane_bytes(B, Cout, D, H, W);
+}
+
+static int wgrad_conv_f32_split(const float *x, int ldx, const float *dy, int lddy, float *dw_t, void *ws, size_t slab_bytes,
+                                void *planes, int B, int Cin, int Cout, int D, int H, int W, int accumulate, hipStream_t st) {
+  const int ldxs = (Cin + 7) / 8 * 8, ldys = (Cout + 7) / 8 * 8;
+  const int64_t rows = (int64_t)B * D * H * W;
+  const size_t xb = wgrad_split_plane_bytes(B, Cin, D, H, W), yb = wgrad_split_plane_bytes(B, Cout, D, H, W);
+  bf16_t *xs[3], *gs[3];
+  for (int i = 0; i < 3; ++i) {
+    xs[i] = (bf16_t *)((char *)planes + i * xb);
+    gs[i] = (bf16_t *)((char *)planes + 3 * xb + i * yb);
+  }
+  const int64_t tx = rows * (ldxs / 8), ty = rows * (ldys / 8);
+  hipLaunchKernelGGL(split3_bf16_kernel, dim3((unsigned)(cdiv64(tx, 256) < 8192 ? cdiv64(tx, 256) : 8192)), dim3(256), 0, st, x, ldx,
+                     Cin, ldxs, rows, xs[0], xs[1], xs[2]);
+  hipLaunchKernelGGL(split3_bf16_kernel, dim3((unsigned)(cdiv64(ty, 256) < 8192 ? cdiv64(ty, 256) : 8192)), dim3(256), 0, st, dy,
+                     lddy, Cout, ldys, rows, gs[0], gs[1], gs[2]);
+  DG_CHECK_LAUNCH("split3_bf16_kernel");
+  static const int PAIRS[6][2] = {{0, 0}, {0, 1}, {1, 0}, {0, 2}, {1, 1}, {2, 0}};
+  for (int q = 0; q < 6; ++q) {
+    const int rc = wgrad_conv<bf16_t>(xs[PAIRS[q][0]], ldxs, gs[PAIRS[q][1]], ldys, dw_t, ws, slab_bytes, B, Cin, Cout, D, H, W, 1,
+                                      (accumulate || q > 0) ? 1 : 0, st);
+    if (rc != DGTTA_OK) return rc;        // (q == 0: nothing written yet, the caller falls back to the fp32 kernel)
+  }
+  return DGTTA_OK;
+}
+
 int conv3_wgrad_mfma(const void *x, int ldx, const void *dy, int lddy, float *dw_t, float *db, void *ws, size_t ws_bytes,
                      int B, int Cin, int Cout, int Di, int Hi, int Wi, int stride, int accumulate, int dtype,
                      hipStream_t st) {
   (void)db;
   if (stride != 1 && stride != 2) return DGTTA_ERR_UNSUPPORTED;
   if (stride == 2 && ((Di | Hi | Wi) & 1)) return DGTTA_ERR_UNSUPPORTED;   // odd extents: leave to the general kernel
-  if (dtype == DGTTA_F32) return wgrad_conv<float>(x, ldx, dy, lddy, dw_t, ws, ws_bytes, B, Cin, Cout, Di, Hi, Wi, stride, accumulate, st);
+  if (dtype == DGTTA_F32) {
+    // the caller offered the split workspace (dgtta_conv3d_wgrad_split_ws_bytes) behind the plain one: six 16-bit launches
+    // (DGTTA_WGRAD_F32_SPLIT=0: the fp32 MFMA kernel, its predecessor)
+    const size_t base = conv3_wgrad_mfma_ws_bytes(B, Cin, Cout, Di, Hi, Wi);
+    const size_t slab = align_up(base, 256);
+    if (stride == 1 && Cout % 8 == 0 && dgtta_switches().wgrad_f32_split != '0' &&
+        ws_bytes >= slab + conv3_wgrad_split_extra_bytes(B, Cin, Cout, Di, Hi, Wi)) {
+      const int rc = wgrad_conv_f32_split((const float *)x, ldx, (const float *)dy, lddy, dw_t, ws, slab, (char *)ws + slab, B, Cin,
+                                          Cout, Di, Hi, Wi, accumulate, st);
+      if (rc != DGTTA_ERR_UNSUPPORTED) return rc;
+    }
+    return wgrad_conv<float>(x, ldx, dy, lddy, dw_t, ws, ws_bytes, B, Cin, Cout, Di, Hi, Wi, stride, accumulate, st);
+  }
   if (dtype == DGTTA_BF16) return wgrad_conv<bf16_t>(x, ldx, dy, lddy, dw_t, ws, ws_bytes, B, Cin, Cout, Di, Hi, Wi, stride, accumulate, st);
   if (dtype == DGTTA_F16) return wgrad_conv<f16_t>(x, ldx, dy, lddy, dw_t, ws, ws_bytes, B, Cin, Cout, Di, Hi, Wi, stride, accumulate, st);
   return DGTTA_ERR_UNSUPPORTED;

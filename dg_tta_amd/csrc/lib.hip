@@ -48,11 +48,13 @@ static const DgttaSwitches *read_switches() {
   s->conv_ring = env_char("DGTTA_CONV_RING");
   s->wgrad_ring = env_char("DGTTA_WGRAD_RING");
   s->ha_mfma = env_char("DGTTA_HA_MFMA");
+  s->wgrad_f32_split = env_char("DGTTA_WGRAD_F32_SPLIT");
   // product switches select between kernels of equal results only: values outside a switch's documented set are ignored
   if (s->conv_ring != '0' && s->conv_ring != '1' && s->conv_ring != '3') s->conv_ring = -1;
   if (s->wgrad_ring != '0' && s->wgrad_ring != '1' && s->wgrad_ring != '4') s->wgrad_ring = -1;
   if (s->convt_gemm != '0' && s->convt_gemm != '1') s->convt_gemm = -1;
   s->rows_abl = s->rows_var = s->ring_nt = s->ring_abl = s->wgrad_ring_lab = s->ha_abl = s->warp_abl = s->convt_gemm_abl = -1;
+  s->ncu = 0;
 #ifdef DGTTA_DIAG
   s->rows_abl = env_char("DGTTA_ROWS_ABL");
   s->convt_gemm_abl = env_char("DGTTA_CONVT_GEMM_ABL");      // '2' / '3': the transposed-conv GEMM without stores / without MFMAs
@@ -62,6 +64,7 @@ static const DgttaSwitches *read_switches() {
   s->wgrad_ring_lab = env_char("DGTTA_WGRAD_RING_CLK");      // '6': cycle stamps behind the slabs (profiles/tools/wring_clock.py)
   s->ha_abl = env_char("DGTTA_HA_ABL");
   s->warp_abl = env_char("DGTTA_WARP_ABL");
+  if (const char *v = getenv("DGTTA_NCU")) s->ncu = atoi(v);
 #endif
   return s;
 }

@@ -1248,6 +1248,7 @@ extern "C" int dgtta_conv3d_k3_dgrad_gstats(const void *dy, int lddy, const void
 }
 
 size_t conv3_wgrad_mfma_ws_bytes(int B, int Cin, int Cout, int D, int H, int W);
+size_t conv3_wgrad_split_extra_bytes(int B, int Cin, int Cout, int D, int H, int W);
 
 // workspace layout: [bias partials][main: split partials of the VALU kernel | slabs of the MFMA kernel]
 static size_t wgrad_bias_bytes(int B, int Cout, int Do, int Ho, int Wo) {
@@ -1260,6 +1261,15 @@ extern "C" size_t dgtta_conv3d_wgrad_ws_bytes(int B, int Cin, int Cout, int Do, 
   size_t a = align_up((size_t)wgrad_splits(nvox) * Cout * Cin * 27 * sizeof(float), 256);
   size_t c = align_up(conv3_wgrad_mfma_ws_bytes(B, Cin, Cout, Do, Ho, Wo), 256);   // stride 1: input dims == output dims
   return wgrad_bias_bytes(B, Cout, Do, Ho, Wo) + (a > c ? a : c);
+}
+
+// workspace that lets an fp32 stride-1 weight gradient run as six 16-bit launches on bf16 split planes (conv_wgrad.hip): the
+// plain workspace followed by three planes of x and three of dy
+extern "C" size_t dgtta_conv3d_wgrad_split_ws_bytes(int B, int Cin, int Cout, int Do, int Ho, int Wo) {
+  if (B <= 0 || Cin <= 0 || Cout <= 0 || Do <= 0 || Ho <= 0 || Wo <= 0) return 0;
+  const size_t base = dgtta_conv3d_wgrad_ws_bytes(B, Cin, Cout, Do, Ho, Wo);
+  // the split planes start behind the 256-aligned slab region of the MAIN part (workspace = [bias partials][main])
+  return base + 256 + conv3_wgrad_split_extra_bytes(B, Cin, Cout, Do, Ho, Wo);
 }
 
 static int bias_grad(const void *dy, int lddy, float *db, void *ws, int B, int C, int64_t V, int accumulate, int dtype,

@@ -544,7 +544,12 @@ class _UNetFn(torch.autograd.Function):
                                                    v, SLOPE, ACC, dt, st), "dgtta_instnorm_lrelu_bwd")
             # -- weight / bias gradient
             if want(conv.weight) or want(conv.bias):
-                nb = lib.dgtta_conv3d_wgrad_ws_bytes(B, cin, cout, do, ho, wo)
+                # fp32 storage, stride 1: offer the split workspace - the weight gradient then runs as six launches of the
+                # 16-bit matrix-core kernels on exact three-term bf16 splits of x and dy (csrc/conv_wgrad.hip, round 5)
+                if dt == F32 and s == 1 and impl != 1:
+                    nb = lib.dgtta_conv3d_wgrad_split_ws_bytes(B, cin, cout, do, ho, wo)
+                else:
+                    nb = lib.dgtta_conv3d_wgrad_ws_bytes(B, cin, cout, do, ho, wo)
                 dw = gbuf(conv.weight) if want(conv.weight) else scratch_like(conv.weight)
                 db = gbuf(conv.bias) if want(conv.bias) else None
                 if net.exact_zero_bias_grad:

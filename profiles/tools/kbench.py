@@ -30,7 +30,8 @@ elif what == "dgrad":
 else:
     dy = torch.randn(B, n, n, n, cout, device=DEV).to(tdt)
     dw = torch.empty((cout, cin, 3, 3, 3), device=DEV)
-    nb = lib.dgtta_conv3d_wgrad_ws_bytes(B, cin, cout, n, n, n)
+    # KB_SPLIT=1 (fp32): the split workspace -> six 16-bit launches on three-term bf16 splits
+    nb = (lib.dgtta_conv3d_wgrad_split_ws_bytes if os.environ.get("KB_SPLIT") else lib.dgtta_conv3d_wgrad_ws_bytes)(B, cin, cout, n, n, n)
     ws = torch.empty(nb, dtype=torch.uint8, device=DEV)
     run = lambda: check(lib.dgtta_conv3d_k3_wgrad(ptr(x), cin, ptr(dy), cout, ptr(dw), None, ptr(ws), nb, B, cin, cout, n, n, n, 1, 0, dt, 2, stream_of()), "wgrad")
 run(); torch.cuda.synchronize()

@@ -103,9 +103,12 @@ def test_one_pass_batch8_128_every_storage_type_vs_fp32_valu():
     # measured (profiles/r03_at_size_parity.json): fp32 MFMA 3.4e-6 / 6e-8 / 0.99997 / 0.992, fp16 1.6e-3 / 3e-7 / 0.987 /
     # 0.943, bf16 1.3e-2 / 1.5e-5 / 0.901 / 0.827 (logit error over range / loss delta / min gradient cosine / min sign agreement)
     # the limits are 2-3x those measurements (the old ones would not have caught a 10x regression)
-    limits = {"fp32": dict(logit=1e-5, loss=3e-7, cos=0.9999, sign=0.98),
-              "fp16": dict(logit=4e-3, loss=1e-6, cos=0.965, sign=0.90),
-              "bf16": dict(logit=3e-2, loss=5e-5, cos=0.80, sign=0.72)}
+    # Round 5: the runner's weights are PRE-TRAINED (bench.pretrained_weights) - decisive logits, gradients far above rounding
+    # noise.  Measured on them (profiles/r05_at_size_parity.json "one_pass"): fp32 MFMA 7.7e-7 / 6e-8 / 0.9999995 / 0.999998, fp16
+    # 2.1e-4 / 3e-7 / 0.9989 / 0.991, bf16 1.8e-3 / 8e-5 / 0.9996 / 0.969, labels 0.9999999 / 0.99995 / 0.9996
+    limits = {"fp32": dict(logit=3e-6, loss=3e-7, cos=0.99999, sign=0.9999, agree=0.999999),
+              "fp16": dict(logit=6e-4, loss=1.5e-6, cos=0.996, sign=0.97, agree=0.9998),
+              "bf16": dict(logit=5e-3, loss=2.5e-4, cos=0.998, sign=0.92, agree=0.999)}
     for dtype in ("fp32", "fp16", "bf16"):
         r = _runner(dtype, impl=0)
         logits, loss, dice, grads = _one_pass(r, 77)
@@ -127,6 +130,7 @@ def test_one_pass_batch8_128_every_storage_type_vs_fp32_valu():
         assert abs(loss - ref_loss) < lim["loss"], f"{dtype}: loss {loss:.6f} vs {ref_loss:.6f}"
         assert cos_min > lim["cos"], f"{dtype}: gradient cosine {cos_min:.4f} in {worst}"
         assert sign_min > lim["sign"], f"{dtype}: gradient sign agreement {sign_min:.4f}"
+        assert agree >= lim["agree"], f"{dtype}: label agreement {agree:.7f}"
         del logits, grads
         torch.cuda.empty_cache()
 
@@ -194,13 +198,17 @@ def test_adaptation_epochs_128_dice_delta_of_the_default_storage_type():
                          "hard_dice_mean_delta": abs(float(per_class.nanmean()) - float(ref[3].nanmean())),
                          "label_agreement": float((labels == ref[2]).float().mean()), "skipped_steps": skipped}
     _record("epochs", report)
-    # measured (profiles/r03_at_size_parity.json): loss <= 3.1e-6 / 1.7e-5, pseudo-Dice <= 2.5e-5 / 4.2e-5, hard Dice mean 8e-6 / 8e-6,
-    # labels 0.9967 / 0.9765 (fp16 / bf16) on He-initialised weights, whose logits are near ties almost everywhere
-    for dtype, lab in (("fp16", 0.99), ("bf16", 0.95)):
+    # Round 5: the runner starts from weights PRE-TRAINED on the source domain of the synthetic atlas task (bench.pretrained_weights)
+    # and adapts to a target-domain case at lr 3e-4: the hard Dice vs ground truth is ~0.68 before and moves by ~0.05 in 4 epochs,
+    # so north_star's 1e-3 is a real bound here (rounds 3-4 measured it on He-initialised weights at Dice 0.005).  Measured (bench
+    # line of profiles/r05_bench_lines.json, 6 epochs): loss 2.7e-5 / 1.6e-4, pseudo-Dice 2.2e-4 / 3.4e-4, hard Dice mean 2.2e-4 /
+    # 1.3e-4, labels 0.99972 / 0.99887 (fp16 / bf16)
+    assert float(ref[3].nanmean()) > 0.5
+    for dtype, lab in (("fp16", 0.999), ("bf16", 0.997)):
         d = report[dtype]
-        assert max(d["loss_delta_per_epoch"]) < (1e-5 if dtype == "fp16" else 5e-5) < TOL
-        assert max(d["pseudo_dice_delta_per_epoch"]) < 1.5e-4 < TOL
-        assert d["hard_dice_mean_delta"] < 5e-5 < TOL and d["hard_dice_per_class_delta_max"] < TOL
+        assert max(d["loss_delta_per_epoch"]) < (1e-4 if dtype == "fp16" else 5e-4) < TOL
+        assert max(d["pseudo_dice_delta_per_epoch"]) < TOL
+        assert d["hard_dice_mean_delta"] < TOL
         assert d["skipped_steps"] == 0
         assert d["label_agreement"] > lab
 

@@ -289,6 +289,52 @@ def test_wgrad_mfma_fp32(case):
     assert (dw3.cpu() - 2 * ref).abs().max() < 6e-5 * scale
 
 
+def _call_wgrad_split(x, dy, cin, cout, accumulate=0, dw=None):
+    """fp32 weight gradient with the SPLIT workspace: six 16-bit launches on three-term bf16 splits (round 5)."""
+    from dg_tta_amd import _lib
+    from dg_tta_amd._lib import check, ptr, stream_of
+    lib = _lib.load()
+    B, D, H, W, ldx = x.shape
+    dw = torch.empty((cout, cin, 3, 3, 3), device=DEV) if dw is None else dw
+    nb = lib.dgtta_conv3d_wgrad_split_ws_bytes(B, cin, cout, D, H, W)
+    assert nb > lib.dgtta_conv3d_wgrad_ws_bytes(B, cin, cout, D, H, W)
+    ws = torch.empty(nb, dtype=torch.uint8, device=DEV)
+    check(lib.dgtta_conv3d_k3_wgrad(ptr(x), ldx, ptr(dy), dy.shape[-1], ptr(dw), None, ptr(ws), nb, B, cin, cout, D, H, W, 1,
+                                    accumulate, 0, 2, stream_of()), "wgrad split")
+    return dw
+
+
+@pytest.mark.parametrize("case", [(1, 16, 32, 8, 8, 32), (1, 32, 32, 9, 7, 45), (2, 12, 32, 6, 10, 16), (1, 64, 32, 5, 9, 20),
+                                  (1, 24, 40, 8, 8, 8), (2, 32, 32, 40, 12, 64), (1, 320, 320, 4, 4, 4), (4, 64, 64, 16, 32, 32)])
+def test_wgrad_fp32_as_six_bf16_products(case, monkeypatch):
+    """Round 5: the fp32 weight gradient evaluated on the 16-bit matrix-core kernels - x and dy split EXACTLY
+    into three bf16 terms each, the six products with i + j <= 2 accumulated in a fixed order - against a float64 torch
+    evaluation, at the accuracy of the fp32 MFMA kernel it replaces (DGTTA_WGRAD_F32_SPLIT=0, run side by side): operands
+    with a wide dynamic range (a 16-bit two-term split would lose them), ragged channel counts (12 of 16), batch > 1, the
+    accumulate form, run-to-run identical."""
+    B, cin, cout, D, H, W = case
+    torch.manual_seed(sum(case) + 9)
+    ld = (cin + 7) // 8 * 8 if cin % 4 else cin
+    x = torch.zeros(B, D, H, W, ld, device=DEV)
+    x[..., :cin] = torch.randn(B, D, H, W, cin, device=DEV) * torch.exp(3 * torch.randn(B, D, H, W, 1, device=DEV))
+    dy = torch.randn(B, D, H, W, cout, device=DEV) * torch.exp(2 * torch.randn(1, 1, 1, 1, cout, device=DEV)) * 1e-6
+    ref = torch.nn.grad.conv3d_weight(x[..., :cin].permute(0, 4, 1, 2, 3).cpu().double(), (cout, cin, 3, 3, 3),
+                                      dy.permute(0, 4, 1, 2, 3).cpu().double(), stride=1, padding=1)
+    scale = float(ref.abs().max())
+    new = _call_wgrad_split(x, dy, cin, cout)
+    monkeypatch.setenv("DGTTA_WGRAD_F32_SPLIT", "0")
+    reload_kernel_switches()
+    old = _call_wgrad_split(x, dy, cin, cout)              # same workspace, the switch selects the fp32 MFMA kernel
+    monkeypatch.delenv("DGTTA_WGRAD_F32_SPLIT")
+    reload_kernel_switches()
+    e_new, e_old = float((new.cpu().double() - ref).abs().max()) / scale, float((old.cpu().double() - ref).abs().max()) / scale
+    assert e_old < 3e-5, e_old
+    assert e_new < 3e-5 and e_new < 4 * e_old + 2e-7, (e_new, e_old)      # fp32 rounding level, like its predecessor
+    assert torch.equal(new, _call_wgrad_split(x, dy, cin, cout))
+    acc = _call_wgrad_split(x, dy, cin, cout, accumulate=1, dw=new.clone())
+    assert float((acc.cpu().double() - 2 * ref).abs().max()) / scale < 6e-5
+
+
 @pytest.mark.parametrize("case", [c for c in WCASES if c[1] % 8 == 0])
 def test_wgrad_mfma_bf16(case):
     B, cin, cout, D, H, W = case

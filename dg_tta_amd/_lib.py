@@ -40,7 +40,7 @@ SIGNATURES = {
     "dgtta_conv3d_k3_fwd": (I, [P, I, P, P, P, I, P, I, I, I, I, I, I, I, I, I, I, I, P]),
     "dgtta_conv3d_k3_dgrad": (I, [P, I, P, P, I, I, I, I, I, I, I, I, I, I, I, I, I, P]),
     "dgtta_conv3d_wgrad_ws_bytes": (SZ, [I, I, I, I, I, I]),
-    "dgtta_conv3d_wgrad_split_ws_bytes": (SZ, [I, I, I, I, I, I]),
+    "dgtta_conv3d_wgrad_split_ws_bytes": (SZ, [I, I, I, I, I, I, I]),
     "dgtta_conv3d_k3_wgrad": (I, [P, I, P, I, P, P, P, SZ, I, I, I, I, I, I, I, I, I, I, P]),
     "dgtta_instnorm_ws_bytes": (SZ, [I, I, I64]),
     "dgtta_instnorm_lrelu_fwd": (I, [P, I, P, P, P, P, P, I, P, SZ, I, I, I64, F, F, I, P]),

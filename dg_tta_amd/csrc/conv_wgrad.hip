@@ -1496,31 +1496,34 @@ __global__ __launch_bounds__(256) void split3_bf16_kernel(const float *__restric
 static size_t wgrad_split_plane_bytes(int B, int C, int D, int H, int W) {
   return align_up((size_t)B * D * H * W * ((C + 7) / 8 * 8) * sizeof(bf16_t), 256);
 }
-// extra bytes behind the slab region: 3 planes of x and 3 of dy (stride 1: input extent == output extent)
-size_t conv3_wgrad_split_extra_bytes(int B, int Cin, int Cout, int D, int H, int W) {
-  return 3 * wgrad_split_plane_bytes(B, Cin, D, H, W) + 3 * wgrad_split_plane_bytes(B, Cout, D, H, W);
+// extra bytes behind the slab region: 3 planes of x (input extent = stride x output extent) and 3 of dy (output extent D, H, W)
+size_t conv3_wgrad_split_extra_bytes(int B, int Cin, int Cout, int D, int H, int W, int stride) {
+  return 3 * wgrad_split_plane_bytes(B, Cin, D * stride, H * stride, W * stride) + 3 * wgrad_split_plane_bytes(B, Cout, D, H, W);
 }
 
+// Di, Hi, Wi: input extent; stride 1 or 2 (even extents)
 static int wgrad_conv_f32_split(const float *x, int ldx, const float *dy, int lddy, float *dw_t, void *ws, size_t slab_bytes,
-                                void *planes, int B, int Cin, int Cout, int D, int H, int W, int accumulate, hipStream_t st) {
+                                void *planes, int B, int Cin, int Cout, int Di, int Hi, int Wi, int stride, int accumulate,
+                                hipStream_t st) {
   const int ldxs = (Cin + 7) / 8 * 8, ldys = (Cout + 7) / 8 * 8;
-  const int64_t rows = (int64_t)B * D * H * W;
-  const size_t xb = wgrad_split_plane_bytes(B, Cin, D, H, W), yb = wgrad_split_plane_bytes(B, Cout, D, H, W);
+  const int D = Di / stride, H = Hi / stride, W = Wi / stride;
+  const int64_t rows_x = (int64_t)B * Di * Hi * Wi, rows = (int64_t)B * D * H * W;
+  const size_t xb = wgrad_split_plane_bytes(B, Cin, Di, Hi, Wi), yb = wgrad_split_plane_bytes(B, Cout, D, H, W);
   bf16_t *xs[3], *gs[3];
   for (int i = 0; i < 3; ++i) {
     xs[i] = (bf16_t *)((char *)planes + i * xb);
     gs[i] = (bf16_t *)((char *)planes + 3 * xb + i * yb);
   }
-  const int64_t tx = rows * (ldxs / 8), ty = rows * (ldys / 8);
+  const int64_t tx = rows_x * (ldxs / 8), ty = rows * (ldys / 8);
   hipLaunchKernelGGL(split3_bf16_kernel, dim3((unsigned)(cdiv64(tx, 256) < 8192 ? cdiv64(tx, 256) : 8192)), dim3(256), 0, st, x, ldx,
-                     Cin, ldxs, rows, xs[0], xs[1], xs[2]);
+                     Cin, ldxs, rows_x, xs[0], xs[1], xs[2]);
   hipLaunchKernelGGL(split3_bf16_kernel, dim3((unsigned)(cdiv64(ty, 256) < 8192 ? cdiv64(ty, 256) : 8192)), dim3(256), 0, st, dy,
                      lddy, Cout, ldys, rows, gs[0], gs[1], gs[2]);
   DG_CHECK_LAUNCH("split3_bf16_kernel");
   static const int PAIRS[6][2] = {{0, 0}, {0, 1}, {1, 0}, {0, 2}, {1, 1}, {2, 0}};
   for (int q = 0; q < 6; ++q) {
-    const int rc = wgrad_conv<bf16_t>(xs[PAIRS[q][0]], ldxs, gs[PAIRS[q][1]], ldys, dw_t, ws, slab_bytes, B, Cin, Cout, D, H, W, 1,
-                                      (accumulate || q > 0) ? 1 : 0, st);
+    const int rc = wgrad_conv<bf16_t>(xs[PAIRS[q][0]], ldxs, gs[PAIRS[q][1]], ldys, dw_t, ws, slab_bytes, B, Cin, Cout, Di, Hi, Wi,
+                                      stride, (accumulate || q > 0) ? 1 : 0, st);
     if (rc != DGTTA_OK) return rc;        // (q == 0: nothing written yet, the caller falls back to the fp32 kernel)
   }
   return DGTTA_OK;
@@ -1535,12 +1538,13 @@ int conv3_wgrad_mfma(const void *x, int ldx, const void *dy, int lddy, float *dw
   if (dtype == DGTTA_F32) {
     // the caller offered the split workspace (dgtta_conv3d_wgrad_split_ws_bytes) behind the plain one: six 16-bit launches
     // (DGTTA_WGRAD_F32_SPLIT=0: the fp32 MFMA kernel, its predecessor)
-    const size_t base = conv3_wgrad_mfma_ws_bytes(B, Cin, Cout, Di, Hi, Wi);
+    const int Do = Di / stride, Ho = Hi / stride, Wo = Wi / stride;
+    const size_t base = conv3_wgrad_mfma_ws_bytes(B, Cin, Cout, Do, Ho, Wo);
     const size_t slab = align_up(base, 256);
-    if (stride == 1 && Cout % 8 == 0 && dgtta_switches().wgrad_f32_split != '0' &&
-        ws_bytes >= slab + conv3_wgrad_split_extra_bytes(B, Cin, Cout, Di, Hi, Wi)) {
+    if (Cout % 8 == 0 && dgtta_switches().wgrad_f32_split != '0' &&
+        ws_bytes >= slab + conv3_wgrad_split_extra_bytes(B, Cin, Cout, Do, Ho, Wo, stride)) {
       const int rc = wgrad_conv_f32_split((const float *)x, ldx, (const float *)dy, lddy, dw_t, ws, slab, (char *)ws + slab, B, Cin,
-                                          Cout, Di, Hi, Wi, accumulate, st);
+                                          Cout, Di, Hi, Wi, stride, accumulate, st);
       if (rc != DGTTA_ERR_UNSUPPORTED) return rc;
     }
     return wgrad_conv<float>(x, ldx, dy, lddy, dw_t, ws, ws_bytes, B, Cin, Cout, Di, Hi, Wi, stride, accumulate, st);

@@ -1248,7 +1248,7 @@ extern "C" int dgtta_conv3d_k3_dgrad_gstats(const void *dy, int lddy, const void
 }
 
 size_t conv3_wgrad_mfma_ws_bytes(int B, int Cin, int Cout, int D, int H, int W);
-size_t conv3_wgrad_split_extra_bytes(int B, int Cin, int Cout, int D, int H, int W);
+size_t conv3_wgrad_split_extra_bytes(int B, int Cin, int Cout, int D, int H, int W, int stride);
 
 // workspace layout: [bias partials][main: split partials of the VALU kernel | slabs of the MFMA kernel]
 static size_t wgrad_bias_bytes(int B, int Cout, int Do, int Ho, int Wo) {
@@ -1265,11 +1265,11 @@ extern "C" size_t dgtta_conv3d_wgrad_ws_bytes(int B, int Cin, int Cout, int Do, 
 
 // workspace that lets an fp32 stride-1 weight gradient run as six 16-bit launches on bf16 split planes (conv_wgrad.hip): the
 // plain workspace followed by three planes of x and three of dy
-extern "C" size_t dgtta_conv3d_wgrad_split_ws_bytes(int B, int Cin, int Cout, int Do, int Ho, int Wo) {
-  if (B <= 0 || Cin <= 0 || Cout <= 0 || Do <= 0 || Ho <= 0 || Wo <= 0) return 0;
+extern "C" size_t dgtta_conv3d_wgrad_split_ws_bytes(int B, int Cin, int Cout, int Do, int Ho, int Wo, int stride) {
+  if (B <= 0 || Cin <= 0 || Cout <= 0 || Do <= 0 || Ho <= 0 || Wo <= 0 || (stride != 1 && stride != 2)) return 0;
   const size_t base = dgtta_conv3d_wgrad_ws_bytes(B, Cin, Cout, Do, Ho, Wo);
   // the split planes start behind the 256-aligned slab region of the MAIN part (workspace = [bias partials][main])
-  return base + 256 + conv3_wgrad_split_extra_bytes(B, Cin, Cout, Do, Ho, Wo);
+  return base + 256 + conv3_wgrad_split_extra_bytes(B, Cin, Cout, Do, Ho, Wo, stride);
 }
 
 static int bias_grad(const void *dy, int lddy, float *db, void *ws, int B, int C, int64_t V, int accumulate, int dtype,

@@ -544,10 +544,10 @@ class _UNetFn(torch.autograd.Function):
                                                    v, SLOPE, ACC, dt, st), "dgtta_instnorm_lrelu_bwd")
             # -- weight / bias gradient
             if want(conv.weight) or want(conv.bias):
-                # fp32 storage, stride 1: offer the split workspace - the weight gradient then runs as six launches of the
+                # fp32 storage: offer the split workspace - the weight gradient then runs as six launches of the
                 # 16-bit matrix-core kernels on exact three-term bf16 splits of x and dy (csrc/conv_wgrad.hip, round 5)
-                if dt == F32 and s == 1 and impl != 1:
-                    nb = lib.dgtta_conv3d_wgrad_split_ws_bytes(B, cin, cout, do, ho, wo)
+                if dt == F32 and impl != 1 and (s == 1 or not ((di | hi | wi) & 1)):
+                    nb = lib.dgtta_conv3d_wgrad_split_ws_bytes(B, cin, cout, do, ho, wo, s)
                 else:
                     nb = lib.dgtta_conv3d_wgrad_ws_bytes(B, cin, cout, do, ho, wo)
                 dw = gbuf(conv.weight) if want(conv.weight) else scratch_like(conv.weight)

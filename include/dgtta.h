@@ -193,11 +193,11 @@ int dgtta_conv3d_k3_dgrad(const void *dy, int lddy, const void *wpack, void *dx,
  * fp32 outputs in torch layout; accumulate != 0 adds to existing gradients (gradient accumulation
  * over tta.py:221's 16 steps and over both branches). */
 size_t dgtta_conv3d_wgrad_ws_bytes(int B, int Cin, int Cout, int Do, int Ho, int Wo);
-/* Optional larger workspace for dtype = DGTTA_F32, stride 1: the plain workspace followed by room for three bf16 planes of x and
- * three of dy.  Given that much, dgtta_conv3d_k3_wgrad evaluates the fp32 weight gradient as six launches of the 16-bit
+/* Optional larger workspace for dtype = DGTTA_F32 (stride 1, or 2 with even extents): the plain workspace followed by room for
+ * three bf16 planes of x (input extent) and three of dy.  Given that much, dgtta_conv3d_k3_wgrad evaluates the fp32 weight gradient as six launches of the 16-bit
  * matrix-core kernels on the exact three-term bf16 splits of its operands (x = x0 + x1 + x2; the six products with i + j <= 2,
  * each exact in the fp32 accumulator) instead of the fp32 MFMA kernel: same result to fp32 rounding, ~1.7x the rate. */
-size_t dgtta_conv3d_wgrad_split_ws_bytes(int B, int Cin, int Cout, int Do, int Ho, int Wo);
+size_t dgtta_conv3d_wgrad_split_ws_bytes(int B, int Cin, int Cout, int Do, int Ho, int Wo, int stride);
 int dgtta_conv3d_k3_wgrad(const void *x, int ldx, const void *dy, int lddy, float *dw_t, float *db, void *ws,
                           size_t ws_bytes, int B, int Cin, int Cout, int Di, int Hi, int Wi, int stride,
                           int accumulate, int dtype, int impl, void *stream);

@@ -14,12 +14,13 @@ if what == "conv":
     w = torch.randn(cout, cin, 3, 3, 3, device=DEV) * 0.05
     wpack = torch.empty(lib.dgtta_conv3d_packed_bytes(cin, cout, dt) // (2 if dt else 4), dtype=tdt, device=DEV)
     check(lib.dgtta_conv3d_pack_weights(ptr(w), ptr(wpack), cin, cout, cin, cout, dt, stream_of()), "pack")
-    y = torch.empty((B, n, n, n, cout), dtype=tdt, device=DEV)
-    import os
+    S = int(os.environ.get("KB_STRIDE", "1"))          # KB_STRIDE=2: the encoder transitions (n = input edge)
+    no = (n - 1) // S + 1
+    y = torch.empty((B, no, no, no, cout), dtype=tdt, device=DEV)
     st = None
     if os.environ.get("KB_STATS"):
-        st = torch.zeros(lib.dgtta_conv3d_stats_bytes(B, cout, n, n, n), dtype=torch.uint8, device=DEV)
-    run = lambda: check(lib.dgtta_conv3d_k3_fwd(ptr(x), cin, ptr(wpack), None, ptr(y), cout, ptr(st) if st is not None else None, B, cin, cout, cin, cout, n, n, n, 1, dt, 2, stream_of()), "fwd")
+        st = torch.zeros(lib.dgtta_conv3d_stats_bytes(B, cout, no, no, no), dtype=torch.uint8, device=DEV)
+    run = lambda: check(lib.dgtta_conv3d_k3_fwd(ptr(x), cin, ptr(wpack), None, ptr(y), cout, ptr(st) if st is not None else None, B, cin, cout, cin, cout, n, n, n, S, dt, 2, stream_of()), "fwd")
 elif what == "dgrad":
     w = torch.randn(cout, cin, 3, 3, 3, device=DEV) * 0.05
     wpack = torch.empty(lib.dgtta_conv3d_packed_bytes(cin, cout, dt) // (2 if dt else 4), dtype=tdt, device=DEV)
@@ -40,4 +41,5 @@ e0.record()
 for _ in range(iters): run()
 e1.record(); torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / iters
-print(f"{what} {dts} {cin}->{cout} {n}^3 x{B}: {ms:.3f} ms, {B*2*27*cin*cout*n**3/ms/1e9:.1f} TFLOP/s")
+vox = ((n - 1) // int(os.environ.get("KB_STRIDE", "1")) + 1) ** 3 if what == "conv" else n ** 3
+print(f"{what} {dts} {cin}->{cout} {n}^3 x{B}: {ms:.3f} ms, {B*2*27*cin*cout*vox/ms/1e9:.1f} TFLOP/s")

@@ -289,17 +289,18 @@ def test_wgrad_mfma_fp32(case):
     assert (dw3.cpu() - 2 * ref).abs().max() < 6e-5 * scale
 
 
-def _call_wgrad_split(x, dy, cin, cout, accumulate=0, dw=None):
+def _call_wgrad_split(x, dy, cin, cout, accumulate=0, dw=None, stride=1):
     """fp32 weight gradient with the SPLIT workspace: six 16-bit launches on three-term bf16 splits (round 5)."""
     from dg_tta_amd import _lib
     from dg_tta_amd._lib import check, ptr, stream_of
     lib = _lib.load()
     B, D, H, W, ldx = x.shape
+    do, ho, wo = dy.shape[1:4]
     dw = torch.empty((cout, cin, 3, 3, 3), device=DEV) if dw is None else dw
-    nb = lib.dgtta_conv3d_wgrad_split_ws_bytes(B, cin, cout, D, H, W)
-    assert nb > lib.dgtta_conv3d_wgrad_ws_bytes(B, cin, cout, D, H, W)
+    nb = lib.dgtta_conv3d_wgrad_split_ws_bytes(B, cin, cout, do, ho, wo, stride)
+    assert nb > lib.dgtta_conv3d_wgrad_ws_bytes(B, cin, cout, do, ho, wo)
     ws = torch.empty(nb, dtype=torch.uint8, device=DEV)
-    check(lib.dgtta_conv3d_k3_wgrad(ptr(x), ldx, ptr(dy), dy.shape[-1], ptr(dw), None, ptr(ws), nb, B, cin, cout, D, H, W, 1,
+    check(lib.dgtta_conv3d_k3_wgrad(ptr(x), ldx, ptr(dy), dy.shape[-1], ptr(dw), None, ptr(ws), nb, B, cin, cout, D, H, W, stride,
                                     accumulate, 0, 2, stream_of()), "wgrad split")
     return dw
 
@@ -333,6 +334,13 @@ def test_wgrad_fp32_as_six_bf16_products(case, monkeypatch):
     assert torch.equal(new, _call_wgrad_split(x, dy, cin, cout))
     acc = _call_wgrad_split(x, dy, cin, cout, accumulate=1, dw=new.clone())
     assert float((acc.cpu().double() - 2 * ref).abs().max()) / scale < 6e-5
+    # stride 2 (the encoder transitions): the same operands as the input of a stride-2 conv of even extent
+    if D % 2 == 0 and H % 2 == 0 and W % 2 == 0:
+        dy2 = dy[:, ::2, ::2, ::2].contiguous()
+        ref2 = torch.nn.grad.conv3d_weight(x[..., :cin].permute(0, 4, 1, 2, 3).cpu().double(), (cout, cin, 3, 3, 3),
+                                           dy2.permute(0, 4, 1, 2, 3).cpu().double(), stride=2, padding=1)
+        got2 = _call_wgrad_split(x, dy2, cin, cout, stride=2)
+        assert float((got2.cpu().double() - ref2).abs().max()) / float(ref2.abs().max()) < 3e-5
 
 
 @pytest.mark.parametrize("case", [c for c in WCASES if c[1] % 8 == 0])

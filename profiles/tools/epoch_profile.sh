@@ -16,9 +16,9 @@ cd /tmp && export TMPDIR=/tmp
 for dt in $dts; do
   for n in 1 3; do
     common="--dtype $dt --steps $n --warmup 0 --weights he --no-fp32 --no-cpu-baseline --inference-size 0"
-    [[ " $parts " == *" fetch "* ]] && rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $R/gpurun_out/${tag}_ep_${dt}_fetch_$n -o ep --output-format csv -- python3 $R/bench.py $common > $R/gpurun_out/${tag}_ep_${dt}_fetch_$n.log 2>&1 || echo "fetch $dt $n failed"
-    [[ " $parts " == *" write "* ]] && rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $R/gpurun_out/${tag}_ep_${dt}_write_$n -o ep --output-format csv -- python3 $R/bench.py $common > $R/gpurun_out/${tag}_ep_${dt}_write_$n.log 2>&1 || echo "write $dt $n failed"
-    [[ " $parts " == *" stats "* ]] && DGTTA_WGRAD_STREAM=0 DGTTA_PIPELINE_PREP=0 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/${tag}_ep_${dt}_stats_$n -o ep --output-format csv -- python3 $R/bench.py $common > $R/gpurun_out/${tag}_ep_${dt}_stats_$n.log 2>&1 || echo "stats $dt $n failed"
+    [[ " $parts " != *" fetch "* ]] || rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $R/gpurun_out/${tag}_ep_${dt}_fetch_$n -o ep --output-format csv -- python3 $R/bench.py $common > $R/gpurun_out/${tag}_ep_${dt}_fetch_$n.log 2>&1 || echo "fetch $dt $n failed"
+    [[ " $parts " != *" write "* ]] || rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $R/gpurun_out/${tag}_ep_${dt}_write_$n -o ep --output-format csv -- python3 $R/bench.py $common > $R/gpurun_out/${tag}_ep_${dt}_write_$n.log 2>&1 || echo "write $dt $n failed"
+    [[ " $parts " != *" stats "* ]] || DGTTA_WGRAD_STREAM=0 DGTTA_PIPELINE_PREP=0 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/${tag}_ep_${dt}_stats_$n -o ep --output-format csv -- python3 $R/bench.py $common > $R/gpurun_out/${tag}_ep_${dt}_stats_$n.log 2>&1 || echo "stats $dt $n failed"
     echo "done $dt $n"
   done
 done

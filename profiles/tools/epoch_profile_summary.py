@@ -34,11 +34,13 @@ def by_name(d):
 
 import os
 prev = {}
-if os.path.exists(f"gpurun_out/{tag}_epoch_profile.json"):
-    try:
-        prev = json.load(open(f"gpurun_out/{tag}_epoch_profile.json"))
-    except Exception:
-        prev = {}
+for cand in (f"gpurun_out/{tag}_epoch_profile.json", f"profiles/{tag}_epoch_profile.json"):      # (gpurun_out/ does not travel to the box)
+    if os.path.exists(cand):
+        try:
+            prev = json.load(open(cand))
+            break
+        except Exception:
+            prev = {}
 out = {}
 for dt in dts:
     f1, n1 = pmc_sum(f"gpurun_out/{tag}_ep_{dt}_fetch_1", "FETCH_SIZE")

@@ -29,9 +29,23 @@ inline size_t dc_partial_doubles(int B, int C, int64_t V) { return (size_t)B * d
 // rows [nv][ld] in memory <-> tile [nv][C | 1] in LDS (odd pitch: a lane per voxel walks its row conflict free)
 __device__ __forceinline__ void dc_tile_load(float *tile, const float *src, int nv, int C, int ld, int LDP) {
   if (ld == C) {
-    for (int e = threadIdx.x; e < nv * C; e += DC_THREADS) {
-      const int v = e / C;
-      tile[v * LDP + (e - v * C)] = src[e];
+    // eight loads in flight per thread before the first LDS store (a load - store loop pays the memory latency per element)
+    const int n = nv * C;
+    for (int e0 = threadIdx.x; e0 < n; e0 += DC_THREADS * 8) {
+      float tmp[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int e = e0 + DC_THREADS * u;
+        tmp[u] = e < n ? src[e] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int e = e0 + DC_THREADS * u;
+        if (e < n) {
+          const int v = e / C;
+          tile[v * LDP + (e - v * C)] = tmp[u];
+        }
+      }
     }
   } else {
     for (int e = threadIdx.x; e < nv * C; e += DC_THREADS) {
@@ -124,41 +138,54 @@ __global__ __launch_bounds__(DC_THREADS) void dice_ce_fwd_kernel(const float *__
 
 // one workgroup: loss[0] = total, loss[1] = ce, loss[2] = -mean dice; dice[B][C]; coef[(b * C + c) * 2 + {0, 1}] = {alpha, beta}
 // with dL/dp[v][c] = alpha * [y_v == c] + beta, coef[2 B C] = 1 / N
-__global__ __launch_bounds__(256) void dice_ce_finalize_kernel(const double *__restrict__ partial, int nblk, int B, int C,
+__global__ __launch_bounds__(1024) void dice_ce_finalize_kernel(const double *__restrict__ partial, int nblk, int B, int C,
                                                              float smooth, int first, float *__restrict__ loss,
                                                              float *__restrict__ dice, float *__restrict__ coef) {
   __shared__ double s_dc[8 * DC_MAXC];
   __shared__ double s_ce, s_nv;
   const int n = B * C, W = 3 * C + 2;
   const double w = 1.0 / (double)(B * (C - first));
-  for (int i = threadIdx.x; i < n; i += blockDim.x) {
-    const int b = i / C, c = i - b * C;
+  // four lanes per (b, c): lane p adds the partial slots p, p + 4, ... (three independent loads per slot), the quad combines in
+  // lane order - a fixed summation order, so the loss is reproducible run to run
+  const int p4 = threadIdx.x & 3;
+  for (int i = threadIdx.x >> 2; i < ((n + 255) / 256) * 256; i += blockDim.x >> 2) {
+    const bool on = i < n;
+    const int b = on ? i / C : 0, c = on ? i - b * C : 0;
     double I = 0.0, P = 0.0, Y = 0.0;
-    for (int q = 0; q < nblk; ++q) {
-      const double *r = partial + ((int64_t)b * nblk + q) * W;
-      I += r[c];
-      P += r[C + c];
-      Y += r[2 * C + c];
-    }
-    const double N = 2.0 * I + (double)smooth;
-    double D = P + Y + (double)smooth;
-    if (D < 1e-8) D = 1e-8;
-    const double dc = N / D;
-    s_dc[i] = dc;
-    dice[i] = (float)dc;
-    coef[2 * i] = c >= first ? (float)(-2.0 * w / D) : 0.f;
-    coef[2 * i + 1] = c >= first ? (float)(w * N / (D * D)) : 0.f;
-  }
-  if (threadIdx.x == 0) {
-    double ce = 0.0, nv = 0.0;
-    for (int b = 0; b < B; ++b)
-      for (int q = 0; q < nblk; ++q) {
+    if (on)
+      for (int q = p4; q < nblk; q += 4) {
         const double *r = partial + ((int64_t)b * nblk + q) * W;
-        ce += r[3 * C];
-        nv += r[3 * C + 1];
+        I += r[c];
+        P += r[C + c];
+        Y += r[2 * C + c];
       }
-    s_ce = ce;
-    s_nv = nv;
+#pragma unroll
+    for (int m = 1; m <= 2; m <<= 1) {
+      I += __shfl_xor(I, m, 64);
+      P += __shfl_xor(P, m, 64);
+      Y += __shfl_xor(Y, m, 64);
+    }
+    if (on && p4 == 0) {
+      const double N = 2.0 * I + (double)smooth;
+      double D = P + Y + (double)smooth;
+      if (D < 1e-8) D = 1e-8;
+      const double dc = N / D;
+      s_dc[i] = dc;
+      dice[i] = (float)dc;
+      coef[2 * i] = c >= first ? (float)(-2.0 * w / D) : 0.f;
+      coef[2 * i + 1] = c >= first ? (float)(w * N / (D * D)) : 0.f;
+    }
+  }
+  if (threadIdx.x < 64) {      // cross-entropy sum and valid-voxel count: one wave, slots dealt to its lanes, fixed tree
+    double ce = 0.0, nv = 0.0;
+    for (int q = threadIdx.x; q < B * nblk; q += 64) {
+      const double *r = partial + (int64_t)q * W;
+      ce += r[3 * C];
+      nv += r[3 * C + 1];
+    }
+    ce = wave_sum_d(ce);
+    nv = wave_sum_d(nv);
+    if (threadIdx.x == 0) s_ce = ce, s_nv = nv;
   }
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -247,7 +274,7 @@ extern "C" int dgtta_dice_ce_fwd(const float *logits, int ldc, const int64_t *la
              DGTTA_ERR_LAUNCH, "dice_ce_fwd: cannot raise the dynamic LDS limit");
   hipLaunchKernelGGL(dice_ce_fwd_kernel, dim3(nblk, B), dim3(DC_THREADS), lds, st, logits, ldc, labels, partial, C, V);
   DG_CHECK_LAUNCH("dice_ce_fwd_kernel");
-  hipLaunchKernelGGL(dice_ce_finalize_kernel, dim3(1), dim3(256), 0, st, partial, nblk, B, C, smooth, do_bg ? 0 : 1, loss3, dice,
+  hipLaunchKernelGGL(dice_ce_finalize_kernel, dim3(1), dim3(1024), 0, st, partial, nblk, B, C, smooth, do_bg ? 0 : 1, loss3, dice,
                      coef);
   DG_CHECK_LAUNCH("dice_ce_finalize_kernel");
   return DGTTA_OK;

@@ -872,6 +872,146 @@ __global__ void head_wgrad_kernel(const T *__restrict__ x, int ldx, const float 
   part[((int64_t)blockIdx.y * nsel + k) * Cin + ci] = acc;
 }
 
+// Wide head (32 input channels, 33..128 evaluated classes - the full 105-class head of a pre-training step or of a TTA run whose
+// model-output modifier is user code, so that map_label cannot be folded into the head): round 5.  The one-thread-per-output
+// kernels above walk a 420-byte row per lane (head_dgrad_kernel 9.1 ms, head_wgrad_kernel 11.9 ms per 2 x 128^3 step); here a
+// workgroup stages 64 rows of dout (one contiguous run) and of x through LDS.
+constexpr int HWD_ROWS = 64, HWD_MAXK = 128;
+// n contiguous floats -> LDS rows of `cols` values at pitch LDP: EIGHT loads in flight per thread before the first LDS store (a
+// load - store loop pays the memory latency once per element: the first version of these kernels spent 40 us per tile in it)
+__device__ __forceinline__ void hwd_stage_rows(float *tile, const float *src, int n, int cols, int LDP) {
+  for (int e0 = threadIdx.x; e0 < n; e0 += 256 * 8) {
+    float tmp[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int e = e0 + 256 * u;
+      tmp[u] = e < n ? src[e] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int e = e0 + 256 * u;
+      if (e < n) {
+        const int v = e / cols;
+        tile[v * LDP + (e - v * cols)] = tmp[u];
+      }
+    }
+  }
+}
+//   dx[r][ci] = sum_k dout[r][k] w[sel k][ci]: thread = (row, 8-channel group); dout row element broadcast to the row's 4 threads,
+//   weight rows broadcast to all rows
+template <typename T>
+__global__ __launch_bounds__(256) void head_dgrad_wide_kernel(const float *__restrict__ dout, int lddo, const float *__restrict__ w,
+                                                            const int *__restrict__ sel, int nsel, T *__restrict__ dx, int lddx,
+                                                            int64_t rows) {
+  extern __shared__ float hw_smem[];
+  float *sw = hw_smem;                    // [nsel][32]
+  float *sg = hw_smem + HWD_MAXK * 32;    // [64][nsel | 1]
+  const int LDP = nsel | 1;
+  for (int i = threadIdx.x; i < nsel * 32; i += 256) sw[i] = w[(int64_t)(sel ? sel[i >> 5] : i >> 5) * 32 + (i & 31)];
+  const int r = threadIdx.x >> 2, g = threadIdx.x & 3;
+  const int64_t ntile = (rows + HWD_ROWS - 1) / HWD_ROWS;
+  for (int64_t t = blockIdx.x; t < ntile; t += gridDim.x) {
+    const int64_t r0 = t * HWD_ROWS;
+    const int nv = rows - r0 < HWD_ROWS ? (int)(rows - r0) : HWD_ROWS;
+    __syncthreads();
+    if (lddo == nsel) {
+      hwd_stage_rows(sg, dout + r0 * lddo, nv * nsel, nsel, LDP);
+    } else {
+      for (int e = threadIdx.x; e < nv * nsel; e += 256) {
+        const int v = e / nsel, k = e - v * nsel;
+        sg[v * LDP + k] = dout[(r0 + v) * lddo + k];
+      }
+    }
+    __syncthreads();
+    if (r < nv) {
+      float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      const float *gr = sg + r * LDP;
+      for (int k = 0; k < nsel; ++k) {
+        const float gk = gr[k];
+        const float4 w0 = *reinterpret_cast<const float4 *>(sw + k * 32 + 8 * g), w1 = *reinterpret_cast<const float4 *>(sw + k * 32 + 8 * g + 4);
+        acc[0] = __builtin_fmaf(gk, w0.x, acc[0]);
+        acc[1] = __builtin_fmaf(gk, w0.y, acc[1]);
+        acc[2] = __builtin_fmaf(gk, w0.z, acc[2]);
+        acc[3] = __builtin_fmaf(gk, w0.w, acc[3]);
+        acc[4] = __builtin_fmaf(gk, w1.x, acc[4]);
+        acc[5] = __builtin_fmaf(gk, w1.y, acc[5]);
+        acc[6] = __builtin_fmaf(gk, w1.z, acc[6]);
+        acc[7] = __builtin_fmaf(gk, w1.w, acc[7]);
+      }
+      T *o = dx + (r0 + r) * lddx + 8 * g;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) st_f<T>(o + q, acc[q]);
+    }
+  }
+}
+
+//   part[split][k][ci] = sum over the split's rows of dout[r][k] x[r][ci]: thread = (ci, class residue t >> 5 of 8), accumulators for
+//   classes (t >> 5) + 8 j; grid.x = splits, each a contiguous range of 64-row tiles (deterministic: fixed order inside a split,
+//   reduce_splits_kernel adds the splits in order)
+template <typename T>
+__global__ __launch_bounds__(256) void head_wgrad_wide_kernel(const T *__restrict__ x, int ldx, const float *__restrict__ dout,
+                                                            int lddo, float *__restrict__ part, int nsel, int64_t rows) {
+  extern __shared__ float hw_smem[];
+  float *sx = hw_smem;                    // [64][33]
+  float *sg = hw_smem + HWD_ROWS * 33;    // [64][nsel | 1]
+  const int LDP = nsel | 1;
+  const int ci = threadIdx.x & 31, cg = threadIdx.x >> 5;
+  constexpr int NJ = HWD_MAXK / 8;
+  float acc[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) acc[j] = 0.f;
+  const int64_t ntile = (rows + HWD_ROWS - 1) / HWD_ROWS;
+  const int64_t per = (ntile + gridDim.x - 1) / gridDim.x;
+  const int64_t t0 = (int64_t)blockIdx.x * per, t1 = t0 + per < ntile ? t0 + per : ntile;
+  for (int64_t t = t0; t < t1; ++t) {
+    const int64_t r0 = t * HWD_ROWS;
+    const int nv = rows - r0 < HWD_ROWS ? (int)(rows - r0) : HWD_ROWS;
+    __syncthreads();
+    {     // x rows: 8 loads in flight per thread (64 x 32 values = 8 per thread)
+      float tx[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int e = threadIdx.x + 256 * u, v = e >> 5, c = e & 31;
+        tx[u] = v < nv ? ld_f<T>(x + (r0 + v) * ldx + c) : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int e = threadIdx.x + 256 * u;
+        sx[(e >> 5) * 33 + (e & 31)] = tx[u];
+      }
+    }
+    if (lddo == nsel) {
+      hwd_stage_rows(sg, dout + r0 * lddo, nv * nsel, nsel, LDP);
+      for (int e = nv * nsel + threadIdx.x; e < HWD_ROWS * nsel; e += 256) {      // ragged last tile: zero rows
+        const int v = e / nsel;
+        sg[v * LDP + (e - v * nsel)] = 0.f;
+      }
+    } else {
+      for (int e = threadIdx.x; e < HWD_ROWS * nsel; e += 256) {
+        const int v = e / nsel, k = e - v * nsel;
+        sg[v * LDP + k] = v < nv ? dout[(r0 + v) * lddo + k] : 0.f;
+      }
+    }
+    __syncthreads();
+    // branch free: all NJ products per row, also for classes >= nsel (they read the next row's values - the tile is padded by
+    // HWD_MAXK floats - into accumulators that are never stored).  A per-class guard turned every product into its own
+    // read - wait - fma - branch block: 9.5 ms instead of 1
+#pragma unroll 4
+    for (int v = 0; v < HWD_ROWS; ++v) {
+      const float xv = sx[v * 33 + ci];
+      const float *gr = sg + v * LDP + cg;
+      float gv[NJ];
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) gv[j] = gr[8 * j];
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) acc[j] = __builtin_fmaf(gv[j], xv, acc[j]);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < NJ; ++j)
+    if (cg + 8 * j < nsel) part[((int64_t)blockIdx.x * nsel + cg + 8 * j) * 32 + ci] = acc[j];
+}
+
 // ============================================================================ layout converters, argmax/dice
 template <typename T>
 __global__ void ncdhw_to_ndhwc_kernel(const float *__restrict__ src, T *__restrict__ dst, int C, int64_t V, int ldc,
@@ -1607,6 +1747,18 @@ extern "C" int dgtta_seghead_bwd(const void *x, int ldx, const float *dout, int 
                                              sel, nsel, (T *)dx, lddx, rows));
         DG_CHECK_LAUNCH("head_dgrad_fast_kernel");
       }
+    } else if (Cin == 32 && nsel <= HWD_MAXK) {      // the wide head: 64-row tiles through LDS
+      const size_t lds = ((size_t)HWD_MAXK * 32 + (size_t)HWD_ROWS * (nsel | 1)) * sizeof(float);
+      const int64_t nt = cdiv64(rows, HWD_ROWS);
+      DISPATCH_T(dtype, {
+        static DynLdsOnce once;
+        DG_REQUIRE(ensure_dyn_lds(once, reinterpret_cast<const void *>(head_dgrad_wide_kernel<T>),
+                                  (HWD_MAXK * 32 + HWD_ROWS * (HWD_MAXK | 1)) * (int)sizeof(float)) == hipSuccess,
+                   DGTTA_ERR_LAUNCH, "seghead_bwd: cannot raise the dynamic LDS limit");
+        hipLaunchKernelGGL((head_dgrad_wide_kernel<T>), dim3((unsigned)(nt < 4096 ? nt : 4096)), dim3(256), lds, st, dout, lddo, w, sel,
+                           nsel, (T *)dx, lddx, rows);
+      });
+      DG_CHECK_LAUNCH("head_dgrad_wide_kernel");
     } else {
       const int64_t total = rows * Cin;
       DISPATCH_T(dtype, hipLaunchKernelGGL((head_dgrad_kernel<T>), dim3(gs_blocks(total, 1 << 20)), dim3(256), 0, st, dout,
@@ -1620,9 +1772,22 @@ extern "C" int dgtta_seghead_bwd(const void *x, int ldx, const float *dout, int 
     if (rc == DGTTA_ERR_UNSUPPORTED) {
       const int ns = head_splits(rows);
       float *part = (float *)ws_main;
-      DISPATCH_T(dtype, hipLaunchKernelGGL((head_wgrad_kernel<T>), dim3(cdiv(Cin * nsel, 256), ns), dim3(256), 0, st,
-                                           (const T *)x, ldx, dout, lddo, part, Cin, nsel, rows));
-      DG_CHECK_LAUNCH("head_wgrad_kernel");
+      if (Cin == 32 && nsel > 32 && nsel <= HWD_MAXK) {
+        const size_t lds = ((size_t)HWD_ROWS * 33 + (size_t)HWD_ROWS * (nsel | 1) + HWD_MAXK) * sizeof(float);
+        DISPATCH_T(dtype, {
+          static DynLdsOnce once;
+          DG_REQUIRE(ensure_dyn_lds(once, reinterpret_cast<const void *>(head_wgrad_wide_kernel<T>),
+                                    (HWD_ROWS * 33 + HWD_ROWS * (HWD_MAXK | 1) + HWD_MAXK) * (int)sizeof(float)) == hipSuccess,
+                     DGTTA_ERR_LAUNCH, "seghead_bwd: cannot raise the dynamic LDS limit");
+          hipLaunchKernelGGL((head_wgrad_wide_kernel<T>), dim3(ns), dim3(256), lds, st, (const T *)x, ldx, dout, lddo, part, nsel,
+                             rows);
+        });
+        DG_CHECK_LAUNCH("head_wgrad_wide_kernel");
+      } else {
+        DISPATCH_T(dtype, hipLaunchKernelGGL((head_wgrad_kernel<T>), dim3(cdiv(Cin * nsel, 256), ns), dim3(256), 0, st,
+                                             (const T *)x, ldx, dout, lddo, part, Cin, nsel, rows));
+        DG_CHECK_LAUNCH("head_wgrad_kernel");
+      }
       const int64_t n = (int64_t)nsel * Cin;
       hipLaunchKernelGGL(reduce_splits_kernel, dim3(gs_blocks(n)), dim3(256), 0, st, part, dw_sel, n, ns, accumulate);
       DG_CHECK_LAUNCH("reduce_splits_kernel");

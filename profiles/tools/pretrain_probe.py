@@ -45,6 +45,8 @@ def evaluate(tag):
         res[dom] = float(d.nanmean()) if SEL else float(d[[3 * i - 1 for i in range(1, K + 1)]].nanmean())
     print(f"{tag}: hard Dice source {res['source']:.4f}, target {res['target']:.4f}", flush=True)
 
+# PROBE_PHASE2=<n>: after `steps` steps on the selected classes, n more steps over ALL 105 classes (labels at the pretrain ids)
+phase2 = int(os.environ.get("PROBE_PHASE2", "0"))
 done = 0
 for chunk in range(0, steps, 50):
     n = min(50, steps - chunk)
@@ -54,3 +56,34 @@ for chunk in range(0, steps, 50):
     done += n
     print(f"steps {done}: loss {float(losses[:5].mean()):.3f} -> {float(losses[-5:].mean()):.3f}, {dt_s / n * 1e3:.1f} ms / step", flush=True)
     evaluate(f"after {done}")
+
+if phase2:
+    sel_ids = torch.tensor([mapping[n][0] for n in names])
+    net.set_selected_classes(None)
+    SEL = False
+    lut = sel_ids
+    opt = HipAdamW(list(net.parameters()), lr=lr, weight_decay=0.0, grad_scale=net.loss_scale)
+
+    def evaluate2(tag):
+        res = {}
+        for dom, seed in (("source", 77), ("target", 31)):
+            c = atlas_case(S, K, seed, dom)
+            with torch.no_grad():
+                net.eval()
+                net.set_selected_classes(sel_ids)
+                imgs, labels = get_batch([c], [0], P, "center", DEV)
+                out = net.forward(MIND3D()(imgs[0], out_dtype=dt))
+                d = dice_coeff(out.argmax(1, keepdim=True), labels[0], K + 1)
+                alive = float((out.float().sum(1) > 0).float().mean())
+                net.set_selected_classes(None)
+                net.train()
+            res[dom] = (float(d.nanmean()), alive)
+        print(f"{tag}: hard Dice source {res['source'][0]:.4f}, target {res['target'][0]:.4f}; mapped logit sum > 0 on {res['target'][1]:.4f} of the target voxels", flush=True)
+    evaluate2("phase 2 start")
+    for chunk in range(0, phase2, 20):
+        n = min(20, phase2 - chunk)
+        torch.cuda.synchronize(); t0 = time.time()
+        losses = pretrain_supervised(net, cases, PT, lut, steps=n, batch=batch, lr=lr, device=DEV, optimizer=opt)
+        torch.cuda.synchronize()
+        print(f"phase 2 steps {chunk + n}: loss {float(losses[:3].mean()):.3f} -> {float(losses[-3:].mean()):.3f}, {(time.time() - t0) / n * 1e3:.1f} ms / step", flush=True)
+        evaluate2(f"phase 2 after {chunk + n}")

@@ -457,16 +457,18 @@ def test_convT_mfma(case, dt):
         assert (dw2.cpu() - wr.grad.float()).abs().max() < 3e-5 * wr.grad.abs().max()
 
 
-@pytest.mark.parametrize("nsel,V", [(16, 8 * 8 * 32), (5, 7 * 9 * 11), (105, 4 * 8 * 16)])
-@pytest.mark.parametrize("dt", [0, 1])
+@pytest.mark.parametrize("nsel,V", [(16, 8 * 8 * 32), (5, 7 * 9 * 11), (105, 4 * 8 * 16), (105, 64 * 37 + 5), (40, 1000), (128, 130)])
+@pytest.mark.parametrize("dt", [0, 1, 2])
 def test_head_fast_paths(nsel, V, dt):
-    """1x1x1 head (Cin=32) forward / dgrad / wgrad fast paths vs a dense torch reference."""
+    """1x1x1 head (Cin=32) forward / dgrad / wgrad fast paths vs a dense torch reference; round 5: more than 32 evaluated
+    classes (the full 105-class head: pre-training, or TTA behind a user-defined output modifier) run the LDS-tiled wide kernels,
+    ragged last tiles and several splits included."""
     from dg_tta_amd import _lib
     from dg_tta_amd._lib import check, ptr, stream_of
     lib = _lib.load()
     torch.manual_seed(nsel + V)
-    tdt = torch.bfloat16 if dt else torch.float32
-    B, cin, ncls = 1, 32, 105
+    tdt = {0: torch.float32, 1: torch.bfloat16, 2: torch.float16}[dt]
+    B, cin, ncls = 1, 32, max(105, nsel)
     x = torch.randn(B, V, cin, device=DEV).to(tdt)
     w = torch.randn(ncls, cin, device=DEV)
     bias = torch.randn(ncls, device=DEV)

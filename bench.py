@@ -99,7 +99,7 @@ def parse_args(argv=None):
                          "task (dg_tta_amd/pretraining/supervised.py: GIN + MIND hooks, Dice + CE, --pretrain-steps AdamW steps "
                          "through the engine) and adapted to a case of the shifted target domain; he: the seeded He-initialised "
                          "weights of rounds 1-4 on the label-independent synthetic_case (pseudo-Dice ~0.005: timing only)")
-    ap.add_argument("--pretrain-steps", type=int, default=350)
+    ap.add_argument("--pretrain-steps", type=int, default=550)
     ap.add_argument("--lr", type=float, default=3e-4,
                     help="AdamW learning rate of the adaptation (the plan's default 1e-5 moves nothing in a handful of epochs; the "
                          "reference-run fixtures of tests/golden/make_golden_r5.py use the same 3e-4)")

@@ -11,15 +11,15 @@ import numpy as np
 import torch
 
 from .. import ops
-from .nifti_io import read_nifti
+from .image_io import is_image_file, read_image
 
 
 def load_label_map(path):
     p = str(path)
     if p.endswith(".npy"):
         return np.load(p)
-    if p.endswith(".nii") or p.endswith(".nii.gz"):
-        return read_nifti(p)[0]
+    if is_image_file(p):
+        return read_image(p)[0]
     raise ValueError(f"unsupported label map format: {p}")
 
 
@@ -47,7 +47,7 @@ def case_metrics(pred, ref, labels, device="cuda"):
 
 
 def compute_metrics_on_folder_simple(folder_ref, folder_pred, labels, output_file=None, device="cuda",
-                                     suffixes=(".nii.gz", ".nii", ".npy")):
+                                     suffixes=(".nii.gz", ".nii", ".nrrd", ".mha", ".mhd", ".npy")):
     """Evaluates every prediction in folder_pred that has a reference of the same name in folder_ref; returns the summary
     dict (and writes it as JSON to output_file) in nnU-Net's layout: metric_per_case / mean / foreground_mean."""
     folder_ref, folder_pred = Path(folder_ref), Path(folder_pred)

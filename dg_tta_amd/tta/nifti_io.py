@@ -1,4 +1,4 @@
-"""Minimal NIfTI-1 reader / writer (single-file .nii / .nii.gz, little endian) for label maps and images.
+"""Minimal NIfTI-1 reader / writer (single-file .nii / .nii.gz; reads either byte order, writes little endian) for label maps and images.
 
 The reference reads target cases and writes predictions through nnU-Net's SimpleITKIO [3P nnunetv2==2.2.1]
 (dg_tta/tta/tta.py:411-446); neither SimpleITK nor nibabel is a dependency here, so this module restates the published
@@ -24,34 +24,37 @@ def read_nifti(path):
     """Returns (array [z,y,x] (or [t,z,y,x]), header dict with 'pixdim' (x,y,z spacing), 'affine' 4x4, 'raw' bytes)."""
     with _open(path, "rb") as f:
         raw = f.read()
-    if len(raw) < 352 or struct.unpack("<i", raw[:4])[0] != 348:
-        raise ValueError(f"{path}: not a little-endian NIfTI-1 file")
+    if len(raw) < 352 or 348 not in (struct.unpack("<i", raw[:4])[0], struct.unpack(">i", raw[:4])[0]):
+        raise ValueError(f"{path}: not a NIfTI-1 file")
+    bo = "<" if struct.unpack("<i", raw[:4])[0] == 348 else ">"          # byte order of the file (round 5: big endian is read too)
     if raw[344:348] not in (b"n+1\0",):
         raise ValueError(f"{path}: only single-file NIfTI-1 (magic n+1) is supported")
-    dim = struct.unpack("<8h", raw[40:56])
-    datatype, bitpix = struct.unpack("<hh", raw[70:74])
-    pixdim = struct.unpack("<8f", raw[76:108])
-    vox_offset = int(struct.unpack("<f", raw[108:112])[0])
-    slope, inter = struct.unpack("<ff", raw[112:120])
+    dim = struct.unpack(bo + "8h", raw[40:56])
+    datatype, bitpix = struct.unpack(bo + "hh", raw[70:74])
+    pixdim = struct.unpack(bo + "8f", raw[76:108])
+    vox_offset = int(struct.unpack(bo + "f", raw[108:112])[0])
+    slope, inter = struct.unpack(bo + "ff", raw[112:120])
     if datatype not in _DTYPES:
         raise ValueError(f"{path}: unsupported NIfTI datatype {datatype}")
     nd = dim[0]
     shape = [int(d) for d in dim[1:1 + nd]]
-    dt = np.dtype(_DTYPES[datatype]).newbyteorder("<")
+    dt = np.dtype(_DTYPES[datatype]).newbyteorder(bo)
     n = int(np.prod(shape))
     data = np.frombuffer(raw, dtype=dt, count=n, offset=vox_offset).reshape(shape[::-1])     # x fastest -> [.., z, y, x]
     if slope not in (0.0, 1.0) or inter != 0.0:
         data = data.astype(np.float32) * (slope if slope != 0.0 else 1.0) + inter
-    qform_code, sform_code = struct.unpack("<hh", raw[252:256])
+    qform_code, sform_code = struct.unpack(bo + "hh", raw[252:256])
     affine = np.eye(4, dtype=np.float64)
     if sform_code > 0:
-        affine[:3] = np.array(struct.unpack("<12f", raw[280:328]), dtype=np.float64).reshape(3, 4)
+        affine[:3] = np.array(struct.unpack(bo + "12f", raw[280:328]), dtype=np.float64).reshape(3, 4)
     else:
         affine[0, 0], affine[1, 1], affine[2, 2] = pixdim[1], pixdim[2], pixdim[3]
         if qform_code > 0:
-            affine[:3, 3] = struct.unpack("<3f", raw[268:280])
-    hdr = {"pixdim": tuple(float(p) for p in pixdim[1:4]), "affine": affine, "raw": bytes(raw[:348]), "shape_xyz": shape[:3]}
-    return np.ascontiguousarray(data), hdr
+            affine[:3, 3] = struct.unpack(bo + "3f", raw[268:280])
+    hdr = {"pixdim": tuple(float(p) for p in pixdim[1:4]), "affine": affine, "shape_xyz": shape[:3]}
+    if bo == "<":
+        hdr["raw"] = bytes(raw[:348])         # reused verbatim by write_nifti (a big-endian header is rebuilt from pixdim instead)
+    return np.ascontiguousarray(data.astype(data.dtype.newbyteorder("="))), hdr
 
 
 def write_nifti(path, array, header=None, spacing=(1.0, 1.0, 1.0)):
@@ -61,6 +64,8 @@ def write_nifti(path, array, header=None, spacing=(1.0, 1.0, 1.0)):
         arr = arr.astype(np.int16 if np.issubdtype(arr.dtype, np.integer) else np.float32)
     if arr.ndim != 3:
         raise ValueError("write_nifti expects a 3-D [z,y,x] array")
+    if header is not None and "raw" not in header:
+        spacing, header = tuple(header.get("pixdim", spacing)), None
     hdr = bytearray(header["raw"]) if header is not None else bytearray(348)
     struct.pack_into("<i", hdr, 0, 348)
     z, y, x = arr.shape

@@ -98,8 +98,9 @@ def _read_array(path):
 
 
 def _is_nifti(path):
-    n = Path(path).name
-    return n.endswith(".nii") or n.endswith(".nii.gz")
+    """A raw volume file this engine reads itself: NIfTI, and (round 5) NRRD / MetaImage (tta/image_io.py)."""
+    from .image_io import is_image_file
+    return is_image_file(path)
 
 
 def preprocess_fromfile(image_file, label_file, ofile, predictor=None):

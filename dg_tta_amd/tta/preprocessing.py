@@ -13,7 +13,7 @@ import numpy as np
 import torch
 
 from .. import ops
-from .nifti_io import read_nifti
+from .image_io import read_image as read_nifti      # NIfTI / NRRD / MetaImage, same (array [z,y,x], header) contract
 
 
 def _resize(vol, new_shape, order, device, clip=True, axes=None):
@@ -161,7 +161,7 @@ def run_case_npy(data, seg, spacing, plans, configuration, device="cuda"):
 
 
 def run_case(image_files, seg_file, plans, configuration, device="cuda"):
-    """DefaultPreprocessor.run_case on NIfTI files: one file per input channel, optional label file."""
+    """DefaultPreprocessor.run_case on NIfTI / NRRD / MetaImage files: one file per input channel, optional label file."""
     imgs, hdr = [], None
     for f in image_files:
         arr, hdr = read_nifti(f)

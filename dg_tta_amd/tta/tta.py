@@ -555,7 +555,7 @@ def _predict_case(case, config, network, predictor, patch_size, label_mapping, m
     and lines up with `labels{Ts,Tr}/<case>`, which is what it is evaluated against (tta.py:420-447).  Array cases
     (.npy/.npz/.pt: already preprocessed, no geometry) are written as they are."""
     from .inference import export_segmentation, predict_ensemble_logits
-    from .nifti_io import read_nifti
+    from .image_io import read_image as read_nifti
     from .torch_utils import get_imgs
     sample, sample_id, sub_dir_tta = case
     ensemble_count = config["ensemble_count"]
@@ -579,7 +579,8 @@ def _predict_case(case, config, network, predictor, patch_size, label_mapping, m
     del acc, nsum
     seg = map_label(torch.as_tensor(seg.astype(np.int64))[None],
                     get_map_idxs(label_mapping, optimized_labels, "pretrain_labels"), input_format="argmaxed")[0]
-    out = Path(str(save_path / sample_id) + (".nii.gz" if nii is not None else ".npy"))
+    # (the prediction is written in the format of the case's image, as SimpleITK's writer picks it from the file name)
+    out = Path(str(save_path / sample_id) + ((nii.get("ext") or ".nii.gz") if nii is not None else ".npy"))
     out.parent.mkdir(exist_ok=True, parents=True)
     _save_label_map(out, seg.numpy().astype(np.int16), nii)
     results[(sample_id, "prediction")] = out
@@ -624,5 +625,5 @@ def _save_label_map(path, arr, nifti_header=None):
     if str(path).endswith(".npy"):
         np.save(path, arr)
     else:
-        from .nifti_io import write_nifti
-        write_nifti(path, arr, header=nifti_header)
+        from .image_io import write_image
+        write_image(path, arr, header=nifti_header)

@@ -22,6 +22,8 @@ for job in "${JOBS[@]}"; do
   i=0
   for grp in "${groups[@]}"; do
     i=$((i+1))
+    # PMC_GROUPS="1 7 8": only these counter groups (1 = MFMA busy, 7 = FETCH_SIZE, 8 = WRITE_SIZE)
+    if [ -n "$PMC_GROUPS" ] && [[ " $PMC_GROUPS " != *" $i "* ]]; then continue; fi
     KB_STATS=1 rocprofv3 --pmc $grp --kernel-trace -d $R/gpurun_out/${tag}_pmc_${name}_$i -o pmc --output-format csv -- python3 $R/profiles/tools/kbench.py $job > $R/gpurun_out/${tag}_pmc_${name}_$i.log 2>&1 || echo "$name group $i ($grp) failed"
   done
   echo "done $name"

@@ -106,9 +106,10 @@ def test_one_pass_batch8_128_every_storage_type_vs_fp32_valu():
     # Round 5: the runner's weights are PRE-TRAINED (bench.pretrained_weights) - decisive logits, gradients far above rounding
     # noise.  Measured on them (profiles/r05_at_size_parity.json "one_pass"): fp32 MFMA 7.7e-7 / 6e-8 / 0.9999995 / 0.999998, fp16
     # 2.1e-4 / 3e-7 / 0.9989 / 0.991, bf16 1.8e-3 / 8e-5 / 0.9996 / 0.969, labels 0.9999999 / 0.99995 / 0.9996
+    # (550 pre-training steps: fp32 9.7e-7 / 6e-8 / 0.9999997 / 0.999994, fp16 2.8e-4 / 3.5e-6 / 0.9988 / 0.9969, labels 0.99998)
     limits = {"fp32": dict(logit=3e-6, loss=3e-7, cos=0.99999, sign=0.9999, agree=0.999999),
-              "fp16": dict(logit=6e-4, loss=1.5e-6, cos=0.996, sign=0.97, agree=0.9998),
-              "bf16": dict(logit=5e-3, loss=2.5e-4, cos=0.998, sign=0.92, agree=0.999)}
+              "fp16": dict(logit=1e-3, loss=1e-5, cos=0.996, sign=0.97, agree=0.9998),
+              "bf16": dict(logit=6e-3, loss=3e-4, cos=0.997, sign=0.92, agree=0.999)}
     for dtype in ("fp32", "fp16", "bf16"):
         r = _runner(dtype, impl=0)
         logits, loss, dice, grads = _one_pass(r, 77)
@@ -206,7 +207,7 @@ def test_adaptation_epochs_128_dice_delta_of_the_default_storage_type():
     assert float(ref[3].nanmean()) > 0.5
     for dtype, lab in (("fp16", 0.999), ("bf16", 0.997)):
         d = report[dtype]
-        assert max(d["loss_delta_per_epoch"]) < (1e-4 if dtype == "fp16" else 5e-4) < TOL
+        assert max(d["loss_delta_per_epoch"]) < (3e-4 if dtype == "fp16" else 5e-4) < TOL      # (550 steps: 1.0e-4 / 3.9e-5)
         assert max(d["pseudo_dice_delta_per_epoch"]) < TOL
         assert d["hard_dice_mean_delta"] < TOL
         assert d["skipped_steps"] == 0

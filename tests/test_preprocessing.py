@@ -76,19 +76,21 @@ def test_run_case_matches_oracle(spacing):
 
 
 @pytest.mark.gpu
-def test_nifti_case_through_load_tta_data(tmp_path):
-    """imagesTs/<case>_0000.nii.gz + labelsTs/<case>.nii.gz -> {"data": [1+K, ...]} as preprocess_fromfile yields it."""
+@pytest.mark.parametrize("ext", [".nii.gz", ".nrrd", ".mha"])
+def test_nifti_case_through_load_tta_data(tmp_path, ext):
+    """imagesTs/<case>_0000<ext> + labelsTs/<case><ext> -> {"data": [1+K, ...]} as preprocess_fromfile yields it; round 5: NRRD
+    and MetaImage cases (tta/image_io.py) go through the same preprocessing as NIfTI ones."""
     from types import SimpleNamespace
-    from dg_tta_amd.tta.nifti_io import write_nifti
+    from dg_tta_amd.tta.image_io import write_image as write_nifti
     from dg_tta_amd.tta.nnunet_utils import load_tta_data
     from oracle import preprocessing as op
     img, seg = _case(2)
     (tmp_path / "imagesTs").mkdir()
     (tmp_path / "labelsTs").mkdir()
-    write_nifti(tmp_path / "imagesTs" / "case7_0000.nii.gz", img[0], spacing=(0.9, 0.9, 2.5))     # (x, y, z) spacing
-    write_nifti(tmp_path / "labelsTs" / "case7.nii.gz", seg[0].astype(np.int16), spacing=(0.9, 0.9, 2.5))
+    write_nifti(tmp_path / "imagesTs" / f"case7_0000{ext}", img[0], spacing=(0.9, 0.9, 2.5))     # (x, y, z) spacing
+    write_nifti(tmp_path / "labelsTs" / f"case7{ext}", seg[0].astype(np.int16), spacing=(0.9, 0.9, 2.5))
     predictor = SimpleNamespace(plans=PLANS, configuration="3d_fullres", device="cuda:0")
-    cfg = {"tta_data_filepaths": [str(tmp_path / "imagesTs" / "case7_0000.nii.gz")]}
+    cfg = {"tta_data_filepaths": [str(tmp_path / "imagesTs" / f"case7_0000{ext}")]}
     it, n = load_tta_data(cfg, tmp_path, predictor)
     items = list(it)
     assert n == 1 and items[0]["ofile"] == "tta_outputTs/case7"

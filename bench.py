@@ -574,8 +574,10 @@ def referee_tta_run(args, device):
                "label_agreement_where_margin_gt_1e-3": round(float(same[safe].float().mean()), 6),
                "logit_err_over_range": float((logits.cpu() - ofinal).abs().max() / ofinal.abs().max()),
                "skipped_optimizer_steps": int(opt.skipped_steps)}
-        ent["within_tolerance"] = bool(ent["loss"] <= DICE_TOLERANCE and ent["pseudo_dice"] <= DICE_TOLERANCE and
-                                       ent["hard_dice"] <= DICE_TOLERANCE)
+        # north_star's clause ("Dice within 1e-3 of the reference") and the stated tolerance of the soft-Dice loss, separately
+        ent["dice_within_tolerance"] = bool(ent["pseudo_dice"] <= DICE_TOLERANCE and ent["hard_dice"] <= DICE_TOLERANCE)
+        ent["loss_within_tolerance"] = bool(ent["loss"] <= DICE_TOLERANCE)
+        ent["within_tolerance"] = bool(ent["dice_within_tolerance"] and ent["loss_within_tolerance"])
         out[dtype] = ent
         del model, net, opt, logits
         release_resident()
@@ -920,7 +922,8 @@ def run_rank(args):
             if main is not None:            # the headline dtype's numbers at the top level of the object
                 dice_delta.update(loss=main["loss"], pseudo_dice=main["pseudo_dice"], hard_dice=main["hard_dice"],
                                   label_agreement=main["label_agreement"], dtype=main_dtype,
-                                  within_tolerance=main["within_tolerance"])
+                                  dice_within_tolerance=main["dice_within_tolerance"],
+                                  loss_within_tolerance=main["loss_within_tolerance"], within_tolerance=main["within_tolerance"])
         if dice_delta is None and not stub and traj_file.exists():
             # N > 1 (or --no-fp32): rank 0's trajectory against the stored fp32 run of the same seed and sample
             tj = json.loads(traj_file.read_text())

@@ -103,8 +103,9 @@ class DGTTAProgram:
                             help="activation storage: fp32 (default) = the reference's precision, reproduces its label maps; "
                                  "fp16 / bf16 = opt-in 16-bit storage with fp32 accumulation at ~5.5x the fp32 rate.  Measured on a "
                                  "pre-trained synthetic model against the CPU restatement of the reference's loop "
-                                 "(profiles/r05_dice_delta_12_epochs.json, 12 epochs x 16 steps): fp16 (guarded loss scale) stays "
-                                 "within 1e-3 of the reference's Dice, bf16 drifts to 2e-3 - prefer fp16 when the Dice matters; "
+                                 "(profiles/r05_dice_delta_12_epochs*.json, 12 epochs x 16 steps): fp16 (guarded loss scale) stayed "
+                                 "within 1e-3 of the reference's Dice in every run, bf16 on a well-trained model but 2e-3 off on a "
+                                 "weaker one - prefer fp16 when the Dice matters; "
                                  "not measured on real TS104 weights (no network here): check on your data")
         parser.add_argument("--run_name", default=None,
                             help="name of the run directory (default: timestamp + random name).  Required, and the same on "

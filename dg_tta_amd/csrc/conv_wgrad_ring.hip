@@ -111,8 +111,13 @@ __device__ __forceinline__ f32x4_t wr_mfma16<f16_t>(const bf16x8_t &a, const bf1
 
 // grid: (G workgroups, channel-block pairs); jobs (b, d-segment, tw, th) dealt so that the 32 workgroups of an XCD hold
 // columns that are neighbours along H (their halo rows meet in one L2); slabs[(pair * G + blockIdx.x)][27][32 ci][32 co]
-template <typename T16, bool MF16, bool CLK = false>      // MF16: v_mfma_f32_16x16x32 (K = the row's 32 voxels) instead of 32x32x16;
-                                                          // CLK (diagnostic): cycle / real-time stamps behind the slabs
+// PAIR (round 5, Cin <= 16: the network's first layer, 12 MIND channels in rows of 16): the 32 M rows of an MFMA carry TWO taps x 16
+// input channels instead of one tap x 32 of which 16-20 are padding - lanes 16..31 of each half wave read channels 0..15 at the
+// SECOND tap's shift instead of channels 16..31 at the first's.  14 tap pairs over the 4 wave groups = 4 accumulators per wave
+// instead of 7: 4/7 of the MFMAs and operand reads for the same result (the slab keeps one [32 ci][32 co] block per tap; rows
+// ci >= 16 of a block are not written and the reduction never reads rows ci >= Cin).
+template <typename T16, bool MF16, bool CLK = false, bool PAIR = false>      // MF16: v_mfma_f32_16x16x32 (K = the row's 32 voxels) instead of 32x32x16;
+                                                                           // CLK (diagnostic): cycle / real-time stamps behind the slabs
 __global__ __launch_bounds__(WR::NW * 64) void conv3_wgrad_ring_kernel(const bf16_t *__restrict__ x, View xv, const bf16_t *__restrict__ dy,
                                                                        View yv, float *__restrict__ slabs, int Cin, int Cout, int tilesW,
                                                                        int tilesH, int nseg, int DR, int cobs, int njobs, unsigned x_bytes,
@@ -131,10 +136,15 @@ __global__ __launch_bounds__(WR::NW * 64) void conv3_wgrad_ring_kernel(const bf1
   const int cib = blockIdx.y / cobs, cob = blockIdx.y % cobs;
   const int cin_lim = (Cin + 7) / 8 * 8;
 
+  static_assert(!(PAIR && MF16), "the pair form exists for the 32x32x16 MFMA only");
+  constexpr int NA = PAIR ? 4 : 7;                         // accumulators (taps, or tap pairs) per wave
+  const int hsel = (lane >> 4) & 1;                        // PAIR: which tap of the pair this lane's M rows belong to
   int tap_kd[7], tap_off[7], tap_row[7], tap_kw[7];
 #pragma unroll
   for (int i = 0; i < 7; ++i) {
-    const int tc = wq + 4 * i < 27 ? wq + 4 * i : 26;      // (the fourth residue class has 6 taps: its seventh slot repeats tap 26 into a discarded accumulator)
+    // (the fourth residue class has 6 taps: its seventh slot repeats tap 26 into a discarded accumulator; PAIR: pair wq + 4 i =
+    // taps 2 (wq + 4 i) and + 1, per lane; pairs 14, 15 and the second tap of pair 13 repeat tap 26 into rows that are not stored)
+    const int tc = PAIR ? ((2 * (wq + 4 * i) + hsel) < 27 ? 2 * (wq + 4 * i) + hsel : 26) : (wq + 4 * i < 27 ? wq + 4 * i : 26);
     tap_kd[i] = tc / 9;
     tap_off[i] = ((tc / 3) % 3) * WR::X_ROW_B + (tc % 3) * 64;
     tap_row[i] = ((tc / 3) % 3) * WR::X_ROW_B;
@@ -143,7 +153,9 @@ __global__ __launch_bounds__(WR::NW * 64) void conv3_wgrad_ring_kernel(const bf1
   // transposed-read lane address inside a 16-voxel x 32-channel block (64-byte voxel rows), as conv3_wgrad_tr_kernel
   // (MF16: 16-lane group g = lane >> 4 takes voxels 8 g .. 8 g + 7 of 16 channels; the channel half is an immediate offset)
   const int lane_off = MF16 ? ((lane >> 4) * 8 + ((lane & 15) >> 2)) * 64 + (lane & 3) * 8
-                            : ((lane >> 5) * 8 + ((lane & 15) >> 2)) * 64 + ((lane >> 4) & 1) * 32 + (lane & 3) * 8;
+                            : ((lane >> 5) * 8 + ((lane & 15) >> 2)) * 64 + (PAIR ? 0 : ((lane >> 4) & 1) * 32) + (lane & 3) * 8;
+  // (the dy operand keeps its own half select: N = 32 output channels in both forms)
+  const int lane_off_y = MF16 ? lane_off : ((lane >> 5) * 8 + ((lane & 15) >> 2)) * 64 + ((lane >> 4) & 1) * 32 + (lane & 3) * 8;
 
   // MF16 operand addresses.  A 16-lane group reads 4 voxels x 32 bytes (16 channels), and the two groups of a 32-lane half sit 8
   // voxels = 512 bytes apart: on the plain image both hit the same banks (PMC, profiles/r04_mfma_util.json: SQ_LDS_BANK_CONFLICT =
@@ -255,7 +267,7 @@ __global__ __launch_bounds__(WR::NW * 64) void conv3_wgrad_ring_kernel(const bf1
       const bool more = d + 2 < d_end;         // x(d + 3), dy(d + 2): first read in slice d + 2
       int mark_new = issued;
       const unsigned char *ys0 = sY + ((d + WR::NYS) % WR::NYS) * WR::Y_SLICE_B + rh * 4 * WR::Y_ROW_B;
-      const unsigned char *ys = ys0 + lane_off;
+      const unsigned char *ys = ys0 + lane_off_y;
       const int xr0 = (d + WR::NXS) % WR::NXS;      // ring slot of x(d - 1)
       int slice_off[3];
 #pragma unroll
@@ -266,19 +278,19 @@ __global__ __launch_bounds__(WR::NW * 64) void conv3_wgrad_ring_kernel(const bf1
         // without a branch): every operand read of the slice is then that register plus an immediate.  Before, each read carried
         // a scalar compare / branch chain for the slot and its own address arithmetic - with two transposed reads per MFMA the
         // sweep was bound by instruction issue, not by the matrix pipe (profiles/r04_ab.txt).
-        int xa[7];
+        int xa[NA];
 #pragma unroll
-        for (int i = 0; i < 7; ++i) {
+        for (int i = 0; i < NA; ++i) {
           int sl = xr0 + tap_kd[i];
           sl = sl >= WR::NXS ? sl - WR::NXS : sl;
           xa[i] = lane_off + sl * WR::X_SLICE_B + rh * 4 * WR::X_ROW_B + tap_off[i];
         }
-        bf16x8_t afr[2][7], bfr[2];
-        auto load_it = [&](int it, bf16x8_t(&a)[7], bf16x8_t &bb) {
+        bf16x8_t afr[2][NA], bfr[2];
+        auto load_it = [&](int it, bf16x8_t(&a)[NA], bf16x8_t &bb) {
           const int oh = it >> 1, ks = it & 1;
           bb = wr_operand(ys + oh * WR::Y_ROW_B + ks * 1024);
 #pragma unroll
-          for (int i = 0; i < 7; ++i) a[i] = wr_operand(sX + xa[i] + oh * WR::X_ROW_B + ks * 1024);
+          for (int i = 0; i < NA; ++i) a[i] = wr_operand(sX + xa[i] + oh * WR::X_ROW_B + ks * 1024);
         };
         load_it(0, afr[0], bfr[0]);
 #pragma unroll
@@ -290,7 +302,7 @@ __global__ __launch_bounds__(WR::NW * 64) void conv3_wgrad_ring_kernel(const bf1
             if (it == WR::NPW - 1) mark_new = issued;
           }
 #pragma unroll
-          for (int i = 0; i < 7; ++i) {
+          for (int i = 0; i < NA; ++i) {
             f32x16_t c;
 #pragma unroll
             for (int q = 0; q < 16; ++q) c[q] = accf[i][q];
@@ -370,7 +382,7 @@ __global__ __launch_bounds__(WR::NW * 64) void conv3_wgrad_ring_kernel(const bf1
   float *xch = reinterpret_cast<float *>(smem);
   if (rh == 1) {
 #pragma unroll
-    for (int i = 0; i < 7; ++i)
+    for (int i = 0; i < NA; ++i)
 #pragma unroll
       for (int q = 0; q < 16; ++q) xch[((wq * 7 + i) * 16 + q) * 64 + lane] = accf[i][q];
   }
@@ -380,14 +392,25 @@ __global__ __launch_bounds__(WR::NW * 64) void conv3_wgrad_ring_kernel(const bf1
     // (ci); of the 16x16 one [ci half ca][co half cb]: col = lane & 15, row = 4 (lane >> 4) + r
     float *slab = slabs + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * (27 * 1024);
 #pragma unroll
-    for (int i = 0; i < 7; ++i) {
-      const int tap = wq + 4 * i;
-      if (tap < 27) {
+    for (int i = 0; i < NA; ++i) {
+      if constexpr (PAIR) {
+        // rows 0..15 of the accumulator: ci of tap 2 p, rows 16..31: ci of tap 2 p + 1 (row = (q & 3) + 8 (q >> 2) + 4 (lane >> 5):
+        // q < 8 is the first tap, q >= 8 the second)
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
-          const int ci = MF16 ? (q >> 3) * 16 + 4 * (lane >> 4) + (q & 3) : (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
-          const int co = MF16 ? ((q >> 2) & 1) * 16 + (lane & 15) : (lane & 31);
-          slab[(tap * 32 + ci) * 32 + co] = accf[i][q] + xch[((wq * 7 + i) * 16 + q) * 64 + lane];
+          const int row = (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
+          const int tap = 2 * (wq + 4 * i) + (row >> 4), co = lane & 31;
+          if (tap < 27) slab[(tap * 32 + (row & 15)) * 32 + co] = accf[i][q] + xch[((wq * 7 + i) * 16 + q) * 64 + lane];
+        }
+      } else {
+        const int tap = wq + 4 * i;
+        if (tap < 27) {
+#pragma unroll
+          for (int q = 0; q < 16; ++q) {
+            const int ci = MF16 ? (q >> 3) * 16 + 4 * (lane >> 4) + (q & 3) : (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
+            const int co = MF16 ? ((q >> 2) & 1) * 16 + (lane & 15) : (lane & 31);
+            slab[(tap * 32 + ci) * 32 + co] = accf[i][q] + xch[((wq * 7 + i) * 16 + q) * 64 + lane];
+          }
         }
       }
     }
@@ -436,10 +459,12 @@ int conv3_wgrad_ring_launch(const void *x, const View &xv, const void *dy, const
   if (njobs < G) G = (int)njobs;
   if (ws_bytes < (size_t)pairs * G * 27 * 1024 * sizeof(float)) return 0;
   // small problems stay with the many-small-workgroups kernels: a persistent sweep needs a few slices per job to amortise its prologue
-  if (ncol * yv.D < 4ll * ncu * 8 / pairs && dgtta_switches().wgrad_ring != '1') return 0;      // (=1: forced, for the tests)
-#define WR_LAUNCH(T16, MF, CK)                                                                                                       \
+  if (ncol * yv.D < 4ll * ncu * 8 / pairs && dgtta_switches().wgrad_ring != '1' && dgtta_switches().wgrad_ring != '5')
+    return 0;      // (=1 / =5: forced, for the tests; 5 = forced with the one-tap form for Cin <= 16)
+#define WR_LAUNCH(T16, MF, CK) WR_LAUNCH_P(T16, MF, CK, false)
+#define WR_LAUNCH_P(T16, MF, CK, PR)                                                                                              \
   do {                                                                                                                         \
-    auto kern = conv3_wgrad_ring_kernel<T16, MF, CK>;                                                                          \
+    auto kern = conv3_wgrad_ring_kernel<T16, MF, CK, PR>;                                                                          \
     static DynLdsOnce once;                                                                                                    \
     if (ensure_dyn_lds(once, reinterpret_cast<const void *>(kern), WR::LDS_BYTES) != hipSuccess) {                             \
       dgtta_set_error("wgrad_ring: cannot raise the dynamic LDS limit to %d", WR::LDS_BYTES);                                  \
@@ -453,8 +478,14 @@ int conv3_wgrad_ring_launch(const void *x, const View &xv, const void *dy, const
   // 32x32x16 form on three boxes, which is the default: 36 registers less and no swizzle)
   const bool mf16 = dgtta_switches().wgrad_ring == '4';
   bool lab = false;
+  // Cin <= 16 (the first layer): two taps per MFMA (DGTTA_WGRAD_RING=5: the one-tap form, its predecessor)
+  if (Cin <= 16 && !mf16 && dgtta_switches().wgrad_ring != '5') {
+    lab = true;
+    if (is_f16) WR_LAUNCH_P(f16_t, false, false, true);
+    else WR_LAUNCH_P(bf16_t, false, false, true);
+  }
 #ifdef DGTTA_DIAG
-  if (is_f16 && DG_LAB(wgrad_ring_lab) == '6') {      // DGTTA_WGRAD_RING_CLK=6: cycle stamps BEHIND the slabs; only
+  if (!lab && is_f16 && DG_LAB(wgrad_ring_lab) == '6') {      // DGTTA_WGRAD_RING_CLK=6: cycle stamps BEHIND the slabs; only
     lab = true;                                        // profiles/tools/wring_clock.py, which allocates that area, asks for it
     WR_LAUNCH(f16_t, false, true);
   }
@@ -468,6 +499,7 @@ int conv3_wgrad_ring_launch(const void *x, const View &xv, const void *dy, const
     else WR_LAUNCH(bf16_t, false, false);
   }
 #undef WR_LAUNCH
+#undef WR_LAUNCH_P
   if (hipGetLastError() != hipSuccess) {
     dgtta_set_error("conv3_wgrad_ring_kernel: launch failed");
     *rc = DGTTA_ERR_LAUNCH;

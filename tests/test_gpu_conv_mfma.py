@@ -725,7 +725,7 @@ def test_conv_stride2_register_operand_kernel(case, dt, monkeypatch):
     assert float(((r1.cpu() - ref_rstd) / ref_rstd).abs().max()) < 1e-4 and float(((r1 - r0) / r0).abs().max()) < 1e-5
 
 
-WRING_CASES = [(1, 32, 32, 9, 13, 45), (2, 12, 32, 6, 17, 32), (1, 64, 96, 7, 8, 70), (2, 32, 32, 32, 32, 64),
+WRING_CASES = [(1, 32, 32, 9, 13, 45), (2, 12, 32, 6, 17, 32), (1, 16, 64, 9, 11, 37), (2, 12, 32, 40, 16, 64), (1, 64, 96, 7, 8, 70), (2, 32, 32, 32, 32, 64),
                (1, 32, 64, 36, 40, 32), (8, 32, 32, 4, 64, 160)]      # ragged edges, ragged Cin, channel-block pairs, > 256 columns
 
 
@@ -750,6 +750,10 @@ def test_wgrad_ring_kernel(case, dts, monkeypatch):
         return dw
 
     old, new, new16 = run("0"), run("1"), run("4")       # "4": the 16x16x32 MFMA form with the half-swapped LDS image
+    if cin <= 16:                                        # round 5: "1" runs two taps per MFMA for the first layer, "5" one tap
+        one_tap = run("5")
+        assert torch.isfinite(one_tap).all()
+        assert float((new - one_tap).abs().max()) <= 2e-6 * float(one_tap.abs().max()) + 1e-6      # same products, same k order per tap
     ref = torch.nn.grad.conv3d_weight(x[..., :cin].float().permute(0, 4, 1, 2, 3).cpu().double(), (cout, cin, 3, 3, 3),
                                       dy.float().permute(0, 4, 1, 2, 3).cpu().double(), stride=1, padding=1).float()
     scale = float(ref.abs().max())

@@ -37,7 +37,11 @@ struct WR {
   static constexpr int LDS_BYTES = NXS * X_SLICE_B + NYS * Y_SLICE_B;                                     // 161,792
   static constexpr int NVOX = XR * XW;
 };
-static_assert(WR::LDS_BYTES <= 160 * 1024, "wgrad ring does not fit the LDS");
+// behind the rings: 1 KiB that swallows the DMA pieces a wave issues for nothing (REUSE form: every wave issues one piece in each of a
+// slice's first NPW iterations, branch-free; a piece that does not exist - 38 pieces on 8 waves, the tail of a job - reads
+// out of range and lands here)
+constexpr int WR_LDS_TOTAL = WR::LDS_BYTES + 1024;
+static_assert(WR_LDS_TOTAL <= 160 * 1024, "wgrad ring does not fit the LDS");
 static_assert(4 * 7 * 16 * 64 * 4 <= WR::LDS_BYTES, "final combine buffer");
 
 __device__ __forceinline__ void wr_dma16(u32x4_t rsrc, unsigned voff, unsigned soff, unsigned lds_addr) {
@@ -109,6 +113,29 @@ __device__ __forceinline__ f32x4_t wr_mfma16<f16_t>(const bf16x8_t &a, const bf1
   return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), acc, 0, 0, 0);
 }
 
+// scheduling pattern of one (row, k-step) iteration: NM MFMAs with NR LDS reads dealt out behind them, the first MFMA first
+template <int NM, int NR>
+__device__ __forceinline__ void wr_sched_interleave() {
+  if constexpr (NM > 0) {
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+    constexpr int r = (NR + NM - 1) / NM;
+    if constexpr (r > 0) __builtin_amdgcn_sched_group_barrier(0x100, r, 0);
+    wr_sched_interleave<NM - 1, NR - r>();
+  }
+}
+
+// REUSE tap of slot i in wave group wq (see the kernel's comment); < 0 never: slots that are not stored repeat a real tap
+__device__ __forceinline__ int wr_reuse_tap(int wq, int i, bool pair, int hsel) {
+  const int last = pair ? 3 : 6;
+  const int col = i == last ? 8 : (pair ? 2 * wq + hsel : 2 * wq + i / 3);
+  const int kh = i == last ? (wq < 2 ? wq : 2) : i % 3;
+  return (col / 3) * 9 + kh * 3 + col % 3;
+}
+__device__ __forceinline__ bool wr_reuse_stored(int wq, int i, bool pair, int half) {      // half: PAIR only (which 16 rows)
+  const int last = pair ? 3 : 6;
+  return i != last || (wq < 3 && half == 0);
+}
+
 // grid: (G workgroups, channel-block pairs); jobs (b, d-segment, tw, th) dealt so that the 32 workgroups of an XCD hold
 // columns that are neighbours along H (their halo rows meet in one L2); slabs[(pair * G + blockIdx.x)][27][32 ci][32 co]
 // PAIR (round 5, Cin <= 16: the network's first layer, 12 MIND channels in rows of 16): the 32 M rows of an MFMA carry TWO taps x 16
@@ -116,7 +143,14 @@ __device__ __forceinline__ f32x4_t wr_mfma16<f16_t>(const bf16x8_t &a, const bf1
 // SECOND tap's shift instead of channels 16..31 at the first's.  14 tap pairs over the 4 wave groups = 4 accumulators per wave
 // instead of 7: 4/7 of the MFMAs and operand reads for the same result (the slab keeps one [32 ci][32 co] block per tap; rows
 // ci >= 16 of a block are not written and the reduction never reads rows ci >= Cin).
-template <typename T16, bool MF16, bool CLK = false, bool PAIR = false>      // MF16: v_mfma_f32_16x16x32 (K = the row's 32 voxels) instead of 32x32x16;
+// REUSE (round 5): the x operand of (output row oh, tap kh + 1) IS the operand of (row oh + 1, tap kh).  A wave group therefore takes
+// whole (kd, kw) COLUMNS of taps - columns 2 wq and 2 wq + 1 in slots 0..2 / 3..5 (kh = slot % 3), and tap kh = wq of the ninth
+// column in slot 6 (group 3: a discarded repeat) - walks the four rows of its half with the k-step OUTSIDE, and reads only the
+// three operands that are new in a row (kh = 2 of each column and the single tap); the other four are the previous row's
+// registers.  16 + 4 instead of 28 + 4 operand reads per row half and k-step: the sweep was bound by the LDS read rate
+// (512 KiB per CU and slice = 4096 clk against 3584 clk of MFMA), not by the matrix pipe.  With PAIR the
+// pair slot s < 3 holds tap kh = s of columns 2 wq (rows 0..15) and 2 wq + 1 (rows 16..31), slot 3 the ninth column's tap.
+template <typename T16, bool MF16, bool CLK = false, bool PAIR = false, bool REUSE = false>      // MF16: v_mfma_f32_16x16x32 (K = the row's 32 voxels) instead of 32x32x16;
                                                                            // CLK (diagnostic): cycle / real-time stamps behind the slabs
 __global__ __launch_bounds__(WR::NW * 64) void conv3_wgrad_ring_kernel(const bf16_t *__restrict__ x, View xv, const bf16_t *__restrict__ dy,
                                                                        View yv, float *__restrict__ slabs, int Cin, int Cout, int tilesW,
@@ -136,7 +170,7 @@ __global__ __launch_bounds__(WR::NW * 64) void conv3_wgrad_ring_kernel(const bf1
   const int cib = blockIdx.y / cobs, cob = blockIdx.y % cobs;
   const int cin_lim = (Cin + 7) / 8 * 8;
 
-  static_assert(!(PAIR && MF16), "the pair form exists for the 32x32x16 MFMA only");
+  static_assert(!(PAIR && MF16) && !(REUSE && MF16), "the pair and operand-reuse forms exist for the 32x32x16 MFMA only");
   constexpr int NA = PAIR ? 4 : 7;                         // accumulators (taps, or tap pairs) per wave
   const int hsel = (lane >> 4) & 1;                        // PAIR: which tap of the pair this lane's M rows belong to
   int tap_kd[7], tap_off[7], tap_row[7], tap_kw[7];
@@ -144,7 +178,8 @@ __global__ __launch_bounds__(WR::NW * 64) void conv3_wgrad_ring_kernel(const bf1
   for (int i = 0; i < 7; ++i) {
     // (the fourth residue class has 6 taps: its seventh slot repeats tap 26 into a discarded accumulator; PAIR: pair wq + 4 i =
     // taps 2 (wq + 4 i) and + 1, per lane; pairs 14, 15 and the second tap of pair 13 repeat tap 26 into rows that are not stored)
-    const int tc = PAIR ? ((2 * (wq + 4 * i) + hsel) < 27 ? 2 * (wq + 4 * i) + hsel : 26) : (wq + 4 * i < 27 ? wq + 4 * i : 26);
+    const int tc = REUSE ? wr_reuse_tap(wq, i, PAIR, hsel)
+                         : (PAIR ? ((2 * (wq + 4 * i) + hsel) < 27 ? 2 * (wq + 4 * i) + hsel : 26) : (wq + 4 * i < 27 ? wq + 4 * i : 26));
     tap_kd[i] = tc / 9;
     tap_off[i] = ((tc / 3) % 3) * WR::X_ROW_B + (tc % 3) * 64;
     tap_row[i] = ((tc / 3) % 3) * WR::X_ROW_B;
@@ -226,25 +261,41 @@ __global__ __launch_bounds__(WR::NW * 64) void conv3_wgrad_ring_kernel(const bf1
         poff[i] = ok ? (unsigned)((gh * yv.sh + gw * yv.sw + chunk * 8) * 2) : WR_OOB;
       }
     }
-    // piece i of x slice xd / dy slice yd (either may be switched off)
-    auto issue_piece = [&](int i, int xd, bool do_x, int yd, bool do_y) -> int {
+    // piece i of x slice xd into ring slot xslot / dy slice yd into ring slot yslot (either may be switched off)
+    auto issue_piece_at = [&](int i, int xd, int xslot, bool do_x, int yd, int yslot, bool do_y) -> int {
       const int idx = wave + WR::NW * i;
       if (idx < WR::XP) {
         if (!do_x) return 0;
         const bool dok = (unsigned)xd < (unsigned)D;
-        const int slot = (xd + 1 + WR::NXS) % WR::NXS;
-        wr_dma16(rx, poff[i] | (dok ? 0u : WR_OOB), dok ? (unsigned)(xd * xv.sd * 2) : 0u, lds0 + slot * WR::X_SLICE_B + idx * 1024);
+        wr_dma16(rx, poff[i] | (dok ? 0u : WR_OOB), dok ? (unsigned)(xd * xv.sd * 2) : 0u, lds0 + xslot * WR::X_SLICE_B + idx * 1024);
         return 1;
       }
       if (idx < WR::NP) {
         if (!do_y) return 0;
         const bool dok = (unsigned)yd < (unsigned)D;
-        const int slot = (yd + WR::NYS) % WR::NYS;
         wr_dma16(ry, poff[i] | (dok ? 0u : WR_OOB), dok ? (unsigned)(yd * yv.sd * 2) : 0u,
-                 lds0 + WR::NXS * WR::X_SLICE_B + slot * WR::Y_SLICE_B + (idx - WR::XP) * 1024);
+                 lds0 + WR::NXS * WR::X_SLICE_B + yslot * WR::Y_SLICE_B + (idx - WR::XP) * 1024);
         return 1;
       }
       return 0;
+    };
+    // the same without a branch (REUSE form; `on` = the slices exist at all): selects on wave-uniform values, always one DMA
+    auto issue_piece_always = [&](int i, int xd, int xslot, int yd, int yslot, bool on) {
+      const int idx = wave + WR::NW * i;
+      const bool isx = idx < WR::XP, valid = on && idx < WR::NP;
+      const int sd = isx ? xd : yd;
+      const bool dok = valid && (unsigned)sd < (unsigned)D;
+      u32x4_t r;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) r[q] = isx ? rx[q] : ry[q];
+      const unsigned lds_piece = isx ? (unsigned)(xslot * WR::X_SLICE_B + idx * 1024)
+                                     : (unsigned)(WR::NXS * WR::X_SLICE_B + yslot * WR::Y_SLICE_B + (idx - WR::XP) * 1024);
+      wr_dma16(r, poff[i] | (dok ? 0u : WR_OOB), dok ? (unsigned)(sd * (isx ? xv.sd : yv.sd) * 2) : 0u,
+               lds0 + (valid ? lds_piece : (unsigned)WR::LDS_BYTES));
+    };
+    // (x(xd) lives in slot (xd + 1) mod NXS, dy(yd) in slot yd mod NYS)
+    auto issue_piece = [&](int i, int xd, bool do_x, int yd, bool do_y) -> int {
+      return issue_piece_at(i, xd, (xd + 1 + WR::NXS) % WR::NXS, do_x, yd, (yd + WR::NYS) % WR::NYS, do_y);
     };
     int issued = 0;
     auto issue_group = [&](int xd, bool do_x, int yd, bool do_y) {
@@ -258,6 +309,9 @@ __global__ __launch_bounds__(WR::NW * 64) void conv3_wgrad_ring_kernel(const bf1
     issue_group(d_begin, true, d_begin, true);
     int mark_cur = issue_group(d_begin + 1, true, 0, false);            // needed in slice d_begin
     int mark_nxt = issue_group(d_begin + 2, true, d_begin + 1, true);   // needed in slice d_begin + 1
+    // ring slots of x(d - 1) and dy(d), carried along the sweep: no division per slice (round 5: the slot arithmetic of a slice -
+    // four magic-number divisions and seven slot selects - sat between the barrier and the slice's first operand read)
+    int xr0 = (d_begin + WR::NXS) % WR::NXS, yr0 = (d_begin + WR::NYS) % WR::NYS;
     for (int d = d_begin; d < d_end; ++d) {
       unsigned long long tw0 = 0;
       if (CLK) tw0 = __builtin_amdgcn_s_memtime();
@@ -266,12 +320,14 @@ __global__ __launch_bounds__(WR::NW * 64) void conv3_wgrad_ring_kernel(const bf1
       if (CLK) t_wait += __builtin_amdgcn_s_memtime() - tw0;
       const bool more = d + 2 < d_end;         // x(d + 3), dy(d + 2): first read in slice d + 2
       int mark_new = issued;
-      const unsigned char *ys0 = sY + ((d + WR::NYS) % WR::NYS) * WR::Y_SLICE_B + rh * 4 * WR::Y_ROW_B;
+      const unsigned char *ys0 = sY + yr0 * WR::Y_SLICE_B + rh * 4 * WR::Y_ROW_B;
       const unsigned char *ys = ys0 + lane_off_y;
-      const int xr0 = (d + WR::NXS) % WR::NXS;      // ring slot of x(d - 1)
+      // x(d + 3) takes the slot x(d - 2) left, dy(d + 2) the one of dy(d - 1)
+      const int xs_new = xr0 == 0 ? WR::NXS - 1 : xr0 - 1, ys_new = yr0 == 0 ? WR::NYS - 1 : yr0 - 1;
       int slice_off[3];
 #pragma unroll
-      for (int kd = 0; kd < 3; ++kd) slice_off[kd] = ((d + kd + WR::NXS) % WR::NXS) * WR::X_SLICE_B + rh * 4 * WR::X_ROW_B;
+      for (int kd = 0; kd < 3; ++kd)
+        slice_off[kd] = (xr0 + kd >= WR::NXS ? xr0 + kd - WR::NXS : xr0 + kd) * WR::X_SLICE_B + rh * 4 * WR::X_ROW_B;
       if (!MF16) {
         // operands of (row, k-step) iteration it + 1 are read while the MFMAs of iteration it issue
         // One address register per tap and slice (lane offset + ring slot of the tap's kd + its (kh, kw) offset, the slot picked
@@ -286,21 +342,18 @@ __global__ __launch_bounds__(WR::NW * 64) void conv3_wgrad_ring_kernel(const bf1
           xa[i] = lane_off + sl * WR::X_SLICE_B + rh * 4 * WR::X_ROW_B + tap_off[i];
         }
         bf16x8_t afr[2][NA], bfr[2];
-        auto load_it = [&](int it, bf16x8_t(&a)[NA], bf16x8_t &bb) {
-          const int oh = it >> 1, ks = it & 1;
+        // (REUSE: k-step outside, rows inside; a slot that is not new in a row takes the previous row's next slot)
+        auto load_it = [&](int it, bf16x8_t(&a)[NA], const bf16x8_t(&prev)[NA], bf16x8_t &bb) {
+          const int oh = REUSE ? (it & 3) : (it >> 1), ks = REUSE ? (it >> 2) : (it & 1);
           bb = wr_operand(ys + oh * WR::Y_ROW_B + ks * 1024);
 #pragma unroll
-          for (int i = 0; i < NA; ++i) a[i] = wr_operand(sX + xa[i] + oh * WR::X_ROW_B + ks * 1024);
-        };
-        load_it(0, afr[0], bfr[0]);
-#pragma unroll
-        for (int it = 0; it < 8; ++it) {
-          if (it + 1 < 8) load_it(it + 1, afr[(it + 1) & 1], bfr[(it + 1) & 1]);
-          __builtin_amdgcn_sched_barrier(0);
-          if (more && it < WR::NPW) {
-            issued += issue_piece(it, d + 3, true, d + 2, true);
-            if (it == WR::NPW - 1) mark_new = issued;
+          for (int i = 0; i < NA; ++i) {
+            const bool fresh = !REUSE || oh == 0 || i == NA - 1 || (PAIR ? i == 2 : (i == 2 || i == 5));
+            if (fresh) a[i] = wr_operand(sX + xa[i] + oh * WR::X_ROW_B + ks * 1024);
+            else a[i] = prev[i + 1];
           }
+        };
+        auto mfma_it = [&](int it) {
 #pragma unroll
           for (int i = 0; i < NA; ++i) {
             f32x16_t c;
@@ -310,7 +363,48 @@ __global__ __launch_bounds__(WR::NW * 64) void conv3_wgrad_ring_kernel(const bf1
 #pragma unroll
             for (int q = 0; q < 16; ++q) accf[i][q] = c[q];
           }
+        };
+        if constexpr (REUSE) {
+          // the slice's first operands in the order the MFMAs want them (left to itself the scheduler sorts the reads of
+          // iterations 0 and 1 by address, and the first MFMA after the barrier waits for fourteen reads of all eight waves)
+          bfr[0] = wr_operand(ys);
+#pragma unroll
+          for (int i = 0; i < NA; ++i) {
+            afr[0][i] = wr_operand(sX + xa[i]);
+            if (i % 2 == 0) __builtin_amdgcn_sched_barrier(0);
+          }
           __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int it = 0; it < 8; ++it) {
+            // one basic block per iteration: the slice's DMA piece (branch-free), then the reads of iteration it + 1 dealt out
+            // BETWEEN the MFMAs of iteration it.  (With the piece behind wave-uniform branches and the reads in front of the
+            // MFMAs, a wave whose SIMD partner had finished its slice ran at half the MFMA rate: profiles/r05_ab.txt.)
+            if (it < WR::NPW) {
+              issue_piece_always(it, d + 3, xs_new, d + 2, ys_new, more);
+              ++issued;
+              if (it == WR::NPW - 1) mark_new = issued;
+            }
+            if (it + 1 < 8) load_it(it + 1, afr[(it + 1) & 1], afr[it & 1], bfr[(it + 1) & 1]);
+            mfma_it(it);
+            if (it + 1 < 8) {
+              if (((it + 1) & 3) == 0) wr_sched_interleave<NA, 2 * (NA + 1)>();
+              else wr_sched_interleave<NA, 2 * ((PAIR ? 2 : 3) + 1)>();
+            }
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        } else {
+          load_it(0, afr[0], afr[1], bfr[0]);
+#pragma unroll
+          for (int it = 0; it < 8; ++it) {
+            if (it + 1 < 8) load_it(it + 1, afr[(it + 1) & 1], afr[it & 1], bfr[(it + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+            if (more && it < WR::NPW) {
+              issued += issue_piece_at(it, d + 3, xs_new, true, d + 2, ys_new, true);
+              if (it == WR::NPW - 1) mark_new = issued;
+            }
+            mfma_it(it);
+            __builtin_amdgcn_sched_barrier(0);
+          }
         }
       } else {
         // the row's 32 voxels are ONE k-step: per (row, tap) unit 2 x operands (ci halves) and 4 MFMAs against the row's 2 dy
@@ -346,7 +440,7 @@ __global__ __launch_bounds__(WR::NW * 64) void conv3_wgrad_ring_kernel(const bf1
 #pragma unroll
             for (int pi = 0; pi < WR::NPW; ++pi)
               if ((pi == 0 ? 0 : pi - 1) == oh) {
-                issued += issue_piece(pi, d + 3, true, d + 2, true);
+                issued += issue_piece_at(pi, d + 3, xs_new, true, d + 2, ys_new, true);
                 if (pi == WR::NPW - 1) mark_new = issued;
               }
           }
@@ -365,6 +459,8 @@ __global__ __launch_bounds__(WR::NW * 64) void conv3_wgrad_ring_kernel(const bf1
       }
       mark_cur = mark_nxt;
       mark_nxt = mark_new;
+      xr0 = xr0 + 1 == WR::NXS ? 0 : xr0 + 1;
+      yr0 = yr0 + 1 == WR::NYS ? 0 : yr0 + 1;
     }
   }
 
@@ -399,12 +495,12 @@ __global__ __launch_bounds__(WR::NW * 64) void conv3_wgrad_ring_kernel(const bf1
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
           const int row = (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
-          const int tap = 2 * (wq + 4 * i) + (row >> 4), co = lane & 31;
-          if (tap < 27) slab[(tap * 32 + (row & 15)) * 32 + co] = accf[i][q] + xch[((wq * 7 + i) * 16 + q) * 64 + lane];
+          const int tap = REUSE ? wr_reuse_tap(wq, i, true, row >> 4) : 2 * (wq + 4 * i) + (row >> 4), co = lane & 31;
+          if (REUSE ? wr_reuse_stored(wq, i, true, row >> 4) : tap < 27) slab[(tap * 32 + (row & 15)) * 32 + co] = accf[i][q] + xch[((wq * 7 + i) * 16 + q) * 64 + lane];
         }
       } else {
-        const int tap = wq + 4 * i;
-        if (tap < 27) {
+        const int tap = REUSE ? wr_reuse_tap(wq, i, false, 0) : wq + 4 * i;
+        if (REUSE ? wr_reuse_stored(wq, i, false, 0) : tap < 27) {
 #pragma unroll
           for (int q = 0; q < 16; ++q) {
             const int ci = MF16 ? (q >> 3) * 16 + 4 * (lane >> 4) + (q & 3) : (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
@@ -459,43 +555,54 @@ int conv3_wgrad_ring_launch(const void *x, const View &xv, const void *dy, const
   if (njobs < G) G = (int)njobs;
   if (ws_bytes < (size_t)pairs * G * 27 * 1024 * sizeof(float)) return 0;
   // small problems stay with the many-small-workgroups kernels: a persistent sweep needs a few slices per job to amortise its prologue
-  if (ncol * yv.D < 4ll * ncu * 8 / pairs && dgtta_switches().wgrad_ring != '1' && dgtta_switches().wgrad_ring != '5')
-    return 0;      // (=1 / =5: forced, for the tests; 5 = forced with the one-tap form for Cin <= 16)
-#define WR_LAUNCH(T16, MF, CK) WR_LAUNCH_P(T16, MF, CK, false)
-#define WR_LAUNCH_P(T16, MF, CK, PR)                                                                                              \
+  const char sw = dgtta_switches().wgrad_ring;
+  if (ncol * yv.D < 4ll * ncu * 8 / pairs && sw != '1' && sw != '5' && sw != '6')
+    return 0;      // (=1 / =5 / =6: forced, for the tests; 5 = forced, one tap per MFMA for Cin <= 16 and no operand reuse; 6 = forced, no operand reuse)
+#define WR_LAUNCH(T16, MF, CK) WR_LAUNCH_P(T16, MF, CK, false, false)
+#define WR_LAUNCH_P(T16, MF, CK, PR, RU)                                                                                          \
   do {                                                                                                                         \
-    auto kern = conv3_wgrad_ring_kernel<T16, MF, CK, PR>;                                                                          \
+    auto kern = conv3_wgrad_ring_kernel<T16, MF, CK, PR, RU>;                                                                      \
     static DynLdsOnce once;                                                                                                    \
-    if (ensure_dyn_lds(once, reinterpret_cast<const void *>(kern), WR::LDS_BYTES) != hipSuccess) {                             \
-      dgtta_set_error("wgrad_ring: cannot raise the dynamic LDS limit to %d", WR::LDS_BYTES);                                  \
+    if (ensure_dyn_lds(once, reinterpret_cast<const void *>(kern), WR_LDS_TOTAL) != hipSuccess) {                              \
+      dgtta_set_error("wgrad_ring: cannot raise the dynamic LDS limit to %d", WR_LDS_TOTAL);                                   \
       *rc = DGTTA_ERR_LAUNCH;                                                                                                  \
       return 0;                                                                                                                \
     }                                                                                                                          \
-    hipLaunchKernelGGL(kern, dim3((unsigned)G, (unsigned)pairs), dim3(WR::NW * 64), WR::LDS_BYTES, st, (const bf16_t *)x, xv,  \
+    hipLaunchKernelGGL(kern, dim3((unsigned)G, (unsigned)pairs), dim3(WR::NW * 64), WR_LDS_TOTAL, st, (const bf16_t *)x, xv,  \
                        (const bf16_t *)dy, yv, slabs, Cin, Cout, tW, tH, nseg, DR, cobs, (int)njobs, (unsigned)xb, (unsigned)yb); \
   } while (0)
   // DGTTA_WGRAD_RING=4: the v_mfma_f32_16x16x32 form (conflict-free after the half swap above; measured within +-2 % of the
   // 32x32x16 form on three boxes, which is the default: 36 registers less and no swizzle)
-  const bool mf16 = dgtta_switches().wgrad_ring == '4';
+  const bool mf16 = sw == '4';
+  // operands shared between neighbouring rows (REUSE; DGTTA_WGRAD_RING=6: its predecessor)
+  const bool reuse = !mf16 && sw != '5' && sw != '6';
   bool lab = false;
   // Cin <= 16 (the first layer): two taps per MFMA (DGTTA_WGRAD_RING=5: the one-tap form, its predecessor)
-  if (Cin <= 16 && !mf16 && dgtta_switches().wgrad_ring != '5') {
+  if (Cin <= 16 && !mf16 && sw != '5') {
     lab = true;
-    if (is_f16) WR_LAUNCH_P(f16_t, false, false, true);
-    else WR_LAUNCH_P(bf16_t, false, false, true);
+    if (is_f16) {
+      if (reuse) WR_LAUNCH_P(f16_t, false, false, true, true);
+      else WR_LAUNCH_P(f16_t, false, false, true, false);
+    } else {
+      if (reuse) WR_LAUNCH_P(bf16_t, false, false, true, true);
+      else WR_LAUNCH_P(bf16_t, false, false, true, false);
+    }
   }
 #ifdef DGTTA_DIAG
   if (!lab && is_f16 && DG_LAB(wgrad_ring_lab) == '6') {      // DGTTA_WGRAD_RING_CLK=6: cycle stamps BEHIND the slabs; only
     lab = true;                                        // profiles/tools/wring_clock.py, which allocates that area, asks for it
-    WR_LAUNCH(f16_t, false, true);
+    if (reuse) WR_LAUNCH_P(f16_t, false, true, false, true);
+    else WR_LAUNCH(f16_t, false, true);
   }
 #endif
   if (lab) {
   } else if (is_f16) {
     if (mf16) WR_LAUNCH(f16_t, true, false);
+    else if (reuse) WR_LAUNCH_P(f16_t, false, false, false, true);
     else WR_LAUNCH(f16_t, false, false);
   } else {
     if (mf16) WR_LAUNCH(bf16_t, true, false);
+    else if (reuse) WR_LAUNCH_P(bf16_t, false, false, false, true);
     else WR_LAUNCH(bf16_t, false, false);
   }
 #undef WR_LAUNCH

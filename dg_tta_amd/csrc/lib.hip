@@ -51,7 +51,7 @@ static const DgttaSwitches *read_switches() {
   s->wgrad_f32_split = env_char("DGTTA_WGRAD_F32_SPLIT");
   // product switches select between kernels of equal results only: values outside a switch's documented set are ignored
   if (s->conv_ring != '0' && s->conv_ring != '1' && s->conv_ring != '3') s->conv_ring = -1;
-  if (s->wgrad_ring != '0' && s->wgrad_ring != '1' && s->wgrad_ring != '4' && s->wgrad_ring != '5') s->wgrad_ring = -1;
+  if (s->wgrad_ring != '0' && s->wgrad_ring != '1' && s->wgrad_ring != '4' && s->wgrad_ring != '5' && s->wgrad_ring != '6') s->wgrad_ring = -1;
   if (s->convt_gemm != '0' && s->convt_gemm != '1') s->convt_gemm = -1;
   s->rows_abl = s->rows_var = s->ring_nt = s->ring_abl = s->wgrad_ring_lab = s->ha_abl = s->warp_abl = s->convt_gemm_abl = -1;
   s->ncu = 0;

@@ -106,9 +106,13 @@ def test_one_pass_batch8_128_every_storage_type_vs_fp32_valu():
     # Round 5: the runner's weights are PRE-TRAINED (bench.pretrained_weights) - decisive logits, gradients far above rounding
     # noise.  Measured on them (profiles/r05_at_size_parity.json "one_pass"): fp32 MFMA 7.7e-7 / 6e-8 / 0.9999995 / 0.999998, fp16
     # 2.1e-4 / 3e-7 / 0.9989 / 0.991, bf16 1.8e-3 / 8e-5 / 0.9996 / 0.969, labels 0.9999999 / 0.99995 / 0.9996
-    # (550 pre-training steps: fp32 9.7e-7 / 6e-8 / 0.9999997 / 0.999994, fp16 2.8e-4 / 3.5e-6 / 0.9988 / 0.9969, labels 0.99998)
-    limits = {"fp32": dict(logit=3e-6, loss=3e-7, cos=0.99999, sign=0.9999, agree=0.999999),
-              "fp16": dict(logit=1e-3, loss=1e-5, cos=0.996, sign=0.97, agree=0.9998),
+    # (550 pre-training steps: fp32 9.7e-7 / 6e-8 / 0.9999997 / 0.999994, fp16 2.8e-4 / 3.5e-6 / 0.9988 / 0.9969, labels 0.99998;
+    # the same 550 steps after the weight-gradient kernel changed its summation order - other weights, the pre-training runs
+    # through it: fp32 9.9e-7 / 0 / 0.9999916 / 0.999976, fp16 2.9e-4 / 2.1e-5 / 0.99976 / 0.99955.  The fp16 loss delta is a
+    # SIGNED sum of rounding errors - 3e-7, 3.5e-6, 2.1e-5 on three sets of weights - and so is the worst tensor's cosine:
+    # their limits leave room for that spread; the logit, label and median limits are the tight ones)
+    limits = {"fp32": dict(logit=3e-6, loss=3e-7, cos=0.99997, sign=0.9999, agree=0.999999),
+              "fp16": dict(logit=1e-3, loss=1e-4, cos=0.996, sign=0.97, agree=0.9998),
               "bf16": dict(logit=6e-3, loss=3e-4, cos=0.997, sign=0.92, agree=0.999)}
     for dtype in ("fp32", "fp16", "bf16"):
         r = _runner(dtype, impl=0)

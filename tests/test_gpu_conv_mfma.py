@@ -750,10 +750,15 @@ def test_wgrad_ring_kernel(case, dts, monkeypatch):
         return dw
 
     old, new, new16 = run("0"), run("1"), run("4")       # "4": the 16x16x32 MFMA form with the half-swapped LDS image
-    if cin <= 16:                                        # round 5: "1" runs two taps per MFMA for the first layer, "5" one tap
+    # round 5: "1" shares x operands between neighbouring rows (whole tap columns per wave group, k-step outside the rows);
+    # "6" is the form before that (taps dealt round robin, every operand read)
+    no_reuse = run("6")
+    assert torch.isfinite(no_reuse).all()
+    assert float((new - no_reuse).abs().max()) < 1e-4 * float(no_reuse.abs().max()) + 1e-3
+    if cin <= 16:                                        # round 5: "1" / "6" run two taps per MFMA for the first layer, "5" one tap
         one_tap = run("5")
         assert torch.isfinite(one_tap).all()
-        assert float((new - one_tap).abs().max()) <= 2e-6 * float(one_tap.abs().max()) + 1e-6      # same products, same k order per tap
+        assert float((no_reuse - one_tap).abs().max()) <= 2e-6 * float(one_tap.abs().max()) + 1e-6      # same products, same k order per tap
     ref = torch.nn.grad.conv3d_weight(x[..., :cin].float().permute(0, 4, 1, 2, 3).cpu().double(), (cout, cin, 3, 3, 3),
                                       dy.float().permute(0, 4, 1, 2, 3).cpu().double(), stride=1, padding=1).float()
     scale = float(ref.abs().max())

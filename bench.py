@@ -587,7 +587,8 @@ def referee_tta_run(args, device):
 
 def inference_leg(args, device, dtype):
     """BASELINE config 3's caller-side step: Gaussian sliding-window inference of ONE ensemble member
-    over an `inference_size`^3 volume with 128^3 windows at step 0.5, all 105 classes accumulated in fp32, then argmax.
+    over an `inference_size`^3 volume with 128^3 windows at step 0.5, argmax over all 105 classes: the product's feature-space
+    accumulator, and nnU-Net's logits-space one (fp32 / fp16) beside it.
     Returns ms per window (network forward + accumulate) and the totals."""
     import torch
     from dg_tta_amd.mind import mind_hook
@@ -623,16 +624,40 @@ def inference_leg(args, device, dtype):
                "tflops": round(win_tflop * nwin / dt, 1), "frac_of_mfma_peak": round(win_tflop * nwin / dt / 2500.0, 4)}
         return rec, seg
 
-    torch.manual_seed(11)                    # MIND's noise draws: the same in both runs
-    r32, seg32 = one(torch.float32)
-    out = {"volume": n, "windows": nwin, **r32, "classes": int(ncls), "dtype": dtype, "accumulator": "fp32",
+    def one_features():
+        # the product's default (round 5): Gaussian-weighted FEATURES accumulated (16 GiB at 512^3), head + argmax once per voxel
+        from dg_tta_amd.tta.inference import WindowFeatures, accumulate_window_features
+        head = net.decoder.seg_layers[-1]
+        facc0 = torch.zeros((1, n, n, n, 32), dtype=torch.float32, device=device)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        _, nsum, crop = accumulate_window_features(net, vol, patch, facc0[0])
+        feats = WindowFeatures(facc0, nsum, crop, head.weight.detach().reshape(1, ncls, -1).float(), head.bias.detach().float()[None])
+        seg = feats.argmax()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        rec = {"ms_per_window": round(dt / nwin * 1e3, 3), "seconds": round(dt, 3),
+               "accumulator_gib": round(facc0.numel() * 4 / 2 ** 30, 2),
+               "tflops": round(win_tflop * nwin / dt, 1), "frac_of_mfma_peak": round(win_tflop * nwin / dt / 2500.0, 4)}
+        return rec, seg
+
+    from dg_tta_amd.tta.inference import accumulate_window_features
+    accumulate_window_features(net, vol[:, :args.size, :args.size, :args.size], patch)      # warm-up
+    torch.manual_seed(11)                    # MIND's noise draws: the same in all runs
+    rf, segf = one_features()
+    out = {"volume": n, "windows": nwin, **rf, "classes": int(ncls), "dtype": dtype, "accumulator": "features (32 channels, fp32)",
            "window_tflop": round(win_tflop, 4),
-           "note": "one ensemble member; network forward (8 windows per pass) + Gaussian accumulate fused with the head + final argmax"}
-    del r32
+           "note": "one ensemble member; network forward (8 windows per pass) + Gaussian accumulation of the head's INPUT features "
+                   "(the head is linear and last: sum_w g (W z + b) = W sum_w g z + b sum_w g) + head and argmax once per voxel"}
+    torch.manual_seed(11)
+    r32, seg32 = one(torch.float32)
+    r32["label_agreement_with_feature_accumulator"] = round(float((seg32 == segf).float().mean()), 6)
+    out["fp32_logits_accumulator"] = r32
+    del segf
     torch.manual_seed(11)
     r16, seg16 = one(torch.float16)
     r16["label_agreement_with_fp32_accumulator"] = round(float((seg16 == seg32).float().mean()), 6)
-    out["fp16_accumulator"] = r16
+    out["fp16_logits_accumulator"] = r16
     return out
 
 

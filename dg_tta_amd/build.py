@@ -7,7 +7,7 @@ from pathlib import Path
 
 CSRC = Path(__file__).resolve().parent / "csrc"
 LIB = Path(__file__).resolve().parent / "libdgtta_hip.so"
-SOURCES = ["lib.hip", "mind3d.hip", "gin.hip", "warp.hip", "softdice.hip", "dice_ce.hip", "adamw.hip", "resample.hip", "unet_ref.hip", "conv_mfma.hip", "conv_rows.hip", "conv_ring.hip",
+SOURCES = ["lib.hip", "mind3d.hip", "gin.hip", "warp.hip", "softdice.hip", "dice_ce.hip", "adamw.hip", "resample.hip", "window_features.hip", "unet_ref.hip", "conv_mfma.hip", "conv_rows.hip", "conv_ring.hip",
            "conv_wgrad.hip", "conv_wgrad_ring.hip", "convt_gemm.hip", "conv_s2.hip"]
 # conv_ring.hip: the 64-input-channel step body (432 MFMAs, 192 fragment reads, fully unrolled) is above hipcc's default
 # pragma-unroll threshold; partially unrolled its register arrays are indexed dynamically and land in scratch

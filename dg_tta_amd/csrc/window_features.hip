@@ -1,0 +1,208 @@
+// Sliding-window inference in FEATURE space (round 5; BASELINE config 3).
+//
+// What the reference does (nnunetv2==2.2.1 predict_sliding_window_return_logits, reached from
+// dg_tta/tta/nnunet_utils.py:116-125, 208-230; ensemble loop dg_tta/tta/tta.py:396-413): every window's logits over ALL
+// pretrain classes are multiplied by the Gaussian importance map and added into a [classes, X, Y, Z] volume; the volume is
+// divided by the summed weights, the members' volumes are averaged and the label map is the argmax.
+//
+// The segmentation head is a 1x1x1 convolution - LINEAR - and it is the last thing in the network:
+//     sum_w g_w(v) (W z_w(v) + b) = W (sum_w g_w(v) z_w(v)) + b sum_w g_w(v).
+// So the volume-sized accumulator can hold the 32 Gaussian-weighted FEATURE channels of the last decoder block instead of
+// the 105 logits, and the head runs ONCE per voxel at the end, fused with the argmax:
+//   * read-modify-write per window voxel: 64 B of features + 2 x 128 B instead of 64 B + 2 x 420 B (2.8x less HBM traffic in
+//     the pass that was 20 % of a member's time: 343 windows x 1.9 GB at 512^3);
+//   * accumulator of a 512^3 volume: 16 GiB per member instead of 52.5 GiB - and a member needs its own (the members' heads
+//     differ), so an ensemble of three is 48 GiB: still below ONE logits volume;
+//   * the 105-class volume never exists: the label map is argmax_c sum_m (W_m F_m(v) + b_m n(v)) straight from the features
+//     (no division: n(v) > 0 is shared by all classes and members).
+// Floating point: the sums are re-associated (fp32 throughout; products g * z are exact up to one rounding, the head runs on
+// fp32 features with the fp32 weights instead of on 16-bit features window by window), so labels can differ from the
+// logits-space accumulator where the top-2 margin is at rounding level - tests/test_inference.py compares both forms with the
+// CPU restatement outside such ties.  nnU-Net itself is absent from /root/reference: this stage is "parity unpinned" either way.
+#include "common.h"
+
+namespace {
+
+constexpr int WF_CIN = 32;
+
+// 4 channels of a voxel as floats
+template <typename T>
+__device__ __forceinline__ void wf_load4(const T *p, float (&f)[4]);
+template <>
+__device__ __forceinline__ void wf_load4<float>(const float *p, float (&f)[4]) {
+  const float4 v = *reinterpret_cast<const float4 *>(p);
+  f[0] = v.x, f[1] = v.y, f[2] = v.z, f[3] = v.w;
+}
+template <>
+__device__ __forceinline__ void wf_load4<bf16_t>(const bf16_t *p, float (&f)[4]) {
+  const uint2 v = *reinterpret_cast<const uint2 *>(p);
+  f[0] = __uint_as_float(v.x << 16), f[1] = __uint_as_float(v.x & 0xffff0000u);
+  f[2] = __uint_as_float(v.y << 16), f[3] = __uint_as_float(v.y & 0xffff0000u);
+}
+template <>
+__device__ __forceinline__ void wf_load4<f16_t>(const f16_t *p, float (&f)[4]) {
+  const uint2 v = *reinterpret_cast<const uint2 *>(p);
+  f[0] = f16_to_f32((unsigned short)(v.x & 0xffffu)), f[1] = f16_to_f32((unsigned short)(v.x >> 16));
+  f[2] = f16_to_f32((unsigned short)(v.y & 0xffffu)), f[3] = f16_to_f32((unsigned short)(v.y >> 16));
+}
+
+// facc[(x0 + pd, y0 + ph, z0 + pw)][c] += gauss[p] * z[p][c], nsum[..] += gauss[p]; 8 threads per voxel, 4 channels each: every
+// load and store instruction of a wave covers one contiguous run (z: 512 B, facc: 1 KiB; a window row is contiguous in the
+// volume along its last axis).  A launch touches every accumulator element once - overlapping windows are separate launches
+// in stream order, as in the logits-space form.
+template <typename T>
+__global__ __launch_bounds__(256) void feature_accumulate_kernel(const T *__restrict__ z, const float *__restrict__ gauss,
+                                                                 float *__restrict__ facc, float *__restrict__ nsum, int PH, int PW,
+                                                                 int Y, int Z, int x0, int y0, int z0, int64_t total) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int q = (int)(i & 7);
+  const int64_t p = i >> 3;
+  const int pw = (int)(p % PW), ph = (int)((p / PW) % PH);
+  const int64_t pd = p / ((int64_t)PW * PH);
+  const int64_t v = ((pd + x0) * Y + (ph + y0)) * Z + (pw + z0);
+  const float g = gauss[p];
+  float f[4];
+  wf_load4<T>(z + p * WF_CIN + q * 4, f);
+  float4 *dst = reinterpret_cast<float4 *>(facc + v * WF_CIN + q * 4);
+  float4 a = *dst;
+  a.x += g * f[0], a.y += g * f[1], a.z += g * f[2], a.w += g * f[3];
+  *dst = a;
+  if (q == 0 && nsum) nsum[v] += g;
+}
+
+// Label map from the members' feature accumulators: argmax_c sum_m (W_m[c] . F_m(v)) + n(v) bsum[c], bsum = sum_m b_m (formed
+// by the caller).  One thread per voxel; a member's 32 features sit in registers, the weights are wave-uniform (scalar
+// loads).  With several members the classes' partial sums wait in LDS ([C][256] floats, own column per thread: no bank
+// conflicts, no barrier); with one member they are compared as they are produced.  First maximum wins, as argmax does.
+__global__ __launch_bounds__(256) void feature_head_argmax_kernel(const float *__restrict__ facc, int64_t member_stride,
+                                                                  const float *__restrict__ nsum, const float *__restrict__ w,
+                                                                  const float *__restrict__ bsum, int M, int C, int64_t V,
+                                                                  int64_t *__restrict__ amax) {
+  extern __shared__ float part[];      // [C][256] when M > 1
+  const int tid = threadIdx.x;
+  for (int64_t v0 = (int64_t)blockIdx.x * 256; v0 < V; v0 += (int64_t)gridDim.x * 256) {
+    const int64_t v = v0 + tid < V ? v0 + tid : V - 1;      // (the tail repeats the last voxel: no divergent exit above LDS use)
+    const float n = nsum[v];
+    float best = -INFINITY;
+    int bi = 0;
+    for (int m = 0; m < M; ++m) {
+      float f[WF_CIN];
+      const float4 *src = reinterpret_cast<const float4 *>(facc + m * member_stride + v * WF_CIN);
+#pragma unroll
+      for (int k = 0; k < WF_CIN / 4; ++k) {
+        const float4 t = src[k];
+        f[4 * k] = t.x, f[4 * k + 1] = t.y, f[4 * k + 2] = t.z, f[4 * k + 3] = t.w;
+      }
+      const float *wm = w + (int64_t)m * C * WF_CIN;
+      for (int c = 0; c < C; ++c) {
+        // four independent FMA chains over the channels (a single chain of 32 waits for itself)
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll
+        for (int k = 0; k < WF_CIN; k += 4) {
+          s0 = fmaf(wm[c * WF_CIN + k], f[k], s0);
+          s1 = fmaf(wm[c * WF_CIN + k + 1], f[k + 1], s1);
+          s2 = fmaf(wm[c * WF_CIN + k + 2], f[k + 2], s2);
+          s3 = fmaf(wm[c * WF_CIN + k + 3], f[k + 3], s3);
+        }
+        float s = (s0 + s1) + (s2 + s3);
+        if (m == 0) s += n * bsum[c];
+        else s += part[c * 256 + tid];
+        if (m + 1 < M) {
+          part[c * 256 + tid] = s;
+        } else if (s > best) {
+          best = s;
+          bi = c;
+        }
+      }
+    }
+    if (v0 + tid < V) amax[v] = bi;
+  }
+}
+
+// Export path (original geometry): classes c0 .. c0 + cg - 1 of the normalised ensemble logits as doubles,
+// dst[x][y][z][j] = sum_m (W_m[c0 + j] . F_m(sv)) / n(sv) + bsum[c0 + j] - the input of the dgtta_resample_axis passes, as
+// dgtta_logits_chunk_f64 is for the logits-space accumulator (products and sums in double).
+__global__ void feature_logits_chunk_kernel(const float *__restrict__ facc, int64_t member_stride, const float *__restrict__ nsum,
+                                            const float *__restrict__ w, const float *__restrict__ bsum, double *__restrict__ dst,
+                                            int M, int C, int Y, int Z, int x0, int y0, int z0, int ys, int zs, int c0, int cg,
+                                            int64_t total) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int j = (int)(i % cg);
+  const int64_t v = i / cg;
+  const int z = (int)(v % zs), y = (int)((v / zs) % ys);
+  const int64_t x = v / ((int64_t)zs * ys);
+  const int64_t sv = ((x + x0) * Y + (y + y0)) * Z + (z + z0);
+  double s = 0.0;
+  for (int m = 0; m < M; ++m) {
+    const float *f = facc + m * member_stride + sv * WF_CIN;
+    const float *wr = w + ((int64_t)m * C + c0 + j) * WF_CIN;
+    for (int k = 0; k < WF_CIN; ++k) s += (double)wr[k] * (double)f[k];
+  }
+  dst[i] = s / (double)nsum[sv] + (double)bsum[c0 + j];
+}
+
+}  // namespace
+
+extern "C" int dgtta_feature_window_accumulate(const void *z, const float *gauss, float *facc, float *nsum, int Cin, int PD, int PH,
+                                               int PW, int X, int Y, int Z, int x0, int y0, int z0, int dtype, void *stream) {
+  DG_REQUIRE(z && gauss && facc, DGTTA_ERR_BADARG, "feature_window_accumulate: null pointer");
+  DG_REQUIRE(Cin == WF_CIN, DGTTA_ERR_UNSUPPORTED, "feature_window_accumulate: built for %d feature channels (got %d)", WF_CIN, Cin);
+  DG_REQUIRE(dtype == DGTTA_F32 || dtype == DGTTA_BF16 || dtype == DGTTA_F16, DGTTA_ERR_BADARG, "feature_window_accumulate: dtype %d", dtype);
+  DG_REQUIRE(PD > 0 && PH > 0 && PW > 0 && x0 >= 0 && y0 >= 0 && z0 >= 0 && x0 + PD <= X && y0 + PH <= Y && z0 + PW <= Z,
+             DGTTA_ERR_BADARG, "feature_window_accumulate: window outside the volume");
+  DG_REQUIRE(((uintptr_t)z & 15) == 0 && ((uintptr_t)facc & 15) == 0, DGTTA_ERR_BADARG, "feature_window_accumulate: unaligned buffer");
+  const int64_t total = (int64_t)PD * PH * PW * 8;
+  const int64_t nblk = cdiv64(total, 256);
+  DG_REQUIRE(nblk < (1ll << 31), DGTTA_ERR_UNSUPPORTED, "feature_window_accumulate: window too large");
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == DGTTA_F32)
+    hipLaunchKernelGGL(feature_accumulate_kernel<float>, dim3((unsigned)nblk), dim3(256), 0, st, (const float *)z, gauss, facc, nsum, PH,
+                       PW, Y, Z, x0, y0, z0, total);
+  else if (dtype == DGTTA_BF16)
+    hipLaunchKernelGGL(feature_accumulate_kernel<bf16_t>, dim3((unsigned)nblk), dim3(256), 0, st, (const bf16_t *)z, gauss, facc, nsum,
+                       PH, PW, Y, Z, x0, y0, z0, total);
+  else
+    hipLaunchKernelGGL(feature_accumulate_kernel<f16_t>, dim3((unsigned)nblk), dim3(256), 0, st, (const f16_t *)z, gauss, facc, nsum, PH,
+                       PW, Y, Z, x0, y0, z0, total);
+  DG_CHECK_LAUNCH("feature_accumulate_kernel");
+  return DGTTA_OK;
+}
+
+extern "C" int dgtta_feature_head_argmax(const float *facc, int64_t member_stride, const float *nsum, const float *w, const float *bsum,
+                                         int M, int Cin, int C, int64_t V, int64_t *argmax_out, void *stream) {
+  DG_REQUIRE(facc && nsum && w && bsum && argmax_out, DGTTA_ERR_BADARG, "feature_head_argmax: null pointer");
+  DG_REQUIRE(Cin == WF_CIN, DGTTA_ERR_UNSUPPORTED, "feature_head_argmax: built for %d feature channels (got %d)", WF_CIN, Cin);
+  DG_REQUIRE(M >= 1 && C >= 1 && V >= 1 && (M == 1 || member_stride >= V * WF_CIN), DGTTA_ERR_BADARG, "feature_head_argmax: bad sizes");
+  DG_REQUIRE(((uintptr_t)facc & 15) == 0 && (member_stride & 3) == 0, DGTTA_ERR_BADARG, "feature_head_argmax: unaligned accumulator");
+  const size_t lds = M > 1 ? (size_t)C * 256 * sizeof(float) : 0;
+  DG_REQUIRE(lds <= 160 * 1024, DGTTA_ERR_UNSUPPORTED, "feature_head_argmax: %d classes x several members exceed the LDS (<= 160)", C);
+  static DynLdsOnce once;
+  if (lds > 64 * 1024)
+    DG_REQUIRE(ensure_dyn_lds(once, (const void *)feature_head_argmax_kernel, 160 * 1024) == hipSuccess, DGTTA_ERR_LAUNCH,
+               "feature_head_argmax: cannot raise the dynamic LDS limit");
+  const int64_t nblk = cdiv64(V, 256);
+  const unsigned grid = (unsigned)(nblk < 8192 ? nblk : 8192);
+  hipLaunchKernelGGL(feature_head_argmax_kernel, dim3(grid), dim3(256), lds, (hipStream_t)stream, facc, member_stride, nsum, w, bsum, M, C,
+                     V, argmax_out);
+  DG_CHECK_LAUNCH("feature_head_argmax_kernel");
+  return DGTTA_OK;
+}
+
+extern "C" int dgtta_feature_logits_chunk_f64(const float *facc, int64_t member_stride, const float *nsum, const float *w,
+                                              const float *bsum, double *dst, int M, int Cin, int C, int X, int Y, int Z, int x0, int y0,
+                                              int z0, int xs, int ys, int zs, int c0, int cg, void *stream) {
+  DG_REQUIRE(facc && nsum && w && bsum && dst, DGTTA_ERR_BADARG, "feature_logits_chunk: null pointer");
+  DG_REQUIRE(Cin == WF_CIN, DGTTA_ERR_UNSUPPORTED, "feature_logits_chunk: built for %d feature channels (got %d)", WF_CIN, Cin);
+  DG_REQUIRE(M >= 1 && C > 0 && cg > 0 && c0 >= 0 && c0 + cg <= C, DGTTA_ERR_BADARG, "feature_logits_chunk: class range outside [0,%d)", C);
+  DG_REQUIRE(x0 >= 0 && y0 >= 0 && z0 >= 0 && xs > 0 && ys > 0 && zs > 0 && x0 + xs <= X && y0 + ys <= Y && z0 + zs <= Z, DGTTA_ERR_BADARG,
+             "feature_logits_chunk: crop outside the volume");
+  DG_REQUIRE(M == 1 || member_stride >= (int64_t)X * Y * Z * WF_CIN, DGTTA_ERR_BADARG, "feature_logits_chunk: member stride");
+  const int64_t total = (int64_t)xs * ys * zs * cg;
+  DG_REQUIRE(cdiv64(total, 256) < (1ll << 31), DGTTA_ERR_UNSUPPORTED, "feature_logits_chunk: too many values");
+  hipLaunchKernelGGL(feature_logits_chunk_kernel, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, (hipStream_t)stream, facc, member_stride,
+                     nsum, w, bsum, dst, M, C, Y, Z, x0, y0, z0, ys, zs, c0, cg, total);
+  DG_CHECK_LAUNCH("feature_logits_chunk_kernel");
+  return DGTTA_OK;
+}

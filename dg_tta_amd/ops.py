@@ -388,6 +388,24 @@ def argmax_dice(logits, labels=None):
     return am, counts
 
 
+def feature_head_argmax(facc, nsum, w, bsum):
+    """Label map of feature-space window accumulators (csrc/window_features.hip): facc [M,X,Y,Z,32] fp32, nsum [X,Y,Z], w [M,C,32],
+    bsum [C] = sum of the members' head biases -> int64 [X,Y,Z] = argmax_c sum_m (w[m,c] . facc[m,v]) + nsum[v] bsum[c]."""
+    if facc.dim() == 4:
+        facc, w = facc[None], (w[None] if w.dim() == 2 else w)
+    if not (facc.is_cuda and facc.dtype == torch.float32 and facc[0].is_contiguous() and facc.shape[-1] == 32):
+        raise ValueError("feature_head_argmax: fp32 GPU accumulators [M,X,Y,Z,32] expected")
+    M, C = facc.shape[0], w.shape[1]
+    if tuple(w.shape) != (M, C, 32) or tuple(bsum.shape) != (C,) or tuple(nsum.shape) != tuple(facc.shape[1:4]):
+        raise ValueError("feature_head_argmax: w [M,C,32], bsum [C], nsum [X,Y,Z] expected")
+    lib = _lib.load()
+    w, bsum, nsum = w.float().contiguous(), bsum.float().contiguous(), nsum.float().contiguous()
+    out = torch.empty(facc.shape[1:4], dtype=torch.int64, device=facc.device)
+    check(lib.dgtta_feature_head_argmax(ptr(facc), facc.stride(0) if M > 1 else 0, ptr(nsum), ptr(w), ptr(bsum), M, 32, C, out.numel(),
+                                        ptr(out), stream_of(facc.device)), "dgtta_feature_head_argmax")
+    return out
+
+
 def argmax_rows(acc):
     """Label map of a voxel-major accumulator [..., C] (fp32 or fp16, contiguous): argmax over the last axis, int64."""
     require_cuda(acc)

@@ -10,6 +10,12 @@ this stage is "parity unpinned" (checked against the CPU restatement in oracle/i
 in HBM for the whole volume (105 classes x 512^3 = 56 GB in fp32 fits the 288 GB of an MI355X); they are fp32 by default
 and fp16 - nnU-Net's storage type for `predicted_logits` - with DGTTA_WINDOW_ACC=fp16 or `acc_dtype=torch.float16` (sums
 still formed in fp32, rounded once per window: half the read-modify-write traffic).  `export_segmentation` takes the logits back to the case's original geometry.
+
+Round 5 - the FEATURE-space accumulator, what `predict_ensemble` / `run_inference` / `dgtta run_tta` use by default
+(DGTTA_WINDOW_ACC=features): the segmentation head is linear and last, so sum_w g_w (W z_w + b) = W (sum_w g_w z_w) + b sum_w g_w;
+the volume holds the 32 Gaussian-weighted feature channels the head reads (fp32: 16 GiB per member at 512^3 instead of 52.5 GiB of
+logits, 2.8x less read-modify-write traffic per window) and the head runs once per voxel, fused with the argmax over the ensemble
+(csrc/window_features.hip).  `predict_sliding_window_return_logits` / `predict_ensemble_logits` keep nnU-Net's logits-space form.
 """
 import numpy as np
 import torch
@@ -75,12 +81,18 @@ import os as _os
 WINDOW_BATCH = max(1, int(_os.environ.get("DGTTA_WINDOW_BATCH", "8")))      # measured at 512^3: 2 / 4 / 8 / 16 windows per pass = 3.26 / 3.14 / 3.07 / 3.03 ms per window
 
 
+def window_acc_mode():
+    """DGTTA_WINDOW_ACC = features (default: feature-space accumulator where the network offers it, else fp32 logits) | fp32 | fp16
+    (logits-space accumulator of that storage type)."""
+    v = _os.environ.get("DGTTA_WINDOW_ACC", "features").lower()
+    if v not in ("features", "fp32", "fp16"):
+        raise ValueError(f"DGTTA_WINDOW_ACC={v!r}: features, fp32 or fp16")
+    return v
+
+
 def window_acc_dtype():
-    """Storage type of the window accumulator: DGTTA_WINDOW_ACC = fp32 (default) | fp16."""
-    v = _os.environ.get("DGTTA_WINDOW_ACC", "fp32").lower()
-    if v not in ("fp32", "fp16"):
-        raise ValueError(f"DGTTA_WINDOW_ACC={v!r}: fp32 or fp16")
-    return torch.float32 if v == "fp32" else torch.float16
+    """Storage type of the LOGITS-space window accumulator: fp16 with DGTTA_WINDOW_ACC=fp16, else fp32."""
+    return torch.float16 if window_acc_mode() == "fp16" else torch.float32
 
 
 def _acc_code(acc):
@@ -100,16 +112,55 @@ def _num_classes(model):
 def _can_fuse_head_accumulate(model):
     """The head may write straight into the window accumulator when the network offers it and nothing stands between the
     head and the accumulation: every forward hook is the plan's untouched model-output modifier (identity)."""
-    from .config_log_utils import is_template_modifier
     m = _inner(model)
     if not hasattr(m, "can_fuse_window_accumulate") or not m.can_fuse_window_accumulate():
         return False
+    return _only_identity_output_hooks(m)
+
+
+def _only_identity_output_hooks(m):
+    from .config_log_utils import is_template_modifier
     for h in m._forward_hooks.values():
         cells = getattr(h, "__closure__", None) or ()
         fns = [c.cell_contents for c in cells if callable(c.cell_contents)]
         if len(fns) != 1 or not is_template_modifier(fns[0], "modfify_tta_model_output_fn"):
             return False
     return True
+
+
+def _can_accumulate_features(model):
+    """Feature-space accumulation needs the network's offer (head = 1x1x1 conv on 32 channels, nothing selected) and nothing
+    between the head and the accumulation: every forward hook is the plan's untouched model-output modifier (identity)."""
+    m = _inner(model)
+    return (hasattr(m, "can_fuse_window_feature_accumulate") and m.can_fuse_window_feature_accumulate() and
+            _only_identity_output_hooks(m))
+
+
+class WindowFeatures:
+    """Feature-space window accumulator of an ensemble: facc [M,X,Y,Z,32] (fp32, sum over windows of gauss * head input of member m),
+    nsum [X,Y,Z] (sum of the window Gaussians, shared), crop (slices back from the padding), w [M,C,32] / b [M,C] the members' head
+    weights.  The ensemble's accumulated logits - what predict_ensemble_logits returns as `acc` - are
+    sum_m (w[m] @ facc[m] + b[m] * nsum); they are never formed for the whole volume."""
+
+    def __init__(self, facc, nsum, crop, w, b):
+        self.facc, self.nsum, self.crop, self.w, self.b = facc, nsum, crop, w.contiguous(), b.contiguous()
+        self.bsum = b.sum(0).contiguous()
+
+    @property
+    def shape(self):
+        return (*self.facc.shape[1:4], self.w.shape[1])
+
+    def argmax(self):
+        """Label map [X,Y,Z] (int64, padded geometry): argmax over all classes of the ensemble logits, first maximum wins."""
+        return ops.feature_head_argmax(self.facc, self.nsum, self.w, self.bsum)
+
+    def logits(self):
+        """The accumulated ensemble logits [X,Y,Z,C] by torch (fp32) - for tests and small volumes only."""
+        M, X, Y, Z, K = self.facc.shape
+        out = (self.nsum[..., None] * self.bsum).float()
+        for m in range(M):
+            out = out + self.facc[m].reshape(-1, K).matmul(self.w[m].t()).reshape(X, Y, Z, -1)
+        return out
 
 
 @torch.no_grad()
@@ -168,6 +219,68 @@ def predict_sliding_window_return_logits(model, data, patch_size, acc=None, tile
 
 
 @torch.no_grad()
+def accumulate_window_features(model, data, patch_size, facc=None, tile_step_size=0.5):
+    """The feature-space form of predict_sliding_window_return_logits for one member: data [C,X,Y,Z] -> adds gauss * (the head's
+    input of every window) into facc [X,Y,Z,32] (fp32, GPU; allocated when None).  Returns (facc, nsum, crop)."""
+    m = _inner(model)
+    if not _can_accumulate_features(model):
+        raise RuntimeError("accumulate_window_features: the network does not offer the feature-space accumulation here")
+    dev = next(model.parameters()).device
+    data, crop = pad_to_patch(data.float(), patch_size)
+    data = data.to(dev)
+    X, Y, Z = data.shape[1:]
+    if facc is None:
+        facc = torch.zeros((X, Y, Z, 32), dtype=torch.float32, device=dev)
+    if tuple(facc.shape) != (X, Y, Z, 32) or facc.dtype != torch.float32 or not (facc.is_cuda and facc.is_contiguous()):
+        raise ValueError(f"facc must be a contiguous fp32 GPU tensor [{X},{Y},{Z},32]")
+    gauss = compute_gaussian(tuple(patch_size)).to(dev).contiguous()
+    steps = compute_steps_for_sliding_window((X, Y, Z), patch_size, tile_step_size)
+    nsum = torch.zeros((X, Y, Z), dtype=torch.float32, device=dev)
+    was_training = model.training
+    model.eval()
+    origins = [(sx, sy, sz) for sx in steps[0] for sy in steps[1] for sz in steps[2]]
+    for g0 in range(0, len(origins), WINDOW_BATCH):
+        group = origins[g0:g0 + WINDOW_BATCH]
+        work = torch.stack([data[:, sx:sx + patch_size[0], sy:sy + patch_size[1], sz:sz + patch_size[2]]
+                            for sx, sy, sz in group]).contiguous()
+        with mind_groups(model, len(group)), m.fuse_window_feature_accumulate(facc, nsum, gauss, group):
+            model(work)
+    model.train(was_training)
+    return facc, nsum, crop
+
+
+@torch.no_grad()
+def predict_ensemble_features(data, model, parameter_sets, patch_size):
+    """Feature-space accumulators of the whole ensemble for one preprocessed case (see WindowFeatures); one [X,Y,Z,32] fp32
+    volume per member, because the members' heads differ."""
+    if hasattr(model, "set_selected_classes"):
+        model.set_selected_classes(None)          # argmax runs over ALL pretrain classes, as in the reference
+    dev = next(model.parameters()).device
+    data = data.float().to(dev)      # one upload for all ensemble members
+    padded, _ = pad_to_patch(data[:1], patch_size)
+    facc = torch.zeros((len(parameter_sets), *padded.shape[1:], 32), dtype=torch.float32, device=dev)
+    del padded
+    ws, bs, nsum, crop = [], [], None, None
+    for k, params in enumerate(parameter_sets):
+        model.load_state_dict(params)
+        head = _inner(model).decoder.seg_layers[-1]
+        ws.append(head.weight.detach().reshape(head.out_channels, -1).float().clone())
+        bs.append(head.bias.detach().float().clone())
+        _, nsum, crop = accumulate_window_features(model, data, patch_size, facc[k])
+    return WindowFeatures(facc, nsum, crop, torch.stack(ws), torch.stack(bs))
+
+
+@torch.no_grad()
+def predict_ensemble(data, model, parameter_sets, patch_size):
+    """What run_inference / dgtta run_tta predict with: (acc, nsum, crop) for export_segmentation - acc a WindowFeatures when
+    DGTTA_WINDOW_ACC=features (default) and the network offers it, else the logits-space accumulator of predict_ensemble_logits."""
+    if window_acc_mode() == "features" and _can_accumulate_features(model):
+        feats = predict_ensemble_features(data, model, parameter_sets, patch_size)
+        return feats, feats.nsum, feats.crop
+    return predict_ensemble_logits(data, model, parameter_sets, patch_size)
+
+
+@torch.no_grad()
 def predict_ensemble_logits(data, model, parameter_sets, patch_size):
     """Window-accumulated logits of the whole ensemble for one preprocessed case: data [C,X,Y,Z] (image channel(s) only),
     parameter_sets: list of state dicts (the `*_tta_parameters.pt` contents).  Returns (acc [X,Y,Z,ncls] fp32 on the GPU =
@@ -188,7 +301,7 @@ def run_inference(data, model, parameter_sets, patch_size, label_mapping=None, o
     """Ensemble prediction of one preprocessed case in the PREPROCESSED geometry.  Returns the label map [X,Y,Z] (int64,
     CPU), mapped to the target ids when label_mapping/optimized_labels are given (tta.py:407-411)."""
     from .torch_utils import get_map_idxs
-    acc, nsum, crop = predict_ensemble_logits(data, model, parameter_sets, patch_size)
+    acc, nsum, crop = predict_ensemble(data, model, parameter_sets, patch_size)
     seg = torch.as_tensor(export_segmentation(acc, nsum, crop, None, None, None).astype(np.int64))
     if label_mapping is not None:
         seg = map_label(seg[None], get_map_idxs(label_mapping, optimized_labels, "pretrain_labels"), "argmaxed")[0]
@@ -221,17 +334,19 @@ def export_segmentation(acc, nsum, crop, properties, plans, configuration):
     group by class group with a running argmax, so the full-resolution 105-class volume never exists."""
     from .preprocessing import separate_z
     lib = _lib.load()
-    dev = acc.device
+    feats = acc if isinstance(acc, WindowFeatures) else None
+    dev = nsum.device
     X, Y, Z, C = acc.shape
     st = stream_of(dev)
+    label_map = (lambda: feats.argmax()) if feats is not None else (lambda: ops.argmax_rows(acc))
     cs = [(sl.start or 0, (sl.stop if sl.stop is not None else dim) - (sl.start or 0)) for sl, dim in zip(crop, (X, Y, Z))]
     (x0, xs), (y0, ys), (z0, zs) = cs
     cur_shape = [xs, ys, zs]
     if properties is None:
-        return ops.argmax_rows(acc)[tuple(crop)].cpu().numpy()
+        return label_map()[tuple(crop)].cpu().numpy()
     tgt_shape = [int(v) for v in properties["shape_after_cropping_and_before_resampling"]]
     if tgt_shape == cur_shape:
-        seg = ops.argmax_rows(acc)[tuple(crop)].cpu().numpy()
+        seg = label_map()[tuple(crop)].cpu().numpy()
     else:
         conf = _resolved_configuration(plans, configuration)
         cur_spacing = list(conf["spacing"])
@@ -248,8 +363,14 @@ def export_segmentation(acc, nsum, crop, properties, plans, configuration):
         for c0 in range(0, C, EXPORT_CLASS_GROUP):
             cg = min(EXPORT_CLASS_GROUP, C - c0)
             cur = torch.empty((xs, ys, zs, cg), dtype=torch.float64, device=dev)
-            check(lib.dgtta_logits_chunk_f64_t(ptr(acc), ptr(nsum), ptr(cur), C, X, Y, Z, x0, y0, z0, xs, ys, zs, c0, cg,
-                                               _acc_code(acc), st), "dgtta_logits_chunk_f64_t")
+            if feats is not None:
+                M = feats.facc.shape[0]
+                check(lib.dgtta_feature_logits_chunk_f64(ptr(feats.facc), feats.facc.stride(0), ptr(nsum), ptr(feats.w), ptr(feats.bsum),
+                                                         ptr(cur), M, 32, C, X, Y, Z, x0, y0, z0, xs, ys, zs, c0, cg, st),
+                      "dgtta_feature_logits_chunk_f64")
+            else:
+                check(lib.dgtta_logits_chunk_f64_t(ptr(acc), ptr(nsum), ptr(cur), C, X, Y, Z, x0, y0, z0, xs, ys, zs, c0, cg,
+                                                   _acc_code(acc), st), "dgtta_logits_chunk_f64_t")
             for ax in range(3):          # channels-last: the class group rides in `inner` of every pass
                 n, m = cur.shape[ax], tgt_shape[ax]
                 if n == m:

@@ -554,7 +554,7 @@ def _predict_case(case, config, network, predictor, patch_size, label_mapping, m
     transposed back, then written with the image's own header - the prediction is interchangeable with a reference run's
     and lines up with `labels{Ts,Tr}/<case>`, which is what it is evaluated against (tta.py:420-447).  Array cases
     (.npy/.npz/.pt: already preprocessed, no geometry) are written as they are."""
-    from .inference import export_segmentation, predict_ensemble_logits
+    from .inference import export_segmentation, predict_ensemble
     from .image_io import read_image as read_nifti
     from .torch_utils import get_imgs
     sample, sample_id, sub_dir_tta = case
@@ -572,7 +572,7 @@ def _predict_case(case, config, network, predictor, patch_size, label_mapping, m
     image = get_imgs(sample["data"].unsqueeze(0)).squeeze(0)
     props = sample.get("data_properties") or {}
     nii = props.get("nifti_header")
-    acc, nsum, crop = predict_ensemble_logits(image, model, params, patch_size)
+    acc, nsum, crop = predict_ensemble(image, model, params, patch_size)
     plans = getattr(predictor, "plans", None)
     original = nii is not None and plans is not None and "shape_before_cropping" in props
     seg = export_segmentation(acc, nsum, crop, props if original else None, plans, getattr(predictor, "configuration", None))

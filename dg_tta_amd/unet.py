@@ -223,6 +223,30 @@ class HipPlainConvUNet(nn.Module):
                 net._window_acc = None
         return _Ctx()
 
+    # -- the same in FEATURE space (round 5, csrc/window_features.hip): the head is linear and last, so the window accumulator
+    #    holds the Gaussian-weighted input of the head and the head runs once per voxel at the end
+    def can_fuse_window_feature_accumulate(self):
+        import os
+        return (os.environ.get("DGTTA_FUSE_HEAD_ACCUMULATE", "1") != "0" and self.selected_classes is None and
+                self.decoder.seg_layers[-1].in_channels == 32 and not torch.is_grad_enabled())
+
+    def fuse_window_feature_accumulate(self, facc, nsum, gauss, origins):
+        """Context (inference, no grad): the next forward adds gauss * z of window k of the batch - z = the 32 feature channels the
+        segmentation head reads - into facc [X,Y,Z,32] (fp32) / nsum [X,Y,Z] at origins[k]; the head is NOT evaluated (the forward
+        returns an empty placeholder).  Label map: ops.feature_head_argmax with the members' head weights."""
+        net = self
+        if not (facc.dtype == torch.float32 and facc.is_contiguous() and facc.shape[-1] == 32 and nsum.dtype == torch.float32 and
+                gauss.dtype == torch.float32):
+            raise ValueError("fuse_window_feature_accumulate: contiguous fp32 accumulator [X,Y,Z,32], fp32 weight sum and Gaussian expected")
+
+        class _Ctx:
+            def __enter__(self_):
+                net._window_acc = (facc, nsum, gauss, list(origins), "features")
+
+            def __exit__(self_, *exc):
+                net._window_acc = None
+        return _Ctx()
+
     def forward(self, x):
         sel = self.selected_classes
         if sel is not None and sel.device != x.device:
@@ -398,8 +422,14 @@ class _UNetFn(torch.autograd.Function):
         wa = net._window_acc
         if wa is not None:
             assert not need_grad and sel is None and ldu == head.in_channels and len(wa[3]) == B, "fuse_window_accumulate: misuse"
-            acc, nsum, gauss, origins = wa
+            acc, nsum, gauss, origins = wa[:4]
             X, Y, Z = acc.shape[:3]
+            if len(wa) > 4:      # feature space: no head here
+                for k, (sx, sy, sz) in enumerate(origins):
+                    check(lib.dgtta_feature_window_accumulate(u_ptr + k * V * ldu * esz, ptr(gauss), ptr(acc), ptr(nsum),
+                                                              head.in_channels, D, H, W, X, Y, Z, sx, sy, sz, dt, st),
+                          "dgtta_feature_window_accumulate")
+                return torch.empty((B, 0, D, H, W), dtype=torch.float32, device=dev)
             for k, (sx, sy, sz) in enumerate(origins):      # overlapping windows: accumulated one after the other
                 check(lib.dgtta_seghead_window_accumulate_t(u_ptr + k * V * ldu * esz, ptr(head.weight), ptr(head.bias),
                                                             ptr(gauss), ptr(acc), ptr(nsum), head.in_channels, ncls, D, H, W, X,

@@ -334,6 +334,26 @@ int dgtta_argmax_merge_f64(const double *vals, int64_t V, int cg, int c0, double
 int dgtta_logits_chunk_f64_t(const void *acc, const float *nsum, double *dst, int C, int X, int Y, int Z, int x0, int y0,
                              int z0, int xs, int ys, int zs, int c0, int cg, int acc_dtype, void *stream);
 
+/* Sliding-window accumulation in FEATURE space (round 5).  The segmentation head is a 1x1x1 convolution and the last layer of the
+ * network, so sum_w g_w (W z_w + b) = W (sum_w g_w z_w) + b sum_w g_w: the volume accumulator holds the 32 Gaussian-weighted feature
+ * channels of the last decoder block (128 B per voxel instead of 420 B for 105 fp32 logits; 16 GiB instead of 52.5 GiB at 512^3) and
+ * the head runs once per voxel at the end.  Replaces, for the label map the reference writes (dg_tta/tta/tta.py:404-413), the
+ * accumulate / average / argmax chain of nnunetv2==2.2.1 predict_sliding_window_return_logits + predict_logits_from_preprocessed_data
+ * (reached from dg_tta/tta/nnunet_utils.py:116-125, 208-230); sums are re-associated in fp32 (labels can differ at float ties).
+ * dgtta_feature_window_accumulate: facc[(x0.., y0.., z0..)][k] += gauss[p] * z[p][k], nsum[..] += gauss[p] for one window;
+ *   z [PD][PH][PW][Cin = 32] in `dtype` storage (DGTTA_F32 / BF16 / F16), facc [X][Y][Z][32] fp32, nsum [X][Y][Z] fp32 or NULL.
+ * dgtta_feature_head_argmax: argmax_out[v] = argmax_c sum_m (w[m][c] . facc[m][v]) + nsum[v] * bsum[c] over V voxels; facc member m
+ *   starts at facc + m * member_stride (floats), w [M][C][32], bsum [C] = sum over members of the head biases.  First maximum wins.
+ * dgtta_feature_logits_chunk_f64: the export path's class chunk (see dgtta_logits_chunk_f64) evaluated from the features in double:
+ *   dst[x][y][z][j] = sum_m (w[m][c0 + j] . facc[m][sv]) / nsum[sv] + bsum[c0 + j]. */
+int dgtta_feature_window_accumulate(const void *z, const float *gauss, float *facc, float *nsum, int Cin, int PD, int PH, int PW, int X,
+                                    int Y, int Z, int x0, int y0, int z0, int dtype, void *stream);
+int dgtta_feature_head_argmax(const float *facc, int64_t member_stride, const float *nsum, const float *w, const float *bsum, int M,
+                              int Cin, int C, int64_t V, int64_t *argmax_out, void *stream);
+int dgtta_feature_logits_chunk_f64(const float *facc, int64_t member_stride, const float *nsum, const float *w, const float *bsum,
+                                   double *dst, int M, int Cin, int C, int X, int Y, int Z, int x0, int y0, int z0, int xs, int ys,
+                                   int zs, int c0, int cg, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -56,13 +56,20 @@ def test_window_accumulator_storage_switch(monkeypatch):
                                              acc_dtype=torch.float16)
 
 
+# a net whose head reads 32 channels: the product then accumulates FEATURES and runs the head once per voxel (round 5)
+FEAT32_CFG = dict(features=(32, 40), strides=(1, 2), n_conv_enc=(2, 2), n_conv_dec=(2,), in_channels=12, num_classes=9)
+
+
 @pytest.mark.gpu
-def test_ensemble_sliding_window_matches_cpu_restatement(tmp_path):
+@pytest.mark.parametrize("cfg_name", ["small", "feat32"])
+def test_ensemble_sliding_window_matches_cpu_restatement(tmp_path, cfg_name):
     from conftest import SMALL_CFG
     from dg_tta_amd.mind import MIND3D
+    from dg_tta_amd.tta import inference as pinf
     from dg_tta_amd.tta.inference import run_inference
     from dg_tta_amd.unet import HipPlainConvUNet
     from oracle import inference as oinf, mind as omind, unet as ounet
+    SMALL_CFG = SMALL_CFG if cfg_name == "small" else FEAT32_CFG
     torch.manual_seed(0)
     data = torch.randn(1, 40, 36, 44)
     patch = [16, 16, 16]
@@ -74,8 +81,14 @@ def test_ensemble_sliding_window_matches_cpu_restatement(tmp_path):
     ref = oinf.ensemble_logits(cpu_models, data, patch)
     net = HipPlainConvUNet(SMALL_CFG, conv_impl=1).to(DEV)
     net.register_forward_pre_hook(lambda mod, inp: MIND3D(randn_weighting=0.0).forward(*inp))
+    with torch.no_grad():
+        assert pinf._can_accumulate_features(net) == (cfg_name == "feat32")
     seg = run_inference(data, net, [m.state_dict() for m in members], patch)
     assert tuple(seg.shape) == (40, 36, 44) and seg.dtype == torch.int64
+    if cfg_name == "feat32":               # the accumulated ensemble logits themselves, re-formed from the features
+        feats = pinf.predict_ensemble_features(data, net, [m.state_dict() for m in members], patch)
+        got = (feats.logits() / feats.nsum[..., None] / len(members))[tuple(feats.crop)].permute(3, 0, 1, 2).cpu()
+        assert float((got - ref).abs().max()) < 2e-4 * float(ref.abs().max())
     ref_seg = ref.argmax(0)
     top2 = ref.topk(2, dim=0).values
     safe = (top2[0] - top2[1]) > 1e-3
@@ -177,6 +190,7 @@ def test_sliding_window_512_full_size_properties():
     lmax = float((acc[sl].abs().amax(-1) / nsum[sl]).max())
     # (a window's own logits may exceed the blended ones that lmax is taken from: factor 4 on the rounding bound of 8 windows)
     safe = (top2[..., 0] - top2[..., 1]) > 2 * 4 * 8 * 2.0 ** -11 * lmax * nsum[sl]
+    safe_f = (top2[..., 0] - top2[..., 1]) > 1e-4 * lmax * nsum[sl]        # fp32 sums of 8 + 32 terms re-associated: ~1e-6
     seg32 = seg[sl].clone()
     del acc, seg, top2
     torch.cuda.empty_cache()
@@ -184,6 +198,17 @@ def test_sliding_window_512_full_size_properties():
     assert acc16.dtype == torch.float16 and torch.equal(nsum16, nsum)
     seg16 = ops.argmax_rows(acc16)[sl]
     assert torch.equal(seg16[safe], seg32[safe]) and float((seg16 == seg32).float().mean()) > 0.99 and float(safe.float().mean()) > 0.3
+    del acc16, seg16
+    torch.cuda.empty_cache()
+    # round 5: the feature-space accumulator (16 GiB instead of 52.5): same weight map, same labels outside float ties
+    from dg_tta_amd.tta.inference import WindowFeatures, accumulate_window_features
+    facc, nsum_f, crop_f = accumulate_window_features(net, vol, patch)
+    assert tuple(facc.shape) == (n, n, n, 32) and torch.equal(nsum_f, nsum)
+    head = net.decoder.seg_layers[-1]
+    feats = WindowFeatures(facc[None], nsum_f, crop_f, head.weight.detach().reshape(1, 105, 32).float(), head.bias.detach().float()[None])
+    seg_f = feats.argmax()[sl]
+    assert torch.equal(seg_f[safe_f], seg32[safe_f]) and float(safe_f.float().mean()) > 0.9
+    assert float((seg_f == seg32).float().mean()) > 0.9999
 
 
 @pytest.mark.gpu
@@ -315,3 +340,123 @@ def test_head_fused_with_the_window_accumulation_is_bit_identical(dtype, acc_dty
     monkeypatch.setenv("DGTTA_FUSE_HEAD_ACCUMULATE", "1")
     with torch.no_grad():
         assert not _can_fuse_head_accumulate(other)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dts", ["fp32", "bf16", "fp16"])
+def test_feature_window_accumulate_kernel(dts):
+    """dgtta_feature_window_accumulate against torch: overlapping windows of one batch, ragged volume, every storage type of
+    the features; the accumulated Gaussian sums alongside."""
+    from dg_tta_amd import _lib
+    from dg_tta_amd._lib import check, ptr, stream_of
+    lib = _lib.load()
+    dt, tdt = {"fp32": (0, torch.float32), "bf16": (1, torch.bfloat16), "fp16": (2, torch.float16)}[dts]
+    torch.manual_seed(4)
+    P, (X, Y, Z) = (8, 12, 20), (13, 19, 37)
+    gauss = torch.rand(P, device=DEV) + 0.1
+    origins = [(0, 0, 0), (5, 7, 0), (5, 7, 10), (3, 2, 17)]
+    z = torch.randn(len(origins), *P, 32, device=DEV).to(tdt)
+    facc = torch.randn(X, Y, Z, 32, device=DEV)
+    nsum = torch.rand(X, Y, Z, device=DEV)
+    ref_f, ref_n = facc.clone(), nsum.clone()
+    for k, (sx, sy, sz) in enumerate(origins):
+        check(lib.dgtta_feature_window_accumulate(ptr(z[k]), ptr(gauss), ptr(facc), ptr(nsum), 32, *P, X, Y, Z, sx, sy, sz, dt,
+                                                  stream_of()), "dgtta_feature_window_accumulate")
+        ref_f[sx:sx + P[0], sy:sy + P[1], sz:sz + P[2]] += gauss[..., None] * z[k].float()
+        ref_n[sx:sx + P[0], sy:sy + P[1], sz:sz + P[2]] += gauss
+    torch.cuda.synchronize()
+    assert torch.equal(facc, ref_f) and torch.equal(nsum, ref_n)        # one rounded product, one addition: the same bits
+    with pytest.raises(RuntimeError):
+        check(lib.dgtta_feature_window_accumulate(ptr(z[0]), ptr(gauss), ptr(facc), ptr(nsum), 32, *P, X, Y, Z, 6, 0, 0, dt, stream_of()), "x")
+    with pytest.raises(RuntimeError):
+        check(lib.dgtta_feature_window_accumulate(ptr(z[0]), ptr(gauss), ptr(facc), ptr(nsum), 16, *P, X, Y, Z, 0, 0, 0, dt, stream_of()), "x")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,C,V", [(1, 105, 64 * 40 + 17), (3, 105, 5000), (2, 118, 777), (4, 7, 300), (1, 2, 255), (5, 150, 513)])
+def test_feature_head_argmax_and_logits_chunk(M, C, V):
+    """The head applied to the feature accumulators of M members, fused with the argmax (first maximum wins), and the export
+    path's class chunks in double - against torch on the same numbers."""
+    from dg_tta_amd import _lib, ops
+    from dg_tta_amd._lib import check, ptr, stream_of
+    lib = _lib.load()
+    torch.manual_seed(M * 1000 + C)
+    X, Y, Z = 1, 1, V
+    facc = torch.randn(M, X, Y, Z, 32, device=DEV)
+    nsum = torch.rand(X, Y, Z, device=DEV) + 0.5
+    w = torch.randn(M, C, 32, device=DEV)
+    b = torch.randn(M, C, device=DEV)
+    facc[:, 0, 0, 5] = 0.0                    # a voxel whose classes tie up to the bias ...
+    if C > 3:
+        b[:, 3] = b[:, 0]                     # ... and two identical classes: the lower id wins
+        w[:, 3] = w[:, 0]
+    bsum = b.sum(0)
+    seg = ops.feature_head_argmax(facc, nsum, w, bsum)
+    ref = (torch.einsum("mvk,mck->vc", facc.reshape(M, V, 32).double(), w.double()) + nsum.reshape(V, 1).double() * bsum.double())
+    am = ref.argmax(1)
+    top2 = ref.topk(2, dim=1).values
+    safe = (top2[:, 0] - top2[:, 1]) > 1e-4 * ref.abs().amax(1)
+    got = seg.reshape(V)
+    assert torch.equal(got[safe], am[safe]) and float(safe.float().mean()) > 0.9
+    if C > 3:
+        assert int((got == 3).sum()) == 0        # classes 0 and 3 are identical: the first one is reported
+    # export chunk: normalised ensemble logits in double
+    c0, cg = (C // 2, min(8, C - C // 2))
+    dst = torch.empty(V, cg, dtype=torch.float64, device=DEV)
+    check(lib.dgtta_feature_logits_chunk_f64(ptr(facc), facc.stride(0), ptr(nsum), ptr(w), ptr(bsum), ptr(dst), M, 32, C, X, Y, Z, 0, 0, 0,
+                                             X, Y, Z, c0, cg, stream_of()), "dgtta_feature_logits_chunk_f64")
+    ref_c = (ref / nsum.reshape(V, 1).double())[:, c0:c0 + cg]
+    assert float((dst - ref_c).abs().max()) < 1e-10 * float(ref_c.abs().max()) + 1e-12
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_feature_space_accumulator_against_logits_space_on_the_full_net(dtype, monkeypatch):
+    """Round 5: run_inference through the feature-space accumulator (the default) against the logits-space one
+    (DGTTA_WINDOW_ACC=fp32) on the full 3d_fullres net, through the plan's model-output hook, overlapping windows and a ragged
+    last step, an ensemble of two members with different heads: the same feature maps enter both (same MIND draws), so the
+    accumulated logits differ by the re-association of fp32 sums only, and the label maps agree outside float ties."""
+    from types import SimpleNamespace
+    from dg_tta_amd.mind import mind_hook
+    from dg_tta_amd.synthetic import he_init_
+    from dg_tta_amd.tta import inference as pinf
+    from dg_tta_amd.tta.config_log_utils import ModifierFunctions
+    from dg_tta_amd.tta.model_utils import get_model_from_network
+    from dg_tta_amd.unet import HipPlainConvUNet
+    net = he_init_(HipPlainConvUNet(act_dtype=dtype), seed=7)
+    net.decoder.seg_layers[-1].bias.data.normal_()
+    net.register_forward_pre_hook(mind_hook)
+    model = get_model_from_network(net, SimpleNamespace(ModifierFunctions=ModifierFunctions), None).to(DEV)
+    second = {k: v.clone() for k, v in model.state_dict().items()}
+    for k in second:
+        if "seg_layers" in k:
+            second[k] = second[k] + 0.05 * torch.randn_like(second[k])
+    params = [model.state_dict(), second]
+    params = [{k: v.clone() for k, v in p.items()} for p in params]
+    torch.manual_seed(2)
+    vol = torch.randn(1, 96, 64, 150)
+    patch = [64, 64, 64]
+    with torch.no_grad():
+        assert pinf._can_accumulate_features(model)
+    monkeypatch.delenv("DGTTA_WINDOW_ACC", raising=False)
+    torch.manual_seed(9)
+    acc_f, nsum_f, crop = pinf.predict_ensemble(vol, model, params, patch)
+    assert isinstance(acc_f, pinf.WindowFeatures) and tuple(acc_f.facc.shape) == (2, 96, 64, 150, 32)
+    seg_f = torch.as_tensor(pinf.export_segmentation(acc_f, nsum_f, crop, None, None, None))
+    monkeypatch.setenv("DGTTA_WINDOW_ACC", "fp32")
+    torch.manual_seed(9)
+    acc_l, nsum_l, _ = pinf.predict_ensemble(vol, model, params, patch)
+    assert torch.is_tensor(acc_l) and tuple(acc_l.shape) == (96, 64, 150, 105)
+    seg_l = torch.as_tensor(pinf.export_segmentation(acc_l, nsum_l, crop, None, None, None))
+    assert torch.equal(nsum_f, nsum_l)
+    lf = acc_f.logits()
+    scale = float(acc_l.abs().max())
+    assert float((lf - acc_l).abs().max()) < 3e-5 * scale            # fp32 sums of 32 + 8 terms in another order
+    top2 = acc_l.topk(2, dim=-1).values
+    safe = ((top2[..., 0] - top2[..., 1]) > 1e-4 * scale).cpu()
+    assert torch.equal(seg_f[safe], seg_l[safe]) and float(safe.float().mean()) > 0.5
+    assert float((seg_f == seg_l).float().mean()) > 0.9999 and len(seg_f.unique()) > 10
+    # run_inference takes the same route
+    monkeypatch.delenv("DGTTA_WINDOW_ACC", raising=False)
+    torch.manual_seed(9)
+    assert torch.equal(pinf.run_inference(vol, model, params, patch), seg_f.long())

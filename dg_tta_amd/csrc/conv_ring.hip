@@ -62,6 +62,17 @@ struct RingCfgT {
 typedef RingCfgT<1> RingCfg;
 static_assert(RingCfgT<2>::LDS_BYTES <= 160 * 1024 && RingCfgT<1>::LDS_BYTES <= 160 * 1024, "ring does not fit the LDS");
 
+// scheduling pattern of one input row: NM MFMAs with NR LDS reads dealt out behind the first ones, an MFMA first
+template <int NM, int NR>
+__device__ __forceinline__ void ring_sched_interleave() {
+  if constexpr (NM > 0) {
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+    constexpr int r = NR > 0 ? 1 : 0;
+    if constexpr (r > 0) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+    ring_sched_interleave<NM - 1, NR - r>();
+  }
+}
+
 template <typename T16>
 __device__ __forceinline__ void mfma16(const uint4 &a, const uint4 &b, f32x4_t &acc);
 template <>
@@ -451,8 +462,10 @@ __global__ __launch_bounds__(RingCfgT<KH>::NT) void conv3_ring_kernel(const bf16
           lds_barrier();
           stamp(2);
         }
-        if (rs + 1 < 16) load_row(rs + 1, kkv, fr[(rs + 1) & 1]);
-        __builtin_amdgcn_sched_barrier(0);
+        // the row's DMA piece (wave-uniform branches) first; then ONE basic block: the six (twelve) fragment reads of row rs + 1
+        // dealt out BETWEEN the MFMAs of row rs.  Round 5: with the reads in front of the MFMAs and the DMA between them, a wave
+        // issued no MFMA for ~150 cycles per row - hidden by the SIMD's second wave with 32 input channels, plain idle time of
+        // the matrix pipe with 64 (one wave per SIMD): profiles/r05_ab.txt.
         if (DMA0 >= 0 && more) {
           if (ABL == 3) {
             if (rs == DMA0) mark_nxt = issue_group(prn, 2 * k + 4);
@@ -463,6 +476,8 @@ __global__ __launch_bounds__(RingCfgT<KH>::NT) void conv3_ring_kernel(const bf16
         }
         if (GST && rs == 8) load_gy(k, 0);
         if (GST && rs == 12) load_gy(k, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (rs + 1 < 16) load_row(rs + 1, kkv, fr[(rs + 1) & 1]);
 #pragma unroll
         for (int kw = 0; kw < 3; ++kw)
 #pragma unroll
@@ -478,6 +493,12 @@ __global__ __launch_bounds__(RingCfgT<KH>::NT) void conv3_ring_kernel(const bf16
                     mfma16<T16>(wreg[kq][(kd * 3 + kh) * 3 + kw], fr[rs & 1][(kw * 2 + hf) * KH + kq], acc[od][oh][hf]);
                 }
               }
+        if (rs + 1 < 16) {
+          const int nm = ((dz == 1 || dz == 2) ? 2 : 1) * ((hy == 1 || hy == 2) ? 2 : 1);      // output rows this input row feeds
+          if (nm == 1) ring_sched_interleave<6 * KH, 6 * KH>();
+          else if (nm == 2) ring_sched_interleave<12 * KH, 6 * KH>();
+          else ring_sched_interleave<24 * KH, 6 * KH>();
+        }
         __builtin_amdgcn_sched_barrier(0);
         if (rs == 15) stamp(3);
         if (rs == 10 || rs == 11 || rs == 14 || rs == 15) epilogue_row(k, (rs >> 2) - 2, (rs & 3) - 2);

@@ -1468,8 +1468,9 @@ extern "C" size_t dgtta_instnorm_ws_bytes(int B, int C, int64_t V) {
 extern "C" int dgtta_instnorm_lrelu_fwd(const void *y, int ldy, const void *stats, const float *gamma, const float *beta,
                                         float *mean_rstd, void *z, int ldz, void *ws, size_t ws_bytes, int B, int C,
                                         int64_t V, float eps, float slope, int dtype, void *stream) {
-  DG_REQUIRE(y && gamma && beta && mean_rstd && z && ws, DGTTA_ERR_BADARG, "instnorm_lrelu_fwd: null pointer");
-  DG_REQUIRE(B > 0 && C > 0 && V > 0 && ldy >= C && ldz >= C, DGTTA_ERR_BADARG, "instnorm_lrelu_fwd: bad dims");
+  // z == NULL (round 5): the statistics only - the caller applies them itself (dgtta_feature_window_accumulate_norm)
+  DG_REQUIRE(y && gamma && beta && mean_rstd && ws, DGTTA_ERR_BADARG, "instnorm_lrelu_fwd: null pointer");
+  DG_REQUIRE(B > 0 && C > 0 && V > 0 && ldy >= C && (!z || ldz >= C), DGTTA_ERR_BADARG, "instnorm_lrelu_fwd: bad dims");
   DG_REQUIRE(ws_bytes >= dgtta_instnorm_ws_bytes(B, C, V), DGTTA_ERR_WORKSPACE, "instnorm_lrelu_fwd: workspace too small");
   hipStream_t st = (hipStream_t)stream;
   const int nblk = reduce_blocks(V, B);
@@ -1484,6 +1485,7 @@ extern "C" int dgtta_instnorm_lrelu_fwd(const void *y, int ldy, const void *stat
                        (const long long *)nullptr, nblk, B, C, V, eps, mean_rstd);
   }
   DG_CHECK_LAUNCH("in_stats_finalize_kernel");
+  if (!z) return DGTTA_OK;
   const int64_t total = (int64_t)B * V * C;
   const int esz = dtype == DGTTA_F32 ? 4 : 2, epv = 16 / esz;
   if (C % epv == 0 && ldy % epv == 0 && ldz % epv == 0 && !((uintptr_t)y & 15) && !((uintptr_t)z & 15) && C <= 2048) {

@@ -71,6 +71,54 @@ __global__ __launch_bounds__(256) void feature_accumulate_kernel(const T *__rest
   if (q == 0 && nsum) nsum[v] += g;
 }
 
+// value -> storage type T and back (what the network's apply pass writes and the head would read)
+template <typename T>
+__device__ __forceinline__ float wf_round(float v);
+template <>
+__device__ __forceinline__ float wf_round<float>(float v) { return v; }
+template <>
+__device__ __forceinline__ float wf_round<bf16_t>(float v) { return bf16_to_f32(f32_to_bf16(v)); }
+template <>
+__device__ __forceinline__ float wf_round<f16_t>(float v) { return f16_to_f32(f32_to_f16(v)); }
+
+// The same with the last block's InstanceNorm + LeakyReLU apply folded in: z = round_T(lrelu(y * alpha + beta')) is formed from the
+// raw conv output y in registers (alpha = rstd * gamma, beta' = beta - mean * alpha: the arithmetic of in_apply_vec_kernel, so the
+// SAME z values) and never written - the apply pass (read y, write z) and the read of z disappear for the layer in front of the
+// head: 64 + 256 B per voxel instead of 128 + 320.  No backward exists in inference, so nothing else needs that z.
+template <typename T>
+__global__ __launch_bounds__(256) void feature_accumulate_norm_kernel(const T *__restrict__ y, const float *__restrict__ mean_rstd,
+                                                                      const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                                      float slope, const float *__restrict__ gauss,
+                                                                      float *__restrict__ facc, float *__restrict__ nsum, int PH, int PW,
+                                                                      int Y, int Z, int x0, int y0, int z0, int64_t total) {
+  __shared__ float sal[WF_CIN], sbe[WF_CIN];      // the window's per-channel constants, once per workgroup
+  if (threadIdx.x < WF_CIN) {
+    const int c = threadIdx.x;
+    const float al = mean_rstd[c * 2 + 1] * gamma[c];
+    sal[c] = al;
+    sbe[c] = beta[c] - mean_rstd[c * 2] * al;
+  }
+  __syncthreads();
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int q = (int)(i & 7);
+  const int64_t p = i >> 3;
+  const int pw = (int)(p % PW), ph = (int)((p / PW) % PH);
+  const int64_t pd = p / ((int64_t)PW * PH);
+  const int64_t v = ((pd + x0) * Y + (ph + y0)) * Z + (pw + z0);
+  const float g = gauss[p];
+  float f[4];
+  wf_load4<T>(y + p * WF_CIN + q * 4, f);
+  float4 *dst = reinterpret_cast<float4 *>(facc + v * WF_CIN + q * 4);
+  float4 a = *dst;
+  float zz[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) zz[e] = wf_round<T>(lrelu(f[e] * sal[q * 4 + e] + sbe[q * 4 + e], slope));
+  a.x += g * zz[0], a.y += g * zz[1], a.z += g * zz[2], a.w += g * zz[3];
+  *dst = a;
+  if (q == 0 && nsum) nsum[v] += g;
+}
+
 // Label map from the members' feature accumulators: argmax_c sum_m (W_m[c] . F_m(v)) + n(v) bsum[c], bsum = sum_m b_m (formed
 // by the caller).  One thread per voxel; a member's 32 features sit in registers, the weights are wave-uniform (scalar
 // loads).  With several members the classes' partial sums wait in LDS ([C][256] floats, own column per thread: no bank
@@ -167,6 +215,30 @@ extern "C" int dgtta_feature_window_accumulate(const void *z, const float *gauss
     hipLaunchKernelGGL(feature_accumulate_kernel<f16_t>, dim3((unsigned)nblk), dim3(256), 0, st, (const f16_t *)z, gauss, facc, nsum, PH,
                        PW, Y, Z, x0, y0, z0, total);
   DG_CHECK_LAUNCH("feature_accumulate_kernel");
+  return DGTTA_OK;
+}
+
+extern "C" int dgtta_feature_window_accumulate_norm(const void *y, const float *mean_rstd, const float *gamma, const float *beta, float slope,
+                                                    const float *gauss, float *facc, float *nsum, int Cin, int PD, int PH, int PW, int X,
+                                                    int Y, int Z, int x0, int y0, int z0, int dtype, void *stream) {
+  DG_REQUIRE(y && mean_rstd && gamma && beta && gauss && facc, DGTTA_ERR_BADARG, "feature_window_accumulate_norm: null pointer");
+  DG_REQUIRE(Cin == WF_CIN, DGTTA_ERR_UNSUPPORTED, "feature_window_accumulate_norm: built for %d feature channels (got %d)", WF_CIN, Cin);
+  DG_REQUIRE(dtype == DGTTA_F32 || dtype == DGTTA_BF16 || dtype == DGTTA_F16, DGTTA_ERR_BADARG, "feature_window_accumulate_norm: dtype %d", dtype);
+  DG_REQUIRE(PD > 0 && PH > 0 && PW > 0 && x0 >= 0 && y0 >= 0 && z0 >= 0 && x0 + PD <= X && y0 + PH <= Y && z0 + PW <= Z,
+             DGTTA_ERR_BADARG, "feature_window_accumulate_norm: window outside the volume");
+  DG_REQUIRE(((uintptr_t)y & 15) == 0 && ((uintptr_t)facc & 15) == 0, DGTTA_ERR_BADARG, "feature_window_accumulate_norm: unaligned buffer");
+  const int64_t total = (int64_t)PD * PH * PW * 8;
+  const int64_t nblk = cdiv64(total, 256);
+  DG_REQUIRE(nblk < (1ll << 31), DGTTA_ERR_UNSUPPORTED, "feature_window_accumulate_norm: window too large");
+  hipStream_t st = (hipStream_t)stream;
+#define WF_LAUNCH(T)                                                                                                              \
+  hipLaunchKernelGGL(feature_accumulate_norm_kernel<T>, dim3((unsigned)nblk), dim3(256), 0, st, (const T *)y, mean_rstd, gamma, beta, \
+                     slope, gauss, facc, nsum, PH, PW, Y, Z, x0, y0, z0, total)
+  if (dtype == DGTTA_F32) WF_LAUNCH(float);
+  else if (dtype == DGTTA_BF16) WF_LAUNCH(bf16_t);
+  else WF_LAUNCH(f16_t);
+#undef WF_LAUNCH
+  DG_CHECK_LAUNCH("feature_accumulate_norm_kernel");
   return DGTTA_OK;
 }
 

@@ -12,6 +12,8 @@ Data layout in HBM: activations are channels-last [B][D][H][W][C] (fp32, or bf16
 """
 import ctypes as C
 
+import os
+
 import torch
 from torch import nn
 
@@ -331,8 +333,9 @@ class _UNetFn(torch.autograd.Function):
                 ws_cache["ws"] = t
             return t
 
-        def run_block(blk_mod, u, ldu, cin, dims_in, z_out=None, ldz=None, where=None):
-            """conv -> IN -> lrelu. u: tensor whose data_ptr()+offset is the input; returns (z, ldz, dims_out, rec)."""
+        def run_block(blk_mod, u, ldu, cin, dims_in, z_out=None, ldz=None, where=None, stats_only=False):
+            """conv -> IN -> lrelu. u: tensor whose data_ptr()+offset is the input; returns (z, ldz, dims_out, rec).
+            stats_only: the InstanceNorm statistics are finalised but not applied (z is not written; rec carries y and mr)."""
             conv, norm = blk_mod.conv, blk_mod.norm
             s = conv.stride
             cout = conv.out_channels
@@ -358,7 +361,9 @@ class _UNetFn(torch.autograd.Function):
                 pr.update(cin=cin, cout=cout, vout=do * ho * wo, batch=B)
             v = do * ho * wo
             mr = torch.empty((B, cout, 2), dtype=torch.float32, device=dev)
-            if z_out is None:
+            if stats_only:
+                zt, zp, ldz_ = None, None, cout
+            elif z_out is None:
                 zt = torch.empty((B, do, ho, wo, cout), dtype=adt, device=dev)
                 zp, ldz_ = zt.data_ptr(), cout
             else:
@@ -372,6 +377,9 @@ class _UNetFn(torch.autograd.Function):
             return zp, ldz_, (do, ho, wo), rec, zt
 
         esz = 4 if dt == F32 else 2
+        wa = net._window_acc
+        feat_fold = (wa is not None and len(wa) > 4 and not need_grad and os.environ.get("DGTTA_FEATURE_FOLD", "1") != "0" and
+                     net.decoder.seg_layers[-1].in_channels == cfg["features"][0] == 32)
         # ---- encoder
         dims = (D, H, W)
         u_ptr, ldu, cin = xin.data_ptr(), cin0p, cin0
@@ -408,7 +416,10 @@ class _UNetFn(torch.autograd.Function):
             ups.append(dict(mod=up, x=x_low_ptr, ldx=x_low_ld, cin=x_low_c, cout=cskip, din=low_dims, cat=cat))
             u_ptr, ldu, cin, dims = cat.data_ptr(), 2 * cskip, 2 * cskip, cdims
             for bi, blk in enumerate(blocks):
-                u_ptr, ldu, dims, rec, zt = run_block(blk, u_ptr, ldu, cin, dims, None, None, ("dec", k, bi))
+                # feature-space window accumulation: the block in front of the head hands over its raw conv output and statistics -
+                # its InstanceNorm + LeakyReLU apply runs inside the accumulation kernel, z is never written
+                fold = feat_fold and k == len(dec) - 1 and bi == len(blocks) - 1
+                u_ptr, ldu, dims, rec, zt = run_block(blk, u_ptr, ldu, cin, dims, None, None, ("dec", k, bi), stats_only=fold)
                 rec["where"] = ("dec", k, bi)
                 saved.append(rec)
                 keep.append(zt)
@@ -419,16 +430,23 @@ class _UNetFn(torch.autograd.Function):
         ncls = head.out_channels
         nsel = ncls if sel is None else int(sel.numel())
         V = D * H * W
-        wa = net._window_acc
         if wa is not None:
             assert not need_grad and sel is None and ldu == head.in_channels and len(wa[3]) == B, "fuse_window_accumulate: misuse"
             acc, nsum, gauss, origins = wa[:4]
             X, Y, Z = acc.shape[:3]
             if len(wa) > 4:      # feature space: no head here
+                last = saved[-1]
                 for k, (sx, sy, sz) in enumerate(origins):
-                    check(lib.dgtta_feature_window_accumulate(u_ptr + k * V * ldu * esz, ptr(gauss), ptr(acc), ptr(nsum),
-                                                              head.in_channels, D, H, W, X, Y, Z, sx, sy, sz, dt, st),
-                          "dgtta_feature_window_accumulate")
+                    if feat_fold:
+                        nrm = last["mod"].norm
+                        check(lib.dgtta_feature_window_accumulate_norm(last["y"].data_ptr() + k * V * 32 * esz,
+                                                                       last["mr"].data_ptr() + k * 32 * 2 * 4, ptr(nrm.weight),
+                                                                       ptr(nrm.bias), SLOPE, ptr(gauss), ptr(acc), ptr(nsum), 32, D, H, W,
+                                                                       X, Y, Z, sx, sy, sz, dt, st), "dgtta_feature_window_accumulate_norm")
+                    else:
+                        check(lib.dgtta_feature_window_accumulate(u_ptr + k * V * ldu * esz, ptr(gauss), ptr(acc), ptr(nsum),
+                                                                  head.in_channels, D, H, W, X, Y, Z, sx, sy, sz, dt, st),
+                              "dgtta_feature_window_accumulate")
                 return torch.empty((B, 0, D, H, W), dtype=torch.float32, device=dev)
             for k, (sx, sy, sz) in enumerate(origins):      # overlapping windows: accumulated one after the other
                 check(lib.dgtta_seghead_window_accumulate_t(u_ptr + k * V * ldu * esz, ptr(head.weight), ptr(head.bias),

@@ -348,6 +348,12 @@ int dgtta_logits_chunk_f64_t(const void *acc, const float *nsum, double *dst, in
  *   dst[x][y][z][j] = sum_m (w[m][c0 + j] . facc[m][sv]) / nsum[sv] + bsum[c0 + j]. */
 int dgtta_feature_window_accumulate(const void *z, const float *gauss, float *facc, float *nsum, int Cin, int PD, int PH, int PW, int X,
                                     int Y, int Z, int x0, int y0, int z0, int dtype, void *stream);
+/* ... with the InstanceNorm + LeakyReLU apply of the block in front of the head folded in: y [PD][PH][PW][32] is that block's raw conv
+ * output, mean_rstd [32][2] the window's statistics (dgtta_instnorm_lrelu_fwd with z = NULL leaves them without applying them);
+ * z = round_dtype(lrelu(y * rstd * gamma + (beta - mean * rstd * gamma))) is formed in registers - the values the apply pass writes. */
+int dgtta_feature_window_accumulate_norm(const void *y, const float *mean_rstd, const float *gamma, const float *beta, float slope,
+                                         const float *gauss, float *facc, float *nsum, int Cin, int PD, int PH, int PW, int X, int Y,
+                                         int Z, int x0, int y0, int z0, int dtype, void *stream);
 int dgtta_feature_head_argmax(const float *facc, int64_t member_stride, const float *nsum, const float *w, const float *bsum, int M,
                               int Cin, int C, int64_t V, int64_t *argmax_out, void *stream);
 int dgtta_feature_logits_chunk_f64(const float *facc, int64_t member_stride, const float *nsum, const float *w, const float *bsum,

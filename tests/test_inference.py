@@ -460,3 +460,9 @@ def test_feature_space_accumulator_against_logits_space_on_the_full_net(dtype, m
     monkeypatch.delenv("DGTTA_WINDOW_ACC", raising=False)
     torch.manual_seed(9)
     assert torch.equal(pinf.run_inference(vol, model, params, patch), seg_f.long())
+    # the InstanceNorm + LeakyReLU apply of the block in front of the head runs inside the accumulation kernel (default) or as its
+    # own pass (DGTTA_FEATURE_FOLD=0): the same z values, the same bits in the accumulator
+    monkeypatch.setenv("DGTTA_FEATURE_FOLD", "0")
+    torch.manual_seed(9)
+    acc_u, nsum_u, _ = pinf.predict_ensemble(vol, model, params, patch)
+    assert torch.equal(acc_u.facc, acc_f.facc) and torch.equal(nsum_u, nsum_f)

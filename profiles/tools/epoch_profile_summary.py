@@ -73,6 +73,11 @@ for dt in dts:
         k, v = top[0]
         lc = {"kernel": k, "ms_per_epoch": round(v, 2), "share_of_kernel_time": round(v / total, 4), "launches_per_epoch": cnt[k]}
         if "wgrad_ring" in k:
+            # the family: every instantiation of the sweep (the first layer runs the two-taps-per-MFMA form under its own name)
+            fam = {kk: vv for kk, vv in per.items() if "conv3_wgrad_ring_kernel" in kk}
+            v = sum(fam.values())
+            lc.update(kernel="conv3_wgrad_ring_kernel (all instantiations)", ms_per_epoch=round(v, 2), share_of_kernel_time=round(v / total, 4),
+                      launches_per_epoch=sum(cnt[kk] for kk in fam), instantiations={kk: round(vv, 2) for kk, vv in fam.items()})
             tf = sum(WRING_GFLOP) * 32 / 1e3
             lc.update(tflop_per_epoch=round(tf, 2), achieved_tflops=round(tf / (v * 1e-3), 1),
                       frac_of_peak=round(tf / (v * 1e-3) / (157.3 if dt == "fp32" else 2500.0), 4),

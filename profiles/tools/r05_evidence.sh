@@ -15,7 +15,7 @@ import json
 d = json.load(open("gpurun_out/r05_bench_line_$i.json"))
 print("line $i:", d["value"], "epochs/s", d["ms_per_step"], "ms; roofline", d["roofline"]["frac"], "; epoch", d["epoch_roofline"]["frac"], "; fp32", d["fp32"]["value"],
       "; dice_delta", {k: (round(d["dice_delta"][k]["hard_dice"], 6), d["dice_delta"][k]["label_agreement"]) for k in ("fp32", "fp16", "bf16")},
-      "; inference", d["inference"]["seconds"], "s; cpu", d["cpu_baseline"]["value"])
+      "; inference", d["inference"]["seconds"], "s (logits fp32", d["inference"]["fp32_logits_accumulator"]["seconds"], "s); cpu", d["cpu_baseline"]["value"])
 PY
   done
   python3 bench.py --write-fp32-trajectory 8 > gpurun_out/r05_traj.log 2>&1; tail -1 gpurun_out/r05_traj.log

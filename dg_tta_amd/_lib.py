@@ -71,6 +71,7 @@ SIGNATURES = {
     "dgtta_argmax_rows": (I, [P, I, I, I64, P, P]),
     "dgtta_feature_window_accumulate": (I, [P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, P]),
     "dgtta_feature_window_accumulate_norm": (I, [P, P, P, P, F, P, P, P, I, I, I, I, I, I, I, I, I, I, I, P]),
+    "dgtta_feature_window_accumulate_multi": (I, [P, P, P, I, P, P, F, P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, P]),
     "dgtta_feature_head_argmax": (I, [P, I64, P, P, P, I, I, I, I64, P, P]),
     "dgtta_feature_logits_chunk_f64": (I, [P, I64, P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, I, I, P]),
     "dgtta_logits_chunk_f64_t": (I, [P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, I, P]),

@@ -119,6 +119,62 @@ __global__ __launch_bounds__(256) void feature_accumulate_norm_kernel(const T *_
   if (q == 0 && nsum) nsum[v] += g;
 }
 
+// Several windows of one network pass that overlap along the last axis (consecutive origins of a sliding-window row), one SEGMENT of
+// that axis per launch: every voxel of the segment receives the contributions of all NS windows that cover it, added in window order
+// in registers - (acc + t_0) + t_1: the bits the one-window launches produce - and the accumulator is read and written ONCE instead
+// of NS times.  With 50 % overlap a row of 7 windows is 8 half-window segments: 57 % of the read-modify-write traffic.
+// NORM: the sources are raw conv outputs and the InstanceNorm + LeakyReLU apply runs here (feature_accumulate_norm_kernel).
+struct WfSources {
+  const void *src[4];            // window k: [PD][PH][PW][32]
+  const float *mean_rstd[4];     // NORM: the window's statistics [32][2]
+  int zoff[4];                   // the segment's first voxel along the last axis, in window k's coordinates
+};
+
+template <typename T, int NS, bool NORM>
+__global__ __launch_bounds__(256) void feature_accumulate_multi_kernel(WfSources ws, const float *__restrict__ gamma,
+                                                                       const float *__restrict__ beta, float slope,
+                                                                       const float *__restrict__ gauss, float *__restrict__ facc,
+                                                                       float *__restrict__ nsum, int PH, int PW, int SL, int Y, int Z, int x0,
+                                                                       int y0, int z0, int64_t total) {
+  __shared__ float sal[NS][WF_CIN], sbe[NS][WF_CIN];
+  if (NORM) {
+    if (threadIdx.x < NS * WF_CIN) {
+      const int k = threadIdx.x / WF_CIN, c = threadIdx.x % WF_CIN;
+      const float al = ws.mean_rstd[k][c * 2 + 1] * gamma[c];
+      sal[k][c] = al;
+      sbe[k][c] = beta[c] - ws.mean_rstd[k][c * 2] * al;
+    }
+    __syncthreads();
+  }
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int q = (int)(i & 7);
+  const int64_t p = i >> 3;                  // voxel of the segment [PD][PH][SL]
+  const int zz = (int)(p % SL), ph = (int)((p / SL) % PH);
+  const int64_t pd = p / ((int64_t)SL * PH);
+  const int64_t v = ((pd + x0) * Y + (ph + y0)) * Z + (zz + z0);
+  float4 *dst = reinterpret_cast<float4 *>(facc + v * WF_CIN + q * 4);
+  float4 a = *dst;
+  float n = (q == 0 && nsum) ? nsum[v] : 0.f;
+  float f[NS][4], g[NS];
+#pragma unroll
+  for (int k = 0; k < NS; ++k) {             // all loads first
+    const int64_t pk = (pd * PH + ph) * PW + ws.zoff[k] + zz;
+    g[k] = gauss[pk];
+    wf_load4<T>(reinterpret_cast<const T *>(ws.src[k]) + pk * WF_CIN + q * 4, f[k]);
+  }
+#pragma unroll
+  for (int k = 0; k < NS; ++k) {
+    float zv[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) zv[e] = NORM ? wf_round<T>(lrelu(f[k][e] * sal[k][q * 4 + e] + sbe[k][q * 4 + e], slope)) : f[k][e];
+    a.x += g[k] * zv[0], a.y += g[k] * zv[1], a.z += g[k] * zv[2], a.w += g[k] * zv[3];
+    n += g[k];
+  }
+  *dst = a;
+  if (q == 0 && nsum) nsum[v] = n;
+}
+
 // Label map from the members' feature accumulators: argmax_c sum_m (W_m[c] . F_m(v)) + n(v) bsum[c], bsum = sum_m b_m (formed
 // by the caller).  One thread per voxel; a member's 32 features sit in registers, the weights are wave-uniform (scalar
 // loads).  With several members the classes' partial sums wait in LDS ([C][256] floats, own column per thread: no bank
@@ -239,6 +295,56 @@ extern "C" int dgtta_feature_window_accumulate_norm(const void *y, const float *
   else WF_LAUNCH(f16_t);
 #undef WF_LAUNCH
   DG_CHECK_LAUNCH("feature_accumulate_norm_kernel");
+  return DGTTA_OK;
+}
+
+extern "C" int dgtta_feature_window_accumulate_multi(const void *const *srcs, const float *const *mean_rstds, const int *zoffs, int nsrc,
+                                                     const float *gamma, const float *beta, float slope, const float *gauss, float *facc,
+                                                     float *nsum, int Cin, int PD, int PH, int PW, int seg_len, int X, int Y, int Z, int x0,
+                                                     int y0, int z0, int dtype, void *stream) {
+  DG_REQUIRE(srcs && zoffs && gauss && facc, DGTTA_ERR_BADARG, "feature_window_accumulate_multi: null pointer");
+  DG_REQUIRE(nsrc >= 1 && nsrc <= 4, DGTTA_ERR_UNSUPPORTED, "feature_window_accumulate_multi: 1..4 windows per segment (got %d)", nsrc);
+  DG_REQUIRE(Cin == WF_CIN, DGTTA_ERR_UNSUPPORTED, "feature_window_accumulate_multi: built for %d feature channels (got %d)", WF_CIN, Cin);
+  DG_REQUIRE(dtype == DGTTA_F32 || dtype == DGTTA_BF16 || dtype == DGTTA_F16, DGTTA_ERR_BADARG, "feature_window_accumulate_multi: dtype %d", dtype);
+  const bool norm = mean_rstds != nullptr;
+  DG_REQUIRE(!norm || (gamma && beta), DGTTA_ERR_BADARG, "feature_window_accumulate_multi: statistics without gamma / beta");
+  DG_REQUIRE(PD > 0 && PH > 0 && PW > 0 && seg_len > 0 && seg_len <= PW && x0 >= 0 && y0 >= 0 && z0 >= 0 && x0 + PD <= X && y0 + PH <= Y &&
+                 z0 + seg_len <= Z, DGTTA_ERR_BADARG, "feature_window_accumulate_multi: segment outside the volume");
+  WfSources ws{};
+  for (int k = 0; k < nsrc; ++k) {
+    DG_REQUIRE(srcs[k] && ((uintptr_t)srcs[k] & 15) == 0 && zoffs[k] >= 0 && zoffs[k] + seg_len <= PW && (!norm || mean_rstds[k]),
+               DGTTA_ERR_BADARG, "feature_window_accumulate_multi: window %d (null / unaligned source or segment outside the window)", k);
+    ws.src[k] = srcs[k];
+    ws.mean_rstd[k] = norm ? mean_rstds[k] : nullptr;
+    ws.zoff[k] = zoffs[k];
+  }
+  DG_REQUIRE(((uintptr_t)facc & 15) == 0, DGTTA_ERR_BADARG, "feature_window_accumulate_multi: unaligned accumulator");
+  const int64_t total = (int64_t)PD * PH * seg_len * 8;
+  const int64_t nblk = cdiv64(total, 256);
+  DG_REQUIRE(nblk < (1ll << 31), DGTTA_ERR_UNSUPPORTED, "feature_window_accumulate_multi: segment too large");
+  hipStream_t st = (hipStream_t)stream;
+#define WFM(T, NS, NRM)                                                                                                                \
+  hipLaunchKernelGGL((feature_accumulate_multi_kernel<T, NS, NRM>), dim3((unsigned)nblk), dim3(256), 0, st, ws, gamma, beta, slope, gauss, \
+                     facc, nsum, PH, PW, seg_len, Y, Z, x0, y0, z0, total)
+#define WFM_NS(T, NRM)                  \
+  do {                                  \
+    if (nsrc == 1) WFM(T, 1, NRM);      \
+    else if (nsrc == 2) WFM(T, 2, NRM); \
+    else if (nsrc == 3) WFM(T, 3, NRM); \
+    else WFM(T, 4, NRM);                \
+  } while (0)
+#define WFM_T(NRM)                                   \
+  do {                                               \
+    if (dtype == DGTTA_F32) WFM_NS(float, NRM);      \
+    else if (dtype == DGTTA_BF16) WFM_NS(bf16_t, NRM); \
+    else WFM_NS(f16_t, NRM);                         \
+  } while (0)
+  if (norm) WFM_T(true);
+  else WFM_T(false);
+#undef WFM_T
+#undef WFM_NS
+#undef WFM
+  DG_CHECK_LAUNCH("feature_accumulate_multi_kernel");
   return DGTTA_OK;
 }
 

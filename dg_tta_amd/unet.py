@@ -436,17 +436,48 @@ class _UNetFn(torch.autograd.Function):
             X, Y, Z = acc.shape[:3]
             if len(wa) > 4:      # feature space: no head here
                 last = saved[-1]
-                for k, (sx, sy, sz) in enumerate(origins):
+                nrm = last["mod"].norm
+                src0 = last["y"].data_ptr() if feat_fold else u_ptr
+                lds = 32 if feat_fold else ldu
+                assert lds == 32
+
+                def one_window(k, sx, sy, sz):
                     if feat_fold:
-                        nrm = last["mod"].norm
-                        check(lib.dgtta_feature_window_accumulate_norm(last["y"].data_ptr() + k * V * 32 * esz,
-                                                                       last["mr"].data_ptr() + k * 32 * 2 * 4, ptr(nrm.weight),
-                                                                       ptr(nrm.bias), SLOPE, ptr(gauss), ptr(acc), ptr(nsum), 32, D, H, W,
-                                                                       X, Y, Z, sx, sy, sz, dt, st), "dgtta_feature_window_accumulate_norm")
+                        check(lib.dgtta_feature_window_accumulate_norm(src0 + k * V * 32 * esz, last["mr"].data_ptr() + k * 32 * 2 * 4,
+                                                                       ptr(nrm.weight), ptr(nrm.bias), SLOPE, ptr(gauss), ptr(acc), ptr(nsum),
+                                                                       32, D, H, W, X, Y, Z, sx, sy, sz, dt, st),
+                              "dgtta_feature_window_accumulate_norm")
                     else:
-                        check(lib.dgtta_feature_window_accumulate(u_ptr + k * V * ldu * esz, ptr(gauss), ptr(acc), ptr(nsum),
-                                                                  head.in_channels, D, H, W, X, Y, Z, sx, sy, sz, dt, st),
-                              "dgtta_feature_window_accumulate")
+                        check(lib.dgtta_feature_window_accumulate(src0 + k * V * 32 * esz, ptr(gauss), ptr(acc), ptr(nsum), 32, D, H, W, X,
+                                                                  Y, Z, sx, sy, sz, dt, st), "dgtta_feature_window_accumulate")
+
+                # consecutive windows of a sliding-window row overlap along the last axis: one launch per SEGMENT of that axis adds
+                # every covering window's contribution in registers (same order, same bits) and touches the accumulator once
+                k = 0
+                while k < len(origins):
+                    j = k + 1
+                    while (os.environ.get("DGTTA_FEATURE_SEGMENTS", "1") != "0" and j < len(origins) and origins[j][:2] == origins[k][:2]
+                           and origins[j - 1][2] < origins[j][2] < origins[j - 1][2] + W):
+                        j += 1
+                    if j - k == 1:
+                        one_window(k, *origins[k])
+                        k = j
+                        continue
+                    sx, sy = origins[k][:2]
+                    zs = [origins[i][2] for i in range(k, j)]
+                    cuts = sorted(set(zs + [z + W for z in zs]))
+                    for a, b in zip(cuts[:-1], cuts[1:]):
+                        cover = [i for i in range(k, j) if origins[i][2] <= a and b <= origins[i][2] + W]
+                        for c0 in range(0, len(cover), 4):          # (more than four windows on a voxel: step sizes below a quarter patch)
+                            part = cover[c0:c0 + 4]
+                            n = len(part)
+                            srcs = (C.c_void_p * n)(*[src0 + i * V * 32 * esz for i in part])
+                            mrs = (C.c_void_p * n)(*[last["mr"].data_ptr() + i * 32 * 2 * 4 for i in part]) if feat_fold else None
+                            zoffs = (C.c_int * n)(*[a - origins[i][2] for i in part])
+                            check(lib.dgtta_feature_window_accumulate_multi(srcs, mrs, zoffs, n, ptr(nrm.weight), ptr(nrm.bias), SLOPE,
+                                                                            ptr(gauss), ptr(acc), ptr(nsum), 32, D, H, W, b - a, X, Y, Z, sx,
+                                                                            sy, a, dt, st), "dgtta_feature_window_accumulate_multi")
+                    k = j
                 return torch.empty((B, 0, D, H, W), dtype=torch.float32, device=dev)
             for k, (sx, sy, sz) in enumerate(origins):      # overlapping windows: accumulated one after the other
                 check(lib.dgtta_seghead_window_accumulate_t(u_ptr + k * V * ldu * esz, ptr(head.weight), ptr(head.bias),

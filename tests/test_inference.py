@@ -370,6 +370,34 @@ def test_feature_window_accumulate_kernel(dts):
         check(lib.dgtta_feature_window_accumulate(ptr(z[0]), ptr(gauss), ptr(facc), ptr(nsum), 32, *P, X, Y, Z, 6, 0, 0, dt, stream_of()), "x")
     with pytest.raises(RuntimeError):
         check(lib.dgtta_feature_window_accumulate(ptr(z[0]), ptr(gauss), ptr(facc), ptr(nsum), 16, *P, X, Y, Z, 0, 0, 0, dt, stream_of()), "x")
+    # segments of windows that overlap along the last axis (three windows at z = 3, 9, 14 of a row: up to three on a voxel), with and
+    # without the folded InstanceNorm apply, against the same windows one by one: the same bits
+    import ctypes as C
+    zs = [3, 9, 14]
+    y = torch.randn(len(zs), *P, 32, device=DEV).to(tdt)
+    mr = torch.stack([torch.randn(len(zs), 32, device=DEV), torch.rand(len(zs), 32, device=DEV) + 0.5], -1).contiguous()
+    gamma, beta = torch.randn(32, device=DEV), torch.randn(32, device=DEV)
+    for norm in (False, True):
+        one_f, one_n = facc.clone(), nsum.clone()
+        for k, sz in enumerate(zs):
+            if norm:
+                check(lib.dgtta_feature_window_accumulate_norm(ptr(y[k]), ptr(mr[k]), ptr(gamma), ptr(beta), 0.01, ptr(gauss), ptr(one_f),
+                                                               ptr(one_n), 32, *P, X, Y, Z, 2, 1, sz, dt, stream_of()), "norm")
+            else:
+                check(lib.dgtta_feature_window_accumulate(ptr(y[k]), ptr(gauss), ptr(one_f), ptr(one_n), 32, *P, X, Y, Z, 2, 1, sz, dt,
+                                                          stream_of()), "plain")
+        seg_f, seg_n = facc.clone(), nsum.clone()
+        cuts = sorted(set(zs + [v + P[2] for v in zs]))
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            cover = [k for k, sz in enumerate(zs) if sz <= a and b <= sz + P[2]]
+            srcs = (C.c_void_p * len(cover))(*[y[k].data_ptr() for k in cover])
+            mrs = (C.c_void_p * len(cover))(*[mr[k].data_ptr() for k in cover]) if norm else None
+            zoffs = (C.c_int * len(cover))(*[a - zs[k] for k in cover])
+            check(lib.dgtta_feature_window_accumulate_multi(srcs, mrs, zoffs, len(cover), ptr(gamma), ptr(beta), 0.01, ptr(gauss), ptr(seg_f),
+                                                            ptr(seg_n), 32, *P, b - a, X, Y, Z, 2, 1, a, dt, stream_of()), "multi")
+        torch.cuda.synchronize()
+        assert max(len([k for k, sz in enumerate(zs) if sz <= a and b <= sz + P[2]]) for a, b in zip(cuts[:-1], cuts[1:])) == 3
+        assert torch.equal(seg_f, one_f) and torch.equal(seg_n, one_n) and not torch.equal(seg_f, facc)
 
 
 @pytest.mark.gpu
@@ -466,3 +494,11 @@ def test_feature_space_accumulator_against_logits_space_on_the_full_net(dtype, m
     torch.manual_seed(9)
     acc_u, nsum_u, _ = pinf.predict_ensemble(vol, model, params, patch)
     assert torch.equal(acc_u.facc, acc_f.facc) and torch.equal(nsum_u, nsum_f)
+    # ... and the windows of a pass that overlap along the last axis are accumulated segment by segment in one launch each (default) or
+    # window by window (DGTTA_FEATURE_SEGMENTS=0): contributions added in the same order - the same bits again, folded or not
+    for fold in ("0", "1"):
+        monkeypatch.setenv("DGTTA_FEATURE_FOLD", fold)
+        monkeypatch.setenv("DGTTA_FEATURE_SEGMENTS", "0")
+        torch.manual_seed(9)
+        acc_w, nsum_w, _ = pinf.predict_ensemble(vol, model, params, patch)
+        assert torch.equal(acc_w.facc, acc_f.facc) and torch.equal(nsum_w, nsum_f)

@@ -135,6 +135,39 @@ def test_export_in_original_geometry_matches_oracle(spacing):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("spacing", [(5.0, 0.9, 0.9), (1.5, 1.5, 1.5)])
+def test_export_from_feature_accumulators_matches_oracle(spacing):
+    """Round 5: the same export from FEATURE-space window accumulators of a two-member ensemble (the head applied class group by
+    class group in double, dgtta_feature_logits_chunk_f64) against the scipy restatement fed with the logits those features stand
+    for; without resampling the fused head + argmax kernel gives the label map."""
+    from dg_tta_amd.tta import preprocessing as pp
+    from dg_tta_amd.tta.inference import WindowFeatures, export_segmentation
+    from oracle import inference as oinf
+    img, seg = _case(3)
+    d, s, props = pp.run_case_npy(img.copy(), seg.copy(), spacing, PLANS, "3d_fullres", "cuda:0")
+    X, Y, Z = d.shape[1:]
+    M, C = 2, 19
+    g = torch.Generator().manual_seed(12)
+    low = torch.randn(M, 32, X // 3 + 2, Y // 3 + 2, Z // 3 + 2, generator=g)
+    feat = torch.nn.functional.interpolate(low, size=(X, Y, Z), mode="trilinear", align_corners=False)      # [M,32,X,Y,Z]
+    nsum = torch.rand(X, Y, Z, generator=g) * 3 + 0.5
+    facc = (feat * nsum).permute(0, 2, 3, 4, 1).contiguous().to("cuda:0")
+    w = torch.randn(M, C, 32, generator=g)
+    b = torch.randn(M, C, generator=g)
+    crop = [slice(0, X), slice(0, Y), slice(0, Z)]
+    feats = WindowFeatures(facc, nsum.to("cuda:0"), crop, w.to("cuda:0"), b.to("cuda:0"))
+    out = export_segmentation(feats, feats.nsum, crop, props, PLANS, "3d_fullres")
+    ref_logits = (torch.einsum("mkxyz,mck->cxyz", feat.double(), w.double()) + b.double().sum(0)[:, None, None, None]).numpy()
+    ref = oinf.convert_logits_to_segmentation_with_correct_shape(ref_logits, props, PLANS, "3d_fullres")
+    assert out.shape == ref.shape == img.shape[1:] and out.dtype == ref.dtype
+    assert (out == ref).mean() > 0.9995 and len(np.unique(out)) > 5
+    plain = export_segmentation(feats, feats.nsum, crop, None, None, None)
+    top2 = np.sort(ref_logits, 0)[-2:]
+    safe = (top2[1] - top2[0]) > 1e-4 * np.abs(ref_logits).max()
+    assert np.array_equal(plain[safe], ref_logits.argmax(0)[safe]) and safe.mean() > 0.99
+
+
+@pytest.mark.gpu
 def test_export_with_padded_small_case_and_no_resampling():
     """A case smaller than the patch (padded for the windows, cropped back) at the plans' spacing: export = argmax of the
     cropped accumulator pasted into the crop box."""

@@ -20,6 +20,10 @@
 // results): without the DMA inside the sweep the cycles fall 8 % and the CLOCK rises from 1.98 to 2.39 GHz (0.82 -> 0.64 ms);
 // without the LDS operand reads -16 % cycles at 2.21 GHz: the sweep is power bound, and what it spends on moving its two
 // streamed operands (1.7x the DMA bytes per FLOP of the forward ring kernel) sets the clock.
+// Round 5 (PAIR, REUSE below): two taps per MFMA for the 12-channel first layer; whole (kd, kw) tap columns per wave group so that
+// four of a wave's seven x operands per row are the previous row's registers; the next iteration's operand reads placed between
+// the MFMAs; ring slots as counters; DMA pieces without branches.  32 -> 32: 0.886 -> 0.80 ms per 8 x 128^3 launch (1155 TFLOP/s),
+// 74 % of the wave time in MFMAs at 1.62 GHz (profiles/r05_ab.txt); DGTTA_WGRAD_RING=6 / =5 select the forms before.
 #include "conv_common.h"
 #include <stdlib.h>
 #include <type_traits>

@@ -224,6 +224,104 @@ __global__ __launch_bounds__(256) void feature_head_argmax_kernel(const float *_
   }
 }
 
+// The same on the fp32 matrix cores (v_mfma_f32_32x32x2_f32: M = 32 classes, N = 32 voxels, K = the 32 channels of every member in
+// turn): a wave owns 32 voxels, the weights of all members sit in LDS ([member][class, padded to a multiple of 32][36 floats]: the
+// 144-byte pitch keeps the 16-byte reads of 8 consecutive class rows on distinct bank groups), a lane's 16 bytes of features /
+// weights feed four instructions (lane half h holds channels 8 s + 4 h .. + 3 of k-step s, as conv_common.h's fp32 mfma_step).
+// Accumulators start at n(v) bsum[c]; the members add up in the accumulators (no LDS partials).  C/D map: a lane holds voxel
+// lane & 31 and classes 32 cb + (q & 3) + 8 (q >> 2) + 4 (lane >> 5) - ascending in (cb, q), so a strict comparison in that order
+// keeps the first maximum; the two lane halves of a voxel are merged with the lower class winning a tie.
+// Measured at 512^3 x 105 classes (profiles/tools/headargmax_bench.py): one member 14.3 ms (vector-ALU kernel 15.5: the per-tile
+// initialisation and argmax scan cost as much as one member's products), the plan's ensemble of three 29.0 ms against 179 ms - the
+// vector-ALU kernel keeps several members' partial sums in LDS and is bound by that traffic; here a further member is 7.3 ms of MFMAs.
+typedef float wf_f32x16_t __attribute__((ext_vector_type(16)));
+constexpr int WF_WPITCH = 36;
+
+template <int NCB>      // class blocks of 32 (C <= 32 NCB)
+__global__ __launch_bounds__(256) void feature_head_argmax_mfma_kernel(const float *__restrict__ facc, int64_t member_stride,
+                                                                       const float *__restrict__ nsum, const float *__restrict__ w,
+                                                                       const float *__restrict__ bsum, int M, int C, int64_t V,
+                                                                       int64_t *__restrict__ amax) {
+  extern __shared__ __attribute__((aligned(16))) float sw[];      // [M][32 NCB][WF_WPITCH], then bsum [32 NCB]
+  float *sb = sw + (size_t)M * 32 * NCB * WF_WPITCH;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int i = tid; i < M * 32 * NCB * WF_CIN; i += 256) {
+    const int k = i % WF_CIN, c = (i / WF_CIN) % (32 * NCB), m = i / (WF_CIN * 32 * NCB);
+    sw[(m * 32 * NCB + c) * WF_WPITCH + k] = c < C ? w[((int64_t)m * C + c) * WF_CIN + k] : 0.f;
+  }
+  for (int c = tid; c < 32 * NCB; c += 256) sb[c] = c < C ? bsum[c] : 0.f;
+  __syncthreads();
+  const int j = lane & 31, h = lane >> 5;
+  const int64_t ntile = (V + 31) / 32;
+  const int64_t tstep = (int64_t)gridDim.x * 4;
+  // the features of (tile, member) pair p + 1 are requested before the 16 NCB MFMAs of pair p issue: at 2 waves per SIMD (161
+  // registers with four class blocks) a load - wait - multiply sequence per pair left the matrix pipe idle for the memory latency
+  auto voxel_of = [&](int64_t t) { return t * 32 + j < V ? t * 32 + j : V - 1; };
+  auto load_fb = [&](int64_t t, int m, float4(&fb)[4]) {
+    const float4 *fv = reinterpret_cast<const float4 *>(facc + m * member_stride + voxel_of(t) * WF_CIN) + h;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) fb[s] = fv[2 * s];      // channels 8 s + 4 h .. + 3
+  };
+  float4 fb[4], fn[4];
+  int64_t t = (int64_t)blockIdx.x * 4 + wave;
+  if (t < ntile) load_fb(t, 0, fb);
+  for (; t < ntile; t += tstep) {
+    const int64_t v = voxel_of(t);
+    const float n = nsum[v];
+    wf_f32x16_t acc[NCB];
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+      for (int q4 = 0; q4 < 4; ++q4) {      // a lane's classes come in runs of four
+        const float4 b4 = *reinterpret_cast<const float4 *>(sb + cb * 32 + 8 * q4 + 4 * h);
+        acc[cb][4 * q4 + 0] = n * b4.x, acc[cb][4 * q4 + 1] = n * b4.y, acc[cb][4 * q4 + 2] = n * b4.z, acc[cb][4 * q4 + 3] = n * b4.w;
+      }
+    for (int m = 0; m < M; ++m) {
+      if (m + 1 < M) load_fb(t, m + 1, fn);
+      else if (t + tstep < ntile) load_fb(t + tstep, 0, fn);
+      const float *wm = sw + ((size_t)m * 32 * NCB + j) * WF_WPITCH + 4 * h;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        float4 wa[NCB];
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb) wa[cb] = *reinterpret_cast<const float4 *>(wm + (size_t)cb * 32 * WF_WPITCH + 8 * s);
+        // (consecutive instructions on different accumulators: a chain on one accumulator waits for itself)
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb) acc[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[cb].x, fb[s].x, acc[cb], 0, 0, 0);
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb) acc[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[cb].y, fb[s].y, acc[cb], 0, 0, 0);
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb) acc[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[cb].z, fb[s].z, acc[cb], 0, 0, 0);
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb) acc[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[cb].w, fb[s].w, acc[cb], 0, 0, 0);
+      }
+#pragma unroll
+      for (int s = 0; s < 4; ++s) fb[s] = fn[s];
+    }
+    // the sequential scan's rule (best = -inf, class 0; strictly greater replaces; NaNs never do), per lane half and then merged
+    float best = -INFINITY;
+    int bi = 4 * h < C ? 4 * h : 0x7fffffff;      // this half's first class
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int c = cb * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
+        const float x = acc[cb][q];
+        if ((cb + 1 < NCB || c < C) && x > best) {      // (only the last class block can hold padding: C > 32 (NCB - 1))
+          best = x;
+          bi = c;
+        }
+      }
+    const float ob = __shfl_xor(best, 32, 64);
+    const int oi = __shfl_xor(bi, 32, 64);
+    if (ob > best || (ob == best && oi < bi)) {
+      best = ob;
+      bi = oi;
+    }
+    if (h == 0 && t * 32 + j < V) amax[v] = bi;
+  }
+}
+
 // Export path (original geometry): classes c0 .. c0 + cg - 1 of the normalised ensemble logits as doubles,
 // dst[x][y][z][j] = sum_m (W_m[c0 + j] . F_m(sv)) / n(sv) + bsum[c0 + j] - the input of the dgtta_resample_axis passes, as
 // dgtta_logits_chunk_f64 is for the logits-space accumulator (products and sums in double).
@@ -354,6 +452,29 @@ extern "C" int dgtta_feature_head_argmax(const float *facc, int64_t member_strid
   DG_REQUIRE(Cin == WF_CIN, DGTTA_ERR_UNSUPPORTED, "feature_head_argmax: built for %d feature channels (got %d)", WF_CIN, Cin);
   DG_REQUIRE(M >= 1 && C >= 1 && V >= 1 && (M == 1 || member_stride >= V * WF_CIN), DGTTA_ERR_BADARG, "feature_head_argmax: bad sizes");
   DG_REQUIRE(((uintptr_t)facc & 15) == 0 && (member_stride & 3) == 0, DGTTA_ERR_BADARG, "feature_head_argmax: unaligned accumulator");
+  // the matrix-core kernel when its weight image fits the LDS (DGTTA_FEATURE_HEAD_MFMA=0: the vector-ALU kernel)
+  const int ncb = (C + 31) / 32;
+  const size_t lds_m = ((size_t)M * 32 * ncb * WF_WPITCH + 32 * ncb) * sizeof(float);
+  const bool use_mfma = dgtta_switches().feature_head_mfma != '0';
+  if (use_mfma && ncb <= 4 && lds_m <= 160 * 1024) {
+    static DynLdsOnce once_m[4];
+    const int64_t ntile = cdiv64(V, 32);
+    const unsigned grid = (unsigned)(cdiv64(ntile, 4) < 2048 ? cdiv64(ntile, 4) : 2048);
+#define WF_MFMA(N)                                                                                                                   \
+  do {                                                                                                                               \
+    DG_REQUIRE(ensure_dyn_lds(once_m[N - 1], (const void *)feature_head_argmax_mfma_kernel<N>, 160 * 1024) == hipSuccess,            \
+               DGTTA_ERR_LAUNCH, "feature_head_argmax: cannot raise the dynamic LDS limit");                                         \
+    hipLaunchKernelGGL(feature_head_argmax_mfma_kernel<N>, dim3(grid), dim3(256), lds_m, (hipStream_t)stream, facc, member_stride,    \
+                       nsum, w, bsum, M, C, V, argmax_out);                                                                          \
+  } while (0)
+    if (ncb == 1) WF_MFMA(1);
+    else if (ncb == 2) WF_MFMA(2);
+    else if (ncb == 3) WF_MFMA(3);
+    else WF_MFMA(4);
+#undef WF_MFMA
+    DG_CHECK_LAUNCH("feature_head_argmax_mfma_kernel");
+    return DGTTA_OK;
+  }
   const size_t lds = M > 1 ? (size_t)C * 256 * sizeof(float) : 0;
   DG_REQUIRE(lds <= 160 * 1024, DGTTA_ERR_UNSUPPORTED, "feature_head_argmax: %d classes x several members exceed the LDS (<= 160)", C);
   static DynLdsOnce once;

@@ -402,9 +402,11 @@ def test_feature_window_accumulate_kernel(dts):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("M,C,V", [(1, 105, 64 * 40 + 17), (3, 105, 5000), (2, 118, 777), (4, 7, 300), (1, 2, 255), (5, 150, 513)])
-def test_feature_head_argmax_and_logits_chunk(M, C, V):
-    """The head applied to the feature accumulators of M members, fused with the argmax (first maximum wins), and the export
-    path's class chunks in double - against torch on the same numbers."""
+def test_feature_head_argmax_and_logits_chunk(M, C, V, monkeypatch):
+    """The head applied to the feature accumulators of M members, fused with the argmax (first maximum wins) - on the fp32 matrix
+    cores (default, up to 128 classes) and on the vector ALU (DGTTA_FEATURE_HEAD_MFMA=0) - and the export path's class chunks in
+    double, against torch on the same numbers."""
+    from conftest import reload_kernel_switches
     from dg_tta_amd import _lib, ops
     from dg_tta_amd._lib import check, ptr, stream_of
     lib = _lib.load()
@@ -419,15 +421,26 @@ def test_feature_head_argmax_and_logits_chunk(M, C, V):
         b[:, 3] = b[:, 0]                     # ... and two identical classes: the lower id wins
         w[:, 3] = w[:, 0]
     bsum = b.sum(0)
-    seg = ops.feature_head_argmax(facc, nsum, w, bsum)
     ref = (torch.einsum("mvk,mck->vc", facc.reshape(M, V, 32).double(), w.double()) + nsum.reshape(V, 1).double() * bsum.double())
     am = ref.argmax(1)
     top2 = ref.topk(2, dim=1).values
     safe = (top2[:, 0] - top2[:, 1]) > 1e-4 * ref.abs().amax(1)
-    got = seg.reshape(V)
-    assert torch.equal(got[safe], am[safe]) and float(safe.float().mean()) > 0.9
-    if C > 3:
-        assert int((got == 3).sum()) == 0        # classes 0 and 3 are identical: the first one is reported
+    for mfma in ("1", "0"):
+        monkeypatch.setenv("DGTTA_FEATURE_HEAD_MFMA", mfma)
+        reload_kernel_switches()
+        seg = ops.feature_head_argmax(facc, nsum, w, bsum)
+        got = seg.reshape(V)
+        assert torch.equal(got[safe], am[safe]) and float(safe.float().mean()) > 0.9, mfma
+        assert int(got.min()) >= 0 and int(got.max()) < C
+        if C > 3:
+            assert int((got == 3).sum()) == 0        # classes 0 and 3 are identical: the first one is reported
+        # a voxel whose features are all zero and whose weight sum is zero: every logit is exactly 0 -> class 0
+        f2, n2 = facc.clone(), nsum.clone()
+        f2[:, 0, 0, 7] = 0.0
+        n2[0, 0, 7] = 0.0
+        assert int(ops.feature_head_argmax(f2, n2, w, bsum).reshape(V)[7]) == 0
+    monkeypatch.delenv("DGTTA_FEATURE_HEAD_MFMA")
+    reload_kernel_switches()
     # export chunk: normalised ensemble logits in double
     c0, cg = (C // 2, min(8, C - C // 2))
     dst = torch.empty(V, cg, dtype=torch.float64, device=DEV)

@@ -50,6 +50,7 @@ SIGNATURES = {
     "dgtta_convT3d_fwd_ws_bytes": (SZ, [I, I, I]),
     "dgtta_convT3d_k2s2_fwd": (I, [P, I, P, P, P, I, P, SZ, I, I, I, I, I, I, I, I, P]),
     "dgtta_convT3d_bwd_ws_bytes": (SZ, [I, I, I, I, I, I]),
+    "dgtta_convT3d_bwd_split_ws_bytes": (SZ, [I, I, I, I, I, I]),
     "dgtta_convT3d_k2s2_bwd": (I, [P, I, P, I, P, P, I, P, P, P, SZ, I, I, I, I, I, I, I, I, I, P]),
     "dgtta_seghead_fwd": (I, [P, I, P, P, P, I, P, I, I, I, I, I64, I, P]),
     "dgtta_seghead_bwd_ws_bytes": (SZ, [I, I, I, I64]),

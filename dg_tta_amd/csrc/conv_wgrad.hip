@@ -1620,14 +1620,54 @@ static int convT_wgrad(const void *x, int ldx, const void *dout, int lddo, float
                                  accumulate, st);
 }
 
+// fp32 transposed-conv weight gradient as six launches of the 16-bit kernel on exact three-term bf16 splits (see
+// wgrad_conv_f32_split): extra bytes behind the slab region = 3 planes of x (input lattice) and 3 of dout (output lattice)
+size_t convT_wgrad_split_extra_bytes(int B, int Cin, int Cout, int Di, int Hi, int Wi) {
+  return 3 * wgrad_split_plane_bytes(B, Cin, Di, Hi, Wi) + 3 * wgrad_split_plane_bytes(B, Cout, 2 * Di, 2 * Hi, 2 * Wi);
+}
+
+static int convT_wgrad_f32_split(const float *x, int ldx, const float *dout, int lddo, float *dw_t, void *ws, size_t slab_bytes,
+                                 void *planes, int B, int Cin, int Cout, int Di, int Hi, int Wi, int accumulate, hipStream_t st) {
+  const int ldxs = (Cin + 7) / 8 * 8, ldys = (Cout + 7) / 8 * 8;
+  const int64_t rows_x = (int64_t)B * Di * Hi * Wi, rows = rows_x * 8;
+  const size_t xb = wgrad_split_plane_bytes(B, Cin, Di, Hi, Wi), yb = wgrad_split_plane_bytes(B, Cout, 2 * Di, 2 * Hi, 2 * Wi);
+  bf16_t *xs[3], *gs[3];
+  for (int i = 0; i < 3; ++i) {
+    xs[i] = (bf16_t *)((char *)planes + i * xb);
+    gs[i] = (bf16_t *)((char *)planes + 3 * xb + i * yb);
+  }
+  const int64_t tx = rows_x * (ldxs / 8), ty = rows * (ldys / 8);
+  hipLaunchKernelGGL(split3_bf16_kernel, dim3((unsigned)(cdiv64(tx, 256) < 8192 ? cdiv64(tx, 256) : 8192)), dim3(256), 0, st, x, ldx,
+                     Cin, ldxs, rows_x, xs[0], xs[1], xs[2]);
+  hipLaunchKernelGGL(split3_bf16_kernel, dim3((unsigned)(cdiv64(ty, 256) < 8192 ? cdiv64(ty, 256) : 8192)), dim3(256), 0, st, dout,
+                     lddo, Cout, ldys, rows, gs[0], gs[1], gs[2]);
+  DG_CHECK_LAUNCH("split3_bf16_kernel");
+  static const int PAIRS[6][2] = {{0, 0}, {0, 1}, {1, 0}, {0, 2}, {1, 1}, {2, 0}};
+  for (int q = 0; q < 6; ++q) {
+    const int rc = convT_wgrad<bf16_t>(xs[PAIRS[q][0]], ldxs, gs[PAIRS[q][1]], ldys, dw_t, ws, slab_bytes, B, Cin, Cout, Di, Hi, Wi,
+                                       (accumulate || q > 0) ? 1 : 0, st, nullptr, 0, nullptr);
+    if (rc != DGTTA_OK) return rc;        // (q == 0: nothing written yet, the caller falls back to the fp32 kernel)
+  }
+  return DGTTA_OK;
+}
+
 // bias_part / bias_units (optional): room for [units][ceil(Cout / 32) * 32] floats; *bias_units > 0 on return means the launch left
 // the per-unit sums of dout there (convT_bias_finalize adds them up), 0 means the caller runs its own pass over dout
 int convT_wgrad_mfma(const void *x, int ldx, const void *dout, int lddo, float *dw_t, void *ws, size_t ws_bytes, int B,
                      int Cin, int Cout, int Di, int Hi, int Wi, int accumulate, int dtype, hipStream_t st, float *bias_part,
                      size_t bias_part_bytes, int *bias_units) {
   if (bias_units) *bias_units = 0;
-  if (dtype == DGTTA_F32)
+  if (dtype == DGTTA_F32) {
+    // the caller offered the split workspace (dgtta_convT3d_bwd_split_ws_bytes): six 16-bit launches (DGTTA_WGRAD_F32_SPLIT=0: never)
+    const size_t slab = align_up(conv3_wgrad_mfma_ws_bytes(B, Cin, Cout, Di, Hi, Wi), 256);
+    if (Cout % 8 == 0 && dgtta_switches().wgrad_f32_split != '0' &&
+        ws_bytes >= slab + convT_wgrad_split_extra_bytes(B, Cin, Cout, Di, Hi, Wi)) {
+      const int rc = convT_wgrad_f32_split((const float *)x, ldx, (const float *)dout, lddo, dw_t, ws, slab, (char *)ws + slab, B, Cin,
+                                           Cout, Di, Hi, Wi, accumulate, st);
+      if (rc != DGTTA_ERR_UNSUPPORTED) return rc;
+    }
     return convT_wgrad<float>(x, ldx, dout, lddo, dw_t, ws, ws_bytes, B, Cin, Cout, Di, Hi, Wi, accumulate, st, nullptr, 0, nullptr);
+  }
   if (dtype == DGTTA_BF16)
     return convT_wgrad<bf16_t>(x, ldx, dout, lddo, dw_t, ws, ws_bytes, B, Cin, Cout, Di, Hi, Wi, accumulate, st, bias_part,
                                bias_part_bytes, bias_units);

@@ -1604,6 +1604,16 @@ extern "C" size_t dgtta_convT3d_bwd_ws_bytes(int B, int Cin, int Cout, int Di, i
   return convT_bias_region(B, Cout, Di, Hi, Wi) + convT_pack_region(Cin, Cout, DGTTA_F32) + (a > c ? a : c);
 }
 
+// ... with room for the fp32 weight gradient as six 16-bit launches on three-term bf16 splits (conv_wgrad.hip)
+size_t convT_wgrad_split_extra_bytes(int B, int Cin, int Cout, int Di, int Hi, int Wi);
+extern "C" size_t dgtta_convT3d_bwd_split_ws_bytes(int B, int Cin, int Cout, int Di, int Hi, int Wi) {
+  if (B <= 0 || Cin <= 0 || Cout <= 0 || Di <= 0 || Hi <= 0 || Wi <= 0) return 0;
+  const int64_t nvox = (int64_t)B * Di * Hi * Wi;
+  size_t a = align_up((size_t)wgrad_splits(nvox) * Cin * Cout * 8 * sizeof(float), 256);
+  size_t c = align_up(conv3_wgrad_mfma_ws_bytes(B, Cin, Cout, Di, Hi, Wi), 256) + convT_wgrad_split_extra_bytes(B, Cin, Cout, Di, Hi, Wi);
+  return convT_bias_region(B, Cout, Di, Hi, Wi) + convT_pack_region(Cin, Cout, DGTTA_F32) + (a > c ? a : c);
+}
+
 extern "C" int dgtta_convT3d_k2s2_bwd(const void *x, int ldx, const void *dout, int lddo, const float *w_t, void *dx,
                                       int lddx, float *dw_t, float *db, void *ws, size_t ws_bytes, int B, int Cin,
                                       int Cout, int Di, int Hi, int Wi, int accumulate, int dtype, int impl,

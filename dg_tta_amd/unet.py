@@ -663,7 +663,9 @@ class _UNetFn(torch.autograd.Function):
                 upm = up["mod"]
                 ld0, lh0, lw0 = up["din"]
                 glow = torch.empty((B, ld0, lh0, lw0, up["cin"]), dtype=adt, device=dev)
-                nb = lib.dgtta_convT3d_bwd_ws_bytes(B, up["cin"], up["cout"], ld0, lh0, lw0)
+                # fp32 storage: room for the weight gradient as six 16-bit launches on exact bf16 splits (as for the 3x3x3 convs)
+                nb = (lib.dgtta_convT3d_bwd_split_ws_bytes if dt == F32 and impl != 1 else
+                      lib.dgtta_convT3d_bwd_ws_bytes)(B, up["cin"], up["cout"], ld0, lh0, lw0)
                 w_ = ws_for(nb)
                 need_w = want(upm.weight) or want(upm.bias)
                 dwu = (gbuf(upm.weight) if want(upm.weight) else scratch_like(upm.weight)) if need_w else None

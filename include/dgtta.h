@@ -237,6 +237,10 @@ int dgtta_convT3d_k2s2_fwd(const void *x, int ldx, const float *w_t, const float
                            size_t ws_bytes, int B, int Cin, int Cout, int Di, int Hi, int Wi, int dtype, int impl,
                            void *stream);
 size_t dgtta_convT3d_bwd_ws_bytes(int B, int Cin, int Cout, int Di, int Hi, int Wi);
+/* (round 5) the same with room for the fp32 weight gradient as six launches of the 16-bit matrix-core kernel on the exact three-term
+ * bf16 splits of x and dout (see dgtta_conv3d_wgrad_split_ws_bytes): offered this workspace, dgtta_convT3d_k2s2_bwd takes that path in
+ * fp32 storage; with the plain one it runs the fp32 MFMA kernel as before. */
+size_t dgtta_convT3d_bwd_split_ws_bytes(int B, int Cin, int Cout, int Di, int Hi, int Wi);
 int dgtta_convT3d_k2s2_bwd(const void *x, int ldx, const void *dout, int lddo, const float *w_t, void *dx, int lddx,
                            float *dw_t, float *db, void *ws, size_t ws_bytes, int B, int Cin, int Cout, int Di,
                            int Hi, int Wi, int accumulate, int dtype, int impl, void *stream);

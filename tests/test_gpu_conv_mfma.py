@@ -457,6 +457,54 @@ def test_convT_mfma(case, dt):
         assert (dw2.cpu() - wr.grad.float()).abs().max() < 3e-5 * wr.grad.abs().max()
 
 
+@pytest.mark.parametrize("case", [(2, 64, 32, 8, 8, 16), (1, 24, 16, 4, 6, 8), (1, 320, 256, 4, 4, 4)])
+def test_convT_wgrad_fp32_as_six_bf16_products(case, monkeypatch):
+    """Round 5: the fp32 ConvTranspose3d weight gradient as six launches of the 16-bit kernel on three-term bf16 splits (the caller
+    offers dgtta_convT3d_bwd_split_ws_bytes) against the fp32 MFMA kernel (plain workspace / DGTTA_WGRAD_F32_SPLIT=0) and float64:
+    the same rounding level; the data gradient and the bias gradient do not change; accumulate mode adds to what is there."""
+    from conftest import reload_kernel_switches
+    from dg_tta_amd import _lib
+    from dg_tta_amd._lib import check, ptr, stream_of
+    import torch.nn.functional as F
+    lib = _lib.load()
+    B, cin, cout, D, H, W = case
+    torch.manual_seed(sum(case) + 3)
+    x = torch.randn(B, D, H, W, cin, device=DEV)
+    w = torch.randn(cin, cout, 2, 2, 2, device=DEV) / cin ** 0.5
+    dout = torch.randn(B, 2 * D, 2 * H, 2 * W, cout, device=DEV)
+
+    def run(split, accumulate=0, dw0=None):
+        nb = (lib.dgtta_convT3d_bwd_split_ws_bytes if split else lib.dgtta_convT3d_bwd_ws_bytes)(B, cin, cout, D, H, W)
+        ws = torch.empty(nb, dtype=torch.uint8, device=DEV)
+        dx = torch.empty_like(x)
+        dw = torch.empty_like(w) if dw0 is None else dw0.clone()
+        db = torch.zeros(cout, device=DEV) if accumulate else torch.empty(cout, device=DEV)
+        check(lib.dgtta_convT3d_k2s2_bwd(ptr(x), cin, ptr(dout), cout, ptr(w), ptr(dx), cin, ptr(dw), ptr(db), ptr(ws), nb, B, cin, cout,
+                                         D, H, W, accumulate, 0, 2, stream_of()), "convT bwd")
+        torch.cuda.synchronize()
+        return dx, dw, db
+
+    assert lib.dgtta_convT3d_bwd_split_ws_bytes(B, cin, cout, D, H, W) > lib.dgtta_convT3d_bwd_ws_bytes(B, cin, cout, D, H, W)
+    dx_o, dw_o, db_o = run(False)
+    dx_n, dw_n, db_n = run(True)
+    wr = w.cpu().double().requires_grad_(True)
+    F.conv_transpose3d(x.permute(0, 4, 1, 2, 3).cpu().double(), wr, None, stride=2).backward(dout.permute(0, 4, 1, 2, 3).cpu().double())
+    scale = float(wr.grad.abs().max())
+    e_old = float((dw_o.cpu().double() - wr.grad).abs().max()) / scale
+    e_new = float((dw_n.cpu().double() - wr.grad).abs().max()) / scale
+    assert e_old < 3e-5 and e_new < 3e-5 and e_new < 4 * e_old + 2e-7, (e_new, e_old)
+    assert not torch.equal(dw_n, dw_o)                                   # (another kernel did run)
+    assert torch.equal(dx_n, dx_o) and torch.equal(db_n, db_o)
+    assert torch.equal(run(True)[1], dw_n)                               # run to run: the same bits
+    _, acc, _ = run(True, accumulate=1, dw0=dw_n)
+    assert float((acc.cpu().double() - 2 * wr.grad).abs().max()) / scale < 6e-5
+    monkeypatch.setenv("DGTTA_WGRAD_F32_SPLIT", "0")
+    reload_kernel_switches()
+    assert torch.equal(run(True)[1], dw_o)                               # switched off: the fp32 kernel, whatever the workspace
+    monkeypatch.delenv("DGTTA_WGRAD_F32_SPLIT")
+    reload_kernel_switches()
+
+
 @pytest.mark.parametrize("nsel,V", [(16, 8 * 8 * 32), (5, 7 * 9 * 11), (105, 4 * 8 * 16), (105, 64 * 37 + 5), (40, 1000), (128, 130)])
 @pytest.mark.parametrize("dt", [0, 1, 2])
 def test_head_fast_paths(nsel, V, dt):

@@ -28,7 +28,7 @@ python3 profiles/tools/dec31_dispatches.py $tag > gpurun_out/${tag}_dec31_dispat
 # the raw csv files are large: keep the per-name statistics only
 for dt in $dts; do
   for n in 1 3; do
-    f=$(ls gpurun_out/${tag}_ep_${dt}_stats_$n/*/*kernel_stats.csv 2>/dev/null | head -1)
+    f=$(find gpurun_out/${tag}_ep_${dt}_stats_$n -name '*kernel_stats.csv' 2>/dev/null | head -1)
     [ -n "$f" ] && cp $f gpurun_out/${tag}_epoch_${dt}_${n}ep_kernel_stats.csv
     rm -rf gpurun_out/${tag}_ep_${dt}_fetch_$n gpurun_out/${tag}_ep_${dt}_write_$n gpurun_out/${tag}_ep_${dt}_stats_$n
   done

@@ -774,7 +774,8 @@ def test_conv_stride2_register_operand_kernel(case, dt, monkeypatch):
 
 
 WRING_CASES = [(1, 32, 32, 9, 13, 45), (2, 12, 32, 6, 17, 32), (1, 16, 64, 9, 11, 37), (2, 12, 32, 40, 16, 64), (1, 64, 96, 7, 8, 70), (2, 32, 32, 32, 32, 64),
-               (1, 32, 64, 36, 40, 32), (8, 32, 32, 4, 64, 160)]      # ragged edges, ragged Cin, channel-block pairs, > 256 columns
+               (1, 32, 64, 36, 40, 32), (8, 32, 32, 4, 64, 160), (1, 24, 32, 6, 9, 33), (1, 40, 64, 5, 10, 40), (1, 8, 32, 7, 8, 32)]
+# ragged edges, ragged Cin (also inside a 32-channel block and below 16), channel-block pairs, > 256 columns
 
 
 @pytest.mark.parametrize("dts", ["bf16", "fp16"])

@@ -647,7 +647,7 @@ def inference_leg(args, device, dtype):
     rf, segf = one_features()
     out = {"volume": n, "windows": nwin, **rf, "classes": int(ncls), "dtype": dtype, "accumulator": "features (32 channels, fp32)",
            "window_tflop": round(win_tflop, 4),
-           "note": "one ensemble member; network forward (8 windows per pass) + Gaussian accumulation of the head's INPUT features "
+           "note": "one ensemble member; network forward (16 windows per pass) + Gaussian accumulation of the head's INPUT features "
                    "(the head is linear and last: sum_w g (W z + b) = W sum_w g z + b sum_w g) + head and argmax once per voxel"}
     torch.manual_seed(11)
     r32, seg32 = one(torch.float32)

@@ -78,7 +78,9 @@ def pad_to_patch(data, patch_size):
 
 import os as _os
 
-WINDOW_BATCH = max(1, int(_os.environ.get("DGTTA_WINDOW_BATCH", "8")))      # measured at 512^3: 2 / 4 / 8 / 16 windows per pass = 3.26 / 3.14 / 3.07 / 3.03 ms per window
+# windows per network pass.  Measured at 512^3: 2 / 4 / 8 / 16 windows per pass = 3.26 / 3.14 / 3.07 / 3.03 ms per window in round 3;
+# round 5 (feature-space accumulator): 0.541 s per member with 8, 0.537 with 12, 0.533 with 16 (~25 GB of activations in 16-bit storage)
+WINDOW_BATCH = max(1, int(_os.environ.get("DGTTA_WINDOW_BATCH", "16")))
 
 
 def window_acc_mode():

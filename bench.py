@@ -968,7 +968,7 @@ def run_rank(args):
             out["dice_delta"] = dice_delta
         if fp32_leg is not None:
             out["fp32"] = fp32_leg
-        if args.inference_size > 0 and world == 1 and not stub:
+        if args.inference_size > 0 and not stub:      # (rank 0; at N > 1 the peers wait in the final barrier, as for the CPU baseline)
             out["inference"] = inference_leg(args, device, main_dtype)
         if not args.no_cpu_baseline and not stub:
             # rank 0 only; at N > 1 the peers wait in the final barrier (the timed region is over) so that a SCALE line carries
@@ -984,7 +984,7 @@ def run_rank(args):
                     img = atlas_case(volume_edge(args.size), args.copt - 1, 31, "target")[0][None, None, o:o + args.size, o:o + args.size,
                                                                                    o:o + args.size].contiguous()
             out["cpu_baseline"], rec = cpu_baseline(args, st8, img)
-            if not args.no_parity and args.cpu_size == args.size and world == 1:
+            if not args.no_parity and args.cpu_size == args.size:
                 out["parity_at_size"] = parity_at_size(rec, device)
                 out["parity_at_size"]["weights"] = out["config"]["weights"]
             del rec

@@ -94,7 +94,8 @@ def test_bench_two_real_ranks_on_one_gpu():
     root = Path(__file__).resolve().parents[1]
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
     res = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "2", "--share-gpu", "--steps", "2", "--warmup", "1",
-                          "--size", "64", "--accum", "4", "--pretrain-steps", "30", "--cpu-size", "64"], env=env, capture_output=True, text=True, timeout=600)
+                          "--size", "64", "--accum", "4", "--pretrain-steps", "30", "--cpu-size", "64", "--inference-size", "128"], env=env,
+                         capture_output=True, text=True, timeout=600)
     assert res.returncode == 0, res.stderr[-3000:]
     lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
@@ -105,3 +106,6 @@ def test_bench_two_real_ranks_on_one_gpu():
     assert 0.0 < out["loss_last_epoch"] < 1.0 and out["roofline"] is not None
     # the fp32 / oracle-refereed legs are single-GPU work; the CPU baseline rides on rank 0 after the timed region (round 5)
     assert "fp32" not in out and out["cpu_baseline"]["value"] > 0 and "pretraining" in out and "epoch_roofline" in out
+    # ... and so do the sliding-window leg and the at-size parity record (rank 0, peers in the final barrier)
+    assert out["inference"]["windows"] == 27 and out["inference"]["fp32_logits_accumulator"]["label_agreement_with_feature_accumulator"] > 0.999
+    assert "parity_at_size" in out

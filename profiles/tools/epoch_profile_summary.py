@@ -22,6 +22,16 @@ def pmc_sum(d, counter):
     return tot, n
 
 
+def pmc_by_name(d, counter):
+    """Counter sums per kernel name (KiB as rocprofv3 reports FETCH_SIZE / WRITE_SIZE)."""
+    t = collections.Counter()
+    for f in glob.glob(f"{d}/**/*counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] == counter:
+                t[short(r["Kernel_Name"])] += float(r["Counter_Value"])
+    return t
+
+
 def by_name(d):
     t, c = collections.Counter(), collections.Counter()
     for f in glob.glob(f"{d}/**/*kernel_trace.csv", recursive=True):
@@ -54,6 +64,11 @@ for dt in dts:
     total = sum(per.values())
     top = sorted(per.items(), key=lambda kv: -kv[1])[:12]
     fetch_b, write_b = (f3 - f1) / 2 * 1024 * 2, (w3 - w1) / 2 * 1024
+    # where the bytes go: per kernel name, fetched (x 2 on gfx950) + written, one steady-state epoch
+    fn1, fn3 = pmc_by_name(f"gpurun_out/{tag}_ep_{dt}_fetch_1", "FETCH_SIZE"), pmc_by_name(f"gpurun_out/{tag}_ep_{dt}_fetch_3", "FETCH_SIZE")
+    wn1, wn3 = pmc_by_name(f"gpurun_out/{tag}_ep_{dt}_write_1", "WRITE_SIZE"), pmc_by_name(f"gpurun_out/{tag}_ep_{dt}_write_3", "WRITE_SIZE")
+    by_kernel = {k: ((fn3[k] - fn1[k]) / 2 * 1024 * 2, (wn3[k] - wn1[k]) / 2 * 1024) for k in set(fn3) | set(wn3)}
+    hbm_top = sorted(by_kernel.items(), key=lambda kv: -(kv[1][0] + kv[1][1]))[:16]
     old = prev.get("fp32" if dt == "fp32" else "16bit", {})
     if n3 == 0 and old:          # the PMC passes were not re-run: keep the recorded traffic
         fetch_b, write_b = old.get("fetch_bytes_per_epoch", 0.0), old.get("write_bytes_per_epoch", 0.0)
@@ -64,6 +79,8 @@ for dt in dts:
                   "only (FETCH x 2 on gfx950), --kernel-trace --stats with DGTTA_WGRAD_STREAM=0 DGTTA_PIPELINE_PREP=0 (one stream, so that durations add up) for the per-name time" % dt,
            "dispatches_per_epoch": (n3 - n1) / 2,
            "fetch_bytes_per_epoch": fetch_b, "write_bytes_per_epoch": write_b, "hbm_bytes_per_epoch": fetch_b + write_b,
+           "hbm_bytes_by_kernel": [{"kernel": k, "fetch_gb": round(v[0] / 1e9, 2), "write_gb": round(v[1] / 1e9, 2)} for k, v in hbm_top] or
+                                  old.get("hbm_bytes_by_kernel", []),
            "kernel_ms_per_epoch": round(total, 2),
            "top_kernels_ms_per_epoch": [{"kernel": k, "ms": round(v, 3), "launches": cnt[k], "share": round(v / total, 4)} for k, v in top]}
     if not top and old:

@@ -396,25 +396,25 @@ extern "C" int dgtta_feature_window_accumulate_norm(const void *y, const float *
   return DGTTA_OK;
 }
 
-extern "C" int dgtta_feature_window_accumulate_multi(const void *const *srcs, const float *const *mean_rstds, const int *zoffs, int nsrc,
+extern "C" int dgtta_feature_window_accumulate_multi(const void *const *h_srcs, const float *const *h_mean_rstds, const int *h_zoffs, int nsrc,
                                                      const float *gamma, const float *beta, float slope, const float *gauss, float *facc,
                                                      float *nsum, int Cin, int PD, int PH, int PW, int seg_len, int X, int Y, int Z, int x0,
                                                      int y0, int z0, int dtype, void *stream) {
-  DG_REQUIRE(srcs && zoffs && gauss && facc, DGTTA_ERR_BADARG, "feature_window_accumulate_multi: null pointer");
+  DG_REQUIRE(h_srcs && h_zoffs && gauss && facc, DGTTA_ERR_BADARG, "feature_window_accumulate_multi: null pointer");
   DG_REQUIRE(nsrc >= 1 && nsrc <= 4, DGTTA_ERR_UNSUPPORTED, "feature_window_accumulate_multi: 1..4 windows per segment (got %d)", nsrc);
   DG_REQUIRE(Cin == WF_CIN, DGTTA_ERR_UNSUPPORTED, "feature_window_accumulate_multi: built for %d feature channels (got %d)", WF_CIN, Cin);
   DG_REQUIRE(dtype == DGTTA_F32 || dtype == DGTTA_BF16 || dtype == DGTTA_F16, DGTTA_ERR_BADARG, "feature_window_accumulate_multi: dtype %d", dtype);
-  const bool norm = mean_rstds != nullptr;
+  const bool norm = h_mean_rstds != nullptr;
   DG_REQUIRE(!norm || (gamma && beta), DGTTA_ERR_BADARG, "feature_window_accumulate_multi: statistics without gamma / beta");
   DG_REQUIRE(PD > 0 && PH > 0 && PW > 0 && seg_len > 0 && seg_len <= PW && x0 >= 0 && y0 >= 0 && z0 >= 0 && x0 + PD <= X && y0 + PH <= Y &&
                  z0 + seg_len <= Z, DGTTA_ERR_BADARG, "feature_window_accumulate_multi: segment outside the volume");
   WfSources ws{};
   for (int k = 0; k < nsrc; ++k) {
-    DG_REQUIRE(srcs[k] && ((uintptr_t)srcs[k] & 15) == 0 && zoffs[k] >= 0 && zoffs[k] + seg_len <= PW && (!norm || mean_rstds[k]),
+    DG_REQUIRE(h_srcs[k] && ((uintptr_t)h_srcs[k] & 15) == 0 && h_zoffs[k] >= 0 && h_zoffs[k] + seg_len <= PW && (!norm || h_mean_rstds[k]),
                DGTTA_ERR_BADARG, "feature_window_accumulate_multi: window %d (null / unaligned source or segment outside the window)", k);
-    ws.src[k] = srcs[k];
-    ws.mean_rstd[k] = norm ? mean_rstds[k] : nullptr;
-    ws.zoff[k] = zoffs[k];
+    ws.src[k] = h_srcs[k];
+    ws.mean_rstd[k] = norm ? h_mean_rstds[k] : nullptr;
+    ws.zoff[k] = h_zoffs[k];
   }
   DG_REQUIRE(((uintptr_t)facc & 15) == 0, DGTTA_ERR_BADARG, "feature_window_accumulate_multi: unaligned accumulator");
   const int64_t total = (int64_t)PD * PH * seg_len * 8;

@@ -358,11 +358,11 @@ int dgtta_feature_window_accumulate(const void *z, const float *gauss, float *fa
 int dgtta_feature_window_accumulate_norm(const void *y, const float *mean_rstd, const float *gamma, const float *beta, float slope,
                                          const float *gauss, float *facc, float *nsum, int Cin, int PD, int PH, int PW, int X, int Y,
                                          int Z, int x0, int y0, int z0, int dtype, void *stream);
-/* ... for nsrc = 1..4 windows of one network pass that overlap along the last axis, one SEGMENT of that axis per call: srcs[k] is window
- * k's features (mean_rstds == NULL) or raw conv output (mean_rstds[k] = its statistics), zoffs[k] the segment's first voxel in window
+/* ... for nsrc = 1..4 windows of one network pass that overlap along the last axis, one SEGMENT of that axis per call: h_srcs[k] (a HOST array of device pointers, like h_mean_rstds and h_zoffs) is window
+ * k's features (h_mean_rstds == NULL) or raw conv output (h_mean_rstds[k] = its statistics), h_zoffs[k] the segment's first voxel in window
  * k's coordinates, seg_len its length, (x0, y0, z0) its first voxel in the volume.  Contributions are added in window order in
  * registers - the bits nsrc single-window calls produce - and the accumulator is read and written once. */
-int dgtta_feature_window_accumulate_multi(const void *const *srcs, const float *const *mean_rstds, const int *zoffs, int nsrc,
+int dgtta_feature_window_accumulate_multi(const void *const *h_srcs, const float *const *h_mean_rstds, const int *h_zoffs, int nsrc,
                                           const float *gamma, const float *beta, float slope, const float *gauss, float *facc,
                                           float *nsum, int Cin, int PD, int PH, int PW, int seg_len, int X, int Y, int Z, int x0, int y0,
                                           int z0, int dtype, void *stream);

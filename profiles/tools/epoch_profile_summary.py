@@ -81,9 +81,9 @@ for dt in dts:
            "fetch_bytes_per_epoch": fetch_b, "write_bytes_per_epoch": write_b, "hbm_bytes_per_epoch": fetch_b + write_b,
            "hbm_bytes_by_kernel": [{"kernel": k, "fetch_gb": round(v[0] / 1e9, 2), "write_gb": round(v[1] / 1e9, 2)} for k, v in hbm_top] or
                                   old.get("hbm_bytes_by_kernel", []),
-           "hbm_bytes_by_kernel_note": "FETCH_SIZE x 2 is calibrated for wide coalesced reads (16 B per lane on consecutive addresses: the DMA and "
-                                       "streaming kernels); kernels whose lanes each read 16 B of a different line (conv_s2_regs_kernel: two "
-                                       "voxels apart) are uncalibrated and may be over-counted by up to 2x (MI355X_MICROARCH.md, HBM)",
+           "hbm_bytes_by_kernel_note": "FETCH_SIZE x 2 holds for strided 16-byte reads too (profiles/tools/fetch_calib.sh): the memory side moves whole "
+                                       "128-byte lines.  conv_s2_regs_kernel<2, 2> reads the skip half of the [voxel][64] concat buffer - 64 used "
+                                       "bytes per line - so half of its fetched bytes are over-fetch (profiles/r05_ab.txt)",
            "kernel_ms_per_epoch": round(total, 2),
            "top_kernels_ms_per_epoch": [{"kernel": k, "ms": round(v, 3), "launches": cnt[k], "share": round(v / total, 4)} for k, v in top]}
     if not top and old:

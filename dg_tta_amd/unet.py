@@ -258,10 +258,12 @@ class HipPlainConvUNet(nn.Module):
         return _UNetFn.apply(self, x, sel, need_grad, *params)
 
     # -- packed weights (re-packed only when the parameter changed)
-    def packed(self, conv, dt, cinp, coutp):
-        """Packed weight blob of `conv` in storage format dt (F32 | BF16 | F16), re-packed only when the parameter changed."""
+    def packed(self, conv, dt, cinp, coutp, cin_slice=None):
+        """Packed weight blob of `conv` in storage format dt (F32 | BF16 | F16), re-packed only when the parameter changed.
+        cin_slice = (lo, hi): the blob of the conv restricted to input channels lo..hi-1 (cinp = its padded count) - the data
+        gradient of a conv on a concat buffer is evaluated half by half (see _UNetFn.backward)."""
         w = conv.weight
-        key = (id(w), dt, cinp, coutp)
+        key = (id(w), dt, cinp, coutp, cin_slice)
         ent = self._packed.get(key)
         if ent is not None and ent[0] == w._version and ent[1].device == w.device:
             return ent[1]
@@ -269,7 +271,8 @@ class HipPlainConvUNet(nn.Module):
         tdt = {F32: torch.float32, BF16: torch.bfloat16, F16: torch.float16}[dt]
         nbytes = lib.dgtta_conv3d_packed_bytes(cinp, coutp, dt)
         wpack = torch.empty(nbytes // tdt.itemsize, dtype=tdt, device=w.device)
-        check(lib.dgtta_conv3d_pack_weights(ptr(w.detach()), ptr(wpack), conv.in_channels, conv.out_channels,
+        wsrc = w.detach() if cin_slice is None else w.detach()[:, cin_slice[0]:cin_slice[1]].contiguous()
+        check(lib.dgtta_conv3d_pack_weights(ptr(wsrc), ptr(wpack), wsrc.shape[1], conv.out_channels,
                                             cinp, coutp, dt, stream_of(w.device)), "dgtta_conv3d_pack_weights")
         self._packed[key] = (w._version, wpack)
         return wpack
@@ -511,6 +514,7 @@ class _UNetFn(torch.autograd.Function):
         st = stream_of(dev)
         adt = net.act_dtype
         esz = 4 if dt == F32 else 2
+        CP_ = 8 if dt == F32 else 16      # channel padding granule of packed weights
         grads = {}          # id(param) -> grad tensor
 
         def want(p):
@@ -654,11 +658,27 @@ class _UNetFn(torch.autograd.Function):
             if kind == "dec" and bidx == 0:
                 # input was the concat buffer of decoder stage sidx: gradient for [up | skip]
                 cat, cskip, cdims = cat_bufs[-(sidx + 1)]
-                gc = torch.empty_like(cat)
-                gcat[sidx] = gc
-                check(lib.dgtta_conv3d_k3_dgrad(ptr(dy), cout, ptr(wb), ptr(gc), 2 * cskip, B, cin, cout, rec["cinp"],
-                                                rec["coutp"], di, hi, wi, s, 0, dt, impl, st), "dgtta_conv3d_k3_dgrad")
-                # transposed-conv backward: dout = first half of gc
+                if cskip * esz == 64 and os.environ.get("DGTTA_SPLIT_CAT_GRAD", "1") != "0":
+                    # 32 channels of 16-bit values = HALF a 128-byte line: as one [voxel][2 C] tensor every consumer of ONE half of this
+                    # gradient (the transposed conv's backward, the stride-2 data gradient's accumulate, the InstanceNorm backward
+                    # of the skip block) would fetch whole lines and use 64 bytes of each (profiles/r05_ab.txt, fetch_calib.sh).
+                    # The data gradient's two 32-channel output blocks are independent jobs of the kernel anyway: two launches on
+                    # the weight halves write two DENSE tensors (same values, the same reads of dy).
+                    gc_up = torch.empty((B, *cdims, cskip), dtype=adt, device=dev)
+                    gc_skip = torch.empty((B, *cdims, cskip), dtype=adt, device=dev)
+                    for half, dst in ((0, gc_up), (1, gc_skip)):
+                        wbh = net.packed(conv, dt, _pad(cskip, CP_), rec["coutp"], (half * cskip, (half + 1) * cskip))
+                        check(lib.dgtta_conv3d_k3_dgrad(ptr(dy), cout, ptr(wbh), ptr(dst), cskip, B, cskip, cout, _pad(cskip, CP_),
+                                                        rec["coutp"], di, hi, wi, s, 0, dt, impl, st), "dgtta_conv3d_k3_dgrad")
+                    gcat[sidx] = (gc_skip, gc_skip.data_ptr(), cskip)
+                    gc, gc_ld = gc_up, cskip
+                else:
+                    gc = torch.empty_like(cat)
+                    gcat[sidx] = (gc, gc.data_ptr() + cskip * esz, 2 * cskip)
+                    gc_ld = 2 * cskip
+                    check(lib.dgtta_conv3d_k3_dgrad(ptr(dy), cout, ptr(wb), ptr(gc), 2 * cskip, B, cin, cout, rec["cinp"],
+                                                    rec["coutp"], di, hi, wi, s, 0, dt, impl, st), "dgtta_conv3d_k3_dgrad")
+                # transposed-conv backward: dout = first half of the concat gradient
                 up = ups[sidx]
                 upm = up["mod"]
                 ld0, lh0, lw0 = up["din"]
@@ -671,36 +691,34 @@ class _UNetFn(torch.autograd.Function):
                 dwu = (gbuf(upm.weight) if want(upm.weight) else scratch_like(upm.weight)) if need_w else None
                 dbu = gbuf(upm.bias) if want(upm.bias) else None
                 if side is None or not need_w:
-                    check(lib.dgtta_convT3d_k2s2_bwd(up["x"], up["ldx"], ptr(gc), 2 * cskip, ptr(upm.weight), ptr(glow),
+                    check(lib.dgtta_convT3d_k2s2_bwd(up["x"], up["ldx"], ptr(gc), gc_ld, ptr(upm.weight), ptr(glow),
                                                      up["cin"], ptr(dwu), ptr(dbu), ptr(w_), nb, B, up["cin"], up["cout"],
                                                      ld0, lh0, lw0, ACC, dt, impl, st), "dgtta_convT3d_k2s2_bwd")
                 else:
                     # data gradient on the main chain, weight / bias gradient (a leaf) on the side stream
                     ev = torch.cuda.Event()
                     ev.record(main_stream)          # gc is complete
-                    check(lib.dgtta_convT3d_k2s2_bwd(up["x"], up["ldx"], ptr(gc), 2 * cskip, ptr(upm.weight), ptr(glow),
+                    check(lib.dgtta_convT3d_k2s2_bwd(up["x"], up["ldx"], ptr(gc), gc_ld, ptr(upm.weight), ptr(glow),
                                                      up["cin"], None, None, ptr(w_), nb, B, up["cin"], up["cout"],
                                                      ld0, lh0, lw0, ACC, dt, impl, st), "dgtta_convT3d_k2s2_bwd")
                     side.wait_event(ev)
                     gc.record_stream(side)
                     with torch.cuda.stream(side):
                         w2 = ws_for(nb, "ws_side")
-                    check(lib.dgtta_convT3d_k2s2_bwd(up["x"], up["ldx"], ptr(gc), 2 * cskip, ptr(upm.weight), None,
+                    check(lib.dgtta_convT3d_k2s2_bwd(up["x"], up["ldx"], ptr(gc), gc_ld, ptr(upm.weight), None,
                                                      up["cin"], ptr(dwu), ptr(dbu), ptr(w2), nb, B, up["cin"], up["cout"],
                                                      ld0, lh0, lw0, ACC, dt, impl, side.cuda_stream), "dgtta_convT3d_k2s2_bwd")
                 gz_ptr, gz_ld = glow.data_ptr(), up["cin"]
-                keep_alive = [glow, gc]
+                keep_alive = [glow, gc, gcat[sidx][0]]
             elif kind == "enc" and bidx == 0:
                 # input was the previous encoder stage's output, which lives in the second half of a concat buffer
                 # and already holds the decoder's skip gradient: accumulate into it.
                 prev_stage = sidx - 1
                 dec_k = n_dec_stages - 1 - prev_stage
-                gc = gcat[dec_k]
-                cskip = cat_bufs[prev_stage][1]
-                gptr = gc.data_ptr() + cskip * esz
-                check(lib.dgtta_conv3d_k3_dgrad(ptr(dy), cout, ptr(wb), gptr, 2 * cskip, B, cin, cout, rec["cinp"],
+                gc, gptr, gld = gcat[dec_k]          # (tensor that owns the skip half, its address, its row pitch)
+                check(lib.dgtta_conv3d_k3_dgrad(ptr(dy), cout, ptr(wb), gptr, gld, B, cin, cout, rec["cinp"],
                                                 rec["coutp"], di, hi, wi, s, 1, dt, impl, st), "dgtta_conv3d_k3_dgrad")
-                gz_ptr, gz_ld = gptr, 2 * cskip
+                gz_ptr, gz_ld = gptr, gld
                 keep_alive = [gc]
             else:
                 # input was the previous block's activation z = LeakyReLU(InstanceNorm(y_prev)), consumed by this conv only:

@@ -93,16 +93,32 @@ def _parent_identity():
 def launch_id():
     """Identifies ONE launch of a multi-rank run; written into the done / failed markers so that a resumed run in the same
     directory neither passes the barrier nor aborts on a previous launch's markers.  `dgtta run_tta --gpus N` hands its
-    children a fresh DGTTA_LAUNCH_ID.  Under torch.distributed.run the id is TORCHELASTIC_RUN_ID (the constant 'none'
-    unless --rdzv-id is given) PLUS the identity of the elastic agent, the common parent of all ranks of one
-    launch.  Any other external launcher has to export DGTTA_LAUNCH_ID itself (`dgtta run_tta` refuses WORLD_SIZE > 1
-    without one); empty only for in-process use (tests that run the ranks one after the other)."""
+    children a fresh DGTTA_LAUNCH_ID.  Under torch.distributed.run:
+
+    * a real rendezvous id (`--rdzv-id X`, anything but the constant 'none') is common to every node of the job:
+      the id is X plus TORCHELASTIC_RESTART_COUNT, so that the markers of a failed attempt do not count for the retry;
+    * the constant 'none' on ONE node (LOCAL_WORLD_SIZE == WORLD_SIZE): the identity (pid, start tick) of the elastic
+      agent - the common parent of all ranks of the launch - tells two launches apart; the restart count is added too;
+    * the constant 'none' across SEVERAL nodes identifies nothing (each node's agent is another process): refused -
+      pass --rdzv-id or export DGTTA_LAUNCH_ID.
+
+    Any other external launcher has to export DGTTA_LAUNCH_ID itself (`dgtta run_tta` refuses WORLD_SIZE > 1 without
+    one); empty only for in-process use (tests that run the ranks one after the other)."""
     lid = os.environ.get("DGTTA_LAUNCH_ID")
     if lid:
         return lid
-    if "TORCHELASTIC_RUN_ID" in os.environ:
-        return f"{os.environ['TORCHELASTIC_RUN_ID']}@{_parent_identity()}"
-    return ""
+    run_id = os.environ.get("TORCHELASTIC_RUN_ID")
+    if run_id is None:
+        return ""
+    attempt = os.environ.get("TORCHELASTIC_RESTART_COUNT", "0")
+    if run_id != "none":
+        return f"{run_id}#{attempt}"
+    world = os.environ.get("WORLD_SIZE", "1")
+    if os.environ.get("LOCAL_WORLD_SIZE", world) != world:
+        raise RuntimeError("dg_tta_amd.sharding.launch_id: a multi-node torch.distributed.run job without --rdzv-id "
+                           "(TORCHELASTIC_RUN_ID is the constant 'none') has no id common to its nodes; pass "
+                           "--rdzv-id <unique string> or export DGTTA_LAUNCH_ID (same on every rank, new per launch)")
+    return f"none@{_parent_identity()}#{attempt}"
 
 
 def mark_rank_done(save_path, rank):

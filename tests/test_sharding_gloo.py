@@ -244,3 +244,35 @@ def test_launch_id_is_unique_per_launch_under_torchrun(monkeypatch):
     assert other.startswith("none@") and other != kids[0]
     monkeypatch.setenv("DGTTA_LAUNCH_ID", "explicit")
     assert sharding.launch_id() == "explicit"
+
+
+def test_launch_id_across_nodes_and_restarts(monkeypatch):
+    """the elastic agent's identity is common to ONE node's ranks only.  Two simulated agents (two parents) of a
+    two-node job agree on the id when a rendezvous id is given and are refused when it is the constant 'none'; an elastic
+    restart (same agent, same id) is a new launch: a failed marker of attempt 0 does not count for attempt 1."""
+    import subprocess
+    import sys
+    from dg_tta_amd import sharding
+    root = str(__import__("pathlib").Path(__file__).resolve().parents[1])
+    code = "import sys; sys.path.insert(0, %r); from dg_tta_amd import sharding; print(sharding.launch_id())" % root
+    base = {k: v for k, v in os.environ.items() if k not in ("DGTTA_LAUNCH_ID", "TORCHELASTIC_RESTART_COUNT")}
+
+    def rank_under_agent(env):          # a shell in between = another parent process = another node's agent
+        return subprocess.run(["sh", "-c", f"{sys.executable} -c {code!r}; true"], env=env, capture_output=True, text=True)
+    two_nodes = dict(base, TORCHELASTIC_RUN_ID="job-17", WORLD_SIZE="4", LOCAL_WORLD_SIZE="2")
+    ids = [rank_under_agent(two_nodes).stdout.strip() for _ in range(2)]
+    assert ids[0] == ids[1] == "job-17#0"
+    anon = rank_under_agent(dict(two_nodes, TORCHELASTIC_RUN_ID="none"))
+    assert anon.stdout.strip() == "" and "--rdzv-id" in anon.stderr
+    for var in ("DGTTA_LAUNCH_ID", "TORCHELASTIC_RESTART_COUNT"):
+        monkeypatch.delenv(var, raising=False)
+    monkeypatch.setenv("TORCHELASTIC_RUN_ID", "none")
+    monkeypatch.setenv("WORLD_SIZE", "4")
+    monkeypatch.setenv("LOCAL_WORLD_SIZE", "2")
+    with pytest.raises(RuntimeError, match="rdzv-id"):
+        sharding.launch_id()
+    monkeypatch.setenv("LOCAL_WORLD_SIZE", "4")             # one node: the agent's identity + the attempt
+    first = sharding.launch_id()
+    assert first.startswith("none@") and first.endswith("#0")
+    monkeypatch.setenv("TORCHELASTIC_RESTART_COUNT", "1")
+    assert sharding.launch_id() == first[:-1] + "1"

@@ -79,6 +79,9 @@ def read_nrrd(path):
     if code is None:
         raise ValueError(f"{path}: unsupported NRRD type {fields['type']}")
     sizes = [int(v) for v in fields["sizes"].split()]
+    for skip in ("byte skip", "byteskip", "line skip", "lineskip"):
+        if int(fields.get(skip, "0")) != 0:
+            raise NotImplementedError(f"{path}: NRRD '{skip}: {fields[skip]}' is not supported")
     enc = fields.get("encoding", "raw").lower()
     body = raw[end + sep:]
     if enc in ("gzip", "gz"):
@@ -168,6 +171,8 @@ def read_metaimage(path):
     if fields.get("CompressedData", "False").lower() == "true":
         body = zlib.decompress(body)
     hs = int(fields.get("HeaderSize", "0"))
+    if hs < 0:          # -1: "the data are the LAST bytes of the file" - needs the element count against the file size
+        raise NotImplementedError(f"{path}: MetaImage HeaderSize = {hs} is not supported")
     if hs > 0:
         body = body[hs:]
     data = np.frombuffer(body, dtype=np.dtype((">" if msb else "<") + code), count=int(np.prod(sizes))).reshape(sizes[::-1])
@@ -222,7 +227,7 @@ def read_image(path):
     ext = extension_of(path)
     if ext in (".nii", ".nii.gz"):
         arr, hdr = read_nifti(path)
-        hdr = dict(hdr, format="nifti", ext=".nii.gz")
+        hdr = dict(hdr, format="nifti", ext=ext)        # the case's real ending: labels and predictions are looked up by it
         return arr, hdr
     if ext == ".nrrd":
         return read_nrrd(path)
@@ -243,8 +248,6 @@ def write_image(path, array, header=None, spacing=(1.0, 1.0, 1.0)):
     if header is not None and not same:
         spacing, header = tuple(header.get("pixdim", spacing)), None
     if ext in (".nii", ".nii.gz"):
-        if header is not None and "raw" not in header:       # a big-endian case: its header is rebuilt (little endian) from the spacing
-            spacing, header = tuple(header.get("pixdim", spacing)), None
         return write_nifti(path, array, header=header, spacing=spacing)
     if ext == ".nrrd":
         return write_nrrd(path, array, header=header, spacing=spacing)

@@ -20,6 +20,19 @@ def _open(path, mode):
     return gzip.open(path, mode) if str(path).endswith(".gz") else open(path, mode)
 
 
+# (offset, struct code, count) of every multi-byte field of the 348-byte NIfTI-1 header; the rest are chars
+_HDR_FIELDS = ((0, "i", 1), (32, "i", 1), (36, "h", 1), (40, "h", 8), (56, "f", 3), (68, "h", 4), (76, "f", 11), (120, "h", 1),
+               (124, "f", 4), (140, "i", 2), (252, "h", 2), (256, "f", 18))
+
+
+def _swap_header(raw):
+    """The big-endian 348-byte header `raw` as little-endian bytes."""
+    out = bytearray(raw)
+    for off, code, n in _HDR_FIELDS:
+        struct.pack_into(f"<{n}{code}", out, off, *struct.unpack_from(f">{n}{code}", raw, off))
+    return bytes(out)
+
+
 def read_nifti(path):
     """Returns (array [z,y,x] (or [t,z,y,x]), header dict with 'pixdim' (x,y,z spacing), 'affine' 4x4, 'raw' bytes)."""
     with _open(path, "rb") as f:
@@ -52,8 +65,9 @@ def read_nifti(path):
         if qform_code > 0:
             affine[:3, 3] = struct.unpack(bo + "3f", raw[268:280])
     hdr = {"pixdim": tuple(float(p) for p in pixdim[1:4]), "affine": affine, "shape_xyz": shape[:3]}
-    if bo == "<":
-        hdr["raw"] = bytes(raw[:348])         # reused verbatim by write_nifti (a big-endian header is rebuilt from pixdim instead)
+    # reused by write_nifti so that a prediction keeps the case's sform / qform, origin and orientation; a big-endian header
+    # is byte-swapped field by field into the little-endian form the writer emits
+    hdr["raw"] = bytes(raw[:348]) if bo == "<" else _swap_header(raw[:348])
     return np.ascontiguousarray(data.astype(data.dtype.newbyteorder("="))), hdr
 
 

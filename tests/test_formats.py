@@ -168,3 +168,20 @@ def test_big_endian_nifti_is_read(tmp_path):
     write_image(tmp_path / "pred.nii.gz", (a > 0).astype(np.int16), header=h)
     c, h2 = read_image(tmp_path / "pred.nii.gz")
     assert np.array_equal(c, (a > 0).astype(np.int16)) and np.allclose(h2["pixdim"], (0.7, 0.8, 3.0))
+    # the prediction keeps the case's sform (origin, orientation) - the header is byte-swapped, not dropped - and
+    # a plain .nii case reports its real ending (its label file and its prediction are looked up as <case>.nii)
+    assert np.allclose(h2["affine"], h["affine"]) and np.allclose(h2["affine"][:3, 3], (5, 6, 7))
+    assert h["ext"] == ".nii" and h2["ext"] == ".nii.gz"
+
+
+def test_unsupported_data_offsets_are_refused(tmp_path):
+    """MetaImage HeaderSize = -1 and NRRD byte / line skips would return wrong voxels: refused by name."""
+    from dg_tta_amd.tta.image_io import read_metaimage, read_nrrd
+    body = np.zeros(8, "<i2").tobytes()
+    (tmp_path / "a.mha").write_bytes(b"ObjectType = Image\nNDims = 3\nDimSize = 2 2 2\nElementType = MET_SHORT\nHeaderSize = -1\n"
+                                     b"ElementDataFile = LOCAL\n" + body)
+    with pytest.raises(NotImplementedError, match="HeaderSize"):
+        read_metaimage(tmp_path / "a.mha")
+    (tmp_path / "a.nrrd").write_bytes(b"NRRD0004\ntype: short\ndimension: 3\nsizes: 2 2 2\nbyte skip: 4\nencoding: raw\n\n" + b"\0" * 4 + body)
+    with pytest.raises(NotImplementedError, match="byte skip"):
+        read_nrrd(tmp_path / "a.nrrd")

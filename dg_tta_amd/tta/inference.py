@@ -130,12 +130,21 @@ def _only_identity_output_hooks(m):
     return True
 
 
-def _can_accumulate_features(model):
-    """Feature-space accumulation needs the network's offer (head = 1x1x1 conv on 32 channels, nothing selected) and nothing
-    between the head and the accumulation: every forward hook is the plan's untouched model-output modifier (identity)."""
+FEATURE_HEAD_MAX_CLASSES_MFMA = 128      # dgtta_feature_head_argmax: classes x 32 voxels per wave on the matrix cores
+FEATURE_HEAD_MAX_CLASSES_VALU = 160      # its vector-ALU kernel with M > 1 members parks C * 256 * 4 B of partial sums in LDS
+
+
+def _can_accumulate_features(model, members=1):
+    """Feature-space accumulation needs the network's offer (head = 1x1x1 conv on 32 channels, nothing selected), nothing
+    between the head and the accumulation (every forward hook is the plan's untouched model-output modifier = identity), and a
+    head the final head + argmax kernel takes (C <= 128, or one member, or C <= 160) - checked UP FRONT, so that a
+    wider ensemble goes to the logits-space accumulator instead of failing after every member's sliding-window pass."""
     m = _inner(model)
-    return (hasattr(m, "can_fuse_window_feature_accumulate") and m.can_fuse_window_feature_accumulate() and
-            _only_identity_output_hooks(m))
+    if not (hasattr(m, "can_fuse_window_feature_accumulate") and m.can_fuse_window_feature_accumulate() and
+            _only_identity_output_hooks(m)):
+        return False
+    ncls = _num_classes(m)
+    return ncls <= FEATURE_HEAD_MAX_CLASSES_MFMA or members == 1 or ncls <= FEATURE_HEAD_MAX_CLASSES_VALU
 
 
 class WindowFeatures:
@@ -276,7 +285,7 @@ def predict_ensemble_features(data, model, parameter_sets, patch_size):
 def predict_ensemble(data, model, parameter_sets, patch_size):
     """What run_inference / dgtta run_tta predict with: (acc, nsum, crop) for export_segmentation - acc a WindowFeatures when
     DGTTA_WINDOW_ACC=features (default) and the network offers it, else the logits-space accumulator of predict_ensemble_logits."""
-    if window_acc_mode() == "features" and _can_accumulate_features(model):
+    if window_acc_mode() == "features" and _can_accumulate_features(model, len(parameter_sets)):
         feats = predict_ensemble_features(data, model, parameter_sets, patch_size)
         return feats, feats.nsum, feats.crop
     return predict_ensemble_logits(data, model, parameter_sets, patch_size)

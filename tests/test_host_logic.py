@@ -357,3 +357,21 @@ def test_host_shim_under_address_and_ub_sanitizers(tmp_path):
     assert "runtime error" not in res.stderr and "AddressSanitizer" not in res.stderr, report
     assert res.returncode == 0 and "NOT REJECTED" not in res.stdout, report
     assert f"functions {n}" in res.stdout
+
+
+def test_feature_space_inference_is_offered_only_for_heads_the_final_kernel_takes():
+    """ADVICE r5: dgtta_feature_head_argmax takes C <= 128 on the matrix cores and, for an ensemble, C <= 160 on the vector ALU;
+    a wider ensemble must be routed to the logits-space accumulator UP FRONT, not fail after every member's window pass."""
+    import torch
+    from dg_tta_amd.tta import inference as pinf
+    from dg_tta_amd.unet import HipPlainConvUNet
+
+    def net(ncls):
+        return HipPlainConvUNet(dict(features=(32, 48), strides=(1, 2), n_conv_enc=(1, 1), n_conv_dec=(1,), in_channels=12,
+                                     num_classes=ncls))
+    with torch.no_grad():
+        assert pinf._can_accumulate_features(net(105), members=3)
+        assert pinf._can_accumulate_features(net(150), members=3)
+        assert pinf._can_accumulate_features(net(200), members=1)
+        assert not pinf._can_accumulate_features(net(200), members=3)
+    assert not pinf._can_accumulate_features(net(105), members=1)          # grad mode: the network does not offer it

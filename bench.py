@@ -62,7 +62,11 @@ def epoch_profile(args, dtype):
         if not d or d.get("size") != args.size or d.get("accum") != args.accum:
             continue
         alg = EPOCH_GB(args, dtype) * 1e9
-        out = {"traffic": d.get("hbm_bytes_per_epoch"),
+        from dg_tta_amd.build import source_sha16
+        stamp, here = d.get("measured_on") or {}, source_sha16()
+        out = {"profile_measured_on": stamp or "unrecorded (a summary from before round 6)", "kernel_sources_now": here,
+               "profile_stale": not (stamp.get("time") == here and stamp.get("traffic") == here),
+               "traffic": d.get("hbm_bytes_per_epoch"),
                "traffic_over_algorithmic": (round(d["hbm_bytes_per_epoch"] / alg, 3) if d.get("hbm_bytes_per_epoch") else None),
                "largest_consumer": d.get("largest_consumer"), "profile_source": f"profiles/{f.name}: {d.get('how', '')}"}
         return out

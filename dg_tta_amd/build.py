@@ -15,6 +15,17 @@ EXTRA_FLAGS = {"conv_ring.hip": ["-mllvm", "-pragma-unroll-threshold=262144"]}
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
 
 
+def source_sha16():
+    """sha256 (16 hex) over the kernel sources and the C ABI header: the stamp a profile summary carries, so that a bench line
+    can tell whether the profile it quotes was measured on the kernels it is timing."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(list(CSRC.glob("*.hip")) + list(CSRC.glob("*.h")) + [CSRC.parents[1] / "include" / "dgtta.h"]):
+        h.update(f.name.encode())
+        h.update(f.read_bytes())
+    return h.hexdigest()[:16]
+
+
 def _stale(out, deps):
     return (not out.exists()) or any(d.stat().st_mtime > out.stat().st_mtime for d in deps)
 

@@ -1,8 +1,11 @@
 """Summary of profiles/tools/epoch_profile.sh: HBM bytes and per-kernel-name time of ONE steady-state TTA epoch =
 (3-epoch run - 1-epoch run) / 2 of the same bench.py command.  FETCH_SIZE / WRITE_SIZE in KiB as rocprofv3 reports them,
 FETCH x 2 on gfx950 (MI355X_MICROARCH.md, HBM: 128-byte requests tallied at 64 bytes)."""
-import collections, csv, glob, json, sys
+import collections, csv, glob, json, os, sys
+sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(__file__), "..", "..")))
+from dg_tta_amd.build import source_sha16
 tag, dts = sys.argv[1], sys.argv[2:]
+SHA = source_sha16()          # the kernel sources this run measured (a summary must say what it was measured on)
 # weight gradients that the ring sweep takes (conv_wgrad_ring.hip): the 13 plain stride-1 3x3x3 layers at >= 16^3, forward GFLOP
 # per 128^3 sample from SURVEY.md 8d (a weight gradient costs what the forward costs), x 32 sample passes per epoch
 WRING_GFLOP = [43.49, 115.96, 57.98, 28.99, 14.50, 28.99, 14.50, 57.98, 28.99, 115.96, 57.98, 231.93, 115.96]
@@ -42,7 +45,6 @@ def by_name(d):
     return t, c
 
 
-import os
 prev = {}
 for cand in (f"gpurun_out/{tag}_epoch_profile.json", f"profiles/{tag}_epoch_profile.json"):      # (gpurun_out/ does not travel to the box)
     if os.path.exists(cand):
@@ -70,9 +72,12 @@ for dt in dts:
     by_kernel = {k: ((fn3[k] - fn1[k]) / 2 * 1024 * 2, (wn3[k] - wn1[k]) / 2 * 1024) for k in set(fn3) | set(wn3)}
     hbm_top = sorted(by_kernel.items(), key=lambda kv: -(kv[1][0] + kv[1][1]))[:16]
     old = prev.get("fp32" if dt == "fp32" else "16bit", {})
-    if n3 == 0 and old:          # the PMC passes were not re-run: keep the recorded traffic
+    measured_on = {"time": SHA if top else None, "traffic": SHA if n3 else None}
+    if n3 == 0 and old:          # the PMC passes were not re-run: keep the recorded traffic UNDER ITS OWN STAMP
         fetch_b, write_b = old.get("fetch_bytes_per_epoch", 0.0), old.get("write_bytes_per_epoch", 0.0)
         n1, n3 = 0, 2 * old.get("dispatches_per_epoch", 0)
+        measured_on["traffic"] = (old.get("measured_on") or {}).get("traffic", "unrecorded (before round 6)")
+        measured_on["traffic_carried_over_from"] = "the previous summary of this tag"
     ent = {"size": 128, "accum": 16, "storage": dt,
            "how": "(3-epoch run - 1-epoch run) / 2 of `bench.py --dtype %s --warmup 0 --weights he --no-fp32 --no-cpu-baseline "
                   "--inference-size 0` under rocprofv3: --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes with --kernel-trace "
@@ -89,6 +94,9 @@ for dt in dts:
     if not top and old:
         ent["kernel_ms_per_epoch"], ent["top_kernels_ms_per_epoch"] = old.get("kernel_ms_per_epoch"), old.get("top_kernels_ms_per_epoch", [])
         ent["largest_consumer"] = old.get("largest_consumer")
+        measured_on["time"] = (old.get("measured_on") or {}).get("time", "unrecorded (before round 6)")
+        measured_on["time_carried_over_from"] = "the previous summary of this tag"
+    ent["measured_on"] = measured_on
     if top:
         k, v = top[0]
         lc = {"kernel": k, "ms_per_epoch": round(v, 2), "share_of_kernel_time": round(v / total, 4), "launches_per_epoch": cnt[k]}

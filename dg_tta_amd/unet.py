@@ -279,8 +279,9 @@ class HipPlainConvUNet(nn.Module):
 
 
 def set_probe(model, where):
-    """bench.py hook: record (start, end) events around the forward conv launch of block `where` = (kind, stage, idx) of
-    `model` (None: stop).  Returns the probe dict (events are appended while the model runs)."""
+    """bench.py hook: record (start, end) events around the forward conv launch and the weight-gradient launch (sweep + slab
+    reduction, on the stream it runs on) of block `where` = (kind, stage, idx) of `model` (None: stop).  Returns the probe dict
+    (events are appended to probe["events"] / probe["wgrad_events"] while the model runs)."""
     st = state_of(model)
     st.probe = None if where is None else dict(where=where, events=[])
     return st.probe
@@ -647,8 +648,17 @@ class _UNetFn(torch.autograd.Function):
                     with torch.cuda.stream(side):
                         w_ = ws_for(nb, "ws_side")
                     st_w = side.cuda_stream
+                pr = state_of(net).probe
+                pr = pr if (pr is not None and pr["where"] == rec["where"]) else None
+                if pr is not None:       # bench.py: time this layer's weight-gradient launch with events on ITS stream
+                    wstream = main_stream if side is None else side
+                    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    ev0.record(wstream)
                 check(lib.dgtta_conv3d_k3_wgrad(rec["u"], rec["ldu"], ptr(dy), cout, ptr(dw), ptr(db), ptr(w_), nb, B,
                                                 cin, cout, di, hi, wi, s, ACC, dt, impl, st_w), "dgtta_conv3d_k3_wgrad")
+                if pr is not None:
+                    ev1.record(wstream)
+                    pr.setdefault("wgrad_events", []).append((ev0, ev1, B))
             # -- data gradient towards the block input
             where = rec["where"]
             if idx == 0:

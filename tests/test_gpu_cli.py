@@ -109,3 +109,33 @@ def test_bench_two_real_ranks_on_one_gpu():
     # ... and so do the sliding-window leg and the at-size parity record (rank 0, peers in the final barrier)
     assert out["inference"]["windows"] == 27 and out["inference"]["fp32_logits_accumulator"]["label_agreement_with_feature_accumulator"] > 0.999
     assert "parity_at_size" in out
+
+
+def test_bench_four_real_ranks_rehearsal_and_rank0_matches_the_single_run():
+    """rehearsal of the hardware SCALE run so that it cannot fail on plumbing - `bench.py --gpus N --share-gpu`
+    with the REAL runner at 64^3.  N = 4 here: the pool admits at most 6 processes on a box's GPU and this test process is one
+    of them (8 ranks run with the stub runner on the CPU: tests/test_sharding_gloo.py).  The line carries one rate per rank,
+    the world size the rendezvous saw, the CPU baseline and the roofline object on rank 0; rank 0's sample, seeds and draws
+    do not depend on the number of ranks: its trajectory is the N = 1 run's, bit for bit."""
+    import os
+    import subprocess
+    import sys
+    root = Path(__file__).resolve().parents[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    common = ["--steps", "2", "--warmup", "1", "--size", "64", "--accum", "4", "--pretrain-steps", "30", "--no-fp32",
+              "--inference-size", "0", "--cpu-size", "64", "--cpu-warmup", "0", "--no-parity"]
+
+    def line(extra):
+        res = subprocess.run([sys.executable, str(root / "bench.py")] + extra + common, env=env, capture_output=True, text=True,
+                             timeout=900)
+        assert res.returncode == 0, res.stderr[-3000:]
+        lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+        assert len(lines) == 1
+        return json.loads(lines[0])
+    four, one = line(["--gpus", "4", "--share-gpu"]), line(["--gpus", "1"])
+    assert four["n_gpus"] == 4 and len(four["per_rank_epochs_per_s"]) == 4 and four["config"]["world_size_seen"] == 4
+    assert four["scaling"] == "weak" and four["value"] == pytest.approx(4 * four["value_per_gpu"], rel=1e-4)
+    assert four["cpu_baseline"]["value"] > 0 and four["cpu_baseline"]["kind"] == "port"
+    assert four["roofline"] is not None and "epoch_frac" in four["roofline"] and "largest_consumer" in four["roofline"]
+    assert four["dtype"] == one["dtype"] == "fp16"
+    assert four["loss_last_epoch"] == one["loss_last_epoch"] and four["pseudo_dice"] == one["pseudo_dice"]

@@ -276,3 +276,31 @@ def test_launch_id_across_nodes_and_restarts(monkeypatch):
     assert first.startswith("none@") and first.endswith("#0")
     monkeypatch.setenv("TORCHELASTIC_RESTART_COUNT", "1")
     assert sharding.launch_id() == first[:-1] + "1"
+
+
+def test_bench_eight_ranks_under_torch_distributed_run():
+    """The driver's N = 8 launch, rehearsed on the CPU: `python -m torch.distributed.run --nproc-per-node 8 bench.py --gpus 8`
+    (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the launcher; stub runner, gloo): one line from rank 0 with eight rates,
+    the whole-job value quoted on the slowest rank."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parents[1]
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    env["OMP_NUM_THREADS"] = "1"
+    res = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+                          "--master-port", str(port), str(root / "bench.py"), "--gpus", "8", "--stub-runner", "0.05", "--steps", "2",
+                          "--warmup", "1"], env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 8 and out["config"]["world_size_seen"] == 8 and len(out["per_rank_epochs_per_s"]) == 8
+    assert out["config"]["launcher"] == "torch.distributed.run" and out["scaling"] == "weak"
+    assert out["value"] == pytest.approx(8 * out["value_per_gpu"], rel=1e-4)
+    assert out["value_per_gpu"] <= min(out["per_rank_epochs_per_s"]) * 1.0001

@@ -798,6 +798,29 @@ def roofline_of(probe, args, dtype):
     return out
 
 
+def merge_schedules(timed, one):
+    """`timed`: the probe of the timed region (three-stream schedule), `one`: the same probe of one epoch on ONE stream.  The
+    top-level achieved / frac / avg_ms are the one-stream figures (the kernel alone on the chip - what a roofline fraction of a
+    KERNEL means, and what the committed one-stream rocprofv3 summaries show); `in_schedule` keeps what the timed region's
+    events read (the launch shares the chip with the other stream's kernels there)."""
+    if one is None:
+        return timed
+
+    def pick(t, o):
+        out = dict(o)
+        out["measured"] = ("events on the launch stream around every launch of this block in ONE epoch run on one stream right after the "
+                           "timed region (DGTTA_WGRAD_STREAM=0 DGTTA_PIPELINE_PREP=0, same process, same workload, bit-identical results)")
+        out["in_schedule"] = {"avg_ms": t["avg_ms"], "achieved": t["achieved"], "frac": t["frac"], "launches": t["launches"],
+                              "note": "the same launches inside the TIMED region (default three-stream schedule): the duration "
+                                      "includes the time the launch shares the chip with the other streams' kernels"}
+        return out
+    fwd_t, fwd_o = timed.get("forward"), one.get("forward")
+    out = pick({k: v for k, v in timed.items() if k != "forward"}, {k: v for k, v in one.items() if k != "forward"})
+    if fwd_t is not None and fwd_o is not None:
+        out["forward"] = pick(fwd_t, fwd_o)
+    return out
+
+
 # ------------------------------------------------------------------------------------------------ one rank
 def run_rank(args):
     import numpy as np
@@ -870,7 +893,32 @@ def run_rank(args):
         barrier()
         dt, per_rank = over_ranks(time.perf_counter() - t0)
         set_probe_(runner, None)
-        return dt, per_rank, runner, roofline_of(probe, args, dtype)
+        roof = roofline_of(probe, args, dtype)
+        if roof is not None and not stub and rank == 0:
+            # The timed region runs the three-stream schedule: the weight gradients (side stream) and the InstanceNorm / data-
+            # gradient chain (main stream) SHARE the chip, so an event pair around a launch there measures the launch plus what
+            # it waits for.  The kernel's own rate is taken from ONE extra epoch right after the timed region with everything on
+            # one stream (DGTTA_WGRAD_STREAM=0 DGTTA_PIPELINE_PREP=0: the schedule of the committed rocprofv3 --stats summaries,
+            # whose per-launch averages these must agree with); results are bit-identical in both schedules.
+            saved_env = {k: os.environ.get(k) for k in ("DGTTA_WGRAD_STREAM", "DGTTA_PIPELINE_PREP")}
+            os.environ.update(DGTTA_WGRAD_STREAM="0", DGTTA_PIPELINE_PREP="0")
+            try:
+                p1 = set_probe_(runner, ("dec", 3, 1))
+                runner.epoch()
+                torch.cuda.synchronize()
+                set_probe_(runner, None)
+                one = roofline_of(p1, args, dtype)
+                runner.losses.pop()                  # (the line reports the last TIMED epoch)
+                runner.dices.pop()
+                runner.dice = runner.dices[-1]
+            finally:
+                for k, v in saved_env.items():
+                    if v is None:
+                        os.environ.pop(k, None)
+                    else:
+                        os.environ[k] = v
+            roof = merge_schedules(roof, one)
+        return dt, per_rank, runner, roof
 
     main_dtype = args.dtype
     traj_file = ROOT / "profiles" / "fp32_trajectory.json"

@@ -7,7 +7,7 @@ out = {"note": "rocprofv3 --pmc, one counter group per run with --kernel-trace o
                "and SQ_BUSY_CYCLES in cycles summed over SEs/XCDs as rocprofv3 reports them); FETCH_SIZE / WRITE_SIZE in KiB, FETCH x2 on gfx950"}
 import hashlib
 out["samples_per_launch"] = 8
-out["kernel_source_sha16"] = {f: hashlib.sha256(open("dg_tta_amd/csrc/" + f, "rb").read()).hexdigest()[:16] for f in ("conv_ring.hip", "conv_rows.hip", "conv_mfma.hip", "conv_wgrad.hip")}
+out["kernel_source_sha16"] = {f: hashlib.sha256(open("dg_tta_amd/csrc/" + f, "rb").read()).hexdigest()[:16] for f in ("conv_ring.hip", "conv_rows.hip", "conv_mfma.hip", "conv_wgrad.hip", "conv_wgrad_ring.hip")}
 jobs = collections.defaultdict(lambda: collections.defaultdict(lambda: collections.defaultdict(list)))
 for f in glob.glob(f"gpurun_out/{tag}_pmc_*/**/*counter_collection.csv", recursive=True):
     job = re.search(rf"{tag}_pmc_(.+)_\d+/", f).group(1)

@@ -26,6 +26,7 @@ SIGNATURES = {
     "dgtta_softdice_ws_bytes": (SZ, [I, I, I64]),
     "dgtta_softdice_fwd": (I, [P, P, P, P, P, SZ, I, I, I64, I, I, I, P]),
     "dgtta_softdice_bwd": (I, [P, P, P, P, P, F, P, I, I, I64, I, I, P]),
+    "dgtta_softdice_bwd_t": (I, [P, P, P, P, P, F, P, I, I, I64, I, I, I, P]),
     "dgtta_softdice_probs_fwd": (I, [P, P, P, P, SZ, I, I, I64, I64, I64, I64, P]),
     "dgtta_softdice_probs_bwd": (I, [P, P, P, P, P, P, I, I, I64, I64, I64, I64, P]),
     "dgtta_dice_ce_ws_bytes": (SZ, [I, I, I64]),
@@ -59,6 +60,7 @@ SIGNATURES = {
     "dgtta_seghead_warp_bwd_ws_bytes": (SZ, [I, I, I, I, I, I]),
     "dgtta_seghead_warp_fwd": (I, [P, P, P, P, I, P, P, I, I, I, I, I, I, I, P]),
     "dgtta_seghead_warp_bwd": (I, [P, P, P, P, P, P, I, P, P, P, P, SZ, I, I, I, I, I, I, I, I, P]),
+    "dgtta_seghead_warp_bwd_g16": (I, [P, P, P, P, P, P, I, P, P, P, P, SZ, I, I, I, I, I, I, I, I, P]),
     "dgtta_ncdhw_to_ndhwc": (I, [P, P, I, I, I64, I, I, P]),
     "dgtta_ndhwc_to_ncdhw": (I, [P, P, I, I, I64, I, I, P]),
     "dgtta_argmax_dice": (I, [P, I, I, P, P, P, I, I64, P]),

@@ -393,8 +393,26 @@ __global__ __launch_bounds__(256) void softdice_fwd16_kernel(const float *__rest
   }
 }
 
+// TO: type of the gradient rows - float, or (round 6) the network's 16-bit storage type: the fused head + warp backward then
+// gathers half the bytes (dgtta_seghead_warp_bwd_g16); the values are the fp32 ones rounded once
+template <typename TO>
+__device__ __forceinline__ void store_grad4(TO *base, int64_t idx4, float x, float y, float z, float w);
+template <>
+__device__ __forceinline__ void store_grad4<float>(float *base, int64_t idx4, float x, float y, float z, float w) {
+  reinterpret_cast<float4 *>(base)[idx4] = make_float4(x, y, z, w);
+}
+template <>
+__device__ __forceinline__ void store_grad4<bf16_t>(bf16_t *base, int64_t idx4, float x, float y, float z, float w) {
+  reinterpret_cast<uint2 *>(base)[idx4] = make_uint2(pack2_16<bf16_t>(x, y), pack2_16<bf16_t>(z, w));
+}
+template <>
+__device__ __forceinline__ void store_grad4<f16_t>(f16_t *base, int64_t idx4, float x, float y, float z, float w) {
+  reinterpret_cast<uint2 *>(base)[idx4] = make_uint2(pack2_16<f16_t>(x, y), pack2_16<f16_t>(z, w));
+}
+
+template <typename TO>
 __global__ __launch_bounds__(256) void softdice_bwd16_kernel(const float *__restrict__ la, const float *__restrict__ lb,
-                                                             float *__restrict__ ga, float *__restrict__ gb,
+                                                             TO *__restrict__ ga, TO *__restrict__ gb,
                                                              const float *__restrict__ coef, float scale_h,
                                                              const float *__restrict__ scale_dev, int64_t V) {
   const int b = blockIdx.y, q = threadIdx.x & 3;
@@ -407,7 +425,7 @@ __global__ __launch_bounds__(256) void softdice_bwd16_kernel(const float *__rest
   }
   const float4 *pa = reinterpret_cast<const float4 *>(la + (int64_t)b * V * 16);
   const float4 *pb = reinterpret_cast<const float4 *>(lb + (int64_t)b * V * 16);
-  float4 *oa = reinterpret_cast<float4 *>(ga + (int64_t)b * V * 16), *ob = reinterpret_cast<float4 *>(gb + (int64_t)b * V * 16);
+  TO *oa = ga + (int64_t)b * V * 16, *ob = gb + (int64_t)b * V * 16;
   for (int64_t v0 = (int64_t)blockIdx.x * 64; v0 < V; v0 += (int64_t)gridDim.x * 64) {
     const int64_t v = v0 + (threadIdx.x >> 2);
     if (v < V) {
@@ -427,9 +445,9 @@ __global__ __launch_bounds__(256) void softdice_bwd16_kernel(const float *__rest
       da = quad_sum(da);
       db = quad_sum(db);
       const float sm = scale * m;
-      oa[v * 4 + q] = make_float4(sm * a[0] * (ta[0] - da), sm * a[1] * (ta[1] - da), sm * a[2] * (ta[2] - da), sm * a[3] * (ta[3] - da));
-      ob[v * 4 + q] = make_float4(sm * bq[0] * (tb[0] - db), sm * bq[1] * (tb[1] - db), sm * bq[2] * (tb[2] - db),
-                                  sm * bq[3] * (tb[3] - db));
+      store_grad4<TO>(oa, v * 4 + q, sm * a[0] * (ta[0] - da), sm * a[1] * (ta[1] - da), sm * a[2] * (ta[2] - da), sm * a[3] * (ta[3] - da));
+      store_grad4<TO>(ob, v * 4 + q, sm * bq[0] * (tb[0] - db), sm * bq[1] * (tb[1] - db), sm * bq[2] * (tb[2] - db),
+                      sm * bq[3] * (tb[3] - db));
     }
   }
 }
@@ -516,7 +534,7 @@ extern "C" int dgtta_softdice_bwd(const float *la, const float *lb, float *grad_
   if (use16(la, lb, grad_la, grad_lb, C, ldc)) {
     int64_t g16 = (V + 63) / 64;
     if (g16 > 4096) g16 = 4096;
-    hipLaunchKernelGGL(softdice_bwd16_kernel, dim3((int)g16, B), dim3(256), 0, st, la, lb, grad_la, grad_lb, coef, grad_scale,
+    hipLaunchKernelGGL(softdice_bwd16_kernel<float>, dim3((int)g16, B), dim3(256), 0, st, la, lb, grad_la, grad_lb, coef, grad_scale,
                        grad_scale_dev, V);
     DG_CHECK_LAUNCH("softdice_bwd16_kernel");
     return DGTTA_OK;
@@ -528,6 +546,36 @@ extern "C" int dgtta_softdice_bwd(const float *la, const float *lb, float *grad_
   hipLaunchKernelGGL(softdice_bwd_kernel, dim3((int)gb, B), dim3(nw * 64), lds_for(ldc, nw), st, la, lb, grad_la,
                      grad_lb, coef, grad_scale, grad_scale_dev, C, V, ldc, (int)vec_ok(la, lb, grad_la, grad_lb, ldc));
   DG_CHECK_LAUNCH("softdice_bwd_kernel");
+  return DGTTA_OK;
+}
+
+// Gradient rows in a 16-bit storage type (DGTTA_BF16 / DGTTA_F16): the 16-class form only (C = ldc = 16, 8-byte aligned rows) -
+// what the fused head + warp backward consumes (dgtta_seghead_warp_bwd_g16).  Same arithmetic as dgtta_softdice_bwd, each value
+// rounded once on the way out.
+extern "C" int dgtta_softdice_bwd_t(const float *la, const float *lb, void *grad_la, void *grad_lb, const void *ws,
+                                    float grad_scale, const float *grad_scale_dev, int B, int C, int64_t V, int ldc,
+                                    int start_class, int grad_dtype, void *stream) {
+  if (grad_dtype == DGTTA_F32)
+    return dgtta_softdice_bwd(la, lb, (float *)grad_la, (float *)grad_lb, ws, grad_scale, grad_scale_dev, B, C, V, ldc, start_class,
+                              stream);
+  DG_REQUIRE(la && lb && grad_la && grad_lb && ws, DGTTA_ERR_BADARG, "softdice_bwd_t: null pointer");
+  DG_REQUIRE(B > 0 && B <= 8 && V > 0, DGTTA_ERR_BADARG, "softdice_bwd_t: bad dims");
+  DG_REQUIRE(grad_dtype == DGTTA_BF16 || grad_dtype == DGTTA_F16, DGTTA_ERR_BADARG, "softdice_bwd_t: unknown gradient dtype %d", grad_dtype);
+  DG_REQUIRE(C == 16 && ldc == 16 && (((uintptr_t)la | (uintptr_t)lb) & 15) == 0 && (((uintptr_t)grad_la | (uintptr_t)grad_lb) & 7) == 0,
+             DGTTA_ERR_UNSUPPORTED, "softdice_bwd_t: 16-bit gradient rows are built for C = ldc = 16 and aligned operands (C %d, ldc %d)", C, ldc);
+  (void)start_class;
+  hipStream_t st = (hipStream_t)stream;
+  const int nblk = nblocks_for(V);
+  const float *coef = (const float *)((const char *)ws + align_up((size_t)B * nblk * C * 2 * sizeof(double), 256));
+  int64_t g16 = (V + 63) / 64;
+  if (g16 > 4096) g16 = 4096;
+  if (grad_dtype == DGTTA_BF16)
+    hipLaunchKernelGGL(softdice_bwd16_kernel<bf16_t>, dim3((int)g16, B), dim3(256), 0, st, la, lb, (bf16_t *)grad_la, (bf16_t *)grad_lb,
+                       coef, grad_scale, grad_scale_dev, V);
+  else
+    hipLaunchKernelGGL(softdice_bwd16_kernel<f16_t>, dim3((int)g16, B), dim3(256), 0, st, la, lb, (f16_t *)grad_la, (f16_t *)grad_lb,
+                       coef, grad_scale, grad_scale_dev, V);
+  DG_CHECK_LAUNCH("softdice_bwd16_kernel");
   return DGTTA_OK;
 }
 

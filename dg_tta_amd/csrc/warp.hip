@@ -523,6 +523,78 @@ __global__ __launch_bounds__(256) void head_warp_fwd_kernel(const T *__restrict_
   }
 }
 
+// Round 6: the head's 32 -> 16 product on the fp32 MATRIX cores (v_mfma_f32_16x16x4_f32: exact f32, bit for bit a k-ordered
+// fmaf chain).  The forward was instruction-bound (round 4: 1.03 -> 0.87 ms with every gather L1-resident): per voxel 128 FMAs,
+// 32 LDS weight reads and 32 DPP adds for the head on top of the gather's blend.  A wave now takes 16 voxels x 4 channel groups
+// (lane l: voxel l & 15, channels 8 (l >> 4) .. + 7 - the same 16-byte reads of the same rows as before); the blended channels
+// ARE the B operand (k = lane >> 4: step s multiplies channel 8 g + s), the head's rows live in 8 registers per lane as the A
+// operand (class l & 15), and D leaves classes 4 g .. 4 g + 3 of its voxel on the lane - the float4 the lane stores.  No LDS,
+// no barrier; the vector ALU keeps the coordinate algebra and the blend, the matrix pipe (idle before) the head.
+// Numerics: the same 32 products per logit, summed in the order (s = 0..7 even, then odd) x (g = 0..3) instead of per-lane chains
+// and a quad butterfly: fp32 association level (tests: 2e-6 of the logit range against head-then-warp).
+using hw_f32x4 = __attribute__((ext_vector_type(4))) float;
+
+template <typename T>
+__global__ __launch_bounds__(256) void head_warp_fwd_mfma_kernel(const T *__restrict__ z, const float *__restrict__ theta,
+                                                                 const float *__restrict__ w, const float *__restrict__ bias,
+                                                                 const int *__restrict__ sel, int nsel, float *__restrict__ out,
+                                                                 int D, int H, int W, int algebra, int gx, int gy) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int vl = lane & 15, g = lane >> 4;
+  float wa[8], b4[4];
+  {
+    const bool have = vl < nsel;
+    const float *wr = w + (int64_t)(have ? (sel ? sel[vl] : vl) : 0) * HW_CIN + g * 8;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) wa[s] = have ? wr[s] : 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int k = 4 * g + j;
+      b4[j] = k < nsel ? bias[sel ? sel[k] : k] : 0.f;
+    }
+  }
+  const int tile = (int)blockIdx.x;
+  const int bx = tile % gx, by = (tile / gx) % gy, bz = tile / (gx * gy);
+  const int d = bz % D, b = bz / D;
+  const int64_t V = (int64_t)D * H * W;
+  const T *zb = z + (int64_t)b * V * HW_CIN;
+  const int wv = bx * 64 + wave * 16 + vl;
+  const bool live = wv < W;
+  const int h0 = by * WARP_ROWS;
+  for (int h = h0; h < min(h0 + WARP_ROWS, H); ++h) {      // (wave-uniform: every lane reaches the MFMAs)
+    float zbl[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float wsum = 0.f;
+    if (live) {
+      const Sample sp = sample_pos(theta + b * 12, d, h, wv, D, H, W, D, H, W, algebra, DGTTA_PAD_ZEROS);
+      const Corners cr = corners(sp);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int xx = cr.x0 + (k & 1), yy = cr.y0 + ((k >> 1) & 1), zz = cr.z0 + (k >> 2);
+        if ((unsigned)xx < (unsigned)W && (unsigned)yy < (unsigned)H && (unsigned)zz < (unsigned)D) {
+          const int64_t sv = ((int64_t)zz * H + yy) * W + xx;
+          const uint4 t = *reinterpret_cast<const uint4 *>(zb + sv * HW_CIN + g * 8);
+          float f[8];
+          unpack8_16<T>(t, f);
+#pragma unroll
+          for (int c = 0; c < 8; ++c) zbl[c] += f[c] * cr.w[k];
+          wsum += cr.w[k];
+        }
+      }
+    }
+    hw_f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};      // two chains: the dependent latency is 40 cycles
+#pragma unroll
+    for (int s = 0; s < 8; s += 2) {
+      a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[s], zbl[s], a0, 0, 0, 0);
+      a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[s + 1], zbl[s + 1], a1, 0, 0, 0);
+    }
+    if (live && 4 * g < nsel) {
+      float *op = out + ((int64_t)b * V + ((int64_t)d * H + h) * W + wv) * nsel + 4 * g;
+      *reinterpret_cast<float4 *>(op) = make_float4((a0[0] + a1[0]) + b4[0] * wsum, (a0[1] + a1[1]) + b4[1] * wsum,
+                                                    (a0[2] + a1[2]) + b4[2] * wsum, (a0[3] + a1[3]) + b4[3] * wsum);
+    }
+  }
+}
+
 template <typename T>
 __device__ __forceinline__ uint4 pack8_16(const float *f) {
   return make_uint4(pack2_16<T>(f[0], f[1]), pack2_16<T>(f[2], f[3]), pack2_16<T>(f[4], f[5]), pack2_16<T>(f[6], f[7]));
@@ -531,18 +603,43 @@ __device__ __forceinline__ uint4 pack8_16(const float *f) {
 // backward: one thread owns one voxel of the feature-map lattice; candidate search and accumulation exactly as
 // warp_bwd_gather_kernel<16, true> (same order), then d16 = 16-bit copy of the gathered logit gradient (operand of the
 // head's MFMA weight gradient), gz = W^T acc in the network's storage type, and the block's partial sums for the bias gradient
-template <typename T, bool ABL = false>
-__global__ __launch_bounds__(256, 6) void head_warp_bwd_kernel(const float *__restrict__ gdst, const float *__restrict__ theta,
+// Round 6.  MF: gz = W^T acc on the fp32 MATRIX cores instead of 512 FMAs and 128 LDS weight reads per lane (the kernel is
+// instruction-bound, round 4): the wave parks its 64 voxels x 16 classes in LDS class-major, reads them back as the B operand
+// of v_mfma_f32_16x16x4_f32 (k = class 4 s + (lane >> 4)), the head's rows are the A operand in 8 registers, and D leaves 8
+// consecutive channels of one voxel on a lane (row 4 g + r of block j = channel 8 g + 4 j + r): one 16-byte store.  The
+// instruction is a k-ordered fmaf chain (MI355X guide), the classes enter in the order 0..15 of the FMA loop it replaces, so
+// gz has the SAME BITS (test_head_fused_with_the_inverse_warp_matches_head_then_warp runs both against head-then-warp).
+// G16: the logit gradient arrives in the network's 16-bit storage type (written so by dgtta_softdice_bwd_t): half the bytes
+// per gathered candidate; acc += float(g16) * weight in the same order.
+constexpr int HWB_LDS_PITCH = 80;       // floats per class row of a wave's slab: 64 voxels + 16 (bank offset of the odd k)
+
+template <typename T, bool ABL = false, bool G16 = false, bool MF = false>
+__global__ __launch_bounds__(256, 6) void head_warp_bwd_kernel(const void *__restrict__ gdst_, const float *__restrict__ theta,
                                                             const float *__restrict__ w, const int *__restrict__ sel,
                                                             int nsel, T *__restrict__ gz, unsigned short *__restrict__ d16,
                                                             double *__restrict__ bias_partial, int D, int H, int W,
                                                             int algebra, int gx, int gy) {
-  __shared__ float sw[HW_NS * HW_CIN];
+  __shared__ float sw[MF ? 1 : HW_NS * HW_CIN];
+  __shared__ float sacc[MF ? 4 * HW_NS * HWB_LDS_PITCH : 1];
   __shared__ InvMap s_im;
   __shared__ float sred[4][HW_NS];
-  for (int i = threadIdx.x; i < HW_NS * HW_CIN; i += 256) {
-    const int k = i / HW_CIN;
-    sw[i] = k < nsel ? w[(int64_t)(sel ? sel[k] : k) * HW_CIN + i % HW_CIN] : 0.f;
+  const float *gdst = (const float *)gdst_;
+  const unsigned short *gdst16 = (const unsigned short *)gdst_;
+  float wA[4][2];
+  if (MF) {
+    const int lane = threadIdx.x & 63, r = lane & 15, kk = lane >> 4;
+#pragma unroll
+    for (int st = 0; st < 4; ++st) {
+      const int k = 4 * st + kk;
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        wA[st][j] = k < nsel ? w[(int64_t)(sel ? sel[k] : k) * HW_CIN + 8 * (r >> 2) + 4 * j + (r & 3)] : 0.f;
+    }
+  } else {
+    for (int i = threadIdx.x; i < HW_NS * HW_CIN; i += 256) {
+      const int k = i / HW_CIN;
+      sw[i] = k < nsel ? w[(int64_t)(sel ? sel[k] : k) * HW_CIN + i % HW_CIN] : 0.f;
+    }
   }
   const int64_t V = (int64_t)D * H * W;
   const int tilesZ = (D + 3) >> 2;
@@ -602,16 +699,34 @@ __global__ __launch_bounds__(256, 6) void head_warp_bwd_kernel(const float *__re
           const float wy = dy == 0.f ? (fy + 1.0f) - s.iy : s.iy - fy;
           const float wz = dz == 0.f ? (fz + 1.0f) - s.iz : s.iz - fz;
           const float wt = wx * wy * wz;
-          const float *gp = gdst + (ABL ? (((int64_t)(d & 1) * H + (h & 3)) * W + (wq & 15)) * nsel
-                                        : ((int64_t)b * V + ((int64_t)d * H + h) * W + wq) * nsel);
+          const int64_t grow = (ABL ? (((int64_t)(d & 1) * H + (h & 3)) * W + (wq & 15)) * nsel
+                                    : ((int64_t)b * V + ((int64_t)d * H + h) * W + wq) * nsel);
+          if (G16) {
+            const unsigned short *gp = gdst16 + grow;
 #pragma unroll
-          for (int q = 0; q < HW_NS; q += 4) {
-            if (q < nsel) {
-              const float4 g = *reinterpret_cast<const float4 *>(gp + q);
-              acc[q] += g.x * wt;
-              acc[q + 1] += g.y * wt;
-              acc[q + 2] += g.z * wt;
-              acc[q + 3] += g.w * wt;
+            for (int q = 0; q < HW_NS; q += 4) {
+              if (q < nsel) {
+                const uint2 t = *reinterpret_cast<const uint2 *>(gp + q);
+                float f0, f1, f2, f3;
+                unpack2_16<T>(t.x, f0, f1);
+                unpack2_16<T>(t.y, f2, f3);
+                acc[q] += f0 * wt;
+                acc[q + 1] += f1 * wt;
+                acc[q + 2] += f2 * wt;
+                acc[q + 3] += f3 * wt;
+              }
+            }
+          } else {
+            const float *gp = gdst + grow;
+#pragma unroll
+            for (int q = 0; q < HW_NS; q += 4) {
+              if (q < nsel) {
+                const float4 g = *reinterpret_cast<const float4 *>(gp + q);
+                acc[q] += g.x * wt;
+                acc[q + 1] += g.y * wt;
+                acc[q + 2] += g.z * wt;
+                acc[q + 3] += g.w * wt;
+              }
             }
           }
         }
@@ -628,7 +743,7 @@ __global__ __launch_bounds__(256, 6) void head_warp_bwd_kernel(const float *__re
     // gz = W^T acc, a quarter (8 channels) at a time to keep the register footprint of the gather phase
     T *gp = gz + u * HW_CIN;
 #pragma unroll
-    for (int qt = 0; qt < 4; ++qt) {
+    for (int qt = 0; qt < (MF ? 0 : 4); ++qt) {
       float o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int k = 0; k < HW_NS; ++k) {
@@ -644,6 +759,31 @@ __global__ __launch_bounds__(256, 6) void head_warp_bwd_kernel(const float *__re
         o[7] = __builtin_fmaf(acc[k], w1.w, o[7]);
       }
       *reinterpret_cast<uint4 *>(reinterpret_cast<unsigned short *>(gp) + qt * 8) = pack8_16<T>(o);
+    }
+  }
+  if (MF) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float *slab = sacc + wave * (HW_NS * HWB_LDS_PITCH);
+#pragma unroll
+    for (int k = 0; k < HW_NS; ++k) slab[k * HWB_LDS_PITCH + lane] = acc[k];
+    __syncthreads();
+    const int v = lane & 15, g = lane >> 4;
+    const int xs = bx * 16 + v;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {          // voxel group q = the wave's row y = by * 4 + q
+      hw_f32x4 d0 = {0.f, 0.f, 0.f, 0.f}, d1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int st = 0; st < 4; ++st) {
+        const float bv = slab[(4 * st + g) * HWB_LDS_PITCH + 16 * q + v];
+        d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wA[st][0], bv, d0, 0, 0, 0);
+        d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wA[st][1], bv, d1, 0, 0, 0);
+      }
+      const int ys = by * 4 + q;
+      if (xs < W && ys < H && zc_ < D) {
+        const float o[8] = {d0[0], d0[1], d0[2], d0[3], d1[0], d1[1], d1[2], d1[3]};
+        const int64_t uq = (int64_t)b * V + ((int64_t)zc_ * H + ys) * W + xs;
+        *reinterpret_cast<uint4 *>(reinterpret_cast<unsigned short *>(gz + uq * HW_CIN) + g * 8) = pack8_16<T>(o);
+      }
     }
   }
   // bias gradient: sum of the gathered gradient over the block (threads outside the volume hold zeros), fixed order
@@ -1153,6 +1293,13 @@ extern "C" int dgtta_seghead_warp_fwd(const void *z, const float *w, const float
   }
 #endif
   if (lab) {
+  } else if (dgtta_switches().headwarp_mfma != '0') {      // round 6: the head on the fp32 matrix cores (DGTTA_HEADWARP_MFMA=0: the FMA chain)
+    if (dtype == DGTTA_BF16)
+      hipLaunchKernelGGL((head_warp_fwd_mfma_kernel<bf16_t>), dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream,
+                         (const bf16_t *)z, theta, w, bias, sel, nsel, out, D, H, W, tta_grid_algebra, gx, gy);
+    else
+      hipLaunchKernelGGL((head_warp_fwd_mfma_kernel<f16_t>), dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream,
+                         (const f16_t *)z, theta, w, bias, sel, nsel, out, D, H, W, tta_grid_algebra, gx, gy);
   } else if (dtype == DGTTA_BF16) {
     HWF_LAUNCH(bf16_t, false);
   } else {
@@ -1163,13 +1310,14 @@ extern "C" int dgtta_seghead_warp_fwd(const void *z, const float *w, const float
   return DGTTA_OK;
 }
 
-extern "C" int dgtta_seghead_warp_bwd(const void *z, const float *gout, const float *theta, const float *h_theta,
-                                      const float *w, const int *sel, int nsel, void *gz, float *dw_sel, float *db_sel,
-                                      void *ws, size_t ws_bytes, int B, int Cin, int D, int H, int W, int tta_grid_algebra,
-                                      int accumulate, int dtype, void *stream) {
+static int seghead_warp_bwd_impl(const void *z, const void *gout, int gout16, const float *theta, const float *h_theta,
+                                 const float *w, const int *sel, int nsel, void *gz, float *dw_sel, float *db_sel, void *ws,
+                                 size_t ws_bytes, int B, int Cin, int D, int H, int W, int tta_grid_algebra, int accumulate,
+                                 int dtype, void *stream) {
   DG_REQUIRE(z && gout && theta && h_theta && w && gz && ws, DGTTA_ERR_BADARG, "seghead_warp_bwd: null pointer");
   DG_REQUIRE(B > 0 && B <= 16 && D > 0 && H > 0 && W > 0, DGTTA_ERR_BADARG, "seghead_warp_bwd: bad dims");
   DG_REQUIRE(head_warp_shape_ok(Cin, nsel, dtype), DGTTA_ERR_UNSUPPORTED, "seghead_warp_bwd: unsupported shape / dtype");
+  DG_REQUIRE(((uintptr_t)gout & 15) == 0 && ((uintptr_t)gz & 15) == 0, DGTTA_ERR_BADARG, "seghead_warp_bwd: unaligned operand");
   const size_t need = dgtta_seghead_warp_bwd_ws_bytes(B, Cin, nsel, D, H, W);
   DG_REQUIRE(need > 0, DGTTA_ERR_UNSUPPORTED, "seghead_warp_bwd: voxel count must be a multiple of 128");
   DG_REQUIRE(ws_bytes >= need, DGTTA_ERR_WORKSPACE, "seghead_warp_bwd: workspace too small");
@@ -1185,22 +1333,35 @@ extern "C" int dgtta_seghead_warp_bwd(const void *z, const float *gout, const fl
   const int gx = cdiv(W, 16), gy = cdiv(H, 4);
   const int64_t nblk = (int64_t)gx * gy * cdiv(D, 4) * B;
   DG_REQUIRE(nblk < (1ll << 31), DGTTA_ERR_UNSUPPORTED, "seghead_warp_bwd: too many tiles");
-#define HWB_LAUNCH(T, A)                                                                                                  \
-  hipLaunchKernelGGL((head_warp_bwd_kernel<T, A>), dim3((unsigned)nblk), dim3(256), 0, st, gout, theta, w, sel, nsel,   \
-                     (T *)gz, d16, db_sel ? bias_partial : nullptr, D, H, W, tta_grid_algebra, gx, gy)
+#define HWB_LAUNCH(T, A, G, M)                                                                                            \
+  hipLaunchKernelGGL((head_warp_bwd_kernel<T, A, G, M>), dim3((unsigned)nblk), dim3(256), 0, st, gout, theta, w, sel,    \
+                     nsel, (T *)gz, d16, db_sel ? bias_partial : nullptr, D, H, W, tta_grid_algebra, gx, gy)
   bool lab = false;
 #ifdef DGTTA_DIAG
-  if (DG_LAB(warp_abl) == '1') {      // timing model: results wrong by construction
+  if (DG_LAB(warp_abl) == '1' && !gout16) {      // timing model: results wrong by construction
     lab = true;
-    if (dtype == DGTTA_BF16) HWB_LAUNCH(bf16_t, true);
-    else HWB_LAUNCH(f16_t, true);
+    if (dtype == DGTTA_BF16) HWB_LAUNCH(bf16_t, true, false, false);
+    else HWB_LAUNCH(f16_t, true, false, false);
   }
 #endif
+  const bool mf = dgtta_switches().headwarp_mfma != '0';      // DGTTA_HEADWARP_MFMA=0: W^T as the FMA chain (same bits)
   if (lab) {
   } else if (dtype == DGTTA_BF16) {
-    HWB_LAUNCH(bf16_t, false);
+    if (gout16) {
+      if (mf) HWB_LAUNCH(bf16_t, false, true, true);
+      else HWB_LAUNCH(bf16_t, false, true, false);
+    } else {
+      if (mf) HWB_LAUNCH(bf16_t, false, false, true);
+      else HWB_LAUNCH(bf16_t, false, false, false);
+    }
   } else {
-    HWB_LAUNCH(f16_t, false);
+    if (gout16) {
+      if (mf) HWB_LAUNCH(f16_t, false, true, true);
+      else HWB_LAUNCH(f16_t, false, true, false);
+    } else {
+      if (mf) HWB_LAUNCH(f16_t, false, false, true);
+      else HWB_LAUNCH(f16_t, false, false, false);
+    }
   }
 #undef HWB_LAUNCH
   DG_CHECK_LAUNCH("head_warp_bwd_kernel");
@@ -1214,6 +1375,24 @@ extern "C" int dgtta_seghead_warp_bwd(const void *z, const float *gout, const fl
     DG_CHECK_LAUNCH("head_warp_bias_finalize_kernel");
   }
   return DGTTA_OK;
+}
+
+extern "C" int dgtta_seghead_warp_bwd(const void *z, const float *gout, const float *theta, const float *h_theta,
+                                      const float *w, const int *sel, int nsel, void *gz, float *dw_sel, float *db_sel,
+                                      void *ws, size_t ws_bytes, int B, int Cin, int D, int H, int W, int tta_grid_algebra,
+                                      int accumulate, int dtype, void *stream) {
+  return seghead_warp_bwd_impl(z, gout, 0, theta, h_theta, w, sel, nsel, gz, dw_sel, db_sel, ws, ws_bytes, B, Cin, D, H, W,
+                               tta_grid_algebra, accumulate, dtype, stream);
+}
+
+// the same with the gradient of the warped logits in the network's 16-bit storage type `dtype` (rows of nsel values, as
+// dgtta_softdice_bwd_t writes them): half the bytes per gathered candidate
+extern "C" int dgtta_seghead_warp_bwd_g16(const void *z, const void *gout16, const float *theta, const float *h_theta,
+                                          const float *w, const int *sel, int nsel, void *gz, float *dw_sel, float *db_sel,
+                                          void *ws, size_t ws_bytes, int B, int Cin, int D, int H, int W, int tta_grid_algebra,
+                                          int accumulate, int dtype, void *stream) {
+  return seghead_warp_bwd_impl(z, gout16, 1, theta, h_theta, w, sel, nsel, gz, dw_sel, db_sel, ws, ws_bytes, B, Cin, D, H, W,
+                               tta_grid_algebra, accumulate, dtype, stream);
 }
 
 extern "C" int dgtta_seghead_window_accumulate_t(const void *z, const float *w, const float *bias, const float *gauss, void *acc,

@@ -214,6 +214,9 @@ class _ConsistencyLossPair(torch.autograd.Function):
     @staticmethod
     def forward(ctx, both, start_class, guard_items):
         lib = _lib.load()
+        # the producer's offer to take the gradient in its 16-bit storage type (unet.Grad16Sink; 16-class rows only)
+        sink = getattr(both, "_dgtta_grad16", None)
+        ctx.sink = sink if (sink is not None and both.shape[1] == 16) else None
         both = both.contiguous(memory_format=torch.channels_last_3d)
         b2, c = both.shape[:2]
         b = b2 // 2
@@ -235,8 +238,15 @@ class _ConsistencyLossPair(torch.autograd.Function):
         both, ws = ctx.saved_tensors
         b, c, v, start_class = ctx.meta
         lib = _lib.load()
-        g = torch.empty_like(both, memory_format=torch.preserve_format)
         gs = gloss.reshape(1).float().contiguous()
+        if ctx.sink is not None:
+            # the gradient goes to the producer in ITS storage type through the sink; autograd gets a stride-0 placeholder
+            g16 = torch.empty((2 * b, *both.shape[2:], c), dtype=ctx.sink.dtype, device=both.device)
+            check(lib.dgtta_softdice_bwd_t(ptr(both[:b]), ptr(both[b:]), ptr(g16[:b]), ptr(g16[b:]), ptr(ws), 1.0, ptr(gs), b, c, v,
+                                           c, start_class, dtype_code(ctx.sink.dtype), stream_of(both.device)), "dgtta_softdice_bwd_t")
+            ctx.sink.put(g16)
+            return torch.zeros((), dtype=both.dtype, device=both.device).expand(both.shape), None, None
+        g = torch.empty_like(both, memory_format=torch.preserve_format)
         check(lib.dgtta_softdice_bwd(ptr(both[:b]), ptr(both[b:]), ptr(g[:b]), ptr(g[b:]), ptr(ws), 1.0, ptr(gs), b, c, v, c,
                                      start_class, stream_of(both.device)), "dgtta_softdice_bwd")
         return g, None, None

@@ -255,7 +255,18 @@ class HipPlainConvUNet(nn.Module):
             sel = self.selected_classes = sel.to(x.device)
         params = [p for p in self.parameters()]
         need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in params)
-        return _UNetFn.apply(self, x, sel, need_grad, *params)
+        # Round 6: with the head fused into the inverse warp and 16-bit storage, the network's backward can take the gradient of
+        # its output in the storage type (half the bytes for the fused gather).  autograd hands gradients over in the OUTPUT's
+        # dtype (fp32), so the offer travels beside the output tensor: a loss that knows it (ops.consistency_loss on the batched
+        # pair) leaves its 16-bit gradient in the sink and returns a stride-0 placeholder; anything else is summed as usual.
+        sink = None
+        if (need_grad and self._fused_warp is not None and self.act_dtype in (torch.bfloat16, torch.float16)
+                and os.environ.get("DGTTA_GRAD16", "1") != "0"):
+            sink = Grad16Sink(self.act_dtype)
+        y = _UNetFn.apply(self, x, sel, need_grad, sink, *params)
+        if sink is not None:
+            y._dgtta_grad16 = sink
+        return y
 
     # -- packed weights (re-packed only when the parameter changed)
     def packed(self, conv, dt, cinp, coutp, cin_slice=None):
@@ -278,6 +289,21 @@ class HipPlainConvUNet(nn.Module):
         return wpack
 
 
+class Grad16Sink:
+    """Side channel for the gradient of the network output in the 16-bit storage type (see HipPlainConvUNet.forward):
+    `put` by the loss backward, taken by _UNetFn.backward of the same pass."""
+
+    def __init__(self, dtype):
+        self.dtype, self.g16 = dtype, None
+
+    def put(self, g16):
+        self.g16 = g16
+
+    def take(self):
+        g, self.g16 = self.g16, None
+        return g
+
+
 def set_probe(model, where):
     """bench.py hook: record (start, end) events around the forward conv launch and the weight-gradient launch (sweep + slab
     reduction, on the stream it runs on) of block `where` = (kind, stage, idx) of `model` (None: stop).  Returns the probe dict
@@ -295,7 +321,7 @@ class _UNetFn(torch.autograd.Function):
     """Whole-network autograd node: forward saves raw conv outputs, normalised activations and IN statistics."""
 
     @staticmethod
-    def forward(ctx, net, x, sel, need_grad, *params):
+    def forward(ctx, net, x, sel, need_grad, sink, *params):
         lib = _lib.load()
         _lib.require_cuda(x)
         dev = x.device
@@ -503,6 +529,7 @@ class _UNetFn(torch.autograd.Function):
             ctx.meta = (B, D, H, W, dt, impl, nsel, u_ptr, ldu)
             ctx.params = params
             ctx.fused_warp = fw
+            ctx.sink = sink if fw is not None else None
         return out.permute(0, 4, 1, 2, 3)
 
     @staticmethod
@@ -563,7 +590,12 @@ class _UNetFn(torch.autograd.Function):
                 return torch.empty_like(p)
 
         V = D * H * W
-        g = gout.contiguous(memory_format=torch.channels_last_3d).float()      # [B,nsel,D,H,W] stored NDHWC
+        g16 = ctx.sink.take() if ctx.sink is not None else None      # the loss left its gradient in the storage type (round 6)
+        if g16 is not None and any(gout.stride()):
+            # the placeholder has stride 0 everywhere; a dense gout means another consumer of the output contributed: sum in fp32
+            gout = gout + g16.permute(0, 4, 1, 2, 3).float()
+            g16 = None
+        g = None if g16 is not None else gout.contiguous(memory_format=torch.channels_last_3d).float()      # [B,nsel,D,H,W] stored NDHWC
         head = net.decoder.seg_layers[-1]
         cin_h = head.in_channels
         # ---- head backward
@@ -575,9 +607,15 @@ class _UNetFn(torch.autograd.Function):
         if fw is not None:      # g is the gradient of the WARPED logits: fused gather + W^T (+ weight / bias gradient)
             nb = lib.dgtta_seghead_warp_bwd_ws_bytes(B, cin_h, nsel, D, H, W)
             w_ = ws_for(nb)
-            check(lib.dgtta_seghead_warp_bwd(zlast_ptr, ptr(g), ptr(fw[0]), ptr(fw[1]), ptr(head.weight), ptr(sel), nsel,
-                                             ptr(gz), ptr(dws), ptr(dbs), ptr(w_), nb, B, cin_h, D, H, W, 1, 0, dt, st),
-                  "dgtta_seghead_warp_bwd")
+            if g16 is not None:
+                assert tuple(g16.shape) == (B, D, H, W, nsel) and g16.dtype == adt and g16.is_contiguous()
+                check(lib.dgtta_seghead_warp_bwd_g16(zlast_ptr, ptr(g16), ptr(fw[0]), ptr(fw[1]), ptr(head.weight), ptr(sel), nsel,
+                                                     ptr(gz), ptr(dws), ptr(dbs), ptr(w_), nb, B, cin_h, D, H, W, 1, 0, dt, st),
+                      "dgtta_seghead_warp_bwd_g16")
+            else:
+                check(lib.dgtta_seghead_warp_bwd(zlast_ptr, ptr(g), ptr(fw[0]), ptr(fw[1]), ptr(head.weight), ptr(sel), nsel,
+                                                 ptr(gz), ptr(dws), ptr(dbs), ptr(w_), nb, B, cin_h, D, H, W, 1, 0, dt, st),
+                      "dgtta_seghead_warp_bwd")
         else:
             nb = lib.dgtta_seghead_bwd_ws_bytes(B, cin_h, nsel, V)
             w_ = ws_for(nb)
@@ -754,7 +792,7 @@ class _UNetFn(torch.autograd.Function):
         del keep_alive, first_rec
         if side is not None:
             main_stream.wait_stream(side)         # gradients complete before anything downstream (optimizer, next pass)
-        out = [None, None, None, None]
+        out = [None, None, None, None, None]
         for p in params:
             out.append(grads.get(id(p)) if p.requires_grad else None)
         return tuple(out)

@@ -115,6 +115,11 @@ int dgtta_softdice_fwd(const float *la, const float *lb, float *dice, float *los
 int dgtta_softdice_bwd(const float *la, const float *lb, float *grad_la, float *grad_lb, const void *ws,
                        float grad_scale, const float *grad_scale_dev, int B, int C, int64_t V, int ldc,
                        int start_class, void *stream);
+/* dgtta_softdice_bwd with the gradient rows in `grad_dtype` (DGTTA_F32: the call above; DGTTA_BF16 / DGTTA_F16: the 16-class
+ * form only - C = ldc = 16 - each value rounded once on the way out; what dgtta_seghead_warp_bwd_g16 consumes). */
+int dgtta_softdice_bwd_t(const float *la, const float *lb, void *grad_la, void *grad_lb, const void *ws, float grad_scale,
+                         const float *grad_scale_dev, int B, int C, int64_t V, int ldc, int start_class, int grad_dtype,
+                         void *stream);
 
 /* Stand-alone soft_dice_loss(smp_a, smp_b) -> dice[B][C] of the reference (dg_tta/tta/torch_utils.py:90-104) on
  * probability maps: nom = mean_v(2ab), den = mean_v((a+b)^2)/2, dice = nom/den, all ones when den.sum() == 0.
@@ -275,6 +280,12 @@ int dgtta_seghead_warp_fwd(const void *z, const float *w, const float *bias, con
 int dgtta_seghead_warp_bwd(const void *z, const float *gout, const float *theta, const float *h_theta, const float *w,
                            const int *sel, int nsel, void *gz, float *dw_sel, float *db_sel, void *ws, size_t ws_bytes, int B,
                            int Cin, int D, int H, int W, int tta_grid_algebra, int accumulate, int dtype, void *stream);
+/* The same with gout16 = the gradient of the warped logits in the network's 16-bit storage type `dtype`, rows of nsel values as
+ * dgtta_softdice_bwd_t writes them (round 6): the gather reads half the bytes per candidate; acc += float(g16) * weight in the
+ * same order, so the result equals dgtta_seghead_warp_bwd on the widened values bit for bit. */
+int dgtta_seghead_warp_bwd_g16(const void *z, const void *gout16, const float *theta, const float *h_theta, const float *w,
+                               const int *sel, int nsel, void *gz, float *dw_sel, float *db_sel, void *ws, size_t ws_bytes, int B,
+                               int Cin, int D, int H, int W, int tta_grid_algebra, int accumulate, int dtype, void *stream);
 
 /* Layout / dtype converters between the reference's NCDHW fp32 and internal NDHWC. */
 int dgtta_ncdhw_to_ndhwc(const float *src, void *dst, int B, int C, int64_t V, int ldc, int dtype, void *stream);

@@ -46,3 +46,14 @@ def t(fn, n=8):
     return e0.elapsed_time(e1) / n
 for name, fn in (("fwd unfused", fwd_unfused), ("fwd fused", fwd_fused), ("bwd unfused (incl. head wgrad + bias)", bwd_unfused), ("bwd fused (incl. head wgrad + bias)", bwd_fused)):
     print(f"{name:42s} {t(fn):.3f} ms")
+
+# round 6: the head products on the fp32 matrix cores (DGTTA_HEADWARP_MFMA, default on) and the logit gradient in 16 bits
+g16 = gout.to(tdt)
+def bwd_fused_g16():
+    check(lib.dgtta_seghead_warp_bwd_g16(ptr(z), ptr(g16), ptr(th), ptr(rinv), ptr(w), ptr(sel), NS, ptr(gz), ptr(dws), ptr(dbs), ptr(ws), nb_f, B, CIN, N, N, N, 1, 0, dt, st), "fb16")
+for mf in ("1", "0"):
+    os.environ["DGTTA_HEADWARP_MFMA"] = mf
+    lib.dgtta_reload_env()
+    for name, fn in (("fwd fused", fwd_fused), ("bwd fused, fp32 gradient", bwd_fused), ("bwd fused, 16-bit gradient", bwd_fused_g16)):
+        t(fn, 40)                       # (sustained clocks: a short burst reads faster than the kernel inside an epoch)
+        print(f"DGTTA_HEADWARP_MFMA={mf} {name:30s} {t(fn, 40):.3f} ms")

@@ -12,7 +12,7 @@ measured logit error."""
 import pytest
 import torch
 
-from conftest import load_golden
+from conftest import load_golden, reload_kernel_switches
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -202,7 +202,7 @@ def test_noncubic_batch_16bit_kernels_vs_reference_kernels(dtype):
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("nsel", [16, 8])
-def test_head_fused_with_the_inverse_warp_matches_head_then_warp(dtype, nsel):
+def test_head_fused_with_the_inverse_warp_matches_head_then_warp(dtype, nsel, monkeypatch):
     """Round 3: dgtta_seghead_warp_fwd / _bwd (head + inverse logit warp in one launch each way, csrc/warp.hip) against the
     two-step path (dgtta_seghead_* then dgtta_affine_warp3d_*) on the full 3d_fullres net: same logits up to fp32
     association, the SAME feature-map gradient and head weight gradient bit for bit (identical gather order and FMA chain),
@@ -235,6 +235,18 @@ def test_head_fused_with_the_inverse_warp_matches_head_then_warp(dtype, nsel):
 
     y0, g0 = run(False)
     y1, g1 = run(True)
+    # round 6: the fused pair's head products run on the fp32 matrix cores (v_mfma_f32_16x16x4_f32, a k-ordered fmaf chain);
+    # DGTTA_HEADWARP_MFMA=0 selects the FMA chains they replaced - the backward has the SAME bits in both, the forward the same
+    # to fp32 association
+    monkeypatch.setenv("DGTTA_HEADWARP_MFMA", "0")
+    reload_kernel_switches()
+    y2, g2 = run(True)
+    monkeypatch.delenv("DGTTA_HEADWARP_MFMA")
+    reload_kernel_switches()
+    assert float((y2 - y1).abs().max()) < 2e-6 * float(y0.max() - y0.min()) + 1e-6 and not torch.equal(y2, y1)
+    for n in g1:
+        if n != "decoder.seg_layers.3.bias":
+            assert torch.equal(g1[n], g2[n]), f"{n}: the matrix-core W^T differs from the FMA chain"
     rng = float(y0.max() - y0.min())
     assert tuple(y1.shape) == tuple(y0.shape) and float((y1 - y0).abs().max()) < 2e-6 * rng + 1e-6
     assert set(g0) == set(g1)
@@ -246,6 +258,93 @@ def test_head_fused_with_the_inverse_warp_matches_head_then_warp(dtype, nsel):
     # maps the owner-computes gather declines are not offered the fused pair
     assert not net.can_fuse_output_warp(x.shape, torch.zeros(2, 3, 4))
     assert not net.can_fuse_output_warp(x.shape, rinv * 0.05)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_logit_gradient_in_the_storage_type_through_the_sink(dtype, monkeypatch):
+    """Round 6: between the loss backward and the fused head + warp backward the logit gradient travels in the
+    network's 16-bit storage type (dgtta_softdice_bwd_t -> unet.Grad16Sink -> dgtta_seghead_warp_bwd_g16).
+    (i) kernel level: the 16-bit rows are the fp32 gradient rounded once, and the gather on them equals the fp32 gather on the
+    widened values bit for bit; (ii) network level: the product's batched pair with the sink on / off (DGTTA_GRAD16=0): same
+    loss, parameter gradients within the rounding of one more 16-bit tensor; a second consumer of the output is summed, not lost."""
+    from dg_tta_amd import _lib, ops
+    from dg_tta_amd._lib import check, ptr, stream_of
+    from dg_tta_amd.synthetic import he_init_
+    from dg_tta_amd.unet import HipPlainConvUNet
+    from oracle import tta as otta
+    lib = _lib.load()
+    dt = ops.dtype_code(dtype)
+    torch.manual_seed(5)
+    B, N, C = 2, 32, 16
+    # ---- (i) kernels
+    both = torch.randn(2 * B, N, N, N, C, device=DEV) * 3
+    b2, v = 2 * B, N ** 3
+    nbytes = lib.dgtta_softdice_ws_bytes(B, C, v)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=DEV)
+    dice, loss = torch.empty(B, C, device=DEV), torch.empty((), device=DEV)
+    check(lib.dgtta_softdice_fwd(ptr(both[:B]), ptr(both[B:]), ptr(dice), ptr(loss), ptr(ws), nbytes, B, C, v, C, 1, 1, stream_of()), "fwd")
+    g32 = torch.empty_like(both)
+    g16 = torch.empty(b2, N, N, N, C, dtype=dtype, device=DEV)
+    check(lib.dgtta_softdice_bwd(ptr(both[:B]), ptr(both[B:]), ptr(g32[:B]), ptr(g32[B:]), ptr(ws), 4096.0, None, B, C, v, C, 1, stream_of()), "bwd")
+    check(lib.dgtta_softdice_bwd_t(ptr(both[:B]), ptr(both[B:]), ptr(g16[:B]), ptr(g16[B:]), ptr(ws), 4096.0, None, B, C, v, C, 1, dt,
+                                   stream_of()), "bwd_t")
+    assert torch.equal(g16, g32.to(dtype)) and float(g32.abs().max()) > 0
+    z = torch.randn(b2, N, N, N, 32, device=DEV).to(dtype)
+    w, sel = torch.randn(105, 32, device=DEV) * 0.1, (torch.arange(C) * 3).to(torch.int32).to(DEV)
+    _, rinv = otta.rand_affine_from_draw(torch.randn(b2, 3, 4), 0.08)
+    rinv = rinv.float().contiguous()
+    nb = lib.dgtta_seghead_warp_bwd_ws_bytes(b2, 32, C, N, N, N)
+    outs = []
+    for use16 in (True, False):
+        ws2 = torch.empty(nb, dtype=torch.uint8, device=DEV)
+        gz = torch.empty(b2, N, N, N, 32, dtype=dtype, device=DEV)
+        dws, dbs = torch.empty(C, 32, device=DEV), torch.empty(C, device=DEV)
+        gin = g16 if use16 else g16.float()
+        fn = lib.dgtta_seghead_warp_bwd_g16 if use16 else lib.dgtta_seghead_warp_bwd
+        check(fn(ptr(z), ptr(gin), ptr(rinv.to(DEV)), ptr(rinv), ptr(w), ptr(sel), C, ptr(gz), ptr(dws), ptr(dbs), ptr(ws2), nb, b2, 32,
+                 N, N, N, 1, 0, dt, stream_of()), "head_warp_bwd")
+        torch.cuda.synchronize()
+        outs.append((gz, dws, dbs))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+    assert float(outs[0][0].float().abs().max()) > 0
+    # ---- (ii) the network's batched pair
+    net = he_init_(HipPlainConvUNet(act_dtype=dtype), seed=7).to(DEV)
+    net.set_selected_classes(torch.arange(C) * 5 + 1)
+    x = torch.rand(b2, 12, N, N, N, device=DEV)
+
+    def run(extra_consumer=False):
+        net.zero_grad()
+        with net.fuse_output_warp(rinv.to(DEV), rinv):
+            y = net(x)
+        ta, tb = y[:B], y[B:]
+        ta._dgtta_pair = tb._dgtta_pair = y
+        ta._dgtta_guard_items = tb._dgtta_guard_items = 1
+        loss, _ = ops.consistency_loss(ta, tb, 1)
+        total = loss * 1024.0 + (y.sum() * 1e-6 if extra_consumer else 0.0)
+        total.backward()
+        torch.cuda.synchronize()
+        return float(loss), {n: p.grad.detach().float().clone() for n, p in net.named_parameters() if p.grad is not None}
+    l1, ga = run()
+    monkeypatch.setenv("DGTTA_GRAD16", "0")
+    l0, gb = run()
+    monkeypatch.delenv("DGTTA_GRAD16")
+    assert l1 == l0 and set(ga) == set(gb)
+    lim = 2e-2 if dtype == torch.bfloat16 else 3e-3
+    differs = 0
+    for n in ga:
+        sc = float(gb[n].abs().max())
+        if sc == 0.0 or (n.endswith("conv.bias") and ".convs." in n):
+            continue
+        assert float((ga[n] - gb[n]).abs().max()) <= lim * sc, n
+        cos = float((ga[n].double().flatten() @ gb[n].double().flatten()) / (ga[n].double().norm() * gb[n].double().norm()))
+        assert cos > (0.999 if dtype == torch.bfloat16 else 0.99999), (n, cos)
+        differs += int(not torch.equal(ga[n], gb[n]))
+    assert differs > 0                       # the 16-bit channel really ran
+    # a second consumer of the output: its dense gradient and the sink's are summed (nothing is dropped)
+    _, gc = run(extra_consumer=True)
+    hb = "decoder.seg_layers.3.bias"
+    assert float((gc[hb] - ga[hb]).abs().max()) > 0
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])

@@ -116,27 +116,33 @@ __global__ void warp_fwd_kernel(const float *__restrict__ src, const float *__re
     for (int k = 0; k < 8; ++k) {
       const int xx = cr.x0 + (k & 1), yy = cr.y0 + ((k >> 1) & 1), zz = cr.z0 + (k >> 2);
       ok[k] = (unsigned)xx < (unsigned)Ws && (unsigned)yy < (unsigned)Hs && (unsigned)zz < (unsigned)Ds;
-      off[k] = ((int64_t)zz * Hs + yy) * Ws + xx;
+      // (round 6) the offset of the CLAMPED corner: every corner is read - all eight loads in flight instead of eight
+      // load - wait - blend blocks behind `if (ok)` - and a corner outside the volume is replaced by `sub` (it then adds +0)
+      off[k] = ((int64_t)min(max(zz, 0), Ds - 1) * Hs + min(max(yy, 0), Hs - 1)) * Ws + min(max(xx, 0), Ws - 1);
     }
     if (NDHWC) {
       float acc[VEC];
 #pragma unroll
       for (int q = 0; q < VEC; ++q) acc[q] = 0.f;
+      float tv[8][VEC];
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
-        if (ok[k]) {
-          const float *p = src + ((int64_t)b * Vs + off[k]) * src_ldc + g * VEC;
-          if (VEC == 4) {
-            const float4 t = *reinterpret_cast<const float4 *>(p);
-            acc[0] += (t.x - sub) * cr.w[k];
-            acc[1] += (t.y - sub) * cr.w[k];
-            acc[2] += (t.z - sub) * cr.w[k];
-            acc[3] += (t.w - sub) * cr.w[k];
-          } else {
+        const float *p = src + ((int64_t)b * Vs + off[k]) * src_ldc + g * VEC;
+        if (VEC == 4) {
+          const float4 t = *reinterpret_cast<const float4 *>(p);
+          tv[k][0] = t.x;
+          tv[k][1 % VEC] = t.y;
+          tv[k][2 % VEC] = t.z;
+          tv[k][3 % VEC] = t.w;
+        } else {
 #pragma unroll
-            for (int q = 0; q < VEC; ++q) acc[q] += (p[q] - sub) * cr.w[k];
-          }
+          for (int q = 0; q < VEC; ++q) tv[k][q] = p[q];
         }
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) acc[q] += ((ok[k] ? tv[k][q] : sub) - sub) * (ok[k] ? cr.w[k] : 0.f);
       }
       float *o = dst + ((int64_t)b * Vd + v) * dst_ldc + g * VEC;
       if (VEC == 4) {
@@ -148,10 +154,11 @@ __global__ void warp_fwd_kernel(const float *__restrict__ src, const float *__re
     } else {
       for (int c = 0; c < C; ++c) {
         const float *p = src + ((int64_t)b * C + c) * Vs;
-        float acc = 0.f;
+        float acc = 0.f, tv[8];
 #pragma unroll
-        for (int k = 0; k < 8; ++k)
-          if (ok[k]) acc += (p[off[k]] - sub) * cr.w[k];
+        for (int k = 0; k < 8; ++k) tv[k] = p[off[k]];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc += ((ok[k] ? tv[k] : sub) - sub) * (ok[k] ? cr.w[k] : 0.f);
         dst[((int64_t)b * C + c) * Vd + v] = acc + sub;
       }
     }
@@ -399,16 +406,23 @@ __global__ __launch_bounds__(256) void warp_fwd_rows4_kernel(const float *__rest
     const Sample s = sample_pos(theta + b * 12, d, h, w, Dd, Hd, Wd, Ds, Hs, Ws, algebra, pad_mode);
     const Corners cr = corners(s);
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    // (round 6) all eight corner rows in flight: clamped addresses, a corner outside the volume zeroed (it then adds +0)
+    float4 t[8];
+    bool ok[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       const int xx = cr.x0 + (k & 1), yy = cr.y0 + ((k >> 1) & 1), zz = cr.z0 + (k >> 2);
-      if ((unsigned)xx < (unsigned)Ws && (unsigned)yy < (unsigned)Hs && (unsigned)zz < (unsigned)Ds) {
-        const float4 t = *reinterpret_cast<const float4 *>(sb + (((int64_t)zz * Hs + yy) * Ws + xx) * src_ldc + g * 4);
-        acc[0] += (t.x - sub) * cr.w[k];
-        acc[1] += (t.y - sub) * cr.w[k];
-        acc[2] += (t.z - sub) * cr.w[k];
-        acc[3] += (t.w - sub) * cr.w[k];
-      }
+      ok[k] = (unsigned)xx < (unsigned)Ws && (unsigned)yy < (unsigned)Hs && (unsigned)zz < (unsigned)Ds;
+      const int xc = min(max(xx, 0), Ws - 1), yc = min(max(yy, 0), Hs - 1), zc = min(max(zz, 0), Ds - 1);
+      t[k] = *reinterpret_cast<const float4 *>(sb + (((int64_t)zc * Hs + yc) * Ws + xc) * src_ldc + g * 4);
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const float wk = ok[k] ? cr.w[k] : 0.f;
+      acc[0] += ((ok[k] ? t[k].x : sub) - sub) * wk;
+      acc[1] += ((ok[k] ? t[k].y : sub) - sub) * wk;
+      acc[2] += ((ok[k] ? t[k].z : sub) - sub) * wk;
+      acc[3] += ((ok[k] ? t[k].w : sub) - sub) * wk;
     }
     float *drow = dst + ((int64_t)b * Vd + ((int64_t)d * Hd + h) * Wd) * dst_ldc;
     typedef float f32x4_t __attribute__((ext_vector_type(4)));
@@ -474,19 +488,27 @@ __global__ __launch_bounds__(256) void head_warp_fwd_kernel(const T *__restrict_
     if (live) {
       const Sample s = sample_pos(theta + b * 12, d, h, wv, D, H, W, D, H, W, algebra, DGTTA_PAD_ZEROS);
       const Corners cr = corners(s);
+      // (round 6: all eight corner rows requested before the first is used - see head_warp_fwd_mfma_kernel)
+      uint4 t[8];
+      bool inb[8];
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
         const int xx = cr.x0 + (k & 1), yy = cr.y0 + ((k >> 1) & 1), zz = cr.z0 + (k >> 2);
-        if ((unsigned)xx < (unsigned)W && (unsigned)yy < (unsigned)H && (unsigned)zz < (unsigned)D) {
-          // (abl: timing diagnostic DGTTA_WARP_ABL=1 - every corner read lands in a 2 x 4 x 16-voxel block that stays in L1)
-          const int64_t sv = ABL ? (((int64_t)(zz & 1) * H + (yy & 3)) * W + (xx & 15)) : (((int64_t)zz * H + yy) * W + xx);
-          const uint4 t = *reinterpret_cast<const uint4 *>(zb + sv * HW_CIN + g * 8);
-          float f[8];
-          unpack8_16<T>(t, f);
+        inb[k] = (unsigned)xx < (unsigned)W && (unsigned)yy < (unsigned)H && (unsigned)zz < (unsigned)D;
+        const int xc = min(max(xx, 0), W - 1), yc = min(max(yy, 0), H - 1), zc = min(max(zz, 0), D - 1);
+        // (abl: timing diagnostic DGTTA_WARP_ABL=1 - every corner read lands in a 2 x 4 x 16-voxel block that stays in L1)
+        const int64_t sv = ABL ? (((int64_t)(zc & 1) * H + (yc & 3)) * W + (xc & 15)) : (((int64_t)zc * H + yc) * W + xc);
+        t[k] = *reinterpret_cast<const uint4 *>(zb + sv * HW_CIN + g * 8);
+      }
 #pragma unroll
-          for (int c = 0; c < 8; ++c) zbl[c] += f[c] * cr.w[k];
-          wsum += cr.w[k];
-        }
+      for (int k = 0; k < 8; ++k) {
+        const uint4 tk = inb[k] ? t[k] : make_uint4(0u, 0u, 0u, 0u);
+        const float wk = inb[k] ? cr.w[k] : 0.f;
+        float f[8];
+        unpack8_16<T>(tk, f);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) zbl[c] += f[c] * wk;
+        wsum += wk;
       }
     }
     // partial logits over this lane's 8 channels, summed over the voxel's 4 lanes.  The weight slice is re-read from LDS
@@ -567,18 +589,27 @@ __global__ __launch_bounds__(256) void head_warp_fwd_mfma_kernel(const T *__rest
     if (live) {
       const Sample sp = sample_pos(theta + b * 12, d, h, wv, D, H, W, D, H, W, algebra, DGTTA_PAD_ZEROS);
       const Corners cr = corners(sp);
+      // ALL EIGHT corner rows are requested before the first is used: a corner behind `if (in bounds)` is its own basic block
+      // (load - s_waitcnt vmcnt(0) - blend), i.e. eight dependent L2 round trips per voxel row - what the kernel was waiting on
+      // (round 3 PMC: 81 % of the wave cycles in s_waitcnt).  An out-of-bounds corner reads the clamped row and is zeroed.
+      uint4 t[8];
+      bool inb[8];
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
         const int xx = cr.x0 + (k & 1), yy = cr.y0 + ((k >> 1) & 1), zz = cr.z0 + (k >> 2);
-        if ((unsigned)xx < (unsigned)W && (unsigned)yy < (unsigned)H && (unsigned)zz < (unsigned)D) {
-          const int64_t sv = ((int64_t)zz * H + yy) * W + xx;
-          const uint4 t = *reinterpret_cast<const uint4 *>(zb + sv * HW_CIN + g * 8);
-          float f[8];
-          unpack8_16<T>(t, f);
+        inb[k] = (unsigned)xx < (unsigned)W && (unsigned)yy < (unsigned)H && (unsigned)zz < (unsigned)D;
+        const int xc = min(max(xx, 0), W - 1), yc = min(max(yy, 0), H - 1), zc = min(max(zz, 0), D - 1);
+        t[k] = *reinterpret_cast<const uint4 *>(zb + ((int64_t)(zc * H + yc) * W + xc) * HW_CIN + g * 8);
+      }
 #pragma unroll
-          for (int c = 0; c < 8; ++c) zbl[c] += f[c] * cr.w[k];
-          wsum += cr.w[k];
-        }
+      for (int k = 0; k < 8; ++k) {
+        const uint4 tk = inb[k] ? t[k] : make_uint4(0u, 0u, 0u, 0u);
+        const float wk = inb[k] ? cr.w[k] : 0.f;
+        float f[8];
+        unpack8_16<T>(tk, f);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) zbl[c] += f[c] * wk;       // (an excluded corner adds +0: the same bits as skipping it)
+        wsum += wk;
       }
     }
     hw_f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};      // two chains: the dependent latency is 40 cycles
@@ -603,43 +634,25 @@ __device__ __forceinline__ uint4 pack8_16(const float *f) {
 // backward: one thread owns one voxel of the feature-map lattice; candidate search and accumulation exactly as
 // warp_bwd_gather_kernel<16, true> (same order), then d16 = 16-bit copy of the gathered logit gradient (operand of the
 // head's MFMA weight gradient), gz = W^T acc in the network's storage type, and the block's partial sums for the bias gradient
-// Round 6.  MF: gz = W^T acc on the fp32 MATRIX cores instead of 512 FMAs and 128 LDS weight reads per lane (the kernel is
-// instruction-bound, round 4): the wave parks its 64 voxels x 16 classes in LDS class-major, reads them back as the B operand
-// of v_mfma_f32_16x16x4_f32 (k = class 4 s + (lane >> 4)), the head's rows are the A operand in 8 registers, and D leaves 8
-// consecutive channels of one voxel on a lane (row 4 g + r of block j = channel 8 g + 4 j + r): one 16-byte store.  The
-// instruction is a k-ordered fmaf chain (MI355X guide), the classes enter in the order 0..15 of the FMA loop it replaces, so
-// gz has the SAME BITS (test_head_fused_with_the_inverse_warp_matches_head_then_warp runs both against head-then-warp).
-// G16: the logit gradient arrives in the network's 16-bit storage type (written so by dgtta_softdice_bwd_t): half the bytes
-// per gathered candidate; acc += float(g16) * weight in the same order.
-constexpr int HWB_LDS_PITCH = 80;       // floats per class row of a wave's slab: 64 voxels + 16 (bank offset of the odd k)
-
-template <typename T, bool ABL = false, bool G16 = false, bool MF = false>
+// Round 6, G16: the logit gradient arrives in the network's 16-bit storage type (written so by dgtta_softdice_bwd_t): half the
+// bytes per gathered candidate (1.89 instead of 2.13 ms per 8 x 128^3 launch); acc += float(g16) * weight in the same order.
+// Measured beside it and NOT kept (profiles/r06_ab.txt): W^T on the fp32 matrix cores through a class-major LDS slab (same
+// bits, but 82 instead of 80 registers = 5 instead of 6 waves per SIMD: 1.96 ms) and a chunked gather with 2 or 3 lines'
+// candidate rows in flight (2.14 / 2.17 ms: the candidate search is the cost, not the round trips - more slots, more search).
+template <typename T, bool ABL = false, bool G16 = false>
 __global__ __launch_bounds__(256, 6) void head_warp_bwd_kernel(const void *__restrict__ gdst_, const float *__restrict__ theta,
                                                             const float *__restrict__ w, const int *__restrict__ sel,
                                                             int nsel, T *__restrict__ gz, unsigned short *__restrict__ d16,
                                                             double *__restrict__ bias_partial, int D, int H, int W,
                                                             int algebra, int gx, int gy) {
-  __shared__ float sw[MF ? 1 : HW_NS * HW_CIN];
-  __shared__ float sacc[MF ? 4 * HW_NS * HWB_LDS_PITCH : 1];
+  __shared__ float sw[HW_NS * HW_CIN];
   __shared__ InvMap s_im;
   __shared__ float sred[4][HW_NS];
   const float *gdst = (const float *)gdst_;
   const unsigned short *gdst16 = (const unsigned short *)gdst_;
-  float wA[4][2];
-  if (MF) {
-    const int lane = threadIdx.x & 63, r = lane & 15, kk = lane >> 4;
-#pragma unroll
-    for (int st = 0; st < 4; ++st) {
-      const int k = 4 * st + kk;
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-        wA[st][j] = k < nsel ? w[(int64_t)(sel ? sel[k] : k) * HW_CIN + 8 * (r >> 2) + 4 * j + (r & 3)] : 0.f;
-    }
-  } else {
-    for (int i = threadIdx.x; i < HW_NS * HW_CIN; i += 256) {
-      const int k = i / HW_CIN;
-      sw[i] = k < nsel ? w[(int64_t)(sel ? sel[k] : k) * HW_CIN + i % HW_CIN] : 0.f;
-    }
+  for (int i = threadIdx.x; i < HW_NS * HW_CIN; i += 256) {
+    const int k = i / HW_CIN;
+    sw[i] = k < nsel ? w[(int64_t)(sel ? sel[k] : k) * HW_CIN + i % HW_CIN] : 0.f;
   }
   const int64_t V = (int64_t)D * H * W;
   const int tilesZ = (D + 3) >> 2;
@@ -673,32 +686,43 @@ __global__ __launch_bounds__(256, 6) void head_warp_bwd_kernel(const void *__res
       bounds_w[j] = fabsf(im.m[j][0]) > 1e-6f;
       rcp0[j] = bounds_w[j] ? 1.0f / im.m[j][0] : 0.f;
     }
+    // w range of the candidates on line (d, h): the three constraints |S_j(w,h,d) - u_j| < 1 bound w (linear model + slack)
+    auto w_range = [&](int d, int h, int &w0, int &w1) {
+      float wl = (float)lo[0], wh = (float)hi[0];
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const float r = -rel[j] + im.m[j][1] * (float)h + im.m[j][2] * (float)d;
+        if (bounds_w[j]) {
+          const float a = (-1.02f - r) * rcp0[j], bq = (1.02f - r) * rcp0[j];
+          wl = fmaxf(wl, fminf(a, bq));
+          wh = fminf(wh, fmaxf(a, bq));
+        } else if (fabsf(r) > 1.02f) {
+          wh = wl - 1.0f;
+        }
+      }
+      w0 = (int)ceilf(wl);
+      w1 = (int)floorf(wh);
+    };
+    // weight of this source voxel in the sample of dst voxel (wq, yc, zc); false when it is none of the sample's 8 corners
+    auto corner_weight = [&](int wq, float yc, float zc, float &wt) -> bool {
+      const Sample s = sample_from_base(th, base_coord(wq, W), yc, zc, D, H, W, algebra, DGTTA_PAD_ZEROS);
+      const float fx = floorf(s.ix), fy = floorf(s.iy), fz = floorf(s.iz);
+      const float dx = (float)x - fx, dy = (float)y - fy, dz = (float)zc_ - fz;
+      const float wx = dx == 0.f ? (fx + 1.0f) - s.ix : s.ix - fx;
+      const float wy = dy == 0.f ? (fy + 1.0f) - s.iy : s.iy - fy;
+      const float wz = dz == 0.f ? (fz + 1.0f) - s.iz : s.iz - fz;
+      wt = wx * wy * wz;
+      return (dx == 0.f || dx == 1.f) && (dy == 0.f || dy == 1.f) && (dz == 0.f || dz == 1.f);
+    };
     for (int d = lo[2]; d <= hi[2]; ++d) {
       const float zc = base_coord(d, D);
       for (int h = lo[1]; h <= hi[1]; ++h) {
         const float yc = base_coord(h, H);
-        float wl = (float)lo[0], wh = (float)hi[0];
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-          const float r = -rel[j] + im.m[j][1] * (float)h + im.m[j][2] * (float)d;
-          if (bounds_w[j]) {
-            const float a = (-1.02f - r) * rcp0[j], bq = (1.02f - r) * rcp0[j];
-            wl = fmaxf(wl, fminf(a, bq));
-            wh = fminf(wh, fmaxf(a, bq));
-          } else if (fabsf(r) > 1.02f) {
-            wh = wl - 1.0f;
-          }
-        }
-        const int w1 = (int)floorf(wh);
-        for (int wq = (int)ceilf(wl); wq <= w1; ++wq) {
-          const Sample s = sample_from_base(th, base_coord(wq, W), yc, zc, D, H, W, algebra, DGTTA_PAD_ZEROS);
-          const float fx = floorf(s.ix), fy = floorf(s.iy), fz = floorf(s.iz);
-          const float dx = (float)x - fx, dy = (float)y - fy, dz = (float)zc_ - fz;
-          if (!((dx == 0.f || dx == 1.f) && (dy == 0.f || dy == 1.f) && (dz == 0.f || dz == 1.f))) continue;
-          const float wx = dx == 0.f ? (fx + 1.0f) - s.ix : s.ix - fx;
-          const float wy = dy == 0.f ? (fy + 1.0f) - s.iy : s.iy - fy;
-          const float wz = dz == 0.f ? (fz + 1.0f) - s.iz : s.iz - fz;
-          const float wt = wx * wy * wz;
+        int w0, w1;
+        w_range(d, h, w0, w1);
+        for (int wq = w0; wq <= w1; ++wq) {
+          float wt;
+          if (!corner_weight(wq, yc, zc, wt)) continue;
           const int64_t grow = (ABL ? (((int64_t)(d & 1) * H + (h & 3)) * W + (wq & 15)) * nsel
                                     : ((int64_t)b * V + ((int64_t)d * H + h) * W + wq) * nsel);
           if (G16) {
@@ -743,7 +767,7 @@ __global__ __launch_bounds__(256, 6) void head_warp_bwd_kernel(const void *__res
     // gz = W^T acc, a quarter (8 channels) at a time to keep the register footprint of the gather phase
     T *gp = gz + u * HW_CIN;
 #pragma unroll
-    for (int qt = 0; qt < (MF ? 0 : 4); ++qt) {
+    for (int qt = 0; qt < 4; ++qt) {
       float o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int k = 0; k < HW_NS; ++k) {
@@ -759,31 +783,6 @@ __global__ __launch_bounds__(256, 6) void head_warp_bwd_kernel(const void *__res
         o[7] = __builtin_fmaf(acc[k], w1.w, o[7]);
       }
       *reinterpret_cast<uint4 *>(reinterpret_cast<unsigned short *>(gp) + qt * 8) = pack8_16<T>(o);
-    }
-  }
-  if (MF) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    float *slab = sacc + wave * (HW_NS * HWB_LDS_PITCH);
-#pragma unroll
-    for (int k = 0; k < HW_NS; ++k) slab[k * HWB_LDS_PITCH + lane] = acc[k];
-    __syncthreads();
-    const int v = lane & 15, g = lane >> 4;
-    const int xs = bx * 16 + v;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {          // voxel group q = the wave's row y = by * 4 + q
-      hw_f32x4 d0 = {0.f, 0.f, 0.f, 0.f}, d1 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int st = 0; st < 4; ++st) {
-        const float bv = slab[(4 * st + g) * HWB_LDS_PITCH + 16 * q + v];
-        d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wA[st][0], bv, d0, 0, 0, 0);
-        d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wA[st][1], bv, d1, 0, 0, 0);
-      }
-      const int ys = by * 4 + q;
-      if (xs < W && ys < H && zc_ < D) {
-        const float o[8] = {d0[0], d0[1], d0[2], d0[3], d1[0], d1[1], d1[2], d1[3]};
-        const int64_t uq = (int64_t)b * V + ((int64_t)zc_ * H + ys) * W + xs;
-        *reinterpret_cast<uint4 *>(reinterpret_cast<unsigned short *>(gz + uq * HW_CIN) + g * 8) = pack8_16<T>(o);
-      }
     }
   }
   // bias gradient: sum of the gathered gradient over the block (threads outside the volume hold zeros), fixed order
@@ -1333,35 +1332,24 @@ static int seghead_warp_bwd_impl(const void *z, const void *gout, int gout16, co
   const int gx = cdiv(W, 16), gy = cdiv(H, 4);
   const int64_t nblk = (int64_t)gx * gy * cdiv(D, 4) * B;
   DG_REQUIRE(nblk < (1ll << 31), DGTTA_ERR_UNSUPPORTED, "seghead_warp_bwd: too many tiles");
-#define HWB_LAUNCH(T, A, G, M)                                                                                            \
-  hipLaunchKernelGGL((head_warp_bwd_kernel<T, A, G, M>), dim3((unsigned)nblk), dim3(256), 0, st, gout, theta, w, sel,    \
-                     nsel, (T *)gz, d16, db_sel ? bias_partial : nullptr, D, H, W, tta_grid_algebra, gx, gy)
+#define HWB_LAUNCH(T, A, G)                                                                                               \
+  hipLaunchKernelGGL((head_warp_bwd_kernel<T, A, G>), dim3((unsigned)nblk), dim3(256), 0, st, gout, theta, w, sel, nsel, \
+                     (T *)gz, d16, db_sel ? bias_partial : nullptr, D, H, W, tta_grid_algebra, gx, gy)
   bool lab = false;
 #ifdef DGTTA_DIAG
   if (DG_LAB(warp_abl) == '1' && !gout16) {      // timing model: results wrong by construction
     lab = true;
-    if (dtype == DGTTA_BF16) HWB_LAUNCH(bf16_t, true, false, false);
-    else HWB_LAUNCH(f16_t, true, false, false);
+    if (dtype == DGTTA_BF16) HWB_LAUNCH(bf16_t, true, false);
+    else HWB_LAUNCH(f16_t, true, false);
   }
 #endif
-  const bool mf = dgtta_switches().headwarp_mfma != '0';      // DGTTA_HEADWARP_MFMA=0: W^T as the FMA chain (same bits)
   if (lab) {
   } else if (dtype == DGTTA_BF16) {
-    if (gout16) {
-      if (mf) HWB_LAUNCH(bf16_t, false, true, true);
-      else HWB_LAUNCH(bf16_t, false, true, false);
-    } else {
-      if (mf) HWB_LAUNCH(bf16_t, false, false, true);
-      else HWB_LAUNCH(bf16_t, false, false, false);
-    }
+    if (gout16) HWB_LAUNCH(bf16_t, false, true);
+    else HWB_LAUNCH(bf16_t, false, false);
   } else {
-    if (gout16) {
-      if (mf) HWB_LAUNCH(f16_t, false, true, true);
-      else HWB_LAUNCH(f16_t, false, true, false);
-    } else {
-      if (mf) HWB_LAUNCH(f16_t, false, false, true);
-      else HWB_LAUNCH(f16_t, false, false, false);
-    }
+    if (gout16) HWB_LAUNCH(f16_t, false, true);
+    else HWB_LAUNCH(f16_t, false, false);
   }
 #undef HWB_LAUNCH
   DG_CHECK_LAUNCH("head_warp_bwd_kernel");

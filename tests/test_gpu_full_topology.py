@@ -235,9 +235,9 @@ def test_head_fused_with_the_inverse_warp_matches_head_then_warp(dtype, nsel, mo
 
     y0, g0 = run(False)
     y1, g1 = run(True)
-    # round 6: the fused pair's head products run on the fp32 matrix cores (v_mfma_f32_16x16x4_f32, a k-ordered fmaf chain);
-    # DGTTA_HEADWARP_MFMA=0 selects the FMA chains they replaced - the backward has the SAME bits in both, the forward the same
-    # to fp32 association
+    # round 6: the fused FORWARD's head products run on the fp32 matrix cores (v_mfma_f32_16x16x4_f32, a k-ordered fmaf chain);
+    # DGTTA_HEADWARP_MFMA=0 selects the FMA chain + quad butterfly it replaced: the same logits to fp32 association (the
+    # backward is one kernel either way)
     monkeypatch.setenv("DGTTA_HEADWARP_MFMA", "0")
     reload_kernel_switches()
     y2, g2 = run(True)
@@ -246,7 +246,7 @@ def test_head_fused_with_the_inverse_warp_matches_head_then_warp(dtype, nsel, mo
     assert float((y2 - y1).abs().max()) < 2e-6 * float(y0.max() - y0.min()) + 1e-6 and not torch.equal(y2, y1)
     for n in g1:
         if n != "decoder.seg_layers.3.bias":
-            assert torch.equal(g1[n], g2[n]), f"{n}: the matrix-core W^T differs from the FMA chain"
+            assert torch.equal(g1[n], g2[n]), n
     rng = float(y0.max() - y0.min())
     assert tuple(y1.shape) == tuple(y0.shape) and float((y1 - y0).abs().max()) < 2e-6 * rng + 1e-6
     assert set(g0) == set(g1)
@@ -288,14 +288,19 @@ def test_logit_gradient_in_the_storage_type_through_the_sink(dtype, monkeypatch)
     check(lib.dgtta_softdice_bwd(ptr(both[:B]), ptr(both[B:]), ptr(g32[:B]), ptr(g32[B:]), ptr(ws), 4096.0, None, B, C, v, C, 1, stream_of()), "bwd")
     check(lib.dgtta_softdice_bwd_t(ptr(both[:B]), ptr(both[B:]), ptr(g16[:B]), ptr(g16[B:]), ptr(ws), 4096.0, None, B, C, v, C, 1, dt,
                                    stream_of()), "bwd_t")
-    assert torch.equal(g16, g32.to(dtype)) and float(g32.abs().max()) > 0
+    # the fp32 value rounded ONCE: equal to torch's cast except where hipcc folds the last multiply into the conversion
+    # (v_fma_mix*: the exact product rounded straight to fp16 - fp32 ties then fall the other way, 14 of 2 M values measured)
+    ref = g32.to(dtype)
+    assert float((g16 != ref).float().mean()) < 1e-4 and float(g32.abs().max()) > 0
+    ulp = 2.0 ** (-10 if dtype == torch.float16 else -7)
+    assert bool(((g16.float() - g32).abs() <= ulp * g32.abs() + 6e-8).all())
     z = torch.randn(b2, N, N, N, 32, device=DEV).to(dtype)
     w, sel = torch.randn(105, 32, device=DEV) * 0.1, (torch.arange(C) * 3).to(torch.int32).to(DEV)
     _, rinv = otta.rand_affine_from_draw(torch.randn(b2, 3, 4), 0.08)
     rinv = rinv.float().contiguous()
     nb = lib.dgtta_seghead_warp_bwd_ws_bytes(b2, 32, C, N, N, N)
     outs = []
-    for use16 in (True, False):
+    for use16 in (True, False):          # the 16-bit gather against the fp32 gather on the widened values
         ws2 = torch.empty(nb, dtype=torch.uint8, device=DEV)
         gz = torch.empty(b2, N, N, N, 32, dtype=dtype, device=DEV)
         dws, dbs = torch.empty(C, 32, device=DEV), torch.empty(C, device=DEV)
@@ -305,8 +310,9 @@ def test_logit_gradient_in_the_storage_type_through_the_sink(dtype, monkeypatch)
                  N, N, N, 1, 0, dt, stream_of()), "head_warp_bwd")
         torch.cuda.synchronize()
         outs.append((gz, dws, dbs))
-    for a, b in zip(*outs):
-        assert torch.equal(a, b)
+    for o in outs[:-1]:
+        for a, b in zip(o, outs[-1]):
+            assert torch.equal(a, b)
     assert float(outs[0][0].float().abs().max()) > 0
     # ---- (ii) the network's batched pair
     net = he_init_(HipPlainConvUNet(act_dtype=dtype), seed=7).to(DEV)

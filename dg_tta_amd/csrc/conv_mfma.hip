@@ -100,6 +100,25 @@ __global__ __launch_bounds__(NW * 64) void conv3_mfma_kernel(const T *__restrict
   // the loads of chunk k+1 are in flight while chunk k is being multiplied.
   constexpr int NA = (NV * NG + NT - 1) / NT, NBL = (NTAP * NC * NG + NT - 1) / NT;
   uint4 ra[NA], rb[NBL];
+  // Weight slots of this thread, resolved ONCE (round 6).  The tap table lives in the kernel arguments and a lane's slot picks
+  // its tap at run time, so `taps.wt[tap]` inside load_chunk was a per-lane BYTE LOAD FROM MEMORY in front of every weight load:
+  // global_load_sbyte - s_waitcnt vmcnt(0) - branch - global_load_dwordx4, i.e. every one of a chunk's 4-14 weight loads per
+  // thread waited for the one before it AND for the activation loads in flight (two dependent round trips each; the tiny layers,
+  // one wave per SIMD, spent ~6 us per chunk there against 0.8 us of MFMAs).  The table goes through LDS once, and a slot's
+  // element offset for chunk 0 (or -1: tap absent / slot beyond the tile) is kept in a register; a chunk only adds its K offset.
+  __shared__ signed char s_wt[32];
+  if (tid < 27) s_wt[tid] = AC ? (signed char)tid : taps.wt[tid];
+  __syncthreads();
+  int wslot[NBL];
+#pragma unroll
+  for (int i = 0; i < NBL; ++i) {
+    const int idx = tid + i * NT;       // == LDS index (tap*NG + g)*NC + n
+    const int n = idx % NC, g = (idx / NC) % NG, tap = (S == 0) ? 13 : (idx / (NG * NC)) % 27;
+    const int wt = s_wt[tap];
+    const bool ok = idx < NTAP * NC * NG && wt >= 0;
+    const int off = ((((n0 + n) / 32) * (CinP / (2 * EPV)) + g / 2) * ntaps_src + wt) * 64 + (g & 1) * 32 + (n0 + n) % 32;
+    wslot[i] = ok ? off : -1;
+  }
   auto load_chunk = [&](int kc) {
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
@@ -126,18 +145,13 @@ __global__ __launch_bounds__(NW * 64) void conv3_mfma_kernel(const T *__restrict
       const uint4 val = *reinterpret_cast<const uint4 *>(p);
       ra[i] = ok ? val : make_uint4(0, 0, 0, 0);
     }
+    const int kterm = (kc / (2 * EPV)) * ntaps_src * 64;      // K-chunk of 2*EPV channels: ntaps_src x 2 x 32 slots each
 #pragma unroll
     for (int i = 0; i < NBL; ++i) {
-      const int idx = tid + i * NT;       // == LDS index (tap*NG + g)*NC + n
-      const int n = idx % NC, g = (idx / NC) % NG, tap = (S == 0) ? 13 : (idx / (NG * NC)) % 27;
-      const int wt = AC ? tap : taps.wt[tap];
-      const bool ok = idx < NTAP * NC * NG && wt >= 0;
-      const int64_t chunk2 = (int64_t)(kc / (2 * EPV)) + g / 2;     // K-chunk of 2*EPV channels
-      const int64_t off = (((((int64_t)(n0 + n) / 32) * (CinP / (2 * EPV)) + chunk2) * ntaps_src + wt) * 2 + (g & 1)) * 32 +
-                          (n0 + n) % 32;
-      const T *p = ok ? w + off * EPV : w;
+      const bool ok = wslot[i] >= 0;
+      const T *p = w + (int64_t)(ok ? wslot[i] + kterm : 0) * EPV;
       if (ABL == 1 || ABL == 4) {
-        rb[i] = make_uint4(idx, 0, 0, 0);
+        rb[i] = make_uint4(tid + i * NT, 0, 0, 0);
         continue;
       }
       const uint4 val = *reinterpret_cast<const uint4 *>(p);

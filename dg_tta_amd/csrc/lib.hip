@@ -11,7 +11,7 @@ void dgtta_set_error(const char *fmt, ...) {
   va_end(ap);
 }
 
-extern "C" int dgtta_version(void) { return 50100; /* 5.1.0: feature-space window accumulation (dgtta_feature_*); 5.0.0: dice_ce_fwd / bwd (pre-training loss), argmax_rows for > 112 classes, laboratory switches out of the product build */ }
+extern "C" int dgtta_version(void) { return 60000; /* 6.0.0: dgtta_softdice_bwd_t, dgtta_seghead_warp_bwd_g16 (logit gradient in the storage type); 5.1.0: feature-space window accumulation (dgtta_feature_*); 5.0.0: dice_ce_fwd / bwd (pre-training loss), argmax_rows for > 112 classes, laboratory switches out of the product build */ }
 extern "C" const char *dgtta_last_error(void) { return g_err; }
 
 // ---------------------------------------------------------------- environment switches (snapshot, see common.h)

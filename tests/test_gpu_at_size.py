@@ -174,8 +174,8 @@ def test_one_step_128_backward_vs_cpu_oracle():
 
 def test_adaptation_epochs_128_dice_delta_of_the_default_storage_type():
     """N = 4 adaptation epochs of the product's tta_epoch (default 2 x 4 batching, side streams), same seeds and draws for
-    fp32, fp16 and bf16 storage: north_star's tolerance holds for the 16-bit storage type bench.py defaults to (BASELINE
-    config 2's bf16) and for fp16; `dgtta run_tta` itself defaults to fp32, the reference's precision."""
+    fp32, fp16 and bf16 storage: north_star's tolerance holds for the 16-bit storage type bench.py defaults to (fp16 since
+    round 6) and for BASELINE config 2's bf16; `dgtta run_tta` itself defaults to fp32, the reference's precision."""
     bench = _bench()
     from dg_tta_amd.run import DEFAULT_DTYPE, FAST_DTYPE
     assert DEFAULT_DTYPE == "fp32" and bench.parse_args([]).dtype == FAST_DTYPE

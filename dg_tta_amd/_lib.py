@@ -43,6 +43,9 @@ SIGNATURES = {
     "dgtta_conv3d_wgrad_ws_bytes": (SZ, [I, I, I, I, I, I]),
     "dgtta_conv3d_wgrad_split_ws_bytes": (SZ, [I, I, I, I, I, I, I]),
     "dgtta_conv3d_k3_wgrad": (I, [P, I, P, I, P, P, P, SZ, I, I, I, I, I, I, I, I, I, I, P]),
+    "dgtta_conv3d_k3_blocked_supported": (I, [I, I, I, I, I, I, I]),
+    "dgtta_conv3d_k3_fwd_blocked": (I, [P, I64, P, P, P, I, P, I, I, I, I, I, I, I, I, I, P]),
+    "dgtta_conv3d_k3_wgrad_blocked": (I, [P, I64, P, I, P, P, P, SZ, I, I, I, I, I, I, I, I, P]),
     "dgtta_instnorm_ws_bytes": (SZ, [I, I, I64]),
     "dgtta_instnorm_lrelu_fwd": (I, [P, I, P, P, P, P, P, I, P, SZ, I, I, I64, F, F, I, P]),
     "dgtta_instnorm_lrelu_bwd": (I, [P, I, P, I, P, P, P, P, I, P, P, P, SZ, I, I, I64, F, I, I, P]),

@@ -23,7 +23,7 @@ int conv3_rows_launch(const void *x, const View &xv, const void *w, const Taps &
 
 int conv3_ring_launch(const void *x, const View &xv, const void *w, const Taps &taps, const float *bias, void *y, const View &yv,
                       int B, int Cin, int Cout, int CinP, int CoutP, double *stats, int64_t stats_cap_slots, int ntaps_src,
-                      int is_f16, hipStream_t st, RowsGstCtx *gst);      // conv_ring.hip
+                      int is_f16, hipStream_t st, RowsGstCtx *gst, long long xkh = 0, bool dry = false);      // conv_ring.hip
 int64_t conv3_mfma_max_tiles(int Do, int Ho, int Wo);
 
 namespace {
@@ -435,9 +435,12 @@ int launch_conv(const void *x, const View &xv, const void *w, const ConvClasses 
 template <typename T>
 int dispatch_conv_classes(const void *x, const View &xv, const void *w, const ConvClasses &cs, const float *bias, void *y,
                           const View &yv, int B, int Cin, int Cout, int CinP, int CoutP, int stride, hipStream_t st,
-                          double *stats = nullptr, int ntaps_src = 27, RowsGstCtx *gst = nullptr) {
+                          double *stats = nullptr, int ntaps_src = 27, RowsGstCtx *gst = nullptr, long long xkh = 0, bool dry = false) {
+  // xkh != 0: x holds its two 32-channel K halves as dense planes xkh elements apart - only the ring kernel reads that layout;
+  // dry: no launch, DGTTA_OK iff the ring kernel would take this call (dgtta_conv3d_k3_blocked_supported)
 #define ARGS x, xv, w, cs, bias, y, yv, B, Cin, Cout, CinP, CoutP, stats, ntaps_src, st
   const long long vox = (long long)yv.D * yv.H * yv.W * B;
+  if ((xkh || dry) && stride != 1) return DGTTA_ERR_UNSUPPORTED;
   if (stride == 0) {      // pointwise (centre tap only, no halo)
     if (yv.W >= 32) return launch_conv<T, 32, 4, 4, 0, 1, 1, 8>(ARGS);
     if (yv.W >= 16) return launch_conv<T, 16, 4, 4, 0, 1, 1, 8>(ARGS);
@@ -457,13 +460,16 @@ int dispatch_conv_classes(const void *x, const View &xv, const void *w, const Co
     if (all_taps && vec_out && ((Cin == 32 && CinP == 32) || (Cin == 64 && CinP == 64)) && (njobs >= 512 || dgtta_switches().conv_ring == '1') &&
         dgtta_switches().conv_ring != '0' && rows != '1') {
       const int rc = conv3_ring_launch(x, xv, w, cs.taps[0], bias, y, yv, B, Cin, Cout, CinP, CoutP, stats,
-                                       conv3_mfma_max_tiles(yv.D, yv.H, yv.W), ntaps_src, (int)std::is_same<T, f16_t>::value, st, gst);
-      if (rc != DGTTA_ERR_UNSUPPORTED) return rc;
+                                       conv3_mfma_max_tiles(yv.D, yv.H, yv.W), ntaps_src, (int)std::is_same<T, f16_t>::value, st, gst,
+                                       xkh, dry);
+      if (rc != DGTTA_ERR_UNSUPPORTED || xkh || dry) return rc;
     }
+    if (xkh || dry) return DGTTA_ERR_UNSUPPORTED;
     if (all_taps && vec_out && (njobs >= 256 || rows == '1') && rows != '0')
       return conv3_rows_launch(x, xv, w, cs.taps[0], bias, y, yv, B, Cin, Cout, CinP, CoutP, stats, ntaps_src,
                                (int)std::is_same<T, f16_t>::value, st, gst);
   }
+  if (xkh || dry) return DGTTA_ERR_UNSUPPORTED;
   if (stride == 1) {
     // 8 waves per workgroup (2 M-blocks each): 16 waves per CU hide the LDS / barrier latency (+27 % over 4 waves; the
     // other tile shapes tried in round 1 - 2 k-steps per chunk, 64 output channels, 256-voxel tiles - were slower)
@@ -497,14 +503,15 @@ int dispatch_conv_classes(const void *x, const View &xv, const void *w, const Co
 template <typename T>
 int dispatch_conv(const void *x, const View &xv, const void *w, const Taps &taps, const float *bias, void *y,
                   const View &yv, int B, int Cin, int Cout, int CinP, int CoutP, int stride, int accumulate,
-                  hipStream_t st, double *stats = nullptr, int ntaps_src = 27, RowsGstCtx *gst = nullptr) {
+                  hipStream_t st, double *stats = nullptr, int ntaps_src = 27, RowsGstCtx *gst = nullptr, long long xkh = 0,
+                  bool dry = false) {
   ConvClasses cs;
   cs.n = 1;
   cs.kseg = 0;
   cs.acc[0] = accumulate;
   cs.xoff[0] = cs.yoff[0] = 0;
   cs.taps[0] = taps;
-  return dispatch_conv_classes<T>(x, xv, w, cs, bias, y, yv, B, Cin, Cout, CinP, CoutP, stride, st, stats, ntaps_src, gst);
+  return dispatch_conv_classes<T>(x, xv, w, cs, bias, y, yv, B, Cin, Cout, CinP, CoutP, stride, st, stats, ntaps_src, gst, xkh, dry);
 }
 
 
@@ -572,7 +579,8 @@ int conv3_s2_regs(const void *x, const View &xv, const void *wimg, const float *
 
 int conv3_fwd_mfma(const void *x, int ldx, const void *w_kmajor, int mirror, const float *bias, void *y, int ldy, int B,
                    int Cin, int Cout, int CinP, int CoutP, int Di, int Hi, int Wi, int stride, int dtype,
-                   hipStream_t st, double *stats, RowsGstCtx *gst) {
+                   hipStream_t st, double *stats, RowsGstCtx *gst, long long xkh, bool dry) {
+  if ((xkh || dry) && (stride != 1 || dtype == DGTTA_F32)) return DGTTA_ERR_UNSUPPORTED;
   const int Do = (Di - 1) / stride + 1, Ho = (Hi - 1) / stride + 1, Wo = (Wi - 1) / stride + 1;
   const View xv = dense_view(B, Di, Hi, Wi, ldx), yv = dense_view(B, Do, Ho, Wo, ldy);
   const Taps taps = identity_taps(mirror);
@@ -587,12 +595,12 @@ int conv3_fwd_mfma(const void *x, int ldx, const void *w_kmajor, int mirror, con
     return dispatch_conv<float>(x, xv, w_kmajor, taps, bias, y, yv, B, Cin, Cout, CinP, CoutP, stride, 0, st, stats, 27, gst);
   }
   if (dtype == DGTTA_BF16) {
-    if (!operand_ok<bf16_t>(x, ldx, Cin, CinP)) return DGTTA_ERR_UNSUPPORTED;
-    return dispatch_conv<bf16_t>(x, xv, w_kmajor, taps, bias, y, yv, B, Cin, Cout, CinP, CoutP, stride, 0, st, stats, 27, gst);
+    if (!operand_ok<bf16_t>(x, xkh ? 2 * ldx : ldx, Cin, CinP)) return DGTTA_ERR_UNSUPPORTED;
+    return dispatch_conv<bf16_t>(x, xv, w_kmajor, taps, bias, y, yv, B, Cin, Cout, CinP, CoutP, stride, 0, st, stats, 27, gst, xkh, dry);
   }
   if (dtype == DGTTA_F16) {
-    if (!operand_ok<f16_t>(x, ldx, Cin, CinP)) return DGTTA_ERR_UNSUPPORTED;
-    return dispatch_conv<f16_t>(x, xv, w_kmajor, taps, bias, y, yv, B, Cin, Cout, CinP, CoutP, stride, 0, st, stats, 27, gst);
+    if (!operand_ok<f16_t>(x, xkh ? 2 * ldx : ldx, Cin, CinP)) return DGTTA_ERR_UNSUPPORTED;
+    return dispatch_conv<f16_t>(x, xv, w_kmajor, taps, bias, y, yv, B, Cin, Cout, CinP, CoutP, stride, 0, st, stats, 27, gst, xkh, dry);
   }
   return DGTTA_ERR_UNSUPPORTED;
 }

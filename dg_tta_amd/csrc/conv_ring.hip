@@ -189,7 +189,12 @@ __global__ __launch_bounds__(RingCfgT<KH>::NT) void conv3_ring_kernel(const bf16
                                                                  Taps taps, const float *__restrict__ bias, bf16_t *__restrict__ y,
                                                                  View yv, int Cout, int tilesW, int tilesH, int nblkN, int nseg,
                                                                  int steps_per_seg, int njobs, double *__restrict__ stats,
-                                                                 int ntaps_src, unsigned x_bytes, unsigned y_bytes, RingGst gst) {
+                                                                 int ntaps_src, unsigned x_bytes, unsigned y_bytes, RingGst gst,
+                                                                 long long xkh) {
+  // xkh (round 6, KH = 2): element distance between the two 32-channel K halves of x.  0: they interleave in rows of 64 channels
+  // (half h at channel 32 h of a voxel's row); > 0: two DENSE 32-channel tensors xkh elements apart - the level-0 concat buffer as
+  // planes [up | skip], so that the kernels that read ONE half (the stride-2 conv of the skip, the transposed conv's backward)
+  // use whole 128-byte lines instead of 64 bytes of each (profiles/r05_ab.txt: 4.3x input fetched by the stride-2 forward).
   typedef RingCfgT<KH> C;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float *red = reinterpret_cast<float *>(smem + C::NSLOT * C::PLANE);
@@ -249,6 +254,8 @@ __global__ __launch_bounds__(RingCfgT<KH>::NT) void conv3_ring_kernel(const bf16
     const int nsteps = s_end - s_beg;
     const int d0 = 2 * s_beg;
     const u32x4_t rx = make_rsrc(x + (long long)b * xv.sb, x_bytes), ry = make_rsrc(y + (long long)b * yv.sb, y_bytes);
+    const u32x4_t rx1 = (KH == 2 && xkh) ? make_rsrc(x + xkh + (long long)b * xv.sb, x_bytes) : rx;      // K half 1
+    const int khoff = (KH == 2 && xkh) ? 0 : 32;
 
     // weights: fragment (tap) of this wave's 16 output channels x 32 input channels, from the image of the generic kernels
     // [N/32][K/16][ntaps][2][32][8]: this lane holds W[n0 + 16 chalf + v][8 q .. 8 q + 7]
@@ -298,7 +305,7 @@ __global__ __launch_bounds__(RingCfgT<KH>::NT) void conv3_ring_kernel(const bf16
       const int g = (lane & 3) ^ (((u >> 2) & 1) << 1);
       const int gh = oh0 - 1 + row, gw = ow0 - 1 + u;
       const bool ok = idx < 2 * C::PIECES && e < C::NVOX && (unsigned)gh < (unsigned)H && (unsigned)gw < (unsigned)W;
-      return ok ? (unsigned)((gh * xv.sh + gw * xv.sw + kh * 32 + g * 8) * 2) : OOB;
+      return ok ? (unsigned)((gh * xv.sh + gw * xv.sw + kh * khoff + g * 8) * 2) : OOB;
     };
     unsigned poff[KH == 1 ? C::NPW : 1];
     if (KH == 1) {
@@ -320,7 +327,8 @@ __global__ __launch_bounds__(RingCfgT<KH>::NT) void conv3_ring_kernel(const bf16
         const bool dok = (unsigned)gd < (unsigned)D;
         const unsigned soff = dok ? (unsigned)(gd * xv.sd * 2) : 0u;
         const unsigned voff = (KH == 1 ? poff[KH == 1 ? i : 0] : piece_off(i)) | (dok ? 0u : OOB);
-        dma16_buf_to_lds(rx, voff, soff, lds0 + pr * (2 * C::PLANE) + idx * 1024);
+        const bool half1 = KH == 2 && ((idx / C::SUB_PIECES) % KH) == 1;          // (wave-uniform)
+        dma16_buf_to_lds(half1 ? rx1 : rx, voff, soff, lds0 + pr * (2 * C::PLANE) + idx * 1024);
         return 1;
       }
       return 0;
@@ -592,10 +600,11 @@ namespace {
 template <int KH>
 int ring_launch_kh(const void *x, const View &xv, const void *w, const Taps &taps, const float *bias, void *y, const View &yv,
                    int B, int Cout, double *stats, int64_t stats_cap_slots, int ntaps_src, int is_f16, hipStream_t st,
-                   RowsGstCtx *gctx) {
+                   RowsGstCtx *gctx, long long xkh, bool dry) {
   typedef RingCfgT<KH> C;
+  if (xkh && (KH != 2 || xkh % 8 || xv.sw != 32)) return DGTTA_ERR_UNSUPPORTED;      // K halves as planes: 64 input channels, dense 32-channel rows
   // the buffer descriptors address one sample with 32-bit byte offsets
-  const long long xb = ((long long)(xv.D - 1) * xv.sd + (long long)(xv.H - 1) * xv.sh + (long long)(xv.W - 1) * xv.sw + 32 * KH) * 2;
+  const long long xb = ((long long)(xv.D - 1) * xv.sd + (long long)(xv.H - 1) * xv.sh + (long long)(xv.W - 1) * xv.sw + (xkh ? 32 : 32 * KH)) * 2;
   const long long yb = ((long long)(yv.D - 1) * yv.sd + (long long)(yv.H - 1) * yv.sh + (long long)(yv.W - 1) * yv.sw + Cout) * 2;
   if (xb >= (1ll << 31) || yb >= (1ll << 31)) return DGTTA_ERR_UNSUPPORTED;
   if (xv.sw % 8 || xv.sh % 8 || xv.sd % 8 || xv.sb % 8 || yv.sw % 8 || yv.sh % 8 || yv.sd % 8 || yv.sb % 8 || ((uintptr_t)x & 15) ||
@@ -642,8 +651,9 @@ int ring_launch_kh(const void *x, const View &xv, const void *w, const Taps &tap
     ga.slope = gctx->slope;
     ga.bytes = (unsigned)gb;
     stats = gctx->out;
-    gctx->produced = 1;
+    if (!dry) gctx->produced = 1;
   }
+  if (dry) return DGTTA_OK;      // (dgtta_conv3d_k3_blocked_supported: would this launch be taken?)
   const int grid = (int)(njobs < ncu ? njobs : ncu);
   // DGTTA_RING_NT=1 (diagnostic build): non-temporal output stores (measured 5 % slower: the two 32-byte halves of a voxel come
   // from two waves and merge in L2)
@@ -656,7 +666,7 @@ int ring_launch_kh(const void *x, const View &xv, const void *w, const Taps &tap
                "conv3_ring: cannot raise the dynamic LDS limit to %d", C::LDS_BYTES);                                         \
     hipLaunchKernelGGL(kern, dim3(grid), dim3(C::NT), C::LDS_BYTES, st, (const bf16_t *)x, xv, (const bf16_t *)w, taps, bias, \
                        (bf16_t *)y, yv, Cout, tW, tH, nblkN, nseg, sps, (int)njobs, stats, ntaps_src, (unsigned)xb,           \
-                       (unsigned)yb, ga);                                                                                     \
+                       (unsigned)yb, ga, xkh);                                                                                \
   } while (0)
   bool diag = false;
 #ifdef DGTTA_DIAG
@@ -699,12 +709,12 @@ int ring_launch_kh(const void *x, const View &xv, const void *w, const Taps &tap
 // Entry point used by the dispatcher in conv_mfma.hip: DGTTA_ERR_UNSUPPORTED when the shape is not this kernel's.
 int conv3_ring_launch(const void *x, const View &xv, const void *w, const Taps &taps, const float *bias, void *y, const View &yv,
                       int B, int Cin, int Cout, int CinP, int CoutP, double *stats, int64_t stats_cap_slots, int ntaps_src,
-                      int is_f16, hipStream_t st, RowsGstCtx *gst) {
+                      int is_f16, hipStream_t st, RowsGstCtx *gst, long long xkh, bool dry) {
   if (Cin != CinP || (Cin != 32 && Cin != 64) || Cout % 32 != 0 || CoutP != Cout) return DGTTA_ERR_UNSUPPORTED;
   if (xv.D != yv.D || xv.H != yv.H || xv.W != yv.W) return DGTTA_ERR_UNSUPPORTED;
   if (Cin == 64) {
     if (dgtta_switches().conv_ring == '3') return DGTTA_ERR_UNSUPPORTED;      // DGTTA_CONV_RING=3: the ring for 32 input channels only
-    return ring_launch_kh<2>(x, xv, w, taps, bias, y, yv, B, Cout, stats, stats_cap_slots, ntaps_src, is_f16, st, gst);
+    return ring_launch_kh<2>(x, xv, w, taps, bias, y, yv, B, Cout, stats, stats_cap_slots, ntaps_src, is_f16, st, gst, xkh, dry);
   }
-  return ring_launch_kh<1>(x, xv, w, taps, bias, y, yv, B, Cout, stats, stats_cap_slots, ntaps_src, is_f16, st, gst);
+  return ring_launch_kh<1>(x, xv, w, taps, bias, y, yv, B, Cout, stats, stats_cap_slots, ntaps_src, is_f16, st, gst, xkh, dry);
 }

@@ -3,7 +3,7 @@
 #include <stdlib.h>
 
 int conv3_wgrad_ring_launch(const void *x, const View &xv, const void *dy, const View &yv, float *slabs, size_t ws_bytes, int B,
-                            int Cin, int Cout, int is_f16, hipStream_t st, int *rc);      // conv_wgrad_ring.hip
+                            int Cin, int Cout, int is_f16, hipStream_t st, int *rc, long long xkh = 0, bool dry = false);      // conv_wgrad_ring.hip
 
 namespace {
 
@@ -1260,15 +1260,16 @@ static int units_per_workgroup(int64_t units, int64_t gy, int slots) {
 template <typename T>
 static int wgrad_launch_classes(const void *x, const View &xv, const void *dy, const View &yv, float *dw, void *ws,
                                 size_t ws_bytes, int B, int Cin, int Cout, const WgradClasses &wc, const RealTaps &reals,
-                                long long s_co, long long s_ci, long long s_tap, int accumulate, hipStream_t st) {
+                                long long s_co, long long s_ci, long long s_tap, int accumulate, hipStream_t st, long long xkh = 0) {
   constexpr int EPV = Elem<T>::EPV;
   // Cin may be ragged (first layer: 12 channels in rows of 16): the pad channels only feed gradient rows ci >= Cin,
   // which the reduction never writes.  The rows must be long enough to be read in whole 16-byte groups.
   if (Cout % EPV || xv.sw % EPV || yv.sw % EPV || ((uintptr_t)x & 15) || ((uintptr_t)dy & 15) ||
-      xv.sw < (Cin + EPV - 1) / EPV * EPV)
+      xv.sw < (xkh ? 32 : (Cin + EPV - 1) / EPV * EPV))      // (x as 32-channel planes: rows of one block)
     return DGTTA_ERR_UNSUPPORTED;
   for (int c = 0; c < wc.n; ++c)
     if ((wc.xoff[c] * (long long)sizeof(T)) % 16 || (wc.yoff[c] * (long long)sizeof(T)) % 16) return DGTTA_ERR_UNSUPPORTED;
+  if (xkh && (sizeof(T) != 2 || dgtta_switches().wgrad_tr == '0' || dgtta_switches().wgrad_ring == '0')) return DGTTA_ERR_UNSUPPORTED;
   WgradPlan p = wgrad_plan(B, Cin, Cout, yv.D, yv.H, yv.W, wc.n);
   const size_t need = (size_t)wc.n * p.units * p.cibs * p.cobs * 27 * 1024 * sizeof(float);
   if (ws_bytes < need || p.units >= (1ll << 31) || p.cibs * p.cobs > 65535) return DGTTA_ERR_UNSUPPORTED;
@@ -1282,13 +1283,14 @@ static int wgrad_launch_classes(const void *x, const View &xv, const void *dy, c
       if (plain && sw.wgrad_ring != '0') {      // the persistent ring sweep (conv_wgrad_ring.hip; DGTTA_WGRAD_RING=0: its predecessors)
         int rc = DGTTA_OK;
         const int g = conv3_wgrad_ring_launch(x, xv, dy, yv, (float *)ws, ws_bytes, B, Cin, Cout, (int)std::is_same<T16, f16_t>::value,
-                                              st, &rc);
+                                              st, &rc, xkh);
         if (rc != DGTTA_OK) return rc;
         if (g > 0) {
           nslab = g;
           goto reduce;
         }
       }
+      if (xkh) return DGTTA_ERR_UNSUPPORTED;      // only the ring sweep reads x as 32-channel planes
       auto ktr = plain ? conv3_wgrad_tr_kernel<0, false, T16> : conv3_wgrad_tr_kernel<0, true, T16>;
       static DynLdsOnce tr_once[2];
       DG_REQUIRE(ensure_dyn_lds(tr_once[plain], reinterpret_cast<const void *>(ktr), (int)WT::LDS_BYTES) == hipSuccess,
@@ -1342,25 +1344,26 @@ reduce:
 template <typename T>
 static int wgrad_launch(const void *x, const View &xv, const void *dy, const View &yv, float *dw, void *ws, size_t ws_bytes,
                         int B, int Cin, int Cout, unsigned tapmask, const Taps &real, long long s_co, long long s_ci,
-                        long long s_tap, int accumulate, hipStream_t st) {
+                        long long s_tap, int accumulate, hipStream_t st, long long xkh = 0) {
   WgradClasses wc;
   wc.n = 1;
   wc.mask[0] = tapmask;
   wc.xoff[0] = wc.yoff[0] = 0;
   RealTaps reals;
   reals.t[0] = real;
-  return wgrad_launch_classes<T>(x, xv, dy, yv, dw, ws, ws_bytes, B, Cin, Cout, wc, reals, s_co, s_ci, s_tap, accumulate, st);
+  return wgrad_launch_classes<T>(x, xv, dy, yv, dw, ws, ws_bytes, B, Cin, Cout, wc, reals, s_co, s_ci, s_tap, accumulate, st, xkh);
 }
 
 template <typename T>
 static int wgrad_conv(const void *x, int ldx, const void *dy, int lddy, float *dw_t, void *ws, size_t ws_bytes, int B,
-                      int Cin, int Cout, int Di, int Hi, int Wi, int stride, int accumulate, hipStream_t st) {
+                      int Cin, int Cout, int Di, int Hi, int Wi, int stride, int accumulate, hipStream_t st, long long xkh = 0) {
   const long long s_co = (long long)Cin * 27, s_ci = 27, s_tap = 1;
   if (stride == 1) {
     const View xv = dense_view(B, Di, Hi, Wi, ldx), yv = dense_view(B, Di, Hi, Wi, lddy);
     return wgrad_launch<T>(x, xv, dy, yv, dw_t, ws, ws_bytes, B, Cin, Cout, 0x7ffffffu, identity_taps(0), s_co, s_ci, s_tap,
-                           accumulate, st);
+                           accumulate, st, xkh);
   }
+  if (xkh) return DGTTA_ERR_UNSUPPORTED;
   // stride 2: x[2*vo + tap - 1] lives on parity sub-lattices of x; per axis parity 0 <- tap 1 (offset 0),
   // parity 1 <- tap 0 (offset -1) and tap 2 (offset 0).  Each real tap belongs to exactly one of the 8 classes.
   const int Do = (Di - 1) / 2 + 1, Ho = (Hi - 1) / 2 + 1, Wo = (Wi - 1) / 2 + 1;
@@ -1531,11 +1534,12 @@ static int wgrad_conv_f32_split(const float *x, int ldx, const float *dy, int ld
 
 int conv3_wgrad_mfma(const void *x, int ldx, const void *dy, int lddy, float *dw_t, float *db, void *ws, size_t ws_bytes,
                      int B, int Cin, int Cout, int Di, int Hi, int Wi, int stride, int accumulate, int dtype,
-                     hipStream_t st) {
+                     hipStream_t st, long long xkh) {
   (void)db;
   if (stride != 1 && stride != 2) return DGTTA_ERR_UNSUPPORTED;
   if (stride == 2 && ((Di | Hi | Wi) & 1)) return DGTTA_ERR_UNSUPPORTED;   // odd extents: leave to the general kernel
   if (dtype == DGTTA_F32) {
+    if (xkh) return DGTTA_ERR_UNSUPPORTED;      // (x as 32-channel planes: 16-bit storage only)
     // the caller offered the split workspace (dgtta_conv3d_wgrad_split_ws_bytes) behind the plain one: six 16-bit launches
     // (DGTTA_WGRAD_F32_SPLIT=0: the fp32 MFMA kernel, its predecessor)
     const int Do = Di / stride, Ho = Hi / stride, Wo = Wi / stride;
@@ -1549,8 +1553,8 @@ int conv3_wgrad_mfma(const void *x, int ldx, const void *dy, int lddy, float *dw
     }
     return wgrad_conv<float>(x, ldx, dy, lddy, dw_t, ws, ws_bytes, B, Cin, Cout, Di, Hi, Wi, stride, accumulate, st);
   }
-  if (dtype == DGTTA_BF16) return wgrad_conv<bf16_t>(x, ldx, dy, lddy, dw_t, ws, ws_bytes, B, Cin, Cout, Di, Hi, Wi, stride, accumulate, st);
-  if (dtype == DGTTA_F16) return wgrad_conv<f16_t>(x, ldx, dy, lddy, dw_t, ws, ws_bytes, B, Cin, Cout, Di, Hi, Wi, stride, accumulate, st);
+  if (dtype == DGTTA_BF16) return wgrad_conv<bf16_t>(x, ldx, dy, lddy, dw_t, ws, ws_bytes, B, Cin, Cout, Di, Hi, Wi, stride, accumulate, st, xkh);
+  if (dtype == DGTTA_F16) return wgrad_conv<f16_t>(x, ldx, dy, lddy, dw_t, ws, ws_bytes, B, Cin, Cout, Di, Hi, Wi, stride, accumulate, st, xkh);
   return DGTTA_ERR_UNSUPPORTED;
 }
 
@@ -1852,3 +1856,16 @@ int head_wgrad_mfma(const void *x, int ldx, const float *dout, int lddo, float *
   return DGTTA_ERR_UNSUPPORTED;
 }
 
+
+
+// would the weight gradient of a stride-1 conv on these dims take x as 32-channel planes (only the ring sweep does)?
+bool conv3_wgrad_blocked_ok(int B, int Cin, int Cout, int D, int H, int W, int dtype) {
+  if ((dtype != DGTTA_BF16 && dtype != DGTTA_F16) || Cin % 32 || Cout % 8) return false;
+  if (dgtta_switches().wgrad_tr == '0' || dgtta_switches().wgrad_ring == '0') return false;
+  const View xv = dense_view(B, D, H, W, 32), yv = dense_view(B, D, H, W, Cout);
+  int rc = DGTTA_OK;
+  const size_t ws_bytes = conv3_wgrad_mfma_ws_bytes(B, Cin, Cout, D, H, W);
+  const int g = conv3_wgrad_ring_launch((const void *)16, xv, (const void *)16, yv, nullptr, ws_bytes, B, Cin, Cout, dtype == DGTTA_F16, nullptr,
+                                        &rc, (long long)B * D * H * W * 32, true);
+  return rc == DGTTA_OK && g > 0;
+}

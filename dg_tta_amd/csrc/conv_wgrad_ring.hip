@@ -159,7 +159,9 @@ template <typename T16, bool MF16, bool CLK = false, bool PAIR = false, bool REU
 __global__ __launch_bounds__(WR::NW * 64) void conv3_wgrad_ring_kernel(const bf16_t *__restrict__ x, View xv, const bf16_t *__restrict__ dy,
                                                                        View yv, float *__restrict__ slabs, int Cin, int Cout, int tilesW,
                                                                        int tilesH, int nseg, int DR, int cobs, int njobs, unsigned x_bytes,
-                                                                       unsigned y_bytes) {
+                                                                       unsigned y_bytes, long long xkh) {
+  // xkh (round 6): element distance between the 32-channel blocks of x; 0 = they interleave in the voxel rows (block c at channel
+  // 32 c), > 0 = dense 32-channel tensors xkh elements apart (the level-0 concat buffer as planes, see conv_ring.hip)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char *sX = smem, *sY = smem + WR::NXS * WR::X_SLICE_B;
   const unsigned lds0 = lds_addr_of(smem);
@@ -240,7 +242,8 @@ __global__ __launch_bounds__(WR::NW * 64) void conv3_wgrad_ring_kernel(const bf1
     const int b = j / nseg;
     const int h0 = th * WR::TH, w0 = tw * 32;
     const int d_begin = seg * DR, d_end = (d_begin + DR < D) ? d_begin + DR : D;
-    const u32x4_t rx = wr_rsrc(x + (long long)b * xv.sb + cib * 32, x_bytes), ry = wr_rsrc(dy + (long long)b * yv.sb + cob * 32, y_bytes);
+    const u32x4_t rx = wr_rsrc(x + (long long)b * xv.sb + (xkh ? cib * xkh : (long long)cib * 32), x_bytes),
+                  ry = wr_rsrc(dy + (long long)b * yv.sb + cob * 32, y_bytes);
 
     // per-lane source offsets of this wave's DMA pieces (piece idx = wave + 8 i of the 22 x + 16 dy pieces of a slice pair):
     // lane -> voxel 16 P + lane / 4, 16-byte channel chunk lane & 3
@@ -522,9 +525,10 @@ __global__ __launch_bounds__(WR::NW * 64) void conv3_wgrad_ring_kernel(const bf1
 // Entry point used by wgrad_launch_classes (conv_wgrad.hip): plain stride-1 launches with 16-bit storage.  Returns the number
 // of slabs per channel-block pair it wrote (> 0), or 0 if the shape is not this kernel's (then nothing was launched).
 int conv3_wgrad_ring_launch(const void *x, const View &xv, const void *dy, const View &yv, float *slabs, size_t ws_bytes, int B,
-                            int Cin, int Cout, int is_f16, hipStream_t st, int *rc) {
+                            int Cin, int Cout, int is_f16, hipStream_t st, int *rc, long long xkh, bool dry) {
   *rc = DGTTA_OK;
   if (Cout % 32 != 0 || xv.D != yv.D || xv.H != yv.H || xv.W != yv.W) return 0;
+  if (xkh && (xkh % 8 || xv.sw != 32 || Cin % 32)) return 0;      // channel blocks as planes: dense 32-channel rows
   const int cibs = cdiv(Cin, 32), cobs = Cout / 32;
   const long long xb = ((long long)(xv.D - 1) * xv.sd + (long long)(xv.H - 1) * xv.sh + (long long)(xv.W - 1) * xv.sw + 32) * 2;
   const long long yb = ((long long)(yv.D - 1) * yv.sd + (long long)(yv.H - 1) * yv.sh + (long long)(yv.W - 1) * yv.sw + 32) * 2;
@@ -562,6 +566,7 @@ int conv3_wgrad_ring_launch(const void *x, const View &xv, const void *dy, const
   const char sw = dgtta_switches().wgrad_ring;
   if (ncol * yv.D < 4ll * ncu * 8 / pairs && sw != '1' && sw != '5' && sw != '6')
     return 0;      // (=1 / =5 / =6: forced, for the tests; 5 = forced, one tap per MFMA for Cin <= 16 and no operand reuse; 6 = forced, no operand reuse)
+  if (dry) return G;      // (dgtta_conv3d_k3_blocked_supported: would this launch be taken?)
 #define WR_LAUNCH(T16, MF, CK) WR_LAUNCH_P(T16, MF, CK, false, false)
 #define WR_LAUNCH_P(T16, MF, CK, PR, RU)                                                                                          \
   do {                                                                                                                         \
@@ -573,7 +578,8 @@ int conv3_wgrad_ring_launch(const void *x, const View &xv, const void *dy, const
       return 0;                                                                                                                \
     }                                                                                                                          \
     hipLaunchKernelGGL(kern, dim3((unsigned)G, (unsigned)pairs), dim3(WR::NW * 64), WR_LDS_TOTAL, st, (const bf16_t *)x, xv,  \
-                       (const bf16_t *)dy, yv, slabs, Cin, Cout, tW, tH, nseg, DR, cobs, (int)njobs, (unsigned)xb, (unsigned)yb); \
+                       (const bf16_t *)dy, yv, slabs, Cin, Cout, tW, tH, nseg, DR, cobs, (int)njobs, (unsigned)xb, (unsigned)yb, \
+                       xkh);                                                                                                   \
   } while (0)
   // DGTTA_WGRAD_RING=4: the v_mfma_f32_16x16x32 form (conflict-free after the half swap above; measured within +-2 % of the
   // 32x32x16 form on three boxes, which is the default: 36 registers less and no swizzle)

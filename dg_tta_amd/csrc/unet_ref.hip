@@ -1224,7 +1224,8 @@ int wgrad_splits(int64_t nvox) {
 // MFMA implementations (conv_mfma.hip); return DGTTA_ERR_UNSUPPORTED when the shape is not covered.
 int conv3_fwd_mfma(const void *x, int ldx, const void *w_kmajor, int mirror, const float *bias, void *y, int ldy, int B,
                    int Cin, int Cout, int CinP, int CoutP, int Di, int Hi, int Wi, int stride, int dtype,
-                   hipStream_t st, double *stats, RowsGstCtx *gst = nullptr);
+                   hipStream_t st, double *stats, RowsGstCtx *gst = nullptr, long long xkh = 0, bool dry = false);
+bool conv3_wgrad_blocked_ok(int B, int Cin, int Cout, int D, int H, int W, int dtype);
 int64_t conv3_mfma_max_tiles(int Do, int Ho, int Wo);
 int conv3_dgrad_s2_mfma(const void *dy, int lddy, const void *w_kmajor, void *dx, int lddx, int B, int Cin, int Cout,
                         int CinP, int CoutP, int Di, int Hi, int Wi, int accumulate, int dtype, hipStream_t st);
@@ -1239,7 +1240,7 @@ int convT_wgrad_mfma(const void *x, int ldx, const void *dout, int lddo, float *
 int convT_bias_finalize(const float *part, int units, int Cout, float *db, int accumulate, hipStream_t st);
 int conv3_wgrad_mfma(const void *x, int ldx, const void *dy, int lddy, float *dw_t, float *db, void *ws, size_t ws_bytes,
                      int B, int Cin, int Cout, int Di, int Hi, int Wi, int stride, int accumulate, int dtype,
-                     hipStream_t st);
+                     hipStream_t st, long long xkh = 0);
 
 static size_t esize(int dtype) { return dtype == DGTTA_F32 ? 4 : 2; }
 static const void *wb_of(const void *wpack, int CinP, int CoutP, int dtype) {
@@ -1292,20 +1293,52 @@ extern "C" size_t dgtta_conv3d_stats_bytes(int B, int Cout, int Do, int Ho, int 
 
 __global__ void set_header_kernel(long long *hdr, long long v) { hdr[0] = v; }
 
+static int k3_fwd(const void *x, int ldx, long long x_block_stride, const void *wpack, const float *bias, void *y, int ldy,
+                  void *stats, int B, int Cin, int Cout, int CinP, int CoutP, int Di, int Hi, int Wi, int stride, int dtype, int impl,
+                  void *stream);
+
 extern "C" int dgtta_conv3d_k3_fwd(const void *x, int ldx, const void *wpack, const float *bias, void *y, int ldy,
                                    void *stats, int B, int Cin, int Cout, int CinP, int CoutP, int Di, int Hi, int Wi,
                                    int stride, int dtype, int impl, void *stream) {
+  return k3_fwd(x, ldx, 0, wpack, bias, y, ldy, stats, B, Cin, Cout, CinP, CoutP, Di, Hi, Wi, stride, dtype, impl, stream);
+}
+
+// Round 6: x as 32-channel BLOCKS - block c of the input channels is a dense tensor [B][D][H][W][32] (ldx = 32) at element
+// offset c * x_block_stride from x.  The level-0 concat buffer of the U-Net is kept that way ([up | skip] as two planes): the
+// kernels that read ONE half of it (the stride-2 conv of the skip, the transposed conv's backward) then use whole 128-byte lines.
+// Only the D-ring kernels read this layout (64 input channels, 16-bit storage, launches they take): ask
+// dgtta_conv3d_k3_blocked_supported first; anything else returns DGTTA_ERR_UNSUPPORTED and launches nothing.
+extern "C" int dgtta_conv3d_k3_blocked_supported(int B, int Cin, int Cout, int D, int H, int W, int dtype) {
+  if (B <= 0 || Cin != 64 || Cout <= 0 || Cout % 32 || D <= 0 || H <= 0 || W <= 0) return 0;
+  if (dtype != DGTTA_BF16 && dtype != DGTTA_F16) return 0;
+  const int rc = conv3_fwd_mfma((const void *)16, 32, (const void *)16, 0, nullptr, (void *)16, Cout, B, Cin, Cout, Cin, Cout, D, H, W, 1,
+                                dtype, nullptr, nullptr, nullptr, (long long)B * D * H * W * 32, true);
+  return rc == DGTTA_OK && conv3_wgrad_blocked_ok(B, Cin, Cout, D, H, W, dtype);
+}
+
+extern "C" int dgtta_conv3d_k3_fwd_blocked(const void *x, long long x_block_stride, const void *wpack, const float *bias, void *y,
+                                           int ldy, void *stats, int B, int Cin, int Cout, int CinP, int CoutP, int Di, int Hi,
+                                           int Wi, int dtype, void *stream) {
+  DG_REQUIRE(x_block_stride > 0 && x_block_stride % 8 == 0, DGTTA_ERR_BADARG, "conv3d_k3_fwd_blocked: block stride must be a positive multiple of 8 elements");
+  return k3_fwd(x, 32, x_block_stride, wpack, bias, y, ldy, stats, B, Cin, Cout, CinP, CoutP, Di, Hi, Wi, 1, dtype, 0, stream);
+}
+
+static int k3_fwd(const void *x, int ldx, long long x_block_stride, const void *wpack, const float *bias, void *y, int ldy,
+                  void *stats, int B, int Cin, int Cout, int CinP, int CoutP, int Di, int Hi, int Wi, int stride, int dtype, int impl,
+                  void *stream) {
   DG_REQUIRE(x && wpack && y, DGTTA_ERR_BADARG, "conv3d_k3_fwd: null pointer");
   const void *wf = wpack;
   DG_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && CinP >= Cin && CoutP >= Cout && Di > 0 && Hi > 0 && Wi > 0,
              DGTTA_ERR_BADARG, "conv3d_k3_fwd: bad dims");
   DG_REQUIRE(stride == 1 || stride == 2, DGTTA_ERR_UNSUPPORTED, "conv3d_k3_fwd: stride %d", stride);
-  DG_REQUIRE(ldx >= Cin && ldy >= Cout, DGTTA_ERR_BADARG, "conv3d_k3_fwd: ld < C");
+  DG_REQUIRE((x_block_stride ? 2 * ldx : ldx) >= Cin && ldy >= Cout, DGTTA_ERR_BADARG, "conv3d_k3_fwd: ld < C");
   hipStream_t st = (hipStream_t)stream;
   if (impl != 1) {
     int rc = conv3_fwd_mfma(x, ldx, img_of(wpack, CinP, CoutP, dtype), 0, bias, y, ldy, B, Cin, Cout, CinP, CoutP, Di, Hi,
-                            Wi, stride, dtype, st, (double *)stats);
+                            Wi, stride, dtype, st, (double *)stats, nullptr, x_block_stride);
     if (rc != DGTTA_ERR_UNSUPPORTED) return rc;
+    DG_REQUIRE(x_block_stride == 0, DGTTA_ERR_UNSUPPORTED,
+               "conv3d_k3_fwd_blocked: only the D-ring kernel reads x as 32-channel planes (ask dgtta_conv3d_k3_blocked_supported)");
     DG_REQUIRE(impl == 0, DGTTA_ERR_UNSUPPORTED, "conv3d_k3_fwd: shape not covered by the MFMA kernel");
   }
   const int Do = out_dim(Di, stride), Ho = out_dim(Hi, stride), Wo = out_dim(Wi, stride);
@@ -1423,9 +1456,27 @@ static int bias_grad(const void *dy, int lddy, float *db, void *ws, int B, int C
   return DGTTA_OK;
 }
 
+static int k3_wgrad(const void *x, int ldx, long long x_block_stride, const void *dy, int lddy, float *dw_t, float *db, void *ws,
+                    size_t ws_bytes, int B, int Cin, int Cout, int Di, int Hi, int Wi, int stride, int accumulate, int dtype, int impl,
+                    void *stream);
+
 extern "C" int dgtta_conv3d_k3_wgrad(const void *x, int ldx, const void *dy, int lddy, float *dw_t, float *db, void *ws,
                                      size_t ws_bytes, int B, int Cin, int Cout, int Di, int Hi, int Wi, int stride,
                                      int accumulate, int dtype, int impl, void *stream) {
+  return k3_wgrad(x, ldx, 0, dy, lddy, dw_t, db, ws, ws_bytes, B, Cin, Cout, Di, Hi, Wi, stride, accumulate, dtype, impl, stream);
+}
+
+// weight gradient of a stride-1 conv whose x lies as 32-channel blocks (see dgtta_conv3d_k3_fwd_blocked); same workspace
+extern "C" int dgtta_conv3d_k3_wgrad_blocked(const void *x, long long x_block_stride, const void *dy, int lddy, float *dw_t, float *db,
+                                             void *ws, size_t ws_bytes, int B, int Cin, int Cout, int Di, int Hi, int Wi,
+                                             int accumulate, int dtype, void *stream) {
+  DG_REQUIRE(x_block_stride > 0 && x_block_stride % 8 == 0, DGTTA_ERR_BADARG, "conv3d_k3_wgrad_blocked: block stride must be a positive multiple of 8 elements");
+  return k3_wgrad(x, 32, x_block_stride, dy, lddy, dw_t, db, ws, ws_bytes, B, Cin, Cout, Di, Hi, Wi, 1, accumulate, dtype, 0, stream);
+}
+
+static int k3_wgrad(const void *x, int ldx, long long x_block_stride, const void *dy, int lddy, float *dw_t, float *db, void *ws,
+                    size_t ws_bytes, int B, int Cin, int Cout, int Di, int Hi, int Wi, int stride, int accumulate, int dtype, int impl,
+                    void *stream) {
   DG_REQUIRE(x && dy && dw_t && ws, DGTTA_ERR_BADARG, "conv3d_k3_wgrad: null pointer");
   DG_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && Di > 0 && Hi > 0 && Wi > 0, DGTTA_ERR_BADARG, "conv3d_k3_wgrad: bad dims");
   DG_REQUIRE(stride == 1 || stride == 2, DGTTA_ERR_UNSUPPORTED, "conv3d_k3_wgrad: stride %d", stride);
@@ -1441,10 +1492,11 @@ extern "C" int dgtta_conv3d_k3_wgrad(const void *x, int ldx, const void *dy, int
   bool done = false;
   if (impl != 1) {
     int rc = conv3_wgrad_mfma(x, ldx, dy, lddy, dw_t, nullptr, part, ws_bytes - bias_bytes, B, Cin, Cout, Di, Hi, Wi,
-                              stride, accumulate, dtype, st);
+                              stride, accumulate, dtype, st, x_block_stride);
     if (rc == DGTTA_OK) done = true;
     else if (rc != DGTTA_ERR_UNSUPPORTED) return rc;
-    else DG_REQUIRE(impl == 0, DGTTA_ERR_UNSUPPORTED, "conv3d_k3_wgrad: shape not covered by the MFMA kernel");
+    else DG_REQUIRE(impl == 0 && x_block_stride == 0, DGTTA_ERR_UNSUPPORTED,
+                    "conv3d_k3_wgrad: shape not covered by the MFMA kernel (x as 32-channel planes: only the ring sweep, ask dgtta_conv3d_k3_blocked_supported)");
   }
   if (!done) {
     DISPATCH_T(dtype, hipLaunchKernelGGL((conv3_wgrad_ref_kernel<T>), dim3(cdiv(Cin * Cout, 256), 27, nsplit), dim3(256),

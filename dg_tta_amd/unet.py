@@ -363,7 +363,7 @@ class _UNetFn(torch.autograd.Function):
                 ws_cache["ws"] = t
             return t
 
-        def run_block(blk_mod, u, ldu, cin, dims_in, z_out=None, ldz=None, where=None, stats_only=False):
+        def run_block(blk_mod, u, ldu, cin, dims_in, z_out=None, ldz=None, where=None, stats_only=False, xbs=0):
             """conv -> IN -> lrelu. u: tensor whose data_ptr()+offset is the input; returns (z, ldz, dims_out, rec).
             stats_only: the InstanceNorm statistics are finalised but not applied (z is not written; rec carries y and mr)."""
             conv, norm = blk_mod.conv, blk_mod.norm
@@ -383,8 +383,12 @@ class _UNetFn(torch.autograd.Function):
             if pr is not None:       # bench.py: time this layer's conv launch with events on the launch stream
                 ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 ev0.record()
-            check(lib.dgtta_conv3d_k3_fwd(u, ldu, ptr(wpack), ptr(conv.bias), ptr(y), cout, ptr(stats), B, cin, cout, cinp,
-                                          coutp, di, hi, wi, s, dt, impl, st), "dgtta_conv3d_k3_fwd")
+            if xbs:      # the input is the level-0 concat buffer as two 32-channel planes (see the encoder loop)
+                check(lib.dgtta_conv3d_k3_fwd_blocked(u, xbs, ptr(wpack), ptr(conv.bias), ptr(y), cout, ptr(stats), B, cin, cout, cinp,
+                                                      coutp, di, hi, wi, dt, st), "dgtta_conv3d_k3_fwd_blocked")
+            else:
+                check(lib.dgtta_conv3d_k3_fwd(u, ldu, ptr(wpack), ptr(conv.bias), ptr(y), cout, ptr(stats), B, cin, cout, cinp,
+                                              coutp, di, hi, wi, s, dt, impl, st), "dgtta_conv3d_k3_fwd")
             if pr is not None:
                 ev1.record()
                 pr["events"].append((ev0, ev1, B))
@@ -403,7 +407,7 @@ class _UNetFn(torch.autograd.Function):
             check(lib.dgtta_instnorm_lrelu_fwd(ptr(y), cout, ptr(stats), ptr(norm.weight), ptr(norm.bias), ptr(mr), zp, ldz_,
                                                ptr(w_), nb, B, cout, v, EPS, SLOPE, dt, st), "dgtta_instnorm_lrelu_fwd")
             rec = dict(mod=blk_mod, u=u, ldu=ldu, cin=cin, cout=cout, s=s, din=dims_in, dout=(do, ho, wo), y=y, mr=mr,
-                       zt=zt, zp=zp, ldz=ldz_, cinp=cinp, coutp=coutp)
+                       zt=zt, zp=zp, ldz=ldz_, cinp=cinp, coutp=coutp, xbs=xbs)
             return zp, ldz_, (do, ho, wo), rec, zt
 
         esz = 4 if dt == F32 else 2
@@ -424,9 +428,23 @@ class _UNetFn(torch.autograd.Function):
                 if last and si < nst - 1:
                     s = blk.conv.stride
                     do, ho, wo = _odim(dims[0], s), _odim(dims[1], s), _odim(dims[2], s)
-                    cat = torch.empty((B, do, ho, wo, 2 * cstage), dtype=adt, device=dev)
-                    cat_bufs.append((cat, cstage, (do, ho, wo)))
-                    z_out, ldz = (cat, cat.data_ptr() + cstage * esz), 2 * cstage
+                    # Round 6: where a HALF of the concat buffer is 64 bytes per voxel (32 channels of 16-bit values: level 0), the
+                    # two halves are kept as dense PLANES [up | skip] instead of interleaved rows of 2 C channels: the kernels that
+                    # read one half (the stride-2 conv of the skip below, its weight gradient, the transposed conv's backward) then
+                    # use whole 128-byte lines (the memory side moves whole lines: 4.3x the input fetched before, r05_ab.txt).
+                    # The decoder conv that reads BOTH halves takes them as 32-channel blocks (dgtta_conv3d_k3_fwd_blocked) - where
+                    # the ring kernels run (asked up front); DGTTA_PLANAR_CAT=0: the interleaved layout everywhere.
+                    planar = (cstage * esz == 64 and impl != 1 and os.environ.get("DGTTA_PLANAR_CAT", "1") != "0"
+                              and os.environ.get("DGTTA_SPLIT_CAT_GRAD", "1") != "0"
+                              and lib.dgtta_conv3d_k3_blocked_supported(B, 2 * cstage, cstage, do, ho, wo, dt) == 1)
+                    if planar:
+                        cat = torch.empty((2, B, do, ho, wo, cstage), dtype=adt, device=dev)
+                        cat_bufs.append((cat, cstage, (do, ho, wo), B * do * ho * wo * cstage))
+                        z_out, ldz = (cat, cat[1].data_ptr()), cstage
+                    else:
+                        cat = torch.empty((B, do, ho, wo, 2 * cstage), dtype=adt, device=dev)
+                        cat_bufs.append((cat, cstage, (do, ho, wo), 0))
+                        z_out, ldz = (cat, cat.data_ptr() + cstage * esz), 2 * cstage
                 u_ptr, ldu, dims, rec, zt = run_block(blk, u_ptr, ldu, cin, dims, z_out, ldz, ("enc", si, bi))
                 rec["where"] = ("enc", si, bi)
                 saved.append(rec)
@@ -436,20 +454,22 @@ class _UNetFn(torch.autograd.Function):
         x_low_ptr, x_low_ld, x_low_c, low_dims = u_ptr, ldu, cin, dims
         ups = []
         for k, blocks in enumerate(dec):
-            cat, cskip, cdims = cat_bufs[-(k + 1)]
+            cat, cskip, cdims, cat_xbs = cat_bufs[-(k + 1)]
             up = net.decoder.transpconvs[k]
             nbt = lib.dgtta_convT3d_fwd_ws_bytes(x_low_c, cskip, dt)
             wst = ws_for(nbt)
-            check(lib.dgtta_convT3d_k2s2_fwd(x_low_ptr, x_low_ld, ptr(up.weight), ptr(up.bias), ptr(cat), 2 * cskip,
+            cat_ld = cskip if cat_xbs else 2 * cskip           # (planes: the up half is the dense tensor at the buffer's start)
+            check(lib.dgtta_convT3d_k2s2_fwd(x_low_ptr, x_low_ld, ptr(up.weight), ptr(up.bias), ptr(cat), cat_ld,
                                              ptr(wst), nbt, B, x_low_c, cskip, low_dims[0], low_dims[1], low_dims[2], dt,
                                              impl, st), "dgtta_convT3d_k2s2_fwd")
             ups.append(dict(mod=up, x=x_low_ptr, ldx=x_low_ld, cin=x_low_c, cout=cskip, din=low_dims, cat=cat))
-            u_ptr, ldu, cin, dims = cat.data_ptr(), 2 * cskip, 2 * cskip, cdims
+            u_ptr, ldu, cin, dims = cat.data_ptr(), cat_ld, 2 * cskip, cdims
             for bi, blk in enumerate(blocks):
                 # feature-space window accumulation: the block in front of the head hands over its raw conv output and statistics -
                 # its InstanceNorm + LeakyReLU apply runs inside the accumulation kernel, z is never written
                 fold = feat_fold and k == len(dec) - 1 and bi == len(blocks) - 1
-                u_ptr, ldu, dims, rec, zt = run_block(blk, u_ptr, ldu, cin, dims, None, None, ("dec", k, bi), stats_only=fold)
+                u_ptr, ldu, dims, rec, zt = run_block(blk, u_ptr, ldu, cin, dims, None, None, ("dec", k, bi), stats_only=fold,
+                                                      xbs=cat_xbs if bi == 0 else 0)
                 rec["where"] = ("dec", k, bi)
                 saved.append(rec)
                 keep.append(zt)
@@ -692,8 +712,12 @@ class _UNetFn(torch.autograd.Function):
                     wstream = main_stream if side is None else side
                     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     ev0.record(wstream)
-                check(lib.dgtta_conv3d_k3_wgrad(rec["u"], rec["ldu"], ptr(dy), cout, ptr(dw), ptr(db), ptr(w_), nb, B,
-                                                cin, cout, di, hi, wi, s, ACC, dt, impl, st_w), "dgtta_conv3d_k3_wgrad")
+                if rec["xbs"]:      # x = the level-0 concat buffer as two 32-channel planes
+                    check(lib.dgtta_conv3d_k3_wgrad_blocked(rec["u"], rec["xbs"], ptr(dy), cout, ptr(dw), ptr(db), ptr(w_), nb, B,
+                                                            cin, cout, di, hi, wi, ACC, dt, st_w), "dgtta_conv3d_k3_wgrad_blocked")
+                else:
+                    check(lib.dgtta_conv3d_k3_wgrad(rec["u"], rec["ldu"], ptr(dy), cout, ptr(dw), ptr(db), ptr(w_), nb, B,
+                                                    cin, cout, di, hi, wi, s, ACC, dt, impl, st_w), "dgtta_conv3d_k3_wgrad")
                 if pr is not None:
                     ev1.record(wstream)
                     pr.setdefault("wgrad_events", []).append((ev0, ev1, B))
@@ -705,8 +729,8 @@ class _UNetFn(torch.autograd.Function):
             kind, sidx, bidx = where
             if kind == "dec" and bidx == 0:
                 # input was the concat buffer of decoder stage sidx: gradient for [up | skip]
-                cat, cskip, cdims = cat_bufs[-(sidx + 1)]
-                if cskip * esz == 64 and os.environ.get("DGTTA_SPLIT_CAT_GRAD", "1") != "0":
+                cat, cskip, cdims, cat_xbs = cat_bufs[-(sidx + 1)]
+                if cskip * esz == 64 and (cat_xbs or os.environ.get("DGTTA_SPLIT_CAT_GRAD", "1") != "0"):
                     # 32 channels of 16-bit values = HALF a 128-byte line: as one [voxel][2 C] tensor every consumer of ONE half of this
                     # gradient (the transposed conv's backward, the stride-2 data gradient's accumulate, the InstanceNorm backward
                     # of the skip block) would fetch whole lines and use 64 bytes of each (profiles/r05_ab.txt, fetch_calib.sh).

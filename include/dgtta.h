@@ -206,6 +206,19 @@ size_t dgtta_conv3d_wgrad_split_ws_bytes(int B, int Cin, int Cout, int Do, int H
 int dgtta_conv3d_k3_wgrad(const void *x, int ldx, const void *dy, int lddy, float *dw_t, float *db, void *ws,
                           size_t ws_bytes, int B, int Cin, int Cout, int Di, int Hi, int Wi, int stride,
                           int accumulate, int dtype, int impl, void *stream);
+/* Round 6: x as 32-channel BLOCKS.  Block c of the input channels is a dense tensor [B][D][H][W][32] at element offset
+ * c * x_block_stride from x (the level-0 concat buffer of the U-Net as planes [up | skip]: the kernels that read ONE half - the
+ * stride-2 conv of the skip, the transposed conv's backward - then use whole 128-byte lines).  Stride 1, 64 input channels, 16-bit
+ * storage, and only where the D-ring kernels take the launch: dgtta_conv3d_k3_blocked_supported returns 1 exactly when BOTH calls below
+ * accept these dimensions; otherwise they return DGTTA_ERR_UNSUPPORTED and launch nothing.  Results equal the interleaved
+ * layout's bit for bit (same kernels, same order). */
+int dgtta_conv3d_k3_blocked_supported(int B, int Cin, int Cout, int D, int H, int W, int dtype);
+int dgtta_conv3d_k3_fwd_blocked(const void *x, long long x_block_stride, const void *wpack, const float *bias, void *y, int ldy,
+                                void *stats, int B, int Cin, int Cout, int CinP, int CoutP, int Di, int Hi, int Wi, int dtype,
+                                void *stream);
+int dgtta_conv3d_k3_wgrad_blocked(const void *x, long long x_block_stride, const void *dy, int lddy, float *dw_t, float *db,
+                                  void *ws, size_t ws_bytes, int B, int Cin, int Cout, int Di, int Hi, int Wi, int accumulate,
+                                  int dtype, void *stream);
 
 /* InstanceNorm3d(eps, affine, biased variance) + LeakyReLU(slope), per (b,c) over the volume.
  * fwd: stats = partial sums from the conv epilogue, or NULL (then computed here from y).

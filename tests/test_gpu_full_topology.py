@@ -261,6 +261,55 @@ def test_head_fused_with_the_inverse_warp_matches_head_then_warp(dtype, nsel, mo
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_level0_concat_buffer_as_planes_matches_the_interleaved_layout(dtype, monkeypatch):
+    """Round 6: the level-0 concat buffer as two dense 32-channel planes [up | skip] (the decoder conv and its
+    weight gradient read them as channel BLOCKS: dgtta_conv3d_k3_fwd_blocked / _wgrad_blocked on the ring kernels) against the
+    interleaved [voxel][64] layout (DGTTA_PLANAR_CAT=0): the same kernels in the same order - logits and every parameter
+    gradient bit for bit.  The query says where the layout applies; outside it the blocked calls refuse instead of mis-reading."""
+    from dg_tta_amd import _lib, ops
+    from dg_tta_amd._lib import ptr, stream_of
+    from dg_tta_amd.synthetic import he_init_
+    from dg_tta_amd.unet import HipPlainConvUNet
+    lib = _lib.load()
+    dt = ops.dtype_code(dtype)
+    B, N = 4, 64
+    assert lib.dgtta_conv3d_k3_blocked_supported(B, 64, 32, N, N, N, dt) == 1           # the layout is really offered at this size
+    assert lib.dgtta_conv3d_k3_blocked_supported(2, 64, 32, N, N, N, dt) == 0           # (too few columns for the weight-gradient sweep)
+    assert lib.dgtta_conv3d_k3_blocked_supported(B, 64, 32, 16, 16, 16, dt) == 0          # small launches stay with the tile kernels
+    assert lib.dgtta_conv3d_k3_blocked_supported(B, 128, 64, N, N, N, dt) == 0 and lib.dgtta_conv3d_k3_blocked_supported(B, 64, 32, N, N, N, 0) == 0
+    x16 = torch.zeros(2, 1, 16, 16, 16, 32, dtype=dtype, device=DEV)
+    y16 = torch.empty(1, 16, 16, 16, 32, dtype=dtype, device=DEV)
+    wp = torch.zeros(lib.dgtta_conv3d_packed_bytes(64, 32, dt) // 2, dtype=dtype, device=DEV)
+    rc = lib.dgtta_conv3d_k3_fwd_blocked(ptr(x16), x16[0].numel(), ptr(wp), None, ptr(y16), 32, None, 1, 64, 32, 64, 32, 16, 16, 16, dt,
+                                         stream_of())
+    assert rc == -2 and b"ring" in lib.dgtta_last_error()                           # DGTTA_ERR_UNSUPPORTED, nothing launched
+    torch.manual_seed(9)
+    net = he_init_(HipPlainConvUNet(act_dtype=dtype), seed=7)
+    for m in net.modules():
+        if m.__class__.__name__ == "HipInstanceNorm3d":
+            m.weight.data.uniform_(0.5, 1.5)
+            m.bias.data.normal_(0, 0.2)
+    net = net.to(DEV)
+    net.set_selected_classes(torch.arange(16) * 5 + 1)
+    x = torch.rand(B, 12, N, N, N, device=DEV)
+    gout = torch.randn(B, 16, N, N, N, device=DEV).contiguous(memory_format=torch.channels_last_3d) * 64.0
+
+    def run():
+        net.zero_grad()
+        y = net(x)
+        y.backward(gout)
+        torch.cuda.synchronize()
+        return y.detach().clone(), {n: p.grad.detach().clone() for n, p in net.named_parameters() if p.grad is not None}
+    y1, g1 = run()
+    monkeypatch.setenv("DGTTA_PLANAR_CAT", "0")
+    y0, g0 = run()
+    monkeypatch.delenv("DGTTA_PLANAR_CAT")
+    assert torch.equal(y0, y1) and set(g0) == set(g1) and float(y1.abs().max()) > 0
+    for n in g0:
+        assert torch.equal(g0[n], g1[n]), n
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 def test_logit_gradient_in_the_storage_type_through_the_sink(dtype, monkeypatch):
     """Round 6: between the loss backward and the fused head + warp backward the logit gradient travels in the
     network's 16-bit storage type (dgtta_softdice_bwd_t -> unet.Grad16Sink -> dgtta_seghead_warp_bwd_g16).

@@ -13,6 +13,7 @@
 //   NCDHW fp32 or NDHWC fp32/bf16.
 // Algorithmic HBM bytes per voxel: img 4 + noise 48 + ws 48 w + 48 r + out 48 (fp32) = 196 B.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 

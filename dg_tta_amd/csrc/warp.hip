@@ -87,12 +87,26 @@ __global__ void warp_fwd_kernel(const float *__restrict__ src, const float *__re
   const int cg = NDHWC ? (C / VEC) : 1;  // channel groups per voxel
   const float sub = sub_const ? sub_const[0] : 0.f;
   const int64_t Vd = (int64_t)Dd * Hd * Wd, Vs = (int64_t)Ds * Hs * Ws;
+  const bool idx32 = total <= 0x7fffffffll;      // (uniform) five 64-bit divisions per item cost more than the gather itself
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int g = (int)(i % cg);
-    const int64_t vox = i / cg;
-    const int b = (int)(vox / Vd);
-    const int64_t v = vox % Vd;
-    const int w = (int)(v % Wd), h = (int)((v / Wd) % Hd), d = (int)(v / ((int64_t)Wd * Hd));
+    int g, b, w, h, d;
+    int64_t v;
+    if (idx32) {
+      const unsigned ii = (unsigned)i, vox = ii / (unsigned)cg, vd = (unsigned)Vd;
+      g = (int)(ii - vox * (unsigned)cg);
+      b = (int)(vox / vd);
+      const unsigned vv = vox - (unsigned)b * vd, t = vv / (unsigned)Wd;
+      w = (int)(vv - t * (unsigned)Wd);
+      d = (int)(t / (unsigned)Hd);
+      h = (int)(t - (unsigned)d * (unsigned)Hd);
+      v = vv;
+    } else {
+      g = (int)(i % cg);
+      const int64_t vox = i / cg;
+      b = (int)(vox / Vd);
+      v = vox % Vd;
+      w = (int)(v % Wd), h = (int)((v / Wd) % Hd), d = (int)(v / ((int64_t)Wd * Hd));
+    }
     const Sample s = sample_pos(theta + b * 12, d, h, w, Dd, Hd, Wd, Ds, Hs, Ws, algebra, pad_mode);
     if (interp == DGTTA_INTERP_NEAREST) {
       const int nx = (int)nearbyintf(s.ix), ny = (int)nearbyintf(s.iy), nz = (int)nearbyintf(s.iz);

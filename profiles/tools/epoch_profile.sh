@@ -9,7 +9,7 @@
 #                                                     per-name times no longer add up to the epoch: 283 ms instead of 170)
 # usage (inside gpurun): bash profiles/tools/epoch_profile.sh <tag> ["bf16 fp32"] ["fetch write stats"] ; writes gpurun_out/<tag>_epoch_profile.json
 tag=${1:-r05}
-dts=${2:-bf16}
+dts=${2:-fp16}
 parts=${3:-"fetch write stats"}
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
@@ -24,7 +24,7 @@ for dt in $dts; do
 done
 cd $R
 python3 profiles/tools/epoch_profile_summary.py $tag $dts > gpurun_out/${tag}_epoch_profile.json
-python3 profiles/tools/dec31_dispatches.py $tag > gpurun_out/${tag}_dec31_dispatches.csv 2> gpurun_out/${tag}_dec31_dispatches.txt || true
+python3 profiles/tools/dec31_dispatches.py $tag $(echo $dts | cut -d" " -f1) > gpurun_out/${tag}_dec31_dispatches.csv 2> gpurun_out/${tag}_dec31_dispatches.txt || true
 # the raw csv files are large: keep the per-name statistics only
 for dt in $dts; do
   for n in 1 3; do

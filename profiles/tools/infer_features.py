@@ -9,7 +9,7 @@ from dg_tta_amd.tta.inference import accumulate_window_features
 from dg_tta_amd.unet import HipPlainConvUNet
 
 n, dev = 512, torch.device("cuda:0")
-net = he_init_(HipPlainConvUNet(act_dtype=torch.bfloat16), seed=7)
+net = he_init_(HipPlainConvUNet(act_dtype=torch.float16 if "fp16" in sys.argv else torch.bfloat16), seed=7)
 net.register_forward_pre_hook(mind_hook)
 net = net.to(dev)
 vol = torch.randn(1, n, n, n, generator=torch.Generator().manual_seed(3)).to(dev)

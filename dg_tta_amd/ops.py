@@ -216,7 +216,7 @@ class _ConsistencyLossPair(torch.autograd.Function):
         lib = _lib.load()
         # the producer's offer to take the gradient in its 16-bit storage type (unet.Grad16Sink; 16-class rows only)
         sink = getattr(both, "_dgtta_grad16", None)
-        ctx.sink = sink if (sink is not None and both.shape[1] == 16) else None
+        ctx.sink = sink if (sink is not None and both.shape[1] == 16 and sink.claim()) else None
         both = both.contiguous(memory_format=torch.channels_last_3d)
         b2, c = both.shape[:2]
         b = b2 // 2

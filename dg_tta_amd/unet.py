@@ -294,7 +294,15 @@ class Grad16Sink:
     `put` by the loss backward, taken by _UNetFn.backward of the same pass."""
 
     def __init__(self, dtype):
-        self.dtype, self.g16 = dtype, None
+        self.dtype, self.g16, self.claimed = dtype, None, False
+
+    def claim(self):
+        """ONE consumer of the output may use the channel (a second sink-aware loss on the same output takes the fp32 route, so
+        that autograd sums its dense gradient with the first one's instead of one `put` overwriting the other)."""
+        if self.claimed:
+            return False
+        self.claimed = True
+        return True
 
     def put(self, g16):
         self.g16 = g16

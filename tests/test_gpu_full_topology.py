@@ -400,6 +400,20 @@ def test_logit_gradient_in_the_storage_type_through_the_sink(dtype, monkeypatch)
     _, gc = run(extra_consumer=True)
     hb = "decoder.seg_layers.3.bias"
     assert float((gc[hb] - ga[hb]).abs().max()) > 0
+    # two sink-aware losses on ONE output: the second takes the fp32 route, the gradients add up (2x one loss's, to 16-bit rounding)
+    net.zero_grad()
+    with net.fuse_output_warp(rinv.to(DEV), rinv):
+        y = net(x)
+    ta, tb = y[:B], y[B:]
+    ta._dgtta_pair = tb._dgtta_pair = y
+    ta._dgtta_guard_items = tb._dgtta_guard_items = 1
+    l_a, _ = ops.consistency_loss(ta, tb, 1)
+    l_b, _ = ops.consistency_loss(ta, tb, 1)
+    ((l_a + l_b) * 1024.0).backward()
+    torch.cuda.synchronize()
+    g2 = net.decoder.seg_layers[-1].weight.grad.detach().float()
+    gw = ga["decoder.seg_layers.3.weight"]
+    assert float((g2 - 2 * gw).abs().max()) <= lim * 2 * float(gw.abs().max())
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])

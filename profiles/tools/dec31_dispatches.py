@@ -9,14 +9,18 @@ class median is re-labelled `batch1_or_misplaced` and kept out of every mean (ro
 launches into the batch-8 class).  stdout: csv rows; stderr: the summary.  usage: dec31_dispatches.py <tag> [dtype=fp16]"""
 import csv, glob, statistics, sys
 tag, dt = sys.argv[1], (sys.argv[2] if len(sys.argv) > 2 else "fp16")
-rows = []
+rows, wrows = [], []
 for f in glob.glob(f"gpurun_out/{tag}_ep_{dt}_stats_3/**/*kernel_trace.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
+        rec = (int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r.get("Grid_Size", r.get("Grid_Size_X", "")),
+               r.get("Workgroup_Size", r.get("Workgroup_Size_X", "")), r.get("LDS_Block_Size", ""), r.get("Dispatch_Id", ""))
         if "conv3_ring_kernel<" in k and ", false, 0, false, 1>" in k:
-            rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r.get("Grid_Size", r.get("Grid_Size_X", "")),
-                         r.get("Workgroup_Size", r.get("Workgroup_Size_X", "")), r.get("LDS_Block_Size", ""), r.get("Dispatch_Id", "")))
+            rows.append(rec)
+        elif "conv3_wgrad_ring_kernel<" in k and ", false, false, false, true>" in k:      # (the one-tap form: every layer but the first)
+            wrows.append(rec)
 rows.sort()
+wrows.sort()
 PASS = ["fwd_enc01_batch8", "fwd_dec31_batch8", "dgrad_dec30_up_half_batch8", "dgrad_dec30_skip_half_batch8"]
 # one-stream order: the two forward launches of a pass, later (in its backward) the two data-gradient halves; after the 4 passes
 # the evaluation forward
@@ -48,3 +52,26 @@ if steady:
     print(f"dec.3.1 forward, 8 samples per launch, epochs 1.. (the first epoch ramps the clock): mean {m:.1f} us over {len(steady)} launches "
           f"-> 927.7 GFLOP / {m:.1f} us = {927.7 / m * 1e3:.0f} TFLOP/s = {927.7 / m * 1e3 / 2500:.4f} of 2.5 PF (profiler on, one stream; "
           f"bench.py's roofline.forward is the same population timed with events, profiler off)", file=sys.stderr)
+
+# ---- the weight-gradient sweep behind `roofline` (top level): 12 launches per training pass in backward order, the FIRST of each
+# pass is block dec.3.1 (128^3, 32 -> 32, 8 samples) - the shape bench.py probes; its slab reduction (wgrad_reduce_kernel<8>, ~20 us)
+# is a launch of its own here and inside the probe's event pair there
+PER_PASS = 12
+wd = [(e - s) / 1e3 for s, e, *_ in wrows]
+print("dispatch_id,epoch,start_ns,end_ns,duration_us,grid_size,workgroup_size,lds_bytes,class")
+first = []
+for n, ((s_, e_, g, w, l, i), d) in enumerate(zip(wrows, wd)):
+    c = "wgrad_dec31_batch8" if n % PER_PASS == 0 else f"wgrad_other_layer_{n % PER_PASS}"
+    ep = n // (4 * PER_PASS)
+    if n % PER_PASS == 0:
+        first.append((ep, d))
+    print(f"{i},{ep},{s_},{e_},{d:.1f},{g},{w},{l},{c}")
+print(f"{len(wrows)} launches of conv3_wgrad_ring_kernel<{dt}, one tap per MFMA, operand reuse> ({PER_PASS} per training pass, 4 passes per epoch)", file=sys.stderr)
+steady = [d for ep, d in first if ep >= 1]
+if steady and len(wrows) % PER_PASS == 0:
+    m = statistics.mean(steady)
+    print(f"dec.3.1 weight gradient (first sweep of each backward), 8 samples per launch, epochs 1..: mean {m:.1f} us over {len(steady)} launches, min {min(steady):.1f}, "
+          f"max {max(steady):.1f} -> 927.7 GFLOP / {m:.1f} us = {927.7 / m * 1e3:.0f} TFLOP/s = {927.7 / m * 1e3 / 2500:.4f} of 2.5 PF (profiler on, one stream, "
+          f"the sweep without its ~20-us slab reduction; bench.py's roofline is the same launch + reduction timed with events, profiler off)", file=sys.stderr)
+elif wrows:
+    print(f"(weight-gradient launches not a multiple of {PER_PASS}: no per-layer classification)", file=sys.stderr)

@@ -174,6 +174,42 @@ def test_one_step_128_backward_vs_cpu_oracle():
     assert report["fp32"]["argmax_agreement_where_margin_gt_1e-3"] == 1.0      # north_star: identical label maps in fp32 (off ties)
 
 
+def test_one_step_128_on_pretrained_weights_vs_cpu_oracle():
+    """the same one-step comparison on the PRE-TRAINED weights and the target-domain patch the bench runs on
+    (the He-initialised net above has pseudo-Dice ~0.005 and near-tied logits: bf16's per-class soft-Dice error reads 3.5e-4 there
+    and 4.8e-3 on a model that segments).  GIN + MIND pre-training through the engine (550 steps, ~23 s), the centre patch of the
+    standard target case, the CPU oracle's accumulation step on the host, the HIP path in all three storage types.  Measured
+    (profiles/r05_bench_lines.json `parity_at_size`): fp32 loss 2e-7 / soft Dice 2.3e-6 / labels 1.0 where the margin > 1e-3 /
+    gradient cosine 0.99998; fp16 5.9e-5 / 4.7e-4 / 0.999998 / 0.96 (one near-cancelling bias; median 0.99999); bf16 4.4e-4 /
+    4.8e-3 / 0.99987 / 0.9992 on the bench's draw pair.  fp32 and fp16 are held to the stated loss tolerances; bf16 is fenced, not claimed."""
+    bench = _bench()
+    import os
+    from dg_tta_amd.synthetic import atlas_case
+    args = bench.parse_args(["--pretrain-hooks", "GIN_MIND", "--target-noise", "0.12", "--lr", "3e-4"])
+    state, rep = bench.pretrained_weights(args, DEV)
+    assert rep["hard_dice_unseen_source_case"] > 0.85
+    o = (bench.volume_edge(128) - 128) // 2
+    img = atlas_case(bench.volume_edge(128), 15, 31, "target", noise=0.12)[0][None, None, o:o + 128, o:o + 128, o:o + 128].contiguous()
+    dt, rec = bench.oracle_step(128, 16, 16, threads=min(16, len(os.sched_getaffinity(0))), state=state, imgs=img)
+    assert 0.02 < rec["loss"] < 0.9                      # the consistency mask is alive on this model
+    # measured on this draw pair (seeds 101 / 102; gpurun_out/at_size_parity.json "oracle_step_pretrained"): fp32 loss 1.4e-6, per-class
+    # soft Dice 2.1e-5, labels 1.0, cosine 0.99999; fp16 1.7e-4 / 1.08e-3 / 0.999997 / 0.976.  The STATED tolerance is on the loss
+    # (DESIGN.md 2: 1e-5 fp32, 1e-3 16-bit - one step is noisier than an epoch's mean of 16); the per-class soft Dice of ONE
+    # augmentation pair (small classes through the reference's hard mask) is fenced at ~3x its measured value, not claimed
+    limits = {"fp32": dict(loss=1e-5, dice=1e-4, agree_safe=1.0, cos=0.9995),
+              "fp16": dict(loss=1e-3, dice=3e-3, agree_safe=0.99995, cos=0.9),
+              "bf16": dict(loss=3e-3, dice=3e-2, agree_safe=0.9995, cos=0.99)}
+    report = {"oracle_loss": rec["loss"], "pretraining": {k: rep[k] for k in ("steps", "hard_dice_unseen_source_case")}}
+    for dtype in ("fp32", "fp16", "bf16"):
+        report[dtype] = r = bench.hip_step_vs_oracle(rec, dtype, DEV)
+        _record("oracle_step_pretrained", report)
+        lim = limits[dtype]
+        assert r["loss_delta"] < lim["loss"], f"{dtype}: loss {r['loss']:.7f} vs oracle {rec['loss']:.7f}"
+        assert r["soft_dice_per_class_delta_max"] < lim["dice"], f"{dtype}: soft Dice off by {r['soft_dice_per_class_delta_max']:.2e}"
+        assert r["argmax_agreement_where_margin_gt_1e-3"] >= lim["agree_safe"], f"{dtype}: {r['argmax_agreement_where_margin_gt_1e-3']:.6f}"
+        assert r["grad_cosine_min"] > lim["cos"], f"{dtype}: gradient cosine {r['grad_cosine_min']:.5f} in {r['grad_cosine_worst_tensor']}"
+
+
 def test_adaptation_epochs_128_dice_delta_of_the_default_storage_type():
     """N = 4 adaptation epochs of the product's tta_epoch (default 2 x 4 batching, side streams), same seeds and draws for
     fp32, fp16 and bf16 storage: north_star's tolerance holds for the 16-bit storage type bench.py defaults to (fp16 since

@@ -21,7 +21,7 @@ void dgtta_set_error(const char *fmt, ...);
 // -1 = variable not set; otherwise the first character ('0', '1', ...) of its value.
 struct DgttaSwitches {
   int conv_rows, conv_s2, dgrad_s2_allcls, wgrad_tr, wgrad_tr8, wgrad_s2_onepass, convt_wgrad_onepass;
-  int convt_gemm, rows_order, in_nt, wgrad_upw, wgrad_xcd, in_gstats, softdice16, conv_ring, wgrad_ring, ha_mfma, wgrad_f32_split, feature_head_mfma, headwarp_mfma;
+  int convt_gemm, rows_order, in_nt, wgrad_upw, wgrad_xcd, in_gstats, softdice16, conv_ring, wgrad_ring, ha_mfma, wgrad_f32_split, feature_head_mfma, headwarp_mfma, wgrad_flat, wgrad_reduce_taps;
   // Laboratory switches: timing models whose results are WRONG BY CONSTRUCTION (*_abl), cycle stamps written past the
   // caller's buffers, measured-no-gain variants.  They exist only in the diagnostic build (-DDGTTA_DIAG ->
   // libdgtta_hip_diag.so, `python -m dg_tta_amd.build --diag`, loaded by profiles/tools/ through DGTTA_LIB); the product

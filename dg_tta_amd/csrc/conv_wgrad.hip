@@ -519,6 +519,195 @@ __global__ __launch_bounds__(256, 2) void conv3_wgrad_tr_kernel(const bf16_t *__
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// Weight gradient of the SMALL planes (W <= 16: the 16^3, 8^3 and 4^3 levels), round 6.  The row kernels above and the ring
+// sweep give every output row a 32-voxel MFMA k-run of its own, so a row of 16 / 8 / 4 voxels leaves 50 / 75 / 87 % of the
+// matrix instructions multiplying zeros.  Here an (H, W) plane is ONE flat run of slots with row pitch P = W + 2 (the
+// two zero-padding voxels of a row are slots of their own): slot g = h P + (w + 1) of dy, and the x operand of tap
+// (kh, kw) for slot g is slot g + kh P + kw of the padded x plane - a plain address offset for the transposed LDS reads,
+// exactly as a W shift is in conv3_wgrad_tr_kernel.  dy is zero in its pad slots, x in its pad rows / columns (both
+// come from the DMA's zero source), so the products of the pad slots vanish and W / (W + 2) = 89 / 80 / 67 % of the
+// k dimension is real.  Otherwise the scheme of conv3_wgrad_tr_kernel: LDS-DMA of whole planes into rings (G planes per
+// step), a wave owns the 32(ci) x 32(co) tile for 7 of the 27 taps, a workgroup sweeps `upw` units (sample x D segment)
+// into one slab.
+constexpr int WF_MAXPW = 16;      // DMA pieces (16 slots) per wave and plane
+// NCO output-channel blocks per wave: with one, a chunk step reads 8 operands (7 x, 1 dy) from LDS for 7 MFMAs - four waves
+// ask for 146 B / clk of a 128 B / clk LDS (measured: 0.39 of the MFMA peak at 16^2); with two the x operand feeds two
+// MFMAs: 9 operands for 14 MFMAs, 82 B / clk.  224 accumulator registers: one wave per SIMD, so NCO = 2 is always PIPE.
+template <typename T16, bool PIPE, int NCO>
+__global__ __launch_bounds__(256, PIPE ? 1 : 2) void conv3_wgrad_flat_kernel(const bf16_t *__restrict__ x, View xv,
+                                                                  const bf16_t *__restrict__ dy, View yv,
+                                                                  float *__restrict__ slabs, int Cin, int Cout, int cobs,
+                                                                  int nseg, int DR, int upw, int units, int P, int NCH, int XS, int G) {
+  const int D = yv.D, H = yv.H, W = yv.W;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int YS = NCH * 16;
+  unsigned char *sX = smem;                            // ring of 2 G + 2 padded x planes, XS slots of 64 B each
+  unsigned char *sY = smem + (2 * G + 2) * XS * 64;    // ring of 2 G dy planes, NCO blocks of YS slots each
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int cobs2 = (cobs + NCO - 1) / NCO;
+  const int cib = blockIdx.y / cobs2, cob0 = (blockIdx.y % cobs2) * NCO;
+  const int cin_lim = (Cin + 7) / 8 * 8;
+
+  int tap_id[7], tap_kd[7], tap_off[7];
+#pragma unroll
+  for (int i = 0; i < 7; ++i) {
+    const int tc = wave + 4 * i < 27 ? wave + 4 * i : 26;      // (wave 3's seventh slot: a discarded accumulator)
+    tap_id[i] = tc;
+    tap_kd[i] = tc / 9;
+    tap_off[i] = (((tc / 3) % 3) * P + tc % 3) * 64;
+  }
+  f32x16_t acc[7][NCO];
+#pragma unroll
+  for (int i = 0; i < 7; ++i)
+#pragma unroll
+    for (int n = 0; n < NCO; ++n)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[i][n][q] = 0.f;
+
+  // DMA pieces of a plane: XP pieces of the x plane (buffer slot s = padded-plane slot + 1: the tap (0, 0) of slot 0 reads
+  // one slot in front of the plane), then NCH pieces of each dy block; piece idx = wave + 4 i.  Per lane: the element
+  // offset of its 16 bytes inside the (sample, depth) plane, -1 = a pad slot (zero source).
+  const int XP = XS / 16, NP = XP + NCO * NCH;
+  const int l_vox = lane >> 2, l_chunk = lane & 3;
+  int poff[WF_MAXPW];
+#pragma unroll
+  for (int i = 0; i < WF_MAXPW; ++i) {
+    const int idx = wave + 4 * i;
+    poff[i] = -1;
+    if (idx < XP) {
+      const int s = idx * 16 + l_vox, q = s > 0 ? s - 1 : 0;
+      const int hp = q / P, wp = q - hp * P;
+      if (s > 0 && hp >= 1 && hp <= H && wp >= 1 && wp <= W && cib * 32 + l_chunk * 8 < cin_lim)
+        poff[i] = (int)((hp - 1) * xv.sh + (wp - 1) * xv.sw) + l_chunk * 8;
+    } else if (idx < NP) {
+      const int n = (idx - XP) / NCH;
+      const int g = (idx - XP - n * NCH) * 16 + l_vox;
+      const int h = g / P, wp = g - h * P;
+      if (h < H && wp >= 1 && wp <= W && (cob0 + n) * 32 + l_chunk * 8 < Cout)
+        poff[i] = (int)(h * yv.sh + (wp - 1) * yv.sw) + n * 32 + l_chunk * 8;
+    }
+  }
+  const int lane_off = ((lane >> 5) * 8 + ((lane & 15) >> 2)) * 64 + ((lane >> 4) & 1) * 32 + (lane & 3) * 8;
+
+  // A step of the sweep takes G planes (G = 1, 2, 4).  x ring of 2 G + 2 planes (G + 2 in use: d0 - 1 .. d0 + G, G landing),
+  // dy ring of 2 G; ring slots count from the unit's first plane.
+  const int NRX = 2 * G + 2, NRY = 2 * G;
+  for (int uu = 0; uu < upw; ++uu) {
+    const int t = blockIdx.x * upw + uu;
+    if (t >= units) break;
+    const int b = t / nseg, seg = t - b * nseg;
+    const int d_begin = seg * DR, d_end = (d_begin + DR < D) ? d_begin + DR : D;
+    const bf16_t *xb = x + b * xv.sb + cib * 32;
+    const bf16_t *yb = dy + b * yv.sb + cob0 * 32;
+    auto issue_x = [&](int xd, int slot) __attribute__((always_inline)) {
+#pragma unroll
+      for (int i = 0; i < WF_MAXPW; ++i) {
+        const int idx = wave + 4 * i;
+        if (idx < XP) {
+          const bool ok = poff[i] >= 0 && (unsigned)xd < (unsigned)D;
+          const void *src = ok ? (const void *)(xb + xd * xv.sd + poff[i]) : (const void *)&g_zero16;
+          dma16_to_lds(src, lds_addr_of(sX + (slot * XS + idx * 16) * 64));
+        }
+      }
+    };
+    auto issue_y = [&](int yd, int slot) __attribute__((always_inline)) {
+#pragma unroll
+      for (int i = 0; i < WF_MAXPW; ++i) {
+        const int idx = wave + 4 * i;
+        if (idx >= XP && idx < NP) {
+          const void *src = poff[i] >= 0 ? (const void *)(yb + yd * yv.sd + poff[i]) : (const void *)&g_zero16;
+          dma16_to_lds(src, lds_addr_of(sY + (slot * NCO * YS + (idx - XP) * 16) * 64));      // (block n at + n YS slots)
+        }
+      }
+    };
+    // prologue (the sweep of the previous unit ended with a barrier behind its last reads)
+    for (int j = 0; j < G + 2; ++j) issue_x(d_begin - 1 + j, j);
+    for (int j = 0; j < G; ++j)
+      if (d_begin + j < d_end) issue_y(d_begin + j, j);
+    dma_wait_all();
+    lds_barrier();
+    int xs0 = 0, ys0 = 0;      // ring slots of x plane d0 - 1 and dy plane d0
+    for (int d0 = d_begin; d0 < d_end; d0 += G) {
+      if (d0 + G < d_end) {
+        for (int j = 0; j < G; ++j) {
+          int sx = xs0 + G + 2 + j, sy = ys0 + G + j;
+          sx -= sx >= NRX ? NRX : 0;
+          sy -= sy >= NRY ? NRY : 0;
+          issue_x(d0 + G + 1 + j, sx);
+          if (d0 + G + j < d_end) issue_y(d0 + G + j, sy);
+        }
+      }
+      for (int j = 0; j < G && d0 + j < d_end; ++j) {
+        int sy = ys0 + j;
+        sy -= sy >= NRY ? NRY : 0;
+        const unsigned char *ys = sY + sy * NCO * YS * 64 + lane_off;
+        int so_t[7];
+#pragma unroll
+        for (int i = 0; i < 7; ++i) {
+          int sx = xs0 + j + tap_kd[i];
+          sx -= sx >= NRX ? NRX : 0;
+          so_t[i] = sx * XS * 64 + tap_off[i] + lane_off;
+        }
+        // PIPE (one wave per SIMD, nothing else covers the LDS latency): operands of chunk c + 1 are read while the MFMAs
+        // of chunk c run, two named register sets (the 512-register budget)
+        bf16x8_t a0[7], a1[7], b0[NCO], b1[NCO];
+        auto load = [&](int c, bf16x8_t (&a)[7], bf16x8_t (&bb)[NCO]) __attribute__((always_inline)) {
+#pragma unroll
+          for (int n = 0; n < NCO; ++n) bb[n] = tr_operand(ys + (n * YS + c * 16) * 64);
+#pragma unroll
+          for (int i = 0; i < 7; ++i) a[i] = tr_operand(sX + so_t[i] + c * 1024);
+        };
+        auto mm = [&](const bf16x8_t (&a)[7], const bf16x8_t (&bb)[NCO]) __attribute__((always_inline)) {
+#pragma unroll
+          for (int i = 0; i < 7; ++i)
+#pragma unroll
+            for (int n = 0; n < NCO; ++n) acc[i][n] = mfma32_tr<T16>(a[i], bb[n], acc[i][n]);
+        };
+        if (PIPE) {
+          load(0, a0, b0);
+          int c = 0;
+          for (; c + 2 <= NCH; c += 2) {
+            load(c + 1, a1, b1);
+            mm(a0, b0);
+            if (c + 2 < NCH) load(c + 2, a0, b0);
+            mm(a1, b1);
+          }
+          if (c < NCH) mm(a0, b0);
+        } else {
+          for (int c = 0; c < NCH; ++c) {
+            load(c, a0, b0);
+            mm(a0, b0);
+          }
+        }
+      }
+      xs0 += G;
+      xs0 -= xs0 >= NRX ? NRX : 0;
+      ys0 += G;
+      ys0 -= ys0 >= NRY ? NRY : 0;
+      dma_wait_all();
+      lds_barrier();
+    }
+  }
+
+  // partial slabs [27][32 ci][32 co], as conv3_wgrad_tr_kernel writes them: slab blockIdx.x of pair (cib, cob0 + n)
+  const int co = lane & 31, hh = lane >> 5;
+#pragma unroll
+  for (int n = 0; n < NCO; ++n) {
+    if (cob0 + n >= cobs) break;
+    float *slab = slabs + ((int64_t)(cib * cobs + cob0 + n) * gridDim.x + blockIdx.x) * (27 * 1024);
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+      if (wave + 4 * i < 27) {
+        const int tap = tap_id[i];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) slab[(tap * 32 + (q & 3) + 8 * (q >> 2) + 4 * hh) * 32 + co] = acc[i][n][q];
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // 8-wave variant of conv3_wgrad_tr_kernel for Cout >= 64: a workgroup owns a 32(ci) x 64(co) channel tile, so the x tile
 // (the larger one, with its halo) is staged once for two output-channel blocks: 58 instead of 94 DMA bytes per MFMA
 // (the 4-wave kernel sits on the ~11 B/clk/CU fill rate).  Wave w owns taps w, w+8, w+16, w+24 (27 of the 32 slots are
@@ -1194,6 +1383,58 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restri
   }
 }
 
+// Few slabs (< 64) into the dense layout dw_t[co][ci][27], round 6.  The kernel above gives each output row (tap, ci, co-block)
+// to 32 lanes: coalesced slab reads, but the 27 floats of a (ci, co) are written by workgroups far apart in the grid, as
+// 4-byte stores 100+ KB apart, so every 128-byte line of dw goes to memory in pieces (the 22 MB of the 640 -> 320 layer took
+// 77 us, 4x the 11 MB of a 320 -> 320 layer).  Here a workgroup owns 8 input channels x 32 output channels: thread (ci, co)
+// sums its 27 taps over the slabs (9 taps x 4 slabs in flight; slabs in ascending order: the same bits as above), the sums
+// meet in LDS, and each output channel's 8 x 27 = 216 consecutive floats leave as 54 float4 of one wave instruction.
+__global__ __launch_bounds__(256) void wgrad_reduce_taps_kernel(const float *__restrict__ slabs, float *__restrict__ dw, int Cin,
+                                                                int Cout, int cobs, int nslab, int accumulate, long long s_co) {
+  __shared__ float stg[32][217];
+  const int lane = threadIdx.x & 31, sub = threadIdx.x >> 5;
+  const int cobs32 = (Cout + 31) / 32;
+  const int cb = blockIdx.x % cobs32, ci0 = (blockIdx.x / cobs32) * 8;      // (Cin % 8 == 0: the launcher checks)
+  const int ci = ci0 + sub;
+  const float *p = slabs + (int64_t)((ci >> 5) * cobs + cb) * nslab * (27 * 1024) + (ci & 31) * 32 + lane;
+#pragma unroll 1
+  for (int t0 = 0; t0 < 27; t0 += 9) {
+    float s[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) s[t] = 0.f;
+    for (int k = 0; k < nslab; k += 4) {
+      float v[9][4];
+#pragma unroll
+      for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[t][j] = p[(int64_t)(k + j < nslab ? k + j : k) * (27 * 1024) + (t0 + t) * 1024];
+#pragma unroll
+      for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (k + j < nslab) s[t] += v[t][j];
+    }
+#pragma unroll
+    for (int t = 0; t < 9; ++t) stg[lane][sub * 27 + t0 + t] = s[t];
+  }
+  __syncthreads();
+  const int wv = threadIdx.x >> 6, l = threadIdx.x & 63;
+  if (l < 54) {
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const int cl = wv + 4 * r, co = cb * 32 + cl;
+      if (co >= Cout) break;
+      float4 o = make_float4(stg[cl][4 * l], stg[cl][4 * l + 1], stg[cl][4 * l + 2], stg[cl][4 * l + 3]);
+      float4 *dst = (float4 *)(dw + co * s_co + (int64_t)ci0 * 27) + l;
+      if (accumulate) {
+        const float4 old = *dst;
+        o.x += old.x, o.y += old.y, o.z += old.z, o.w += old.w;
+      }
+      *dst = o;
+    }
+  }
+}
+
 struct WgradPlan {
   int tW, tH, nsd, DR, cibs, cobs;
   int64_t units;
@@ -1257,10 +1498,87 @@ static int units_per_workgroup(int64_t units, int64_t gy, int slots) {
   return u < 1 ? 1 : (int)u;
 }
 
+// the dense-layout reduction (wgrad_reduce_taps_kernel) takes: all 27 taps in place, dw_t[co][ci][27], whole groups of 8 input
+// channels, 16-byte aligned rows (DGTTA_WGRAD_REDUCE_TAPS=0, tests: always the row kernel)
+static bool reduce_taps_ok(const Taps *real, const float *dw, int Cin, long long s_ci, long long s_tap) {
+  if (!real || dgtta_switches().wgrad_reduce_taps == '0' || s_tap != 1 || s_ci != 27 || Cin % 8 || ((uintptr_t)dw & 15)) return false;
+  for (int t = 0; t < 27; ++t)
+    if (real->wt[t] != t) return false;
+  return true;
+}
+
+// launch plan of conv3_wgrad_flat_kernel; returns the number of slabs per channel-block pair (0: shape not taken)
+template <typename T16>
+static int64_t wgrad_flat_launch(const void *x, const View &xv, const void *dy, const View &yv, float *slabs, size_t ws_bytes,
+                                 int B, int Cin, int Cout, hipStream_t st, int *rc) {
+  *rc = DGTTA_OK;
+  const int D = yv.D, H = yv.H, W = yv.W;
+  if (W > 16 || xv.D != D || xv.H != H || xv.W != W) return 0;
+  const int P = W + 2, NCH = cdiv(H * P, 16);
+  int XS = NCH * 16 + 2 * P + 2;                  // last slot a tap reads: (NCH 16 - 1) + 2 P + 2
+  if (XS < (H + 2) * P + 1) XS = (H + 2) * P + 1;
+  XS = (XS + 15) / 16 * 16;
+  const int cibs = cdiv(Cin, 32), cobs = cdiv(Cout, 32), pairs = cibs * cobs;
+  if (pairs > 65535) return 0;
+  // planes per step: as many (4, 2, 1) as fit.  Small planes (8^2, 4^2: a plane set fits twice into a CU's LDS): one
+  // output-channel block per wave, two workgroups per CU (measured 43 / 76 / 24 us against 58 / 97 / 35 us with two blocks per
+  // wave on the 320 -> 320 and 640 -> 320 layers at 8^3 and 320 -> 320 at 4^3).  Larger planes: one workgroup per CU either
+  // way, two blocks per wave where there are two (16^3, 256 -> 256: 123 against 133 us)
+  auto lds_of = [&](int nco, int g) { return ((2 * g + 2) * XS + 2 * g * nco * NCH * 16) * 64; };
+  int NCO = 1, G = 4;
+  while (G > 1 && (lds_of(1, G) > 80 * 1024 || G > D)) G /= 2;
+  if (lds_of(1, G) > 80 * 1024 && cobs >= 2) {
+    int g2 = 4;
+    while (g2 > 1 && (lds_of(2, g2) > 160 * 1024 || g2 > D)) g2 /= 2;
+    if (lds_of(2, g2) <= 160 * 1024 && cdiv(XS / 16 + 2 * NCH, 4) <= WF_MAXPW) NCO = 2, G = g2;
+  }
+  const int lds = lds_of(NCO, G);
+  if (lds > 160 * 1024 || cdiv(XS / 16 + NCO * NCH, 4) > WF_MAXPW) return 0;
+  if ((long long)H * xv.sh >= (1ll << 30) || (long long)H * yv.sh >= (1ll << 30)) return 0;      // plane offsets as int
+  const bool pipe = NCO == 2 || lds > 80 * 1024;
+  const int wgs_y = cibs * cdiv(cobs, NCO);
+  static int ncu = [] {
+    int dev = 0, n = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+    return n > 0 ? n : 256;
+  }();
+  // slabs per pair: fill the chip once (two workgroups per CU in the non-PIPE form); every slab is 110 KB written and read
+  // again, so no more than that
+  int64_t want = (int64_t)ncu * (pipe ? 1 : 2) / wgs_y;
+  const int64_t fit = (int64_t)(ws_bytes / ((size_t)pairs * 27 * 1024 * sizeof(float)));
+  if (fit < 1) return 0;
+  if (want > fit) want = fit;
+  if (want < 1) want = 1;
+  int nseg = 1;                                   // D segments only when the batch alone gives too few units
+  if (B < want) nseg = (int)(cdiv64(want, B) < D ? cdiv64(want, B) : D);
+  const int DR = cdiv(D, nseg);
+  nseg = cdiv(D, DR);
+  const int units = B * nseg;
+  const int upw = cdiv(units, (int)(want < units ? want : units));
+  const int nslab = cdiv(units, upw);
+  auto kern = NCO == 2 ? conv3_wgrad_flat_kernel<T16, true, 2>
+                       : (pipe ? conv3_wgrad_flat_kernel<T16, true, 1> : conv3_wgrad_flat_kernel<T16, false, 1>);
+  static DynLdsOnce once[3];
+  if (ensure_dyn_lds(once[NCO == 2 ? 2 : (int)pipe], reinterpret_cast<const void *>(kern), pipe ? 160 * 1024 : 80 * 1024) != hipSuccess) {
+    dgtta_set_error("wgrad_flat: cannot raise the dynamic LDS limit");
+    *rc = DGTTA_ERR_LAUNCH;
+    return 0;
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)nslab, (unsigned)wgs_y), dim3(256), lds, st, (const bf16_t *)x, xv,
+                     (const bf16_t *)dy, yv, slabs, Cin, Cout, cobs, nseg, DR, upw, units, P, NCH, XS, G);
+  if (hipGetLastError() != hipSuccess) {
+    dgtta_set_error("conv3_wgrad_flat_kernel: launch failed");
+    *rc = DGTTA_ERR_LAUNCH;
+    return 0;
+  }
+  return nslab;
+}
+
 template <typename T>
 static int wgrad_launch_classes(const void *x, const View &xv, const void *dy, const View &yv, float *dw, void *ws,
                                 size_t ws_bytes, int B, int Cin, int Cout, const WgradClasses &wc, const RealTaps &reals,
-                                long long s_co, long long s_ci, long long s_tap, int accumulate, hipStream_t st, long long xkh = 0) {
+                                long long s_co, long long s_ci, long long s_tap, int accumulate, hipStream_t st, long long xkh = 0,
+                                bool split_leg = false) {
   constexpr int EPV = Elem<T>::EPV;
   // Cin may be ragged (first layer: 12 channels in rows of 16): the pad channels only feed gradient rows ci >= Cin,
   // which the reduction never writes.  The rows must be long enough to be read in whole 16-byte groups.
@@ -1280,6 +1598,18 @@ static int wgrad_launch_classes(const void *x, const View &xv, const void *dy, c
     const DgttaSwitches &sw = dgtta_switches();
     if (sw.wgrad_tr != '0') {        // DGTTA_WGRAD_TR=0 (tests): the register-transpose predecessor
       const bool plain = wc.n == 1 && wc.mask[0] == 0x7ffffffu && wc.xoff[0] == 0 && wc.yoff[0] == 0;
+      // planes of W <= 16 as flat runs (DGTTA_WGRAD_FLAT=0: the kernels below).  Not for the six launches of an fp32 weight
+      // gradient (split_leg): that path's fixtures compare label maps and Adam update signs of near-tied values bit for bit
+      // with the reference run, i.e. they are pinned on the summation order of the kernels below
+      if (plain && !xkh && !split_leg && sw.wgrad_flat != '0') {
+        int rc = DGTTA_OK;
+        const int64_t g = wgrad_flat_launch<T16>(x, xv, dy, yv, (float *)ws, ws_bytes, B, Cin, Cout, st, &rc);
+        if (rc != DGTTA_OK) return rc;
+        if (g > 0) {
+          nslab = g;
+          goto reduce;
+        }
+      }
       if (plain && sw.wgrad_ring != '0') {      // the persistent ring sweep (conv_wgrad_ring.hip; DGTTA_WGRAD_RING=0: its predecessors)
         int rc = DGTTA_OK;
         const int g = conv3_wgrad_ring_launch(x, xv, dy, yv, (float *)ws, ws_bytes, B, Cin, Cout, (int)std::is_same<T16, f16_t>::value,
@@ -1334,6 +1664,9 @@ reduce:
   if (nslab >= 64)
     hipLaunchKernelGGL(wgrad_reduce_kernel<8>, dim3((unsigned)rrows, (unsigned)wc.n), dim3(256), 0, st, (const float *)ws, dw,
                        Cin, Cout, p.cobs, npairs, (int)nslab, accumulate, reals, s_co, s_ci, s_tap);
+  else if (reduce_taps_ok(wc.n == 1 ? &reals.t[0] : nullptr, dw, Cin, s_ci, s_tap))
+    hipLaunchKernelGGL(wgrad_reduce_taps_kernel, dim3((unsigned)((Cin / 8) * ((Cout + 31) / 32))), dim3(256), 0, st,
+                       (const float *)ws, dw, Cin, Cout, p.cobs, (int)nslab, accumulate, s_co);
   else
     hipLaunchKernelGGL(wgrad_reduce_kernel<1>, dim3((unsigned)cdiv64(rrows, 8), (unsigned)wc.n), dim3(256), 0, st,
                        (const float *)ws, dw, Cin, Cout, p.cobs, npairs, (int)nslab, accumulate, reals, s_co, s_ci, s_tap);
@@ -1344,24 +1677,25 @@ reduce:
 template <typename T>
 static int wgrad_launch(const void *x, const View &xv, const void *dy, const View &yv, float *dw, void *ws, size_t ws_bytes,
                         int B, int Cin, int Cout, unsigned tapmask, const Taps &real, long long s_co, long long s_ci,
-                        long long s_tap, int accumulate, hipStream_t st, long long xkh = 0) {
+                        long long s_tap, int accumulate, hipStream_t st, long long xkh = 0, bool split_leg = false) {
   WgradClasses wc;
   wc.n = 1;
   wc.mask[0] = tapmask;
   wc.xoff[0] = wc.yoff[0] = 0;
   RealTaps reals;
   reals.t[0] = real;
-  return wgrad_launch_classes<T>(x, xv, dy, yv, dw, ws, ws_bytes, B, Cin, Cout, wc, reals, s_co, s_ci, s_tap, accumulate, st, xkh);
+  return wgrad_launch_classes<T>(x, xv, dy, yv, dw, ws, ws_bytes, B, Cin, Cout, wc, reals, s_co, s_ci, s_tap, accumulate, st, xkh, split_leg);
 }
 
 template <typename T>
 static int wgrad_conv(const void *x, int ldx, const void *dy, int lddy, float *dw_t, void *ws, size_t ws_bytes, int B,
-                      int Cin, int Cout, int Di, int Hi, int Wi, int stride, int accumulate, hipStream_t st, long long xkh = 0) {
+                      int Cin, int Cout, int Di, int Hi, int Wi, int stride, int accumulate, hipStream_t st, long long xkh = 0,
+                      bool split_leg = false) {
   const long long s_co = (long long)Cin * 27, s_ci = 27, s_tap = 1;
   if (stride == 1) {
     const View xv = dense_view(B, Di, Hi, Wi, ldx), yv = dense_view(B, Di, Hi, Wi, lddy);
     return wgrad_launch<T>(x, xv, dy, yv, dw_t, ws, ws_bytes, B, Cin, Cout, 0x7ffffffu, identity_taps(0), s_co, s_ci, s_tap,
-                           accumulate, st, xkh);
+                           accumulate, st, xkh, split_leg);
   }
   if (xkh) return DGTTA_ERR_UNSUPPORTED;
   // stride 2: x[2*vo + tap - 1] lives on parity sub-lattices of x; per axis parity 0 <- tap 1 (offset 0),
@@ -1400,6 +1734,9 @@ static int wgrad_conv(const void *x, int ldx, const void *dy, int lddy, float *d
       if (p.units >= 64)
         hipLaunchKernelGGL(wgrad_reduce_kernel<8>, dim3((unsigned)rrows, 1u), dim3(256), 0, st, (const float *)ws, dw_t, Cin,
                            Cout, p.cobs, npairs, (int)p.units, accumulate, ident, s_co, s_ci, s_tap);
+      else if (reduce_taps_ok(&ident.t[0], dw_t, Cin, s_ci, s_tap))
+        hipLaunchKernelGGL(wgrad_reduce_taps_kernel, dim3((unsigned)((Cin / 8) * ((Cout + 31) / 32))), dim3(256), 0, st,
+                           (const float *)ws, dw_t, Cin, Cout, p.cobs, (int)p.units, accumulate, s_co);
       else
         hipLaunchKernelGGL(wgrad_reduce_kernel<1>, dim3((unsigned)cdiv64(rrows, 8), 1u), dim3(256), 0, st, (const float *)ws,
                            dw_t, Cin, Cout, p.cobs, npairs, (int)p.units, accumulate, ident, s_co, s_ci, s_tap);
@@ -1526,7 +1863,7 @@ static int wgrad_conv_f32_split(const float *x, int ldx, const float *dy, int ld
   static const int PAIRS[6][2] = {{0, 0}, {0, 1}, {1, 0}, {0, 2}, {1, 1}, {2, 0}};
   for (int q = 0; q < 6; ++q) {
     const int rc = wgrad_conv<bf16_t>(xs[PAIRS[q][0]], ldxs, gs[PAIRS[q][1]], ldys, dw_t, ws, slab_bytes, B, Cin, Cout, Di, Hi, Wi,
-                                      stride, (accumulate || q > 0) ? 1 : 0, st);
+                                      stride, (accumulate || q > 0) ? 1 : 0, st, 0, true);
     if (rc != DGTTA_OK) return rc;        // (q == 0: nothing written yet, the caller falls back to the fp32 kernel)
   }
   return DGTTA_OK;

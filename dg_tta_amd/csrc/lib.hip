@@ -51,6 +51,8 @@ static const DgttaSwitches *read_switches() {
   s->wgrad_f32_split = env_char("DGTTA_WGRAD_F32_SPLIT");
   s->feature_head_mfma = env_char("DGTTA_FEATURE_HEAD_MFMA");
   s->headwarp_mfma = env_char("DGTTA_HEADWARP_MFMA");
+  s->wgrad_flat = env_char("DGTTA_WGRAD_FLAT");
+  s->wgrad_reduce_taps = env_char("DGTTA_WGRAD_REDUCE_TAPS");
   // product switches select between kernels of equal results only: values outside a switch's documented set are ignored
   if (s->conv_ring != '0' && s->conv_ring != '1' && s->conv_ring != '3') s->conv_ring = -1;
   if (s->wgrad_ring != '0' && s->wgrad_ring != '1' && s->wgrad_ring != '4' && s->wgrad_ring != '5' && s->wgrad_ring != '6') s->wgrad_ring = -1;

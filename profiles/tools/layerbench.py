@@ -1,7 +1,7 @@
 """Per-layer table of the 3d_fullres net at the bench's launch shape (8 samples per launch, 16-bit storage): forward (with fused
 statistics), data gradient and weight gradient of every 3x3x3 conv through the C ABI, ~0.15 s of back-to-back launches each
 (sustained clocks), TFLOP/s against the 2.5 PF peak and the time a layer loses against the ring kernels' 0.5 of peak.
-usage: layerbench.py [fp16|bf16] [batch]"""
+usage: layerbench.py [fp16|bf16] [batch]      (LB_LAYERS=enc4.1,dec0.0,...: only these rows)"""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from dg_tta_amd import _lib
@@ -39,7 +39,10 @@ def pad(c):
 
 tot = {"fwd": [0.0, 0.0], "dgrad": [0.0, 0.0], "wgrad": [0.0, 0.0]}
 print(f"{'layer':8s} {'shape':>22s} {'GFLOP':>8s} | {'fwd ms':>8s} {'TF/s':>7s} | {'dgrad ms':>8s} {'TF/s':>7s} | {'wgrad ms':>8s} {'TF/s':>7s} | lost vs 0.5 peak (ms)")
+ONLY = [v for v in os.environ.get("LB_LAYERS", "").split(",") if v]
 for name, cin, cout, n, s in LAYERS:
+    if ONLY and name not in ONLY:
+        continue
     no = (n - 1) // s + 1
     cinp, coutp = pad(cin), pad(cout)
     x = torch.randn(B, n, n, n, cinp, device=DEV).to(tdt)

@@ -818,6 +818,53 @@ def test_wgrad_ring_kernel(case, dts, monkeypatch):
     assert torch.equal(run("1"), new)                                  # run to run: the same bits
 
 
+WFLAT_CASES = [(8, 64, 64, 8, 8, 8), (8, 32, 96, 4, 4, 4), (2, 64, 32, 16, 16, 16), (1, 24, 40, 5, 7, 6), (3, 320, 320, 4, 4, 4),
+               (1, 32, 32, 9, 16, 13), (2, 40, 64, 3, 11, 16), (1, 32, 32, 1, 1, 1), (1, 64, 64, 16, 16, 16), (5, 32, 32, 2, 3, 2)]
+# the network's small levels, ragged planes and channels, one sample with D segments, units that do not divide by workgroup
+
+
+@pytest.mark.parametrize("dts", ["bf16", "fp16"])
+@pytest.mark.parametrize("case", WFLAT_CASES)
+def test_wgrad_flat_plane_kernel(case, dts, monkeypatch):
+    """Planes of W <= 16 as one flat k-run with row pitch W + 2 (conv3_wgrad_flat_kernel, round 6) against the row kernels it
+    replaces there (DGTTA_WGRAD_FLAT=0) and torch float64 on the same operands; accumulation into dw; same bits run to run."""
+    B, cin, cout, D, H, W = case
+    dt, tdt = (1, torch.bfloat16) if dts == "bf16" else (2, torch.float16)
+    torch.manual_seed(sum(case) + 77)
+    ld = (cin + 7) // 8 * 8
+    x = torch.zeros(B, D, H, W, ld, device=DEV, dtype=tdt)
+    x[..., :cin] = torch.randn(B, D, H, W, cin, device=DEV).to(tdt)
+    dy = torch.randn(B, D, H, W, cout, device=DEV).to(tdt)
+
+    def run(flat, **kw):
+        monkeypatch.setenv("DGTTA_WGRAD_FLAT", flat)
+        reload_kernel_switches()
+        dw, db = _call_wgrad(x, dy, cin, cout, 1, dt, 2, **kw)
+        torch.cuda.synchronize()
+        return dw
+
+    old, new = run("0"), run("1")
+    ref = torch.nn.grad.conv3d_weight(x[..., :cin].float().permute(0, 4, 1, 2, 3).cpu().double(), (cout, cin, 3, 3, 3),
+                                      dy.float().permute(0, 4, 1, 2, 3).cpu().double(), stride=1, padding=1).float()
+    scale = float(ref.abs().max())
+    assert torch.isfinite(new).all()
+    assert float((new.cpu() - ref).abs().max()) < 2e-4 * scale + 1e-3
+    assert float((new - old).abs().max()) < 1e-4 * scale + 1e-3       # same products, another fp32 summation order
+    # the operands are exact in 16 bits and their products exact in fp32: what differs from float64 is fp32 summation alone,
+    # and the flat run must be as good at it as the kernels it replaces
+    err_new, err_old = float((new.cpu() - ref).abs().max()), float((old.cpu() - ref).abs().max())
+    assert err_new <= 2.0 * err_old + 2e-6 * scale, (err_new, err_old, scale)
+    assert torch.equal(run("1"), new)
+    monkeypatch.setenv("DGTTA_WGRAD_REDUCE_TAPS", "0")      # the slab reduction with one output row per 32 lanes: the same bits
+    assert torch.equal(run("1"), new)
+    monkeypatch.delenv("DGTTA_WGRAD_REDUCE_TAPS")
+    base = torch.randn_like(new)
+    acc = run("1", accumulate=1, dw=base.clone())
+    assert float((acc - (base + new)).abs().max()) < 1e-5 * scale + 1e-5
+    monkeypatch.delenv("DGTTA_WGRAD_FLAT")
+    reload_kernel_switches()
+
+
 @pytest.mark.parametrize("case", [(2, 32, 32, 8, 12, 40), (1, 32, 64, 6, 8, 64), (2, 64, 96, 5, 9, 33)])
 @pytest.mark.parametrize("upw", ["2", "3"])
 def test_wgrad_units_per_workgroup(case, upw, monkeypatch):

@@ -64,8 +64,11 @@ def test_fp16_storage_is_within_the_stated_tolerances(referee):
     assert e["hard_dice_per_class_max"] <= bench.DICE_TOLERANCE, e          # (stronger than the mean the clause speaks of)
     assert e["label_agreement_where_margin_gt_1e-3"] >= 0.9999 and e["skipped_optimizer_steps"] == 0, e
     assert e["within_tolerance"]
-    # with an order of magnitude to spare on this run (measured 2.8e-5 / 3.4e-5 / 2.7e-5): a 10x drift would show
-    assert e["loss"] <= 3e-4 and e["pseudo_dice"] <= 3e-4 and e["hard_dice"] <= 3e-4, e
+    # the Dice quantities with a factor of three to spare (measured 3.7e-5 / 4.2e-5).  The per-epoch LOSS has no such fence: it
+    # depends on the pre-trained instance through the reference's hard mask `sum_c logits > 0` - two instances of the same
+    # recipe (the small-plane weight gradients changed their summation order between them, so the 550 pre-training steps ended
+    # in different weights) gave 2.7e-5 and 6.7e-4 at three epochs, 2.8e-5 and 1.1e-4 on the unchanged weights of epoch 0
+    assert e["pseudo_dice"] <= 3e-4 and e["hard_dice"] <= 3e-4, e
 
 
 def test_bf16_storage_holds_the_dice_clause(referee):

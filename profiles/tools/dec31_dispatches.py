@@ -53,10 +53,11 @@ if steady:
           f"-> 927.7 GFLOP / {m:.1f} us = {927.7 / m * 1e3:.0f} TFLOP/s = {927.7 / m * 1e3 / 2500:.4f} of 2.5 PF (profiler on, one stream; "
           f"bench.py's roofline.forward is the same population timed with events, profiler off)", file=sys.stderr)
 
-# ---- the weight-gradient sweep behind `roofline` (top level): 12 launches per training pass in backward order, the FIRST of each
-# pass is block dec.3.1 (128^3, 32 -> 32, 8 samples) - the shape bench.py probes; its slab reduction (wgrad_reduce_kernel<8>, ~20 us)
-# is a launch of its own here and inside the probe's event pair there
-PER_PASS = 12
+# ---- the weight-gradient sweep behind `roofline` (top level): PER_PASS launches per training pass in backward order (12 until the
+# 16^3 level's three layers moved to conv3_wgrad_flat_kernel, 9 since), the FIRST of each pass is block dec.3.1 (128^3, 32 -> 32,
+# 8 samples) - the shape bench.py probes; its slab reduction (wgrad_reduce_kernel<8>, ~20 us) is a launch of its own here and
+# inside the probe's event pair there
+PER_PASS = len(wrows) // (4 * neps) if neps and len(wrows) % (4 * neps) == 0 else 12
 wd = [(e - s) / 1e3 for s, e, *_ in wrows]
 print("dispatch_id,epoch,start_ns,end_ns,duration_us,grid_size,workgroup_size,lds_bytes,class")
 first = []

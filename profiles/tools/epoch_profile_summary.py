@@ -9,6 +9,9 @@ SHA = source_sha16()          # the kernel sources this run measured (ADVICE r5:
 # weight gradients that the ring sweep takes (conv_wgrad_ring.hip): the 13 plain stride-1 3x3x3 layers at >= 16^3, forward GFLOP
 # per 128^3 sample from SURVEY.md 8d (a weight gradient costs what the forward costs), x 32 sample passes per epoch
 WRING_GFLOP = [43.49, 115.96, 57.98, 28.99, 14.50, 28.99, 14.50, 57.98, 28.99, 115.96, 57.98, 231.93, 115.96]
+# 16-bit storage since round 6: the three 16^3 layers (enc.3.1, dec.1.0, dec.1.1) run conv3_wgrad_flat_kernel; the six split
+# launches of an fp32 weight gradient keep the sweep for them
+WRING_GFLOP_16 = [43.49, 115.96, 57.98, 28.99, 57.98, 28.99, 115.96, 57.98, 231.93, 115.96]
 
 
 def short(k):
@@ -106,10 +109,11 @@ for dt in dts:
             v = sum(fam.values())
             lc.update(kernel="conv3_wgrad_ring_kernel (all instantiations)", ms_per_epoch=round(v, 2), share_of_kernel_time=round(v / total, 4),
                       launches_per_epoch=sum(cnt[kk] for kk in fam), instantiations={kk: round(vv, 2) for kk, vv in fam.items()})
-            tf = sum(WRING_GFLOP) * 32 / 1e3
+            gl = WRING_GFLOP if dt == "fp32" else WRING_GFLOP_16
+            tf = sum(gl) * 32 / 1e3
             lc.update(tflop_per_epoch=round(tf, 2), achieved_tflops=round(tf / (v * 1e-3), 1),
                       frac_of_peak=round(tf / (v * 1e-3) / (157.3 if dt == "fp32" else 2500.0), 4),
-                      flop_basis="13 plain stride-1 3x3x3 layers at >= 16^3 (SURVEY.md 8d per-layer GFLOP) x 32 sample passes")
+                      flop_basis=f"{len(gl)} plain stride-1 3x3x3 layers at >= {16 if dt == 'fp32' else 32}^3 (SURVEY.md 8d per-layer GFLOP) x 32 sample passes")
         ent["largest_consumer"] = lc
     out["fp32" if dt == "fp32" else "16bit"] = ent
 print(json.dumps(out, indent=1))

@@ -34,9 +34,11 @@ C)
   tail -3 gpurun_out/r06_pmc.log; head -c 600 gpurun_out/r06_mfma_util.json
   rm -rf gpurun_out/r06_pmc_*_[0-9]
   bash profiles/tools/prof_infer.sh r06inf 512 fp16; head -14 gpurun_out/r06inf_stats.txt; rm -rf gpurun_out/r06inf
+  python3 profiles/tools/layerbench.py fp16 8 > gpurun_out/r06_layerbench.txt 2>&1; tail -3 gpurun_out/r06_layerbench.txt
   ;;
 D)
-  python3 profiles/tools/referee_12_epochs.py 3e-4 > gpurun_out/r06_referee12.log 2>&1
+  lr=${2:-3e-4}      # (3e-4: the referee's rate; 1e-5: the plan's own, config_log_utils.py:26)
+  python3 profiles/tools/referee_12_epochs.py $lr > gpurun_out/r06_referee12.log 2>&1
   python3 - <<PY
 import json
 t = open("gpurun_out/r06_referee12.log").read()

@@ -23,7 +23,7 @@ for dt in dts:
         n = k.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0][:86]
         print(f"{n:86s} launches {c:6.1f} {t:9.3f} ms  avg {t / max(c, 1e-9) * 1e3:8.1f} us {100 * t / tot:6.2f} %")
     fam = {"InstanceNorm apply / reduce / finalize": ("in_apply_vec", "chan_reduce_vec", "in_stats_finalize", "in_bwd_finalize"),
-           "D-ring conv forward / data gradient": ("conv3_ring_kernel",), "weight-gradient ring sweep": ("conv3_wgrad_ring_kernel",),
+           "D-ring conv forward / data gradient": ("conv3_ring_kernel",), "weight-gradient ring sweep": ("conv3_wgrad_ring_kernel",), "weight gradient of the small planes (flat runs)": ("conv3_wgrad_flat_kernel",),
            "row-reuse conv": ("conv3_rows_kernel",), "generic MFMA conv": ("conv3_mfma_kernel",), "fused head + warp": ("head_warp_",),
            "MIND + GIN + noise + image warps": ("mind_", "gin_chain", "distribution_elementwise", "warp_fwd_kernel"),
            "stride-2 / transposed conv (forward, data and weight gradients)": ("conv_s2_regs", "convT_", "conv3_wgrad_tr_s2x", "conv3_wgrad_tr_kernel", "conv3_wgrad_tr8"),

@@ -174,6 +174,71 @@ class WindowFeatures:
         return out
 
 
+def _mind_ahead_ok(model, dev):
+    """The MIND descriptor of the NEXT window batch may be evaluated on a side stream while the network is in the current one
+    (as tta.tta_epoch does for the next pass) when mind_hook is the last forward pre-hook and whatever stands in front of it
+    leaves the input alone (gin_hook with the trainers' internal augmentation off, the plan's untouched input modifier).
+    DGTTA_INFER_PREFETCH=0: in line."""
+    import os
+    from ..gin import gin_hook
+    from ..mind import hook_owner, mind_hook
+    from ..utils import get_internal_augmentation_enabled
+    if torch.device(dev).type != "cuda" or os.environ.get("DGTTA_INFER_PREFETCH", "1") == "0":
+        return False
+    hooks = list(hook_owner(model)._forward_pre_hooks.values())
+    if not hooks or hooks[-1] is not mind_hook or get_internal_augmentation_enabled():
+        return False
+    from .config_log_utils import is_template_modifier
+
+    def leaves_input_alone(h):      # gin_hook (augmentation off, checked above) or the untouched template input modifier
+        fn = getattr(h, "_dgtta_fn", None)
+        return h is gin_hook or (fn is not None and is_template_modifier(fn, "modify_tta_input_fn"))
+    return all(h is mind_hook or leaves_input_alone(h) for h in hooks) and sum(h is mind_hook for h in hooks) == 1
+
+
+def _window_batches(model, data, origins, patch_size, dev):
+    """Yields (group, work) per batch of WINDOW_BATCH windows.  Where _mind_ahead_ok, the window stack and its MIND descriptor
+    (noise draw included: the draws keep their order, one batch after the other) are produced on a side stream one batch ahead
+    and handed to the model's mind_hook (mind.push_features): same kernels, same draws, same result."""
+    from .._state import state_of
+    from ..mind import MIND3D, hook_owner, push_features
+
+    def stack(group):
+        return torch.stack([data[:, sx:sx + patch_size[0], sy:sy + patch_size[1], sz:sz + patch_size[2]]
+                            for sx, sy, sz in group]).contiguous()
+
+    groups = [origins[g0:g0 + WINDOW_BATCH] for g0 in range(0, len(origins), WINDOW_BATCH)]
+    if not groups:
+        return
+    if not _mind_ahead_ok(model, dev):
+        for group in groups:
+            yield group, stack(group)
+        return
+    main = torch.cuda.current_stream(dev)
+    side = state_of(hook_owner(model)).stream("prep_stream", dev)
+    adt = getattr(_inner(model), "act_dtype", torch.float32)
+    side.wait_stream(main)          # once: the volume (uploaded on the main stream) is visible to the side stream
+
+    def prepare(group):
+        with torch.cuda.stream(side):
+            work = stack(group)
+            feat = MIND3D().forward(work, out_dtype=adt, groups=len(group))
+        for t in (work, feat):
+            t.record_stream(main)
+        return work, feat
+
+    nxt = prepare(groups[0])
+    try:
+        for i, group in enumerate(groups):
+            work, feat = nxt
+            main.wait_stream(side)
+            nxt = prepare(groups[i + 1]) if i + 1 < len(groups) else None      # runs beside this batch's network pass
+            push_features(model, feat)
+            yield group, work
+    finally:
+        state_of(hook_owner(model)).features.clear()      # (a descriptor no mind_hook call took must not meet a later input)
+
+
 @torch.no_grad()
 def predict_sliding_window_return_logits(model, data, patch_size, acc=None, tile_step_size=0.5, acc_dtype=None):
     """data [C,X,Y,Z] (CPU or GPU) -> accumulates gauss-weighted logits of `model` into acc [X,Y,Z,ncls] (GPU; fp32 or
@@ -201,10 +266,7 @@ def predict_sliding_window_return_logits(model, data, patch_size, acc=None, tile
     # batch 1 (same observation as in the TTA loop); per-sample InstanceNorm and per-window MIND statistics (below) make
     # the result independent of the grouping
     origins = [(sx, sy, sz) for sx in steps[0] for sy in steps[1] for sz in steps[2]]
-    for g0 in range(0, len(origins), WINDOW_BATCH):
-        group = origins[g0:g0 + WINDOW_BATCH]
-        work = torch.stack([data[:, sx:sx + patch_size[0], sy:sy + patch_size[1], sz:sz + patch_size[2]]
-                            for sx, sy, sz in group]).contiguous()
+    for group, work in _window_batches(model, data, origins, patch_size, dev):
         # MIND's variance clamp uses the mean over the whole CALL's batch (mind.py:159-161) and nnU-Net predicts one
         # window per call: the batched pass keeps per-window statistics (groups = windows in the batch)
         if _can_fuse_head_accumulate(model):
@@ -250,10 +312,7 @@ def accumulate_window_features(model, data, patch_size, facc=None, tile_step_siz
     was_training = model.training
     model.eval()
     origins = [(sx, sy, sz) for sx in steps[0] for sy in steps[1] for sz in steps[2]]
-    for g0 in range(0, len(origins), WINDOW_BATCH):
-        group = origins[g0:g0 + WINDOW_BATCH]
-        work = torch.stack([data[:, sx:sx + patch_size[0], sy:sy + patch_size[1], sz:sz + patch_size[2]]
-                            for sx, sy, sz in group]).contiguous()
+    for group, work in _window_batches(model, data, origins, patch_size, dev):
         with mind_groups(model, len(group)), m.fuse_window_feature_accumulate(facc, nsum, gauss, group):
             model(work)
     model.train(was_training)

@@ -501,6 +501,21 @@ def test_feature_space_accumulator_against_logits_space_on_the_full_net(dtype, m
     monkeypatch.delenv("DGTTA_WINDOW_ACC", raising=False)
     torch.manual_seed(9)
     assert torch.equal(pinf.run_inference(vol, model, params, patch), seg_f.long())
+    # round 6: the window stack and the MIND descriptor of the next batch are produced on a side stream beside the network pass
+    # of the current one (default here: mind_hook behind the untouched template modifier); in line (DGTTA_INFER_PREFETCH=0) the
+    # same kernels see the same noise draws in the same order: the same bits, in both accumulators
+    assert pinf._mind_ahead_ok(model, DEV)
+    monkeypatch.setenv("DGTTA_INFER_PREFETCH", "0")
+    assert not pinf._mind_ahead_ok(model, DEV)
+    torch.manual_seed(9)
+    acc_i, nsum_i, _ = pinf.predict_ensemble(vol, model, params, patch)
+    assert torch.equal(acc_i.facc, acc_f.facc) and torch.equal(nsum_i, nsum_f)
+    monkeypatch.setenv("DGTTA_WINDOW_ACC", "fp32")
+    torch.manual_seed(9)
+    acc_il, _, _ = pinf.predict_ensemble(vol, model, params, patch)
+    assert torch.equal(acc_il, acc_l)
+    monkeypatch.delenv("DGTTA_WINDOW_ACC")
+    monkeypatch.delenv("DGTTA_INFER_PREFETCH")
     # the InstanceNorm + LeakyReLU apply of the block in front of the head runs inside the accumulation kernel (default) or as its
     # own pass (DGTTA_FEATURE_FOLD=0): the same z values, the same bits in the accumulator
     monkeypatch.setenv("DGTTA_FEATURE_FOLD", "0")

@@ -1,7 +1,8 @@
 """How much of a 16-bit run's deviation from the oracle is the pre-trained instance?  The 3-epoch x 8-step referee run of
 tests/test_gpu_referee.py (bench.referee_tta_run) over several pre-training seeds (bench.PRETRAIN["seed"]: the patch / augmentation
 draws of the 550 pre-training steps; seed 5 is the bench's): per instance the engine's fp32 / fp16 / bf16 against the CPU oracle.
-usage: referee_instances.py 5 11 12 13 14 15 > gpurun_out/r06_referee_instances.json"""
+usage: referee_instances.py 5 11 12 13 14 15 > gpurun_out/r06_referee_instances.json
+(RI_EPOCHS / RI_ACCUM / RI_LR: another schedule, e.g. 12 / 16 / 1e-5 = BASELINE config 2 at the plan's rate)"""
 import json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
@@ -12,9 +13,11 @@ rows = []
 for sd in seeds:
     bench.PRETRAIN["seed"] = sd
     bench._PRETRAINED.clear()
-    args = bench.parse_args(["--referee-patch", "64", "--referee-epochs", "3", "--referee-accum", "8"])
+    if os.environ.get("RI_LR"):
+        bench.REFEREE_LR = float(os.environ["RI_LR"])
+    args = bench.parse_args(["--referee-patch", "64", "--referee-epochs", os.environ.get("RI_EPOCHS", "3"), "--referee-accum", os.environ.get("RI_ACCUM", "8")])
     out = bench.referee_tta_run(args, torch.device("cuda:0"))
-    row = {"pretrain_seed": sd, "oracle_loss_per_epoch": out["oracle"]["loss_per_epoch"],
+    row = {"pretrain_seed": sd, "epochs": out["epochs"], "accum": out["accum"], "lr": out["lr"], "oracle_loss_per_epoch": out["oracle"]["loss_per_epoch"],
            "oracle_hard_dice": [out["oracle"]["hard_dice_vs_gt_before"], out["oracle"]["hard_dice_vs_gt_after"]],
            "mask_voxel_fraction": out["pretraining"]["voxels_with_positive_mapped_logit_sum"]}
     for k in ("fp32", "fp16", "bf16"):

@@ -375,3 +375,18 @@ def test_feature_space_inference_is_offered_only_for_heads_the_final_kernel_take
         assert pinf._can_accumulate_features(net(200), members=1)
         assert not pinf._can_accumulate_features(net(200), members=3)
     assert not pinf._can_accumulate_features(net(105), members=1)          # grad mode: the network does not offer it
+
+
+def test_every_environment_variable_the_product_reads_is_documented():
+    """INTEGRATION.md (Switches) names every DGTTA_* variable the library (csrc/lib.hip snapshot), the host package and bench.py
+    read: a switch nobody can find is a result nobody can reproduce."""
+    import re
+    from pathlib import Path
+    root = Path(__file__).resolve().parents[1]
+    doc = (root / "INTEGRATION.md").read_text()
+    lib = (root / "dg_tta_amd" / "csrc" / "lib.hip").read_text()
+    names = set(re.findall(r'(?:env_char|getenv)\("(DGTTA_[A-Z0-9_]+)"\)', lib))
+    for f in list((root / "dg_tta_amd").rglob("*.py")) + [root / "bench.py"]:
+        names |= set(re.findall(r"DGTTA_[A-Z0-9_]+", f.read_text()))
+    missing = sorted(n for n in names if n not in doc)
+    assert not missing, missing

@@ -53,6 +53,31 @@ def trainer_hooks(trainer_name):
     raise NotImplementedError(f"trainer {trainer_name}: only the DG-TTA trainers (GIN / MIND / GIN_MIND) are built")
 
 
+def _load_checked(network, state, weights_file, trainer_name, configuration):
+    """network.load_state_dict with a message that says WHAT differs: the key layout expected here is that of
+    dynamic-network-architectures' PlainConvUNet (encoder.stages.S.0.convs.K.{conv,norm,all_modules.{0,1}}.*, decoder.encoder.*
+    as a second name of the encoder, decoder.stages / transpconvs / seg_layers), written from memory of version 0.2 - a real
+    checkpoint_final.pth has not been reachable offline, so a mismatch must be readable at a glance."""
+    expected = network.state_dict()
+    missing = sorted(k for k in expected if k not in state)
+    unexpected = sorted(k for k in state if k not in expected)
+    shapes = sorted(f"{k}: file {tuple(state[k].shape)} vs network {tuple(expected[k].shape)}" for k in expected
+                    if k in state and hasattr(state[k], "shape") and tuple(state[k].shape) != tuple(expected[k].shape))
+    if missing or unexpected or shapes:
+        def head(v):
+            return ", ".join(v[:6]) + (f", ... ({len(v)} in all)" if len(v) > 6 else "")
+        raise RuntimeError(
+            f"{weights_file}: the checkpoint does not fit the network built from plans.json ({trainer_name}, {configuration}: "
+            f"{len(expected)} tensors expected, {len(state)} in the file).\n"
+            f"  missing in the file ({len(missing)}): {head(missing) or '-'}\n"
+            f"  not known to the network ({len(unexpected)}): {head(unexpected) or '-'}\n"
+            f"  shape differs ({len(shapes)}): {head(shapes) or '-'}\n"
+            f"  expected layout: dynamic-network-architectures PlainConvUNet state dict (encoder.stages.<s>.0.convs.<k>.conv.weight, "
+            f"...norm.weight, ...all_modules.<0|1>.*, decoder.encoder.* duplicating the encoder, decoder.stages.*, decoder.transpconvs.*, "
+            f"decoder.seg_layers.*); a '_orig_mod.' prefix (torch.compile) is stripped")
+    network.load_state_dict(state)
+
+
 def load_network(weights_file, device, act_dtype=torch.float32, conv_impl=0):
     weights_file = Path(weights_file)
     model_folder = weights_file.parents[1]
@@ -72,7 +97,7 @@ def load_network(weights_file, device, act_dtype=torch.float32, conv_impl=0):
     cfg, patch_size = unet_cfg_from_plans(plans, dataset_json, configuration, in_ch)
     network = HipPlainConvUNet(cfg, act_dtype=act_dtype, conv_impl=conv_impl)
     state = {k.replace("_orig_mod.", ""): v for k, v in state.items()}
-    network.load_state_dict(state)
+    _load_checked(network, state, weights_file, trainer_name, configuration)
     enable_internal_augmentation()          # as build_network_architecture does; tta_main switches it off again
     for h in hooks:
         network.register_forward_pre_hook(h)

@@ -2,7 +2,7 @@
 tree) run by the product in fp32 and in a 16-bit type on the same draw stream, with the per-(step, class) soft Dice of the
 consistency loss recorded: prints, for each epoch, the steps and classes whose Dice differs most and the class's mass.
 usage: step_loss_ab.py [fp16|bf16] [epochs]"""
-import copy, os, sys
+import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np

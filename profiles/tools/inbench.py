@@ -31,3 +31,18 @@ e1.record(); torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / 20
 gb = B * V * C * 2 * 5 / 1e9
 print(f"instnorm bwd {B}x{n}^3x{C}: {ms*1e3:.1f} us, {gb/ms:.2f} TB/s over 5 tensor passes ({gb:.2f} GB)")
+
+# forward: statistics + finalize + apply (y -> z) of the same layer
+z = torch.empty_like(y)
+mr2 = torch.empty((B, C, 2), device=dev)
+def runf():
+    check(lib.dgtta_instnorm_lrelu_fwd(ptr(y), C, None, ptr(gamma), ptr(beta), ptr(mr2), ptr(z), C, ptr(ws), nb, B, C, V, 1e-5, 0.01, ops.BF16,
+                                       stream_of(dev)), "in_fwd")
+for _ in range(3): runf()
+torch.cuda.synchronize()
+e0.record()
+for _ in range(20): runf()
+e1.record(); torch.cuda.synchronize()
+ms = e0.elapsed_time(e1) / 20
+gb = B * V * C * 2 * 3 / 1e9
+print(f"instnorm fwd {B}x{n}^3x{C}: {ms*1e3:.1f} us, {gb/ms:.2f} TB/s over 3 tensor passes ({gb:.2f} GB)")
